@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""LED-Net hot-path benchmark (driver contract: see the round prompt).
+
+  python bench.py --gpus N --steps K --warmup W [--mode train|infer] [--dtype bf16|f32]
+
+One "step" = one pass of the hot path over one synthetic batch already resident
+in HBM: mode=train -> forward + OHEM-CE loss + backward + SGD on 16 x 3 x 1024 x 1024
+per GPU (BASELINE.json configs[2]/[3]); mode=infer -> forward + multi-scale logit
+fusion + argmax on 8 x 3 x 1024 x 1024 per GPU (configs[1]).  N>1 is launched by
+torch.distributed.run, one rank per GPU (RCCL); images are sharded across ranks
+(weak scaling), value = images of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline":     dominant kernel's achieved rate vs the gfx950 peak, timed with
+                  HIP events on the launch stream inside the timed region;
+  "cpu_baseline": the CPU oracle (oracle/spec.py, stock PyTorch fp32 ops) timed on
+                  this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}   # dense peaks, same guide
+
+
+def synthetic_batch(n, h, w, dev, seed=304):
+    """uint8 BGR images, labels in {0,1} with a 16-px ignore border."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (n, 3, h, w), dtype=torch.uint8, generator=g)
+    lab = torch.randint(0, 2, (n, 1, h, w), dtype=torch.int64, generator=g)
+    lab[:, :, :16, :] = 255
+    lab[:, :, -16:, :] = 255
+    lab[:, :, :, :16] = 255
+    lab[:, :, :, -16:] = 255
+    return img.to(dev), lab.to(dev)
+
+
+def build_model(dev, dtype, train):
+    import led_net_amd as L
+    torch.manual_seed(304)
+    cfg = L.load_config(os.path.join(ROOT, 'tests', 'data', 'lednet_test_config.py'))
+    model = L.MODELS.build(cfg['model'])
+    model.set_act_dtype(torch.bfloat16 if dtype == 'bf16' else torch.float32)
+    model.to(dev)
+    model.train(train)
+    return model, cfg
+
+
+def cpu_baseline(mode, h, w, budget_s=20.0):
+    """Time the CPU oracle on a bounded sample (bs=1 images, a few iterations)."""
+    from oracle import spec
+    import led_net_amd as L
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(304)
+    cfg = L.load_config(os.path.join(ROOT, 'tests', 'data', 'lednet_test_config.py'))
+    model = L.MODELS.build(cfg['model'])
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    bs = 2 if mode == 'train' else 1
+    img, lab = synthetic_batch(bs, h, w, 'cpu')
+    x = spec.preprocess(img)
+    if mode == 'train':
+        for k, v in sd.items():
+            if v.is_floating_point() and 'running_' not in k:
+                v.requires_grad_(True)
+
+        def step():
+            out = spec.loss(x, lab, sd)
+            (out['decode.loss_context'] + out['decode.loss_spatial']).backward()
+            with torch.no_grad():
+                for v in sd.values():
+                    if v.grad is not None:
+                        v -= 0.01 * v.grad
+                        v.grad = None
+    else:
+        def step():
+            with torch.no_grad():
+                spec.predict(x, sd)
+    step()  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 20:
+            break
+    dt = time.perf_counter() - t0
+    return {'value': round(bs * n / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} iterations of oracle.spec.{"loss+backward+SGD" if mode == "train" else "predict"} '
+                      f'at batch {bs}, {h}x{w}, fp32, torch CPU ops, {cores} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--mode', default=None, choices=['train', 'infer'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--height', type=int, default=1024)
+    ap.add_argument('--width', type=int, default=1024)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    import led_net_amd as L
+    from led_net_amd import ops
+    has_train = hasattr(L, 'Trainer')
+    mode = args.mode or ('train' if has_train else 'infer')
+    bs = args.batch or (16 if mode == 'train' else 8)
+    H, W = args.height, args.width
+    model, cfg = build_model(dev, args.dtype, mode == 'train')
+    img, lab = synthetic_batch(bs, H, W, dev, seed=304 + rank)
+
+    if mode == 'train':
+        trainer = L.Trainer(model, cfg, world_size=world)
+        samples = [L.SegDataSample(gt=lab[i]) for i in range(bs)]
+
+        def step():
+            return trainer.train_step(img, samples)
+    else:
+        def step():
+            with torch.no_grad():
+                return model.decode_head.predict_with_mask(model.extract_feat(img))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.start_timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    launches = ops.stop_timing()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        # ---- dominant kernel (by summed HIP-event time over the timed region)
+        agg = {}
+        for r in launches:
+            k = (r['entry'], r['sig'])
+            a = agg.setdefault(k, dict(ms=0.0, n=0, bytes=r['bytes'], flops=r['flops']))
+            a['ms'] += r['ms']
+            a['n'] += 1
+        top = sorted(agg.items(), key=lambda kv: -kv[1]['ms'])
+        (entry, sig), a = top[0]
+        avg_ms = a['ms'] / a['n']
+        if entry in ('ledn_conv2d', 'ledn_conv2d_wgrad', 'ledn_window_attn'):
+            peak = MFMA_PEAK_TFLOPS[args.dtype]
+            ach = a['flops'] / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound='mfma', achieved=round(ach, 3), peak=peak, unit='TFLOP/s',
+                        frac=round(ach / peak, 5), traffic=None)
+        else:
+            ach = a['bytes'] / (avg_ms * 1e-3) / 1e9
+            roof = dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
+        roof.update(kernel=f'{entry} [{sig}]', avg_us=round(avg_ms * 1e3, 2), launches_per_step=a['n'] // args.steps,
+                    share_of_gpu_time=round(a['ms'] / max(1e-9, sum(v['ms'] for v in agg.values())), 4))
+        total_flops = sum(v['flops'] * v['n'] for k, v in agg.items() if k[0] in ('ledn_conv2d', 'ledn_conv2d_wgrad', 'ledn_window_attn'))
+        total_bytes = sum(v['bytes'] * v['n'] for v in agg.values())
+        gpu_ms = sum(v['ms'] for v in agg.values())
+        out = {
+            'metric': 'images/sec at 1024x1024, LED-Net fwd+bwd' if mode == 'train'
+                      else 'images/sec at 1024x1024, LED-Net fwd (inference)',
+            'value': round(bs * world * args.steps / dt, 3), 'unit': 'images/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+            'data': 'synthetic',
+            'config': {'workload': (f'LED-Net {H}x{W} train_step (fwd+OHEM-CE+bwd+SGD) batch {bs}/GPU' if mode == 'train'
+                                    else f'LED-Net {H}x{W} inference (fwd+fusion+argmax) batch {bs}/GPU'),
+                       'global_batch': bs * world, 'parallelism': f'dp{world}',
+                       'kernel_launches_per_step': len(launches) // args.steps,
+                       'conv_gemm_tflops_whole_step': round(total_flops / (gpu_ms * 1e-3) / 1e12, 3),
+                       'hbm_alg_gbs_whole_step': round(total_bytes / (gpu_ms * 1e-3) / 1e9, 1),
+                       'gpu_busy_frac': round(gpu_ms / (dt * 1e3), 3)},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(mode, H, W)
+        if os.environ.get('LEDN_BENCH_VERBOSE'):
+            for (e, sg), v in top[:25]:
+                print(f'{v["ms"] / args.steps:9.3f} ms/step  x{v["n"] // args.steps:3d}  {e} [{sg}]', file=sys.stderr)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

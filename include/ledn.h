@@ -1,0 +1,254 @@
+/* ledn.h -- C ABI of libledn_hip.so: the MI355X (gfx950) kernels behind the
+ * LED-Net forward/backward hot path.
+ *
+ * The reference (ly27253/LED-Net) has NO native code and no FFI: every op on
+ * its hot path is an implicit ATen/cuDNN call issued from Python
+ * (SURVEY.md section 2.2).  Each entry point below therefore names the
+ * reference call site (file:line under /root/reference) whose ATen op(s) it
+ * replaces.  INTEGRATION.md shows the ctypes binding and the mmseg-registry
+ * registration a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every tensor is a DEVICE pointer, dense NHWC ([N][H][W][C], C fastest);
+ *   - activations are f32 or bf16 (LEDN_F32 / LEDN_BF16), parameters,
+ *     statistics and accumulators are always f32;
+ *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it;
+ *   - every function validates its arguments on the host and returns
+ *     LEDN_OK / LEDN_EINVAL / LEDN_ELAUNCH; it never launches a kernel whose
+ *     grid does not match the operand shapes;
+ *   - no torch types, no ownership transfer: the caller owns every buffer.
+ */
+#ifndef LEDN_H
+#define LEDN_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LEDN_ABI_VERSION 1
+
+enum { LEDN_OK = 0, LEDN_EINVAL = 1, LEDN_ELAUNCH = 2 };
+enum { LEDN_F32 = 0, LEDN_BF16 = 1, LEDN_U8 = 2 };
+enum { LEDN_ACT_NONE = 0, LEDN_ACT_RELU = 1, LEDN_ACT_RELU6 = 2, LEDN_ACT_PRELU = 3, LEDN_ACT_SIGMOID = 4 };
+enum { LEDN_RES_NONE = 0, LEDN_RES_ADD = 1, LEDN_RES_GATE = 2 }; /* v+res | v*res+res */
+
+int ledn_abi_version(void);
+
+/* ------------------------------------------------------------------------- *
+ * Dense / grouped convolution, forward and data-gradient.
+ *   z[n,ho,wo,co] = sum_{kh,kw,ci} pre(x)[n, ho*s-pad+kh*dil, wo*s-pad+kw*dil, ci] * W[co][ci][kh][kw]
+ *   pre(x) = act_in((x [+ xadd]) * in_scale[ci] + in_shift[ci])   (zero padding AFTER pre)
+ *   v      = z * out_scale[co] + out_shift[co]                     (stats of v -> stat_sum/stat_sqsum)
+ *   y      = act_out(res_mode(v, res))
+ * transposed=1 computes the data gradient of the same convolution: x is dz
+ * [N,H,W,Cin] with Cin = forward Cout, y is dx [N,Ho,Wo,Cout] with Cout = forward Cin.
+ * Weights are addressed by element strides so PyTorch's OIHW master copy is used
+ * in place:  W(co,ci,tap) = w[co*ws_co + ci*ws_ci + tap*ws_tap]  (ci is the
+ * index inside the group).
+ * Replaces: F.conv2d inside mmcv ConvModule (mmseg/models/utils/basic_block.py:43-57,
+ * backbones/ddrnet.py:68-105,123-138, decode_heads/led_head.py:87-94,
+ * decode_head.py:158), nn_layers/espnet_utils.py:22-36 (grouped 1x1),
+ * backbones/UNetFormer_GETB.py:83-85,111 (1x1 qkv / Mlp), fused with the
+ * BatchNorm / ReLU / PReLU / residual ops that follow them there.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    const void* x;
+    const void* xadd;      /* optional, same shape/dtype as x */
+    const float* w;
+    void* y;
+    const void* res;       /* optional [N,Ho,Wo,Cout], dtype_y */
+    const float* in_scale; /* optional [Cin] */
+    const float* in_shift; /* optional [Cin] */
+    const float* out_scale;/* optional [Cout] (NULL = 1) */
+    const float* out_shift;/* optional [Cout] (NULL = 0) */
+    const float* slope;    /* [Cout] when act_out == PRELU */
+    float* stat_sum;       /* optional [Cout], accumulated atomically */
+    float* stat_sqsum;     /* optional [Cout] */
+    long long ws_co, ws_ci, ws_tap;
+    int N, H, W, Cin, Ho, Wo, Cout;
+    int KH, KW, stride, pad, dil, groups;
+    int in_act, act_out, res_mode;
+    int dtype_x, dtype_y;
+    int transposed;
+} ledn_conv_desc;
+int ledn_conv2d(const ledn_conv_desc* d, void* stream);
+
+/* Weight (and bias) gradient of the same convolution:
+ *   dw(co,ci,tap) += sum_{n,ho,wo} pre(x)[n, ho*s-pad+kh*dil, .., ci] * dz[n,ho,wo,co]
+ *   db[co]        += sum dz[n,ho,wo,co]
+ * dw uses the same stride addressing as w above; dw/db are ACCUMULATED (caller zeroes). */
+typedef struct {
+    const void* x;
+    const void* xadd;
+    const void* dz;        /* [N,Ho,Wo,Cout] */
+    float* dw;
+    float* db;             /* optional [Cout] */
+    const float* in_scale;
+    const float* in_shift;
+    long long ws_co, ws_ci, ws_tap;
+    int N, H, W, Cin, Ho, Wo, Cout;
+    int KH, KW, stride, pad, dil, groups;
+    int in_act;
+    int dtype_x, dtype_dz;
+} ledn_wgrad_desc;
+int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Depthwise convolution (KxK, per-channel-group dilation, pad = dil*(K-1)/2
+ * unless `pad` >= 0 is given), with the same post-op as ledn_conv2d.
+ *   channel c uses dilation dil[c / group_size] (up to 4 groups).
+ *   ext1=1: the input is read as if reflect-extended by one row/column at the
+ *   bottom/right (index H -> H-2, W -> W-2) -- GETB `pad_out`.
+ *   w is [KH][KW][C] f32 (packed by the host from PyTorch's [C][1][KH][KW]).
+ * Replaces: CDilated depthwise convs of SESP (nn_layers/eesp.py:60-68,92-97)
+ * and SeparableConvBN's depthwise 8x8 (backbones/UNetFormer_GETB.py:59-65,118,160-162,201-204).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    const void* x;         /* [N,H,W,C] */
+    const float* w;
+    void* y;               /* [N,Ho,Wo,C] */
+    const float* out_scale;
+    const float* out_shift;
+    const float* slope;
+    float* stat_sum;
+    float* stat_sqsum;
+    int N, H, W, C, Ho, Wo;
+    int KH, KW, stride, pad;     /* pad < 0: per-group dil*(K-1)/2 */
+    int dil[4], group_size;
+    int act_out, ext1;
+    int dtype_x, dtype_y;
+} ledn_dw_desc;
+int ledn_dwconv2d(const ledn_dw_desc* d, void* stream);
+
+/* SESP split/transform stage 1 with hierarchical feature fusion:
+ *   y[..., b*n + c] = sum_{b' <= b} dw3x3_{dil[b'], stride}(x)[..., c]     b = 0..3
+ * x [N,H,W,n], w [4][3][3][n], y [N,Ho,Wo,4n].
+ * Replaces: nn_layers/eesp.py:81-91 (4 CDilated convs + 3 adds + later torch.cat). */
+typedef struct {
+    const void* x;
+    const float* w;
+    void* y;
+    int N, H, W, n, Ho, Wo, stride;
+    int dil[4];
+    int dtype_x, dtype_y;
+} ledn_pyr_desc;
+int ledn_sesp_pyramid(const ledn_pyr_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Per-channel statistics and elementwise affine / activation.
+ * Replaces: nn.BatchNorm2d (+ReLU/PReLU/ReLU6, + residual add) wherever it is
+ * not fused into a convolution above (eesp.py:99-103, espnet_utils.py:53-57,
+ * UNetFormer_GETB.py:212,219, led_head.py:87-96).
+ * ------------------------------------------------------------------------- */
+/* sum[c] += sum_p x[p,c], sqsum[c] += sum_p x[p,c]^2   (x: [P][C]) */
+int ledn_channel_stats(const void* x, const void* xadd, long long P, int C, int dtype,
+                       float* sum, float* sqsum, void* stream);
+/* batch-norm bookkeeping from accumulated sums (count = elements per channel):
+ *   mean, biased var -> scale = gamma*invstd, shift = beta - mean*scale;
+ *   running stats updated with `momentum` (unbiased var), if given. */
+int ledn_bn_finalize(const float* sum, const float* sqsum, double count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, float* scale, float* shift, float* mean, float* invstd, int C,
+                     void* stream);
+/* y = act(res_mode((x [+ xadd]) * scale[c] + shift[c], res))   x,y: [P][C] */
+typedef struct {
+    const void* x;
+    const void* xadd;
+    void* y;
+    const void* res;
+    const float* scale;
+    const float* shift;
+    const float* slope;
+    long long P;
+    int C, act, res_mode;
+    int dtype_x, dtype_y;
+} ledn_affine_desc;
+int ledn_affine_act(const ledn_affine_desc* d, void* stream);
+
+/* Planar-to-interleaved input transform (the step in front of the stem):
+ *   y[n,h,w,c] = x[n, map[c], h, w] * scale[c] + shift[c]
+ * x: [N][C][H][W] u8 / f32 / bf16, y: [N][H][W][C] f32 / bf16; map NULL = identity.
+ * Replaces: SegDataPreProcessor's BGR->RGB flip and (x-mean)/std
+ * (mmseg/models/data_preprocessor.py:117-127) plus the NCHW->NHWC re-layout. */
+int ledn_nchw_to_nhwc(const void* x, int dtype_x, void* y, int dtype_y, int N, int C, int H, int W,
+                      const float* scale, const float* shift, const int* map, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Resampling.
+ * ------------------------------------------------------------------------- */
+/* y = (add ? add : 0) + bilinear(x -> Ho x Wo), align_corners=False semantics of
+ * F.interpolate (mmseg/models/utils/wrappers.py:27; call sites ddrnet.py:195-199,
+ * led_head.py:106-138, decode_head.py:364-378).  out_nchw=1 writes y as
+ * [N][C][Ho][Wo] f32 and, if argmax != NULL, the first-max channel index per
+ * pixel (segmentors/base.py:188) as uint8. */
+typedef struct {
+    const void* x;         /* [N,H,W,C] */
+    const void* add;       /* optional [N,Ho,Wo,C] dtype_y (NHWC) */
+    void* y;
+    unsigned char* argmax; /* optional [N,Ho,Wo] */
+    int N, H, W, C, Ho, Wo;
+    int out_nchw;
+    int dtype_x, dtype_y;
+} ledn_resize_desc;
+int ledn_bilinear(const ledn_resize_desc* d, void* stream);
+
+/* y[n,oy,ox,c] = mean over the adaptive window of (x [+ xadd]); y f32 [N,S,S,C].
+ * Replaces nn.AdaptiveAvgPool2d in Muti_AFF (classification/model_utils.py:373-400). */
+int ledn_adaptive_avgpool(const void* x, const void* xadd, float* y, int N, int H, int W, int C,
+                          int S, int dtype, void* stream);
+/* 3x3 stride-2 pad-1 average pool, count_include_pad (nn_layers/eesp.py:74,111). */
+int ledn_avgpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo,
+                      int dtype, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * GETB (backbones/UNetFormer_GETB.py:97-206).
+ * ------------------------------------------------------------------------- */
+/* 8x8-window multi-head attention on a 1x1-conv qkv map.
+ *   qkv [N,H,W,3*C] (channel = which*C + head*d + j), reflect-extended to
+ *   multiples of ws at the bottom/right (:145-152); out [N,H,W,C] (cropped, :195).
+ *   biasT [heads][ws*ws (key j)][ws*ws (query i)] f32: relative-position bias
+ *   gathered by the host from the (2ws-1)^2 x heads table (:181-187). */
+int ledn_window_attn(const void* qkv, const float* biasT, void* out, int N, int H, int W, int C,
+                     int heads, int ws, int dtype, void* stream);
+/* out = avgpool_(ws,1)(reflect-pad-bottom(a)) + avgpool_(1,ws)(reflect-pad-right(a)) + local
+ * (:197-199); a, local, out: [N,H,W,C]. */
+int ledn_getb_pool(const void* a, const void* local, void* out, int N, int H, int W, int C, int ws,
+                   int dtype, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * MFAF gate (classification/model_utils.py:405-429):
+ *   wei = sigmoid( aff0(xl) + aff1(c1)^ + aff2(c2)^ + aff3(c3)^ + aff4(xg) ),  ^ = nearest upsample
+ *   out = 2*x*wei + 2*r*(1-wei)
+ * xl [N,H,W,C] (dtype), c1 [N,4,4,C], c2 [N,8,8,C], c3 [N,16,16,C], xg [N,1,1,C] (f32),
+ * aff: 5 pairs (scale,shift) of [C] f32 = the trailing BatchNorm of each branch. */
+typedef struct {
+    const void* x;
+    const void* r;
+    const void* xl;
+    const float* ctx[4];   /* c1, c2, c3, xg */
+    int ctx_size[4];       /* 4, 8, 16, 1 */
+    const float* scale[5]; /* xl, c1, c2, c3, xg */
+    const float* shift[5];
+    void* out;
+    int N, H, W, C;
+    int dtype;
+    int act;               /* LEDN_ACT_NONE or LEDN_ACT_RELU applied to out (the next stage's ReLU) */
+} ledn_mfaf_desc;
+int ledn_mfaf_gate(const ledn_mfaf_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * SEAM edge map (prototype tools/speed/ddrnet_speed.py:24-37,282-338; percentile
+ * rule: supplementary PDF section 4.2 eq.1).
+ *   seg [N,h,w] f32 -> per-image min-max normalise -> Laplacian at strides 1/2/4,
+ *   clamp >= 0, nearest upsample -> binarise (b > T; T = the kth smallest response
+ *   (1-based; kth = ceil(q*h*w) for the q-percentile rule) per image and scale
+ *   if kth > 0, else the fixed threshold `thr`) -> 0.6/0.3/0.1 fuse ->
+ *   binarise (> final_thr) -> edge [N,h,w] f32 in {0,1}.
+ *   scratch: 3*N*h*w floats + 16*N words.  One workgroup per image. */
+int ledn_seam_edge(const float* seg, float* edge, float* scratch, int N, int h, int w, int kth,
+                   float thr, float final_thr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEDN_H */

@@ -1,0 +1,150 @@
+"""ctypes binding of the C ABI in include/ledn.h.
+
+The product path loads exactly one library: ``csrc/libledn_hip.so`` (gfx950).
+If it is missing, or a tensor handed to an op is not on a HIP device, the op
+raises -- there is no CPU fallback.  (The test-suite may bind the CPU emulation
+build of the same kernel sources through :func:`use_library`; nothing in the
+product does.)
+"""
+import contextlib
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, 'csrc', 'libledn_hip.so')
+
+OK, EINVAL, ELAUNCH = 0, 1, 2
+F32, BF16, U8 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+RES_NONE, RES_ADD, RES_GATE = 0, 1, 2
+
+vp, fp, i32, i64 = C.c_void_p, C.c_void_p, C.c_int, C.c_longlong
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x', vp), ('xadd', vp), ('w', fp), ('y', vp), ('res', vp),
+                ('in_scale', fp), ('in_shift', fp), ('out_scale', fp), ('out_shift', fp),
+                ('slope', fp), ('stat_sum', fp), ('stat_sqsum', fp),
+                ('ws_co', i64), ('ws_ci', i64), ('ws_tap', i64),
+                ('N', i32), ('H', i32), ('W', i32), ('Cin', i32), ('Ho', i32), ('Wo', i32), ('Cout', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('groups', i32),
+                ('in_act', i32), ('act_out', i32), ('res_mode', i32),
+                ('dtype_x', i32), ('dtype_y', i32), ('transposed', i32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('x', vp), ('xadd', vp), ('dz', vp), ('dw', fp), ('db', fp),
+                ('in_scale', fp), ('in_shift', fp),
+                ('ws_co', i64), ('ws_ci', i64), ('ws_tap', i64),
+                ('N', i32), ('H', i32), ('W', i32), ('Cin', i32), ('Ho', i32), ('Wo', i32), ('Cout', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('groups', i32),
+                ('in_act', i32), ('dtype_x', i32), ('dtype_dz', i32)]
+
+
+class DwDesc(C.Structure):
+    _fields_ = [('x', vp), ('w', fp), ('y', vp), ('out_scale', fp), ('out_shift', fp), ('slope', fp),
+                ('stat_sum', fp), ('stat_sqsum', fp),
+                ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('Ho', i32), ('Wo', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
+                ('dil', i32 * 4), ('group_size', i32), ('act_out', i32), ('ext1', i32),
+                ('dtype_x', i32), ('dtype_y', i32)]
+
+
+class PyrDesc(C.Structure):
+    _fields_ = [('x', vp), ('w', fp), ('y', vp),
+                ('N', i32), ('H', i32), ('W', i32), ('n', i32), ('Ho', i32), ('Wo', i32), ('stride', i32),
+                ('dil', i32 * 4), ('dtype_x', i32), ('dtype_y', i32)]
+
+
+class AffineDesc(C.Structure):
+    _fields_ = [('x', vp), ('xadd', vp), ('y', vp), ('res', vp), ('scale', fp), ('shift', fp), ('slope', fp),
+                ('P', i64), ('C', i32), ('act', i32), ('res_mode', i32), ('dtype_x', i32), ('dtype_y', i32)]
+
+
+class ResizeDesc(C.Structure):
+    _fields_ = [('x', vp), ('add', vp), ('y', vp), ('argmax', vp),
+                ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('Ho', i32), ('Wo', i32),
+                ('out_nchw', i32), ('dtype_x', i32), ('dtype_y', i32)]
+
+
+class MfafDesc(C.Structure):
+    _fields_ = [('x', vp), ('r', vp), ('xl', vp), ('ctx', fp * 4), ('ctx_size', i32 * 4),
+                ('scale', fp * 5), ('shift', fp * 5), ('out', vp),
+                ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('dtype', i32), ('act', i32)]
+
+
+_PROTOS = {
+    'ledn_abi_version': ([], i32),
+    'ledn_conv2d': ([C.POINTER(ConvDesc), vp], i32),
+    'ledn_conv2d_wgrad': ([C.POINTER(WgradDesc), vp], i32),
+    'ledn_dwconv2d': ([C.POINTER(DwDesc), vp], i32),
+    'ledn_sesp_pyramid': ([C.POINTER(PyrDesc), vp], i32),
+    'ledn_channel_stats': ([vp, vp, i64, i32, i32, fp, fp, vp], i32),
+    'ledn_bn_finalize': ([fp, fp, C.c_double, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, fp, fp, i32, vp], i32),
+    'ledn_affine_act': ([C.POINTER(AffineDesc), vp], i32),
+    'ledn_nchw_to_nhwc': ([vp, i32, vp, i32, i32, i32, i32, i32, fp, fp, vp, vp], i32),
+    'ledn_bilinear': ([C.POINTER(ResizeDesc), vp], i32),
+    'ledn_adaptive_avgpool': ([vp, vp, fp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_avgpool3x3s2': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_window_attn': ([vp, fp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_getb_pool': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_mfaf_gate': ([C.POINTER(MfafDesc), vp], i32),
+    'ledn_seam_edge': ([fp, fp, fp, i32, i32, i32, i32, C.c_float, C.c_float, vp], i32),
+}
+EXPORTS = tuple(_PROTOS)
+
+
+class LednError(RuntimeError):
+    pass
+
+
+class Library:
+    """One loaded build of the kernel library."""
+
+    def __init__(self, path, is_hip):
+        if not os.path.exists(path):
+            raise LednError(
+                f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+        self.path = path
+        self.is_hip = is_hip
+        self.cdll = C.CDLL(path)
+        for name, (argtypes, restype) in _PROTOS.items():
+            fn = getattr(self.cdll, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        v = self.cdll.ledn_abi_version()
+        if v != 1:
+            raise LednError(f'{path}: ABI version {v}, expected 1')
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != OK:
+            raise LednError(f'{name} failed: ' + {EINVAL: 'invalid argument (shape/dtype/pointer check)',
+                                                   ELAUNCH: 'kernel launch error'}.get(rc, str(rc)))
+
+
+_hip = None
+_override = None
+
+
+def get_lib():
+    """The library every op dispatches to: libledn_hip.so, loaded on first use."""
+    global _hip
+    if _override is not None:
+        return _override
+    if _hip is None:
+        _hip = Library(HIP_LIB_PATH, is_hip=True)
+    return _hip
+
+
+@contextlib.contextmanager
+def use_library(lib):
+    """TEST HOOK ONLY: temporarily bind another build (the CPU emulation)."""
+    global _override
+    prev = _override
+    _override = lib
+    try:
+        yield lib
+    finally:
+        _override = prev

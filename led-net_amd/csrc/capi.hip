@@ -1,0 +1,102 @@
+// capi.hip -- the extern "C" surface of libledn_hip.so (declared in include/ledn.h).
+// Thin: validate on the host, dispatch to the kernel launchers, report status.
+#include "ledn_rt.h"
+
+namespace ledn {
+int conv_validate(const ledn_conv_desc& d);
+int conv_direct(const ledn_conv_desc& d, hipStream_t s);
+int wgrad_validate(const ledn_wgrad_desc& d);
+int conv_wgrad_direct(const ledn_wgrad_desc& d, hipStream_t s);
+int dwconv_impl(const ledn_dw_desc& d, hipStream_t s);
+int sesp_pyramid_impl(const ledn_pyr_desc& d, hipStream_t s);
+int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
+                       float* sqsum, hipStream_t s);
+int bn_finalize_impl(const float* sum, const float* sqsum, double count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, float* scale, float* shift, float* mean, float* invstd, int C,
+                     hipStream_t s);
+int affine_act_impl(const ledn_affine_desc& d, hipStream_t s);
+int bilinear_impl(const ledn_resize_desc& d, hipStream_t s);
+int nchw_to_nhwc_impl(const void* x, int dtype_x, void* y, int dtype_y, int N, int C, int H, int W,
+                      const float* scale, const float* shift, const int* map, hipStream_t s);
+int adaptive_avgpool_impl(const void* x, const void* xadd, float* y, int N, int H, int W, int C, int S,
+                          int dtype, hipStream_t s);
+int avgpool3x3s2_impl(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int dtype,
+                      hipStream_t s);
+int window_attn_impl(const void* qkv, const float* biasT, void* out, int N, int H, int W, int C,
+                     int heads, int ws, int dtype, hipStream_t s);
+int getb_pool_impl(const void* a, const void* local, void* out, int N, int H, int W, int C, int ws,
+                   int dtype, hipStream_t s);
+int mfaf_gate_impl(const ledn_mfaf_desc& d, hipStream_t s);
+int seam_edge_impl(const float* seg, float* edge, float* scratch, int N, int h, int w, int kth, float thr,
+                   float final_thr, hipStream_t s);
+}  // namespace ledn
+
+using namespace ledn;
+#define S(stream) ((hipStream_t)(stream))
+
+extern "C" {
+
+int ledn_abi_version(void) { return LEDN_ABI_VERSION; }
+
+int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
+    if (!d) return LEDN_EINVAL;
+    const int rc = conv_validate(*d);
+    if (rc != LEDN_OK) return rc;
+    return conv_direct(*d, S(stream));
+}
+
+int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream) {
+    if (!d) return LEDN_EINVAL;
+    const int rc = wgrad_validate(*d);
+    if (rc != LEDN_OK) return rc;
+    return conv_wgrad_direct(*d, S(stream));
+}
+
+int ledn_dwconv2d(const ledn_dw_desc* d, void* stream) { return d ? dwconv_impl(*d, S(stream)) : LEDN_EINVAL; }
+int ledn_sesp_pyramid(const ledn_pyr_desc* d, void* stream) {
+    return d ? sesp_pyramid_impl(*d, S(stream)) : LEDN_EINVAL;
+}
+
+int ledn_channel_stats(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
+                       float* sqsum, void* stream) {
+    return channel_stats_impl(x, xadd, P, C, dtype, sum, sqsum, S(stream));
+}
+int ledn_bn_finalize(const float* sum, const float* sqsum, double count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, float* scale, float* shift, float* mean, float* invstd, int C,
+                     void* stream) {
+    return bn_finalize_impl(sum, sqsum, count, gamma, beta, running_mean, running_var, momentum, eps, scale,
+                            shift, mean, invstd, C, S(stream));
+}
+int ledn_affine_act(const ledn_affine_desc* d, void* stream) {
+    return d ? affine_act_impl(*d, S(stream)) : LEDN_EINVAL;
+}
+int ledn_nchw_to_nhwc(const void* x, int dtype_x, void* y, int dtype_y, int N, int C, int H, int W,
+                      const float* scale, const float* shift, const int* map, void* stream) {
+    return nchw_to_nhwc_impl(x, dtype_x, y, dtype_y, N, C, H, W, scale, shift, map, S(stream));
+}
+int ledn_bilinear(const ledn_resize_desc* d, void* stream) { return d ? bilinear_impl(*d, S(stream)) : LEDN_EINVAL; }
+int ledn_adaptive_avgpool(const void* x, const void* xadd, float* y, int N, int H, int W, int C, int Sz,
+                          int dtype, void* stream) {
+    return adaptive_avgpool_impl(x, xadd, y, N, H, W, C, Sz, dtype, S(stream));
+}
+int ledn_avgpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int dtype,
+                      void* stream) {
+    return avgpool3x3s2_impl(x, y, N, H, W, C, Ho, Wo, dtype, S(stream));
+}
+int ledn_window_attn(const void* qkv, const float* biasT, void* out, int N, int H, int W, int C, int heads,
+                     int ws, int dtype, void* stream) {
+    return window_attn_impl(qkv, biasT, out, N, H, W, C, heads, ws, dtype, S(stream));
+}
+int ledn_getb_pool(const void* a, const void* local, void* out, int N, int H, int W, int C, int ws,
+                   int dtype, void* stream) {
+    return getb_pool_impl(a, local, out, N, H, W, C, ws, dtype, S(stream));
+}
+int ledn_mfaf_gate(const ledn_mfaf_desc* d, void* stream) { return d ? mfaf_gate_impl(*d, S(stream)) : LEDN_EINVAL; }
+int ledn_seam_edge(const float* seg, float* edge, float* scratch, int N, int h, int w, int kth, float thr,
+                   float final_thr, void* stream) {
+    return seam_edge_impl(seg, edge, scratch, N, h, w, kth, thr, final_thr, S(stream));
+}
+
+}  // extern "C"

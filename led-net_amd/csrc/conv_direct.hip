@@ -1,0 +1,304 @@
+// conv_direct.hip -- generic dense / grouped convolution on the vector ALUs.
+//
+// The universal path: any Cin/Cout (3->32 stem, 32->2 heads, 64->1 / 1->64
+// SEAM, 16-channel MFAF MLPs, grouped 1x1 of SESP), forward and data-gradient
+// (transposed), f32 or bf16 activations, f32 accumulation.  The MFMA
+// implicit-GEMM engine (conv_mfma.hip) takes the heavy 3x3 / 1x1 layers; this
+// kernel is also its on-device cross-check.
+//
+// Mapping: one thread = one output pixel x CO_T output channels.  blockIdx.y
+// selects the channel group, so every weight address is wave-uniform and the
+// compiler keeps weights on the scalar path (s_load + SGPR FMA operands); the
+// per-lane traffic is the NHWC input vector (16 B / lane for VEC=4).
+// HBM-side: x is read once per tap from L1/L2 (3x3 halo reuse), y written once.
+#include "ledn_rt.h"
+
+namespace ledn {
+
+template <typename TX, typename TY, int CO_T, int VEC>
+__global__ void __launch_bounds__(256) conv_direct_kernel(ledn_conv_desc d) {
+    const long npix = (long)d.N * d.Ho * d.Wo;
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = pix < npix;
+    const int cog = d.Cout / d.groups, cig = d.Cin / d.groups;
+    const int co0 = blockIdx.y * CO_T;
+    const int g = co0 / cog;
+    const int ci0 = g * cig;
+    const int col0 = co0 - g * cog;  // channel index inside the group
+
+    float acc[CO_T];
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) acc[j] = 0.f;
+
+    int wo = 0, ho = 0, n = 0;
+    if (active) {
+        wo = (int)(pix % d.Wo);
+        ho = (int)((pix / d.Wo) % d.Ho);
+        n = (int)(pix / ((long)d.Wo * d.Ho));
+        const TX* x = reinterpret_cast<const TX*>(d.x);
+        const TX* xadd = reinterpret_cast<const TX*>(d.xadd);
+        for (int kh = 0; kh < d.KH; ++kh) {
+            int hi;
+            if (!d.transposed) {
+                hi = ho * d.stride - d.pad + kh * d.dil;
+            } else {
+                const int t = ho + d.pad - kh * d.dil;
+                if (t < 0 || (t % d.stride) != 0) continue;
+                hi = t / d.stride;
+            }
+            if (hi < 0 || hi >= d.H) continue;
+            for (int kw = 0; kw < d.KW; ++kw) {
+                int wi;
+                if (!d.transposed) {
+                    wi = wo * d.stride - d.pad + kw * d.dil;
+                } else {
+                    const int t = wo + d.pad - kw * d.dil;
+                    if (t < 0 || (t % d.stride) != 0) continue;
+                    wi = t / d.stride;
+                }
+                if (wi < 0 || wi >= d.W) continue;
+                const long xoff = (((long)n * d.H + hi) * d.W + wi) * d.Cin + ci0;
+                const long wtap = (long)(kh * d.KW + kw) * d.ws_tap;
+                for (int ci = 0; ci < cig; ci += VEC) {
+                    float xv[VEC];
+                    ldv<VEC>(x + xoff + ci, xv);
+                    if (xadd) {
+                        float xa[VEC];
+                        ldv<VEC>(xadd + xoff + ci, xa);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) xv[v] += xa[v];
+                    }
+                    if (d.in_scale) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v)
+                            xv[v] = xv[v] * d.in_scale[ci0 + ci + v] + d.in_shift[ci0 + ci + v];
+                    }
+                    if (d.in_act == LEDN_ACT_RELU) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) xv[v] = fmaxf(xv[v], 0.f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < CO_T; ++j) {
+                        // forward: W(co_global, ci_local); transposed: W(ci_global_fwd, co_local_fwd)
+                        const float* wp = d.w + wtap +
+                            (d.transposed ? (long)(col0 + j) * d.ws_co + (long)ci0 * d.ws_ci
+                                          : (long)(co0 + j) * d.ws_co);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v)
+                            acc[j] = fmaf(xv[v], wp[(long)(ci + v) * d.ws_ci], acc[j]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: affine, statistics, residual, activation, store
+    float v[CO_T];
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) {
+        const int co = co0 + j;
+        const float s = d.out_scale ? d.out_scale[co] : 1.f;
+        const float b = d.out_shift ? d.out_shift[co] : 0.f;
+        v[j] = acc[j] * s + b;
+    }
+    if (d.stat_sum) {
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j) {
+            const float t = active ? v[j] : 0.f;
+            const float s1 = wave_sum(t);
+            const float s2 = wave_sum(t * t);
+            if (lane_id() == 0) {
+                atomicAdd(d.stat_sum + co0 + j, s1);
+                atomicAdd(d.stat_sqsum + co0 + j, s2);
+            }
+        }
+    }
+    if (!active) return;
+    const long yoff = pix * d.Cout + co0;
+    if (d.res_mode != LEDN_RES_NONE) {
+        const TY* r = reinterpret_cast<const TY*>(d.res) + yoff;
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j) {
+            const float rv = ld(r + j);
+            v[j] = d.res_mode == LEDN_RES_ADD ? v[j] + rv : v[j] * rv + rv;
+        }
+    }
+    if (d.act_out != LEDN_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j)
+            v[j] = act_apply(d.act_out, v[j], d.slope ? d.slope[co0 + j] : 0.f);
+    }
+    TY* y = reinterpret_cast<TY*>(d.y) + yoff;
+    if constexpr (CO_T % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < CO_T; j += 4) st4(y + j, v + j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j) st(y + j, v[j]);
+    }
+}
+
+template <typename TX, typename TY, int CO_T>
+static int launch_vec(const ledn_conv_desc& d, hipStream_t s) {
+    const long npix = (long)d.N * d.Ho * d.Wo;
+    const dim3 grid((unsigned)cdiv(npix, 256), (unsigned)(d.Cout / CO_T));
+    const int cig = d.Cin / d.groups;
+    if (cig % 4 == 0 && d.ws_ci != 0)
+        LEDN_LAUNCH((conv_direct_kernel<TX, TY, CO_T, 4>), grid, dim3(256), 0, s, d);
+    else
+        LEDN_LAUNCH((conv_direct_kernel<TX, TY, CO_T, 1>), grid, dim3(256), 0, s, d);
+    return check_launch();
+}
+
+template <typename TX, typename TY>
+static int launch_cot(const ledn_conv_desc& d, hipStream_t s) {
+    const int cog = d.Cout / d.groups;
+    if (cog % 16 == 0) return launch_vec<TX, TY, 16>(d, s);
+    if (cog % 8 == 0) return launch_vec<TX, TY, 8>(d, s);
+    if (cog % 4 == 0) return launch_vec<TX, TY, 4>(d, s);
+    if (cog % 2 == 0) return launch_vec<TX, TY, 2>(d, s);
+    return launch_vec<TX, TY, 1>(d, s);
+}
+
+int conv_direct(const ledn_conv_desc& d, hipStream_t s) {
+    if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_F32) return launch_cot<float, float>(d, s);
+    if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_BF16) return launch_cot<bf16_t, bf16_t>(d, s);
+    if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_F32) return launch_cot<bf16_t, float>(d, s);
+    if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_BF16) return launch_cot<float, bf16_t>(d, s);
+    return LEDN_EINVAL;
+}
+
+int conv_validate(const ledn_conv_desc& d) {
+    LEDN_REQUIRE(d.x && d.w && d.y);
+    LEDN_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Ho > 0 && d.Wo > 0 && d.Cout > 0);
+    LEDN_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.dil > 0 && d.pad >= 0 && d.groups > 0);
+    LEDN_REQUIRE(d.Cin % d.groups == 0 && d.Cout % d.groups == 0);
+    LEDN_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr));
+    LEDN_REQUIRE((d.stat_sum == nullptr) == (d.stat_sqsum == nullptr));
+    LEDN_REQUIRE(d.res_mode == LEDN_RES_NONE || d.res != nullptr);
+    LEDN_REQUIRE(d.act_out != LEDN_ACT_PRELU || d.slope != nullptr);
+    LEDN_REQUIRE(d.in_act == LEDN_ACT_NONE || d.in_act == LEDN_ACT_RELU);
+    const int kh_ext = (d.KH - 1) * d.dil + 1, kw_ext = (d.KW - 1) * d.dil + 1;
+    if (!d.transposed) {
+        LEDN_REQUIRE(d.Ho == (d.H + 2 * d.pad - kh_ext) / d.stride + 1);
+        LEDN_REQUIRE(d.Wo == (d.W + 2 * d.pad - kw_ext) / d.stride + 1);
+    } else {  // (H,W) is the forward OUTPUT size, (Ho,Wo) the forward INPUT size
+        LEDN_REQUIRE(d.H == (d.Ho + 2 * d.pad - kh_ext) / d.stride + 1);
+        LEDN_REQUIRE(d.W == (d.Wo + 2 * d.pad - kw_ext) / d.stride + 1);
+    }
+    return LEDN_OK;
+}
+
+}  // namespace ledn
+
+// ---------------------------------------------------------------------------
+// weight gradient (direct): one workgroup = one filter tap x a 64(ci) x 64(co)
+// tile of dW x a chunk of output pixels; each thread owns a 4x4 register tile
+// and walks the pixel chunk; partial tiles are added to dW with f32 atomics
+// (256 contiguous bytes per wave-instruction along co for OIHW^T strides is not
+// guaranteed -- this is the correctness path; the MFMA wgrad is the fast one).
+// ---------------------------------------------------------------------------
+namespace ledn {
+
+template <typename TX, typename TZ>
+__global__ void __launch_bounds__(256) conv_wgrad_direct_kernel(ledn_wgrad_desc d, int pix_per_block,
+                                                                int ci_tiles, int co_tiles) {
+    const int cog = d.Cout / d.groups, cig = d.Cin / d.groups;
+    int t = blockIdx.y;
+    const int co_tile = t % co_tiles; t /= co_tiles;
+    const int ci_tile = t % ci_tiles; t /= ci_tiles;
+    const int g = t;
+    const int tap = blockIdx.z;
+    const int kh = tap / d.KW, kw = tap % d.KW;
+    const int tci = threadIdx.x / 16, tco = threadIdx.x % 16;
+    const int cil = ci_tile * 64 + tci * 4;   // local (in-group) ci of this thread's tile
+    const int col = co_tile * 64 + tco * 4;   // local co
+    const int nci = min(4, cig - cil), nco = min(4, cog - col);
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    if (nci > 0 && nco > 0) {
+        const TX* x = reinterpret_cast<const TX*>(d.x);
+        const TX* xadd = reinterpret_cast<const TX*>(d.xadd);
+        const TZ* dz = reinterpret_cast<const TZ*>(d.dz);
+        const long npix = (long)d.N * d.Ho * d.Wo;
+        const long p0 = (long)blockIdx.x * pix_per_block;
+        const long p1 = min(npix, p0 + pix_per_block);
+        const int cig0 = g * cig + cil, cog0 = g * cog + col;
+        for (long p = p0; p < p1; ++p) {
+            const int wo = (int)(p % d.Wo);
+            const int ho = (int)((p / d.Wo) % d.Ho);
+            const int n = (int)(p / ((long)d.Wo * d.Ho));
+            const int hi = ho * d.stride - d.pad + kh * d.dil;
+            const int wi = wo * d.stride - d.pad + kw * d.dil;
+            if (hi < 0 || hi >= d.H || wi < 0 || wi >= d.W) continue;
+            const long xoff = (((long)n * d.H + hi) * d.W + wi) * d.Cin + cig0;
+            float xv[4], zv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float v = 0.f;
+                if (a < nci) {
+                    v = ld(x + xoff + a);
+                    if (xadd) v += ld(xadd + xoff + a);
+                    if (d.in_scale) v = v * d.in_scale[cig0 + a] + d.in_shift[cig0 + a];
+                    if (d.in_act == LEDN_ACT_RELU) v = fmaxf(v, 0.f);
+                }
+                xv[a] = v;
+            }
+            const long zoff = p * d.Cout + cog0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) zv[b] = b < nco ? ld(dz + zoff + b) : 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(xv[a], zv[b], acc[a][b]);
+        }
+        for (int a = 0; a < nci; ++a)
+            for (int b = 0; b < nco; ++b)
+                atomicAdd(d.dw + (long)(g * cog + col + b) * d.ws_co + (long)(cil + a) * d.ws_ci +
+                              (long)tap * d.ws_tap,
+                          acc[a][b]);
+    }
+}
+
+int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
+                       float* sqsum, hipStream_t s);
+
+int conv_wgrad_direct(const ledn_wgrad_desc& d, hipStream_t s) {
+    const int cog = d.Cout / d.groups, cig = d.Cin / d.groups;
+    const int ci_tiles = (int)cdiv(cig, 64), co_tiles = (int)cdiv(cog, 64);
+    const long npix = (long)d.N * d.Ho * d.Wo;
+    const int tiles = ci_tiles * co_tiles * d.groups * d.KH * d.KW;
+    long ppb = cdiv(npix * tiles, 4096);
+    if (ppb < 64) ppb = 64;
+    if (ppb > 4096) ppb = 4096;
+    const dim3 grid((unsigned)cdiv(npix, ppb), (unsigned)(ci_tiles * co_tiles * d.groups),
+                    (unsigned)(d.KH * d.KW));
+#define LEDN_WG(TX, TZ) \
+    LEDN_LAUNCH((conv_wgrad_direct_kernel<TX, TZ>), grid, dim3(256), 0, s, d, (int)ppb, ci_tiles, co_tiles)
+    if (d.dtype_x == LEDN_F32 && d.dtype_dz == LEDN_F32) LEDN_WG(float, float);
+    else if (d.dtype_x == LEDN_BF16 && d.dtype_dz == LEDN_BF16) LEDN_WG(bf16_t, bf16_t);
+    else if (d.dtype_x == LEDN_BF16 && d.dtype_dz == LEDN_F32) LEDN_WG(bf16_t, float);
+    else if (d.dtype_x == LEDN_F32 && d.dtype_dz == LEDN_BF16) LEDN_WG(float, bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_WG
+    int rc = check_launch();
+    if (rc != LEDN_OK) return rc;
+    if (d.db) rc = channel_stats_impl(d.dz, nullptr, npix, d.Cout, d.dtype_dz, d.db, nullptr, s);
+    return rc;
+}
+
+int wgrad_validate(const ledn_wgrad_desc& d) {
+    LEDN_REQUIRE(d.x && d.dz && d.dw);
+    LEDN_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Ho > 0 && d.Wo > 0 && d.Cout > 0);
+    LEDN_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.dil > 0 && d.pad >= 0 && d.groups > 0);
+    LEDN_REQUIRE(d.Cin % d.groups == 0 && d.Cout % d.groups == 0);
+    LEDN_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr));
+    LEDN_REQUIRE(d.Ho == (d.H + 2 * d.pad - ((d.KH - 1) * d.dil + 1)) / d.stride + 1);
+    LEDN_REQUIRE(d.Wo == (d.W + 2 * d.pad - ((d.KW - 1) * d.dil + 1)) / d.stride + 1);
+    return LEDN_OK;
+}
+
+}  // namespace ledn

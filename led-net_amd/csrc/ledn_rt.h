@@ -1,0 +1,125 @@
+// ledn_rt.h -- common device-side helpers for the LED-Net HIP kernels (gfx950).
+//
+// The only place that knows about the test-only CPU emulation build
+// (LEDN_CPU_EMU, see emu.h); kernel sources are written once against this
+// header.  Wave = 64 lanes everywhere.
+#pragma once
+#include <stdint.h>
+
+#ifdef LEDN_CPU_EMU
+#include "emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define LEDN_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
+#endif
+
+#include "../../include/ledn.h"
+
+namespace ledn {
+
+// ---- storage types ----------------------------------------------------------
+struct bf16_t {
+    unsigned short v;
+};
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {  // round-to-nearest-even, NaN stays NaN
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ float ld(const float* p) { return *p; }
+__device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(p->v); }
+__device__ __forceinline__ void st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
+
+// 4-element vector access (pointer must be 16 B / 8 B aligned)
+__device__ __forceinline__ void ld4(const float* p, float* o) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void ld4(const bf16_t* p, float* o) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st4(bf16_t* p, const float* v) {
+    uint2 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = o;
+}
+template <int V, typename T> __device__ __forceinline__ void ldv(const T* p, float* o) {
+    if constexpr (V == 4) ld4(p, o);
+    else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = ld(p + i);
+    }
+}
+template <int V, typename T> __device__ __forceinline__ void stv(T* p, const float* v) {
+    if constexpr (V == 4) st4(p, v);
+    else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) st(p + i, v[i]);
+    }
+}
+
+// ---- activations --------------------------------------------------------------
+__device__ __forceinline__ float act_apply(int act, float v, float slope) {
+    switch (act) {
+        case LEDN_ACT_RELU: return v > 0.f ? v : 0.f;
+        case LEDN_ACT_RELU6: return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
+        case LEDN_ACT_PRELU: return v > 0.f ? v : v * slope;
+        case LEDN_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+// d act(v) / dv, as a function of the pre-activation v
+__device__ __forceinline__ float act_grad(int act, float v, float slope) {
+    switch (act) {
+        case LEDN_ACT_RELU: return v > 0.f ? 1.f : 0.f;
+        case LEDN_ACT_RELU6: return (v > 0.f && v < 6.f) ? 1.f : 0.f;
+        case LEDN_ACT_PRELU: return v > 0.f ? 1.f : slope;
+        case LEDN_ACT_SIGMOID: { float s = 1.f / (1.f + __expf(-v)); return s * (1.f - s); }
+        default: return 1.f;
+    }
+}
+
+// ---- wave reductions (64 lanes; every lane of the wave must call) --------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// ---- host-side helpers ----------------------------------------------------------
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LEDN_OK : LEDN_ELAUNCH;
+}
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+}  // namespace ledn
+
+#define LEDN_REQUIRE(cond) \
+    do {                   \
+        if (!(cond)) return LEDN_EINVAL; \
+    } while (0)

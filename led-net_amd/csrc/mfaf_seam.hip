@@ -1,0 +1,187 @@
+// mfaf_seam.hip -- MFAF (Muti_AFF) gate blend and the SEAM edge-map pipeline.
+#include "ledn_rt.h"
+
+namespace ledn {
+
+// wei = sigmoid(aff0(xl) + sum_k aff_k(ctx_k nearest-upsampled) + aff4(xg))
+// out = 2*x*wei + 2*r*(1-wei).   One thread = one pixel x 4 channels.
+template <typename T, int V>
+__global__ void __launch_bounds__(256) mfaf_gate_kernel(ledn_mfaf_desc d) {
+    const int cv = d.C / V;
+    const long total = (long)d.N * d.H * d.W * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int x = (int)(pix % d.W);
+    const int y = (int)((pix / d.W) % d.H);
+    const int n = (int)(pix / ((long)d.W * d.H));
+    float s[V], t[V];
+    ldv<V>(reinterpret_cast<const T*>(d.xl) + pix * d.C + c, t);
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = t[v] * d.scale[0][c + v] + d.shift[0][c + v];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int S = d.ctx_size[k];
+        // F.interpolate(mode='nearest'): src = floor(dst * in / out)
+        int sy = (int)((float)y * ((float)S / (float)d.H));
+        int sx = (int)((float)x * ((float)S / (float)d.W));
+        if (sy > S - 1) sy = S - 1;
+        if (sx > S - 1) sx = S - 1;
+        ldv<V>(d.ctx[k] + (((long)n * S + sy) * S + sx) * d.C + c, t);
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[v] += t[v] * d.scale[k + 1][c + v] + d.shift[k + 1][c + v];
+    }
+    float xv[V], rv[V], o[V];
+    ldv<V>(reinterpret_cast<const T*>(d.x) + pix * d.C + c, xv);
+    ldv<V>(reinterpret_cast<const T*>(d.r) + pix * d.C + c, rv);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const float w = 1.f / (1.f + __expf(-s[v]));
+        o[v] = 2.f * xv[v] * w + 2.f * rv[v] * (1.f - w);
+        if (d.act == LEDN_ACT_RELU) o[v] = fmaxf(o[v], 0.f);
+    }
+    stv<V>(reinterpret_cast<T*>(d.out) + pix * d.C + c, o);
+}
+
+int mfaf_gate_impl(const ledn_mfaf_desc& d, hipStream_t s) {
+    LEDN_REQUIRE(d.x && d.r && d.xl && d.out && d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.C % 4 == 0);
+    for (int k = 0; k < 4; ++k) LEDN_REQUIRE(d.ctx[k] && d.ctx_size[k] > 0);
+    for (int k = 0; k < 5; ++k) LEDN_REQUIRE(d.scale[k] && d.shift[k]);
+    const long total = (long)d.N * d.H * d.W * (d.C / 4);
+    const dim3 grid((unsigned)cdiv(total, 256));
+    if (d.dtype == LEDN_F32) LEDN_LAUNCH((mfaf_gate_kernel<float, 4>), grid, dim3(256), 0, s, d);
+    else if (d.dtype == LEDN_BF16) LEDN_LAUNCH((mfaf_gate_kernel<bf16_t, 4>), grid, dim3(256), 0, s, d);
+    else return LEDN_EINVAL;
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// SEAM edge map.  One 256-thread workgroup per image (h*w is 1/64 of the input
+// pixel count: 16 K values at 1024^2).  Phases, separated by __syncthreads():
+//   1 min / max of seg                      (wave + LDS reduction)
+//   2 three clamped Laplacian responses, upsampled (nearest) -> scratch[3][h*w]
+//   3 per scale: k-th order statistic by 4-pass 8-bit radix select on the f32
+//     bit patterns (responses are >= 0, so the patterns are order-preserving)
+//   4 binarise, 0.6/0.3/0.1 fuse, binarise -> edge
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float seam_lap(const float* seg, int h, int w, int cy, int cx, float mn,
+                                          float den) {
+    // 3x3 Laplacian [-1..8..-1] on the min-max normalised map, zero padding
+    float acc = 0.f;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = cy + dy, xx = cx + dx;
+            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+            const float v = (seg[yy * w + xx] - mn) / den;
+            acc += (dy == 0 && dx == 0) ? 8.f * v : -v;
+        }
+    return acc > 0.f ? acc : 0.f;
+}
+
+__global__ void __launch_bounds__(256) seam_edge_kernel(const float* seg_all, float* edge_all,
+                                                        float* scratch, int h, int w, int kth,
+                                                        float thr, float final_thr) {
+    __shared__ float s_red[2][4];
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_sel[2];  // prefix, remaining rank
+    __shared__ float s_thr[3];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int hw = h * w;
+    const float* seg = seg_all + (long)n * hw;
+    float* edge = edge_all + (long)n * hw;
+    float* resp = scratch + (long)n * 3 * hw;
+
+    // phase 1
+    float mn = 3.0e38f, mx = -3.0e38f;
+    for (int i = tid; i < hw; i += 256) {
+        const float v = seg[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) {
+        s_red[0][tid >> 6] = mn;
+        s_red[1][tid >> 6] = mx;
+    }
+    __syncthreads();
+    mn = fminf(fminf(s_red[0][0], s_red[0][1]), fminf(s_red[0][2], s_red[0][3]));
+    mx = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+    const float den = mx - mn;
+
+    // phase 2
+    for (int i = tid; i < hw; i += 256) {
+        const int y = i / w, x = i % w;
+        resp[i] = seam_lap(seg, h, w, y, x, mn, den);
+#pragma unroll
+        for (int sidx = 1; sidx < 3; ++sidx) {
+            const int st = sidx == 1 ? 2 : 4;
+            const int hs = (h - 1) / st + 1, wss = (w - 1) / st + 1;  // conv2d(stride, pad 1) size
+            int sy = (int)((float)y * ((float)hs / (float)h));
+            int sx = (int)((float)x * ((float)wss / (float)w));
+            if (sy > hs - 1) sy = hs - 1;
+            if (sx > wss - 1) sx = wss - 1;
+            resp[sidx * hw + i] = seam_lap(seg, h, w, sy * st, sx * st, mn, den);
+        }
+    }
+    __syncthreads();
+
+    // phase 3
+    if (kth > 0) {
+        const int kk = kth > hw ? hw : kth;
+        for (int sidx = 0; sidx < 3; ++sidx) {
+            const float* r = resp + sidx * hw;
+            if (tid == 0) {
+                s_sel[0] = 0u;
+                s_sel[1] = (unsigned)(kk - 1);  // 0-based rank still to locate
+            }
+            for (int pass = 0; pass < 4; ++pass) {
+                const int shift = 24 - 8 * pass;
+                s_hist[tid] = 0u;
+                __syncthreads();
+                const unsigned prefix = s_sel[0];
+                const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+                for (int i = tid; i < hw; i += 256) {
+                    const unsigned u = __float_as_uint(r[i]);
+                    if ((u & himask) == prefix) atomicAdd(&s_hist[(u >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned rank = s_sel[1], b = 0;
+                    for (; b < 256u; ++b) {
+                        if (rank < s_hist[b]) break;
+                        rank -= s_hist[b];
+                    }
+                    s_sel[0] = prefix | (b << shift);
+                    s_sel[1] = rank;
+                }
+                __syncthreads();
+            }
+            if (tid == 0) s_thr[sidx] = __uint_as_float(s_sel[0]);
+            __syncthreads();
+        }
+    } else {
+        if (tid < 3) s_thr[tid] = thr;
+        __syncthreads();
+    }
+
+    // phase 4
+    for (int i = tid; i < hw; i += 256) {
+        const float f = 0.6f * (resp[i] > s_thr[0] ? 1.f : 0.f) +
+                        0.3f * (resp[hw + i] > s_thr[1] ? 1.f : 0.f) +
+                        0.1f * (resp[2 * hw + i] > s_thr[2] ? 1.f : 0.f);
+        edge[i] = f > final_thr ? 1.f : 0.f;
+    }
+}
+
+int seam_edge_impl(const float* seg, float* edge, float* scratch, int N, int h, int w, int kth, float thr,
+                   float final_thr, hipStream_t s) {
+    LEDN_REQUIRE(seg && edge && scratch && N > 0 && h > 0 && w > 0);
+    LEDN_REQUIRE(kth >= 0);
+    LEDN_LAUNCH(seam_edge_kernel, dim3((unsigned)N), dim3(256), 0, s, seg, edge, scratch, h, w, kth, thr,
+                final_thr);
+    return check_launch();
+}
+
+}  // namespace ledn

@@ -1,0 +1,209 @@
+// norm_act.hip -- per-channel statistics (wavefront / LDS reductions), BatchNorm
+// bookkeeping and the elementwise affine + residual + activation pass.
+// All HBM-bound: one read (+ one write) of the activation, 16 B per lane.
+#include "ledn_rt.h"
+
+namespace ledn {
+
+// x: [P][C].  Thread (r, cv): channel vector cv, pixel rows r, r+rows, ...
+template <typename T, int V>
+__global__ void __launch_bounds__(256) channel_stats_kernel(const T* x, const T* xadd, long P, int C,
+                                                            float* sum, float* sqsum,
+                                                            int pix_per_block) {
+    __shared__ float s_part[2][256 * 4];
+    const int cvn = C / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    float a[V], b[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) a[v] = b[v] = 0.f;
+    const bool worker = r < rows;
+    if (worker) {
+        const long p0 = (long)blockIdx.x * pix_per_block;
+        const long p1 = min(P, p0 + (long)pix_per_block);
+        for (long p = p0 + r; p < p1; p += rows) {
+            float xv[V];
+            ldv<V>(x + p * C + cv * V, xv);
+            if (xadd) {
+                float xa[V];
+                ldv<V>(xadd + p * C + cv * V, xa);
+#pragma unroll
+                for (int v = 0; v < V; ++v) xv[v] += xa[v];
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                a[v] += xv[v];
+                b[v] = fmaf(xv[v], xv[v], b[v]);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        s_part[0][threadIdx.x * V + v] = a[v];
+        s_part[1][threadIdx.x * V + v] = b[v];
+    }
+    __syncthreads();
+    if (threadIdx.x < cvn) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float sa = 0.f, sb = 0.f;
+            for (int rr = 0; rr < rows; ++rr) {
+                sa += s_part[0][(rr * cvn + cv) * V + v];
+                sb += s_part[1][(rr * cvn + cv) * V + v];
+            }
+            atomicAdd(sum + cv * V + v, sa);
+            if (sqsum) atomicAdd(sqsum + cv * V + v, sb);
+        }
+    }
+}
+
+int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
+                       float* sqsum, hipStream_t s) {
+    LEDN_REQUIRE(x && sum && P > 0 && C > 0);
+    const int V = (C % 4 == 0) ? 4 : 1;
+    LEDN_REQUIRE(C / V <= 256);
+    long ppb = cdiv(P, 2048);
+    if (ppb < 256) ppb = 256;
+    const dim3 grid((unsigned)cdiv(P, ppb));
+#define LEDN_CS(T)                                                                              \
+    do {                                                                                        \
+        if (V == 4)                                                                             \
+            LEDN_LAUNCH((channel_stats_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x,       \
+                        (const T*)xadd, (long)P, C, sum, sqsum, (int)ppb);                      \
+        else                                                                                    \
+            LEDN_LAUNCH((channel_stats_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x,       \
+                        (const T*)xadd, (long)P, C, sum, sqsum, (int)ppb);                      \
+    } while (0)
+    if (dtype == LEDN_F32) LEDN_CS(float);
+    else if (dtype == LEDN_BF16) LEDN_CS(bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_CS
+    return check_launch();
+}
+
+__global__ void bn_finalize_kernel(const float* sum, const float* sqsum, double count,
+                                   const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, float* scale,
+                                   float* shift, float* mean_o, float* invstd_o, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = (double)sum[c] / count;
+    double var = (double)sqsum[c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)m * sc;
+    if (mean_o) mean_o[c] = (float)m;
+    if (invstd_o) invstd_o[c] = invstd;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+template <typename TX, typename TY, int V>
+__global__ void __launch_bounds__(256) affine_act_kernel(ledn_affine_desc d) {
+    const long total = d.P * (d.C / V);
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % (d.C / V)) * V;
+    const long off = idx * V;
+    float v[V];
+    ldv<V>(reinterpret_cast<const TX*>(d.x) + off, v);
+    if (d.xadd) {
+        float a[V];
+        ldv<V>(reinterpret_cast<const TX*>(d.xadd) + off, a);
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] += a[i];
+    }
+    if (d.scale) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = v[i] * d.scale[c + i] + d.shift[c + i];
+    }
+    if (d.res_mode != LEDN_RES_NONE) {
+        float r[V];
+        ldv<V>(reinterpret_cast<const TY*>(d.res) + off, r);
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = d.res_mode == LEDN_RES_ADD ? v[i] + r[i] : v[i] * r[i] + r[i];
+    }
+    if (d.act != LEDN_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = act_apply(d.act, v[i], d.slope ? d.slope[c + i] : 0.f);
+    }
+    stv<V>(reinterpret_cast<TY*>(d.y) + off, v);
+}
+
+int affine_act_impl(const ledn_affine_desc& d, hipStream_t s) {
+    LEDN_REQUIRE(d.x && d.y && d.P > 0 && d.C > 0);
+    LEDN_REQUIRE((d.scale == nullptr) == (d.shift == nullptr));
+    LEDN_REQUIRE(d.res_mode == LEDN_RES_NONE || d.res != nullptr);
+    LEDN_REQUIRE(d.act != LEDN_ACT_PRELU || d.slope != nullptr);
+    const bool v4 = d.C % 4 == 0;
+    const long total = d.P * (v4 ? d.C / 4 : d.C);
+    const dim3 grid((unsigned)cdiv(total, 256));
+#define LEDN_AF(TX, TY)                                                                  \
+    do {                                                                                 \
+        if (v4) LEDN_LAUNCH((affine_act_kernel<TX, TY, 4>), grid, dim3(256), 0, s, d);   \
+        else LEDN_LAUNCH((affine_act_kernel<TX, TY, 1>), grid, dim3(256), 0, s, d);      \
+    } while (0)
+    if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_F32) LEDN_AF(float, float);
+    else if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_BF16) LEDN_AF(bf16_t, bf16_t);
+    else if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_F32) LEDN_AF(bf16_t, float);
+    else if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_BF16) LEDN_AF(float, bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_AF
+    return check_launch();
+}
+
+// ---- planar (NCHW) -> interleaved (NHWC) with per-channel affine and channel map
+__device__ __forceinline__ float ld(const unsigned char* p) { return (float)*p; }
+
+template <typename TX, typename TY>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const TX* x, TY* y, int N, int C, int H, int W,
+                                                           const float* scale, const float* shift,
+                                                           const int* map) {
+    const long plane = (long)H * W;
+    const long total = (long)N * plane;
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= total) return;
+    const long n = pix / plane, hw = pix % plane;
+    for (int c = 0; c < C; ++c) {
+        const int cs = map ? map[c] : c;
+        float v = ld(x + (n * C + cs) * plane + hw);
+        if (scale) v = v * scale[c] + shift[c];
+        st(y + pix * C + c, v);
+    }
+}
+
+int nchw_to_nhwc_impl(const void* x, int dtype_x, void* y, int dtype_y, int N, int C, int H, int W,
+                      const float* scale, const float* shift, const int* map, hipStream_t s) {
+    LEDN_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0);
+    LEDN_REQUIRE((scale == nullptr) == (shift == nullptr));
+    const dim3 grid((unsigned)cdiv((long)N * H * W, 256));
+#define LEDN_L(TX, TY) \
+    LEDN_LAUNCH((nchw_to_nhwc_kernel<TX, TY>), grid, dim3(256), 0, s, (const TX*)x, (TY*)y, N, C, H, W, scale, shift, map)
+    if (dtype_x == LEDN_F32 && dtype_y == LEDN_F32) LEDN_L(float, float);
+    else if (dtype_x == LEDN_F32 && dtype_y == LEDN_BF16) LEDN_L(float, bf16_t);
+    else if (dtype_x == LEDN_BF16 && dtype_y == LEDN_BF16) LEDN_L(bf16_t, bf16_t);
+    else if (dtype_x == LEDN_U8 && dtype_y == LEDN_F32) LEDN_L(unsigned char, float);
+    else if (dtype_x == LEDN_U8 && dtype_y == LEDN_BF16) LEDN_L(unsigned char, bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_L
+    return check_launch();
+}
+
+int bn_finalize_impl(const float* sum, const float* sqsum, double count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, float* scale, float* shift, float* mean, float* invstd, int C,
+                     hipStream_t s) {
+    LEDN_REQUIRE(sum && sqsum && scale && shift && C > 0 && count > 0);
+    LEDN_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    LEDN_LAUNCH(bn_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, s, sum, sqsum, count,
+                gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C);
+    return check_launch();
+}
+
+}  // namespace ledn

@@ -1,0 +1,222 @@
+// resize_pool.hip -- bilinear resampling (+add, +NCHW/argmax output), adaptive
+// average pooling and the 3x3/s2 average pool.  HBM-bound gathers; the output
+// is written once, 16 B per lane where the channel count allows.
+#include "ledn_rt.h"
+
+namespace ledn {
+
+// F.interpolate(mode='bilinear', align_corners=False) source coordinates
+// (ATen area_pixel_compute_source_index: scale*(dst+0.5)-0.5 clamped at 0).
+struct Lerp {
+    int i0, i1;
+    float w0, w1;
+};
+__device__ __forceinline__ Lerp lerp_coord(int dst, int in, int out) {
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    Lerp l;
+    l.i0 = (int)src;
+    if (l.i0 > in - 1) l.i0 = in - 1;
+    l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+template <typename TX, typename TY, int V>
+__global__ void __launch_bounds__(256) bilinear_nhwc_kernel(ledn_resize_desc d) {
+    const int cv = d.C / V;
+    const long total = (long)d.N * d.Ho * d.Wo * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int wo = (int)(pix % d.Wo);
+    const int ho = (int)((pix / d.Wo) % d.Ho);
+    const int n = (int)(pix / ((long)d.Wo * d.Ho));
+    const Lerp ly = lerp_coord(ho, d.H, d.Ho), lx = lerp_coord(wo, d.W, d.Wo);
+    const TX* x = reinterpret_cast<const TX*>(d.x) + (long)n * d.H * d.W * d.C + c;
+    float v00[V], v01[V], v10[V], v11[V], o[V];
+    ldv<V>(x + ((long)ly.i0 * d.W + lx.i0) * d.C, v00);
+    ldv<V>(x + ((long)ly.i0 * d.W + lx.i1) * d.C, v01);
+    ldv<V>(x + ((long)ly.i1 * d.W + lx.i0) * d.C, v10);
+    ldv<V>(x + ((long)ly.i1 * d.W + lx.i1) * d.C, v11);
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+        o[i] = ly.w0 * (lx.w0 * v00[i] + lx.w1 * v01[i]) + ly.w1 * (lx.w0 * v10[i] + lx.w1 * v11[i]);
+    if (d.add) {
+        float a[V];
+        ldv<V>(reinterpret_cast<const TY*>(d.add) + pix * d.C + c, a);
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] += a[i];
+    }
+    stv<V>(reinterpret_cast<TY*>(d.y) + pix * d.C + c, o);
+}
+
+// small-C variant: one thread per output pixel, y written planar [N][C][Ho][Wo] f32,
+// optional first-max argmax.
+template <typename TX, int C>
+__global__ void __launch_bounds__(256) bilinear_nchw_kernel(ledn_resize_desc d) {
+    const long total = (long)d.N * d.Ho * d.Wo;
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= total) return;
+    const int wo = (int)(pix % d.Wo);
+    const int ho = (int)((pix / d.Wo) % d.Ho);
+    const int n = (int)(pix / ((long)d.Wo * d.Ho));
+    const Lerp ly = lerp_coord(ho, d.H, d.Ho), lx = lerp_coord(wo, d.W, d.Wo);
+    const TX* x = reinterpret_cast<const TX*>(d.x) + (long)n * d.H * d.W * C;
+    float v00[C], v01[C], v10[C], v11[C], o[C];
+    ldv<C>(x + ((long)ly.i0 * d.W + lx.i0) * C, v00);
+    ldv<C>(x + ((long)ly.i0 * d.W + lx.i1) * C, v01);
+    ldv<C>(x + ((long)ly.i1 * d.W + lx.i0) * C, v10);
+    ldv<C>(x + ((long)ly.i1 * d.W + lx.i1) * C, v11);
+    float* y = reinterpret_cast<float*>(d.y);
+    const long plane = (long)d.Ho * d.Wo;
+    int best = 0;
+    float bv = 0.f;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        o[i] = ly.w0 * (lx.w0 * v00[i] + lx.w1 * v01[i]) + ly.w1 * (lx.w0 * v10[i] + lx.w1 * v11[i]);
+        if (d.add) o[i] += reinterpret_cast<const float*>(d.add)[pix * C + i];
+        y[((long)n * C + i) * plane + (long)ho * d.Wo + wo] = o[i];
+        if (i == 0 || o[i] > bv) {
+            bv = o[i];
+            best = i;
+        }
+    }
+    if (d.argmax) d.argmax[pix] = (unsigned char)best;
+}
+
+int bilinear_impl(const ledn_resize_desc& d, hipStream_t s) {
+    LEDN_REQUIRE(d.x && d.y);
+    LEDN_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.Ho > 0 && d.Wo > 0);
+    if (d.out_nchw) {
+        LEDN_REQUIRE(d.dtype_y == LEDN_F32);
+        const dim3 grid((unsigned)cdiv((long)d.N * d.Ho * d.Wo, 256));
+#define LEDN_BN(C)                                                                               \
+    do {                                                                                         \
+        if (d.dtype_x == LEDN_F32) LEDN_LAUNCH((bilinear_nchw_kernel<float, C>), grid, dim3(256), 0, s, d);  \
+        else LEDN_LAUNCH((bilinear_nchw_kernel<bf16_t, C>), grid, dim3(256), 0, s, d);           \
+    } while (0)
+        switch (d.C) {
+            case 1: LEDN_BN(1); break;
+            case 2: LEDN_BN(2); break;
+            case 3: LEDN_BN(3); break;
+            case 4: LEDN_BN(4); break;
+            case 5: LEDN_BN(5); break;
+            case 8: LEDN_BN(8); break;
+            case 19: LEDN_BN(19); break;
+            default: return LEDN_EINVAL;
+        }
+#undef LEDN_BN
+        return check_launch();
+    }
+    LEDN_REQUIRE(d.argmax == nullptr);
+    const bool v4 = d.C % 4 == 0;
+    const long total = (long)d.N * d.Ho * d.Wo * (v4 ? d.C / 4 : d.C);
+    const dim3 grid((unsigned)cdiv(total, 256));
+#define LEDN_BL(TX, TY)                                                                    \
+    do {                                                                                   \
+        if (v4) LEDN_LAUNCH((bilinear_nhwc_kernel<TX, TY, 4>), grid, dim3(256), 0, s, d);  \
+        else LEDN_LAUNCH((bilinear_nhwc_kernel<TX, TY, 1>), grid, dim3(256), 0, s, d);     \
+    } while (0)
+    if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_F32) LEDN_BL(float, float);
+    else if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_BF16) LEDN_BL(bf16_t, bf16_t);
+    else if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_F32) LEDN_BL(bf16_t, float);
+    else if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_BF16) LEDN_BL(float, bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_BL
+    return check_launch();
+}
+
+// ---- adaptive average pool to S x S (PyTorch window: [floor(i*H/S), ceil((i+1)*H/S)) )
+template <typename T>
+__global__ void adaptive_avgpool_kernel(const T* x, const T* xadd, float* y, int N, int H, int W,
+                                        int C, int S) {
+    const int cell = blockIdx.x;
+    const int ox = cell % S, oy = (cell / S) % S, n = cell / (S * S);
+    const int h0 = (oy * H) / S, h1 = ((oy + 1) * H + S - 1) / S;
+    const int w0 = (ox * W) / S, w1 = ((ox + 1) * W + S - 1) / S;
+    const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) {
+                const long off = (((long)n * H + h) * W + w) * C + c;
+                float v = ld(x + off);
+                if (xadd) v += ld(xadd + off);
+                acc += v;
+            }
+        y[(long)cell * C + c] = acc * inv;
+    }
+}
+
+int adaptive_avgpool_impl(const void* x, const void* xadd, float* y, int N, int H, int W, int C, int S,
+                          int dtype, hipStream_t s) {
+    LEDN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && S > 0);
+    const dim3 grid((unsigned)(N * S * S));
+    const int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+    if (dtype == LEDN_F32)
+        LEDN_LAUNCH(adaptive_avgpool_kernel<float>, grid, dim3(threads), 0, s, (const float*)x,
+                    (const float*)xadd, y, N, H, W, C, S);
+    else if (dtype == LEDN_BF16)
+        LEDN_LAUNCH(adaptive_avgpool_kernel<bf16_t>, grid, dim3(threads), 0, s, (const bf16_t*)x,
+                    (const bf16_t*)xadd, y, N, H, W, C, S);
+    else return LEDN_EINVAL;
+    return check_launch();
+}
+
+// ---- 3x3 / stride 2 / pad 1 average pool, divisor always 9
+template <typename T, int V>
+__global__ void __launch_bounds__(256) avgpool3x3s2_kernel(const T* x, T* y, int N, int H, int W, int C,
+                                                           int Ho, int Wo) {
+    const int cv = C / V;
+    const long total = (long)N * Ho * Wo * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long)Wo * Ho));
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho * 2 - 1 + kh;
+        if (hi < 0 || hi >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wi = wo * 2 - 1 + kw;
+            if (wi < 0 || wi >= W) continue;
+            float xv[V];
+            ldv<V>(x + (((long)n * H + hi) * W + wi) * C + c, xv);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] += xv[v];
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] *= (1.f / 9.f);
+    stv<V>(y + pix * C + c, acc);
+}
+
+int avgpool3x3s2_impl(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int dtype,
+                      hipStream_t s) {
+    LEDN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0);
+    LEDN_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1);
+    const bool v4 = C % 4 == 0;
+    const long total = (long)N * Ho * Wo * (v4 ? C / 4 : C);
+    const dim3 grid((unsigned)cdiv(total, 256));
+#define LEDN_AP(T)                                                                                 \
+    do {                                                                                           \
+        if (v4) LEDN_LAUNCH((avgpool3x3s2_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x, (T*)y, N, H, W, C, Ho, Wo); \
+        else LEDN_LAUNCH((avgpool3x3s2_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x, (T*)y, N, H, W, C, Ho, Wo);    \
+    } while (0)
+    if (dtype == LEDN_F32) LEDN_AP(float);
+    else if (dtype == LEDN_BF16) LEDN_AP(bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_AP
+    return check_launch();
+}
+
+}  // namespace ledn

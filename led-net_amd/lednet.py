@@ -1,0 +1,118 @@
+"""LEDNet backbone (registered as ``type='LEDNet'``).
+
+The reference withholds ``mmseg/models/backbones/lednet.py`` (8-line notice), so
+this is the reconstruction described in SURVEY.md section 8 row a2-R and
+DESIGN.md: DDRNet stem and bilateral skeleton (backbones/ddrnet.py:53-224),
+SESP/CESPB stages (nn_layers/eesp.py:15-118), two GETB blocks
+(backbones/UNetFormer_GETB.py:209-226), MFAF cross-branch fusion
+(classification/model_utils.py:356-429), SEAM edge gate
+(tools/speed/ddrnet_speed.py:282-338,388-389).  Its I/O contract is pinned by
+LEDHead (decode_heads/led_head.py:62-81): train -> (c3, c5, x1, x2), eval ->
+(c5, x1, x2), NCHW shapes, with x1: C @1/2, x2: C @1/4, c3: 2C @1/8, c5: 4C @1/8.
+
+Returned tensors are NCHW *views* of NHWC storage (channels-last), so LEDHead
+consumes them without a copy and foreign callers still see reference shapes.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .blocks import (CESPB, GETB, MFAF, SEAM, SESP, BasicBlock, Block, ConvModule, kaiming_init)
+from .ops import ACT_RELU, RES_ADD
+
+
+def to_nhwc(t, dtype=None):
+    """NCHW-shaped tensor -> dense NHWC tensor; zero-copy for channels-last views."""
+    v = t.permute(0, 2, 3, 1)
+    if v.is_contiguous() and (dtype is None or v.dtype == dtype):
+        return v
+    return ops.nchw_to_nhwc(t.contiguous(), dtype or t.dtype)
+
+
+def to_nchw_view(t):
+    return t.permute(0, 3, 1, 2)
+
+
+class LEDNet(Block):
+    def __init__(self, in_channels=3, channels=32, ppm_channels=128, norm_cfg=None,
+                 align_corners=False, act_cfg=None, init_cfg=None, num_heads=8, window_size=8,
+                 seam_percentile=0.8, act_dtype=torch.float32):
+        super().__init__()
+        if norm_cfg is not None and norm_cfg.get('type') not in ('BN', 'SyncBN'):
+            raise ValueError(f'unsupported norm_cfg {norm_cfg}')
+        if align_corners:
+            raise NotImplementedError('align_corners=True is not used by any LED-Net config')
+        C = channels
+        self.in_channels, self.channels, self.ppm_channels = in_channels, C, ppm_channels
+        self.sync_bn = bool(norm_cfg and norm_cfg.get('type') == 'SyncBN')
+        self.act_dtype = act_dtype
+        # stem: ddrnet.py:121-149 (Sequential indices 0,1,2,(3=ReLU),4,(5=ReLU) kept)
+        self.stem = nn.ModuleDict({
+            '0': ConvModule(in_channels, C, 3, 2, 1),
+            '1': ConvModule(C, C, 3, 2, 1),
+            '2': nn.Sequential(BasicBlock(C, C), BasicBlock(C, C, act_out=False)),
+            '4': nn.Sequential(BasicBlock(C, 2 * C, 2, downsample=True), BasicBlock(2 * C, 2 * C, act_out=False)),
+        })
+        # spatial branch (names layer3_/layer4_/layer5_: tools/feature_map_visual.py:147, dsnet.py:70-72)
+        self.layer3_ = CESPB(2 * C, 2 * C, 1, True)
+        self.layer4_ = CESPB(2 * C, 2 * C, 1, True)
+        self.layer5_ = SESP(2 * C, 4 * C, 1, 4, 7, True)
+        # context branch
+        self.layer3 = CESPB(2 * C, 4 * C, 2, False)
+        self.layer4 = CESPB(4 * C, 8 * C, 2, False)
+        self.layer5 = CESPB(8 * C, 16 * C, 2, False)
+        self.getb1 = GETB(4 * C, num_heads, window_size)
+        self.spp = ConvModule(16 * C, ppm_channels, 1)
+        self.getb2 = GETB(ppm_channels, num_heads, window_size)
+        assert ppm_channels == 4 * C, 'context tail width must equal the spatial tail (4C)'
+        # bilateral fusion (ddrnet.py:68-105)
+        self.compression_1 = ConvModule(4 * C, 2 * C, 1, act=None)
+        self.compression_2 = ConvModule(8 * C, 2 * C, 1, act=None)
+        self.down_1 = ConvModule(2 * C, 4 * C, 3, 2, 1, act=None)
+        self.down_2 = nn.Sequential(ConvModule(2 * C, 4 * C, 3, 2, 1), ConvModule(4 * C, 8 * C, 3, 2, 1, act=None))
+        self.aff1 = MFAF(2 * C)
+        self.aff2 = MFAF(2 * C)
+        self.seam = SEAM(2 * C, seam_percentile)
+        self.init_weights()
+
+    def init_weights(self):
+        kaiming_init(self)
+
+    # ------------------------------------------------------------------ #
+    def forward(self, x, pre=None):
+        """x: [N,3,H,W] float (normalised) or, with pre=(scale, shift, map), raw
+        uint8/float planes normalised on the fly (SegDataPreProcessor fusion)."""
+        if self.training:
+            from .train import lednet_forward_train
+            return lednet_forward_train(self, x, pre)
+        N, _, H, W = x.shape
+        out_size = (math.ceil(H / 8), math.ceil(W / 8))                      # ddrnet.py:185
+        s, b, m = pre if pre is not None else (None, None, None)
+        xin = ops.nchw_to_nhwc(x.contiguous(), self.act_dtype, s, b, m)
+        x1 = self.stem['0'](xin)                                               # C  @1/2
+        x2 = self.stem['1'](x1)                                                # C  @1/4
+        y = self.stem['2'][1](self.stem['2'][0](x2), final_relu=True)
+        y = self.stem['4'][1](self.stem['4'][0](y), final_relu=True)           # 2C @1/8
+        edge = self.seam.edge(y)
+        # stage 3
+        x_s = self.layer3_(y)
+        x_c = self.getb1(self.layer3(y))                                       # 4C @1/16
+        comp = self.compression_1(x_c, in_act=ACT_RELU)
+        x_c_r = self.down_1(x_s, in_act=ACT_RELU, res=x_c, res_mode=RES_ADD, act_override=ACT_RELU)
+        x_s_r = self.aff1(x_s, ops.bilinear(comp, out_size), out_relu=True)     # relu(x_s) for stage 4
+        # stage 4
+        x_c = self.layer4(x_c_r)                                               # 8C @1/32
+        x_s = self.layer4_(x_s_r)
+        comp = self.compression_2(x_c, in_act=ACT_RELU)
+        d = self.down_2[0](x_s, in_act=ACT_RELU)
+        x_c_r = self.down_2[1](d, res=x_c, res_mode=RES_ADD, act_override=ACT_RELU)
+        x_s = self.aff2(x_s, ops.bilinear(comp, out_size))
+        x_s = self.seam.gate(edge, x_s)
+        # stage 5
+        x_s = self.layer5_(x_s, in_relu=True)                                  # 4C @1/8
+        x_c = self.layer5(x_c_r)                                               # 16C @1/64
+        x_c = self.getb2(self.spp(x_c))
+        c5 = ops.bilinear(x_c, out_size, add=x_s)
+        return tuple(to_nchw_view(t) for t in (c5, x1, x2))

@@ -1,0 +1,382 @@
+"""Tensor-level wrappers over the C ABI (include/ledn.h).
+
+All activations are dense NHWC torch tensors (float32 or bfloat16); torch is
+used for device memory and the current HIP stream only.  Every function checks
+shapes/dtypes/devices before handing raw pointers to the library.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_NONE, ACT_PRELU, ACT_RELU, ACT_RELU6, ACT_SIGMOID, BF16, F32,  # noqa: F401
+                   RES_ADD, RES_GATE, RES_NONE, LednError)
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise LednError(f'unsupported activation dtype {t.dtype}')
+
+
+def _check(lib, *tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_contiguous():
+            raise LednError('non-contiguous tensor passed to a ledn op')
+        if lib.is_hip and not t.is_cuda:
+            raise LednError('ledn ops run on the HIP device only (tensor is on %s); '
+                            'there is no CPU fallback' % t.device)
+        if not lib.is_hip and t.is_cuda:
+            raise LednError('emulation library bound but tensor is on the GPU')
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t, n=None):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise LednError('parameter tensors must be contiguous float32')
+    if n is not None and t.numel() != n:
+        raise LednError(f'parameter length {t.numel()} != {n}')
+    return t
+
+
+def _stream(lib, ref):
+    if lib.is_hip:
+        return torch.cuda.current_stream(ref.device).cuda_stream
+    return None
+
+
+# ---- optional per-launch timing with HIP events (bench.py roofline leg) -------
+_TIMING = None
+
+
+def start_timing():
+    """Record a pair of HIP events (on the launch stream) around every kernel launch."""
+    global _TIMING
+    _TIMING = []
+
+
+def stop_timing():
+    """-> list of dicts {entry, sig, bytes, flops, ms}; call after a device sync."""
+    global _TIMING
+    rec, _TIMING = _TIMING or [], None
+    return [dict(entry=n, sig=w[0], bytes=w[1], flops=w[2], ms=e0.elapsed_time(e1)) for n, w, e0, e1 in rec]
+
+
+def _nb(*ts):
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
+
+
+def _run(lib, name, ref, *args, work=('', 0, 0)):
+    stream = _stream(lib, ref)
+    if _TIMING is not None and lib.is_hip:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.call(name, *args, stream)
+        e1.record()
+        _TIMING.append((name, work, e0, e1))
+    else:
+        lib.call(name, *args, stream)
+
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - ((k - 1) * dil + 1)) // stride + 1
+
+
+def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, in_shift=None,
+           in_act=ACT_NONE, out_scale=None, out_shift=None, act=ACT_NONE, slope=None, res=None,
+           res_mode=RES_NONE, stats=None, out_dtype=None, transposed=False, out_hw=None):
+    """Dense/grouped convolution.  x: [N,H,W,Cin]; w: OIHW f32 [Cout_f, Cin_f/groups, KH, KW].
+    transposed=True: x is dz [N,Ho_f,Wo_f,Cout_f]; returns dx [N,*out_hw,Cin_f]."""
+    lib = _lib.get_lib()
+    N, H, W, Cin = x.shape
+    cof, cigf, KH, KW = w.shape
+    _f32(w)
+    d = _lib.ConvDesc()
+    if not transposed:
+        if Cin != cigf * groups:
+            raise LednError(f'conv2d: Cin {Cin} != {cigf}*{groups}')
+        Cout = cof
+        Ho, Wo = conv_out_size(H, KH, stride, pad, dil), conv_out_size(W, KW, stride, pad, dil)
+        d.ws_co, d.ws_ci, d.ws_tap = cigf * KH * KW, KH * KW, 1
+    else:
+        if Cin != cof:
+            raise LednError(f'conv2d(transposed): dz channels {Cin} != {cof}')
+        Cout = cigf * groups
+        Ho, Wo = out_hw
+        d.ws_co, d.ws_ci, d.ws_tap = KH * KW, cigf * KH * KW, 1
+    y = torch.empty((N, Ho, Wo, Cout), dtype=out_dtype or x.dtype, device=x.device)
+    if res is not None and (res.shape != y.shape or res.dtype != y.dtype):
+        raise LednError('conv2d: residual shape/dtype mismatch')
+    if xadd is not None and (xadd.shape != x.shape or xadd.dtype != x.dtype):
+        raise LednError('conv2d: xadd shape/dtype mismatch')
+    _check(lib, x, w, y, res, xadd, in_scale, in_shift, out_scale, out_shift, slope)
+    d.x, d.xadd, d.w, d.y, d.res = _p(x), _p(xadd), _p(w), _p(y), _p(res)
+    d.in_scale, d.in_shift = _p(_f32(in_scale, Cin)), _p(_f32(in_shift, Cin))
+    d.out_scale, d.out_shift = _p(_f32(out_scale, Cout)), _p(_f32(out_shift, Cout))
+    d.slope = _p(_f32(slope, Cout))
+    if stats is not None:
+        _f32(stats[0], Cout), _f32(stats[1], Cout)
+        _check(lib, stats[0], stats[1])
+        d.stat_sum, d.stat_sqsum = _p(stats[0]), _p(stats[1])
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, Cout
+    d.KH, d.KW, d.stride, d.pad, d.dil, d.groups = KH, KW, stride, pad, dil, groups
+    d.in_act, d.act_out, d.res_mode = in_act, act, res_mode if res is not None else RES_NONE
+    d.dtype_x, d.dtype_y, d.transposed = _dt(x), _dt(y), int(transposed)
+    flops = 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW
+    sig = f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}'
+    _run(lib, 'ledn_conv2d', x, d, work=(sig, _nb(x, xadd, y, res, w), flops))
+    return y
+
+
+def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None,
+                 in_shift=None, in_act=ACT_NONE, bias=False):
+    """Returns (dw [OIHW f32], db or None) of conv2d(pre(x), w)."""
+    lib = _lib.get_lib()
+    N, H, W, Cin = x.shape
+    cof, cigf, KH, KW = w_shape
+    _, Ho, Wo, Cout = dz.shape
+    if Cout != cof or Cin != cigf * groups:
+        raise LednError('conv2d_wgrad: channel mismatch')
+    dw = torch.zeros(w_shape, dtype=torch.float32, device=x.device)
+    db = torch.zeros((Cout,), dtype=torch.float32, device=x.device) if bias else None
+    _check(lib, x, dz, xadd, in_scale, in_shift)
+    d = _lib.WgradDesc()
+    d.x, d.xadd, d.dz, d.dw, d.db = _p(x), _p(xadd), _p(dz), _p(dw), _p(db)
+    d.in_scale, d.in_shift = _p(_f32(in_scale, Cin)), _p(_f32(in_shift, Cin))
+    d.ws_co, d.ws_ci, d.ws_tap = cigf * KH * KW, KH * KW, 1
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, Cout
+    d.KH, d.KW, d.stride, d.pad, d.dil, d.groups = KH, KW, stride, pad, dil, groups
+    d.in_act, d.dtype_x, d.dtype_dz = in_act, _dt(x), _dt(dz)
+    flops = 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW
+    _run(lib, 'ledn_conv2d_wgrad', x, d,
+         work=(f'wgrad{KH}x{KW} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W}', _nb(x, xadd, dz, dw), flops))
+    return dw, db
+
+
+def dwconv2d(x, w_khwc, *, stride=1, pad=-1, dil=(1, 1, 1, 1), group_size=None, out_scale=None,
+             out_shift=None, act=ACT_NONE, slope=None, stats=None, ext1=False, out_dtype=None):
+    """Depthwise conv.  x: [N,H,W,C]; w_khwc: [KH,KW,C] f32."""
+    lib = _lib.get_lib()
+    N, H, W, Cc = x.shape
+    KH, KW, Cw = w_khwc.shape
+    if Cw != Cc:
+        raise LednError('dwconv2d: channel mismatch')
+    group_size = group_size or Cc
+    Hx, Wx = H + int(ext1), W + int(ext1)
+    d0 = dil[0]
+    ph = pad if pad >= 0 else d0 * (KH - 1) // 2
+    pw = pad if pad >= 0 else d0 * (KW - 1) // 2
+    Ho, Wo = conv_out_size(Hx, KH, stride, ph, d0), conv_out_size(Wx, KW, stride, pw, d0)
+    y = torch.empty((N, Ho, Wo, Cc), dtype=out_dtype or x.dtype, device=x.device)
+    _check(lib, x, w_khwc, y, out_scale, out_shift, slope)
+    d = _lib.DwDesc()
+    d.x, d.w, d.y = _p(x), _p(_f32(w_khwc)), _p(y)
+    d.out_scale, d.out_shift, d.slope = _p(_f32(out_scale, Cc)), _p(_f32(out_shift, Cc)), _p(_f32(slope, Cc))
+    if stats is not None:
+        _check(lib, stats[0], stats[1])
+        d.stat_sum, d.stat_sqsum = _p(_f32(stats[0], Cc)), _p(_f32(stats[1], Cc))
+    d.N, d.H, d.W, d.C, d.Ho, d.Wo = N, H, W, Cc, Ho, Wo
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    for i in range(4):
+        d.dil[i] = dil[i] if i < len(dil) else dil[-1]
+    d.group_size, d.act_out, d.ext1 = group_size, act, int(ext1)
+    d.dtype_x, d.dtype_y = _dt(x), _dt(y)
+    _run(lib, 'ledn_dwconv2d', x, d, work=(f'dw{KH}x{KW} C{Cc} s{stride} {N}x{H}x{W}', _nb(x, y, w_khwc), 2 * y.numel() * KH * KW))
+    return y
+
+
+def sesp_pyramid(x, w_b33n, dil, stride):
+    """x: [N,H,W,n]; w: [4,3,3,n] f32 -> [N,Ho,Wo,4n] (cat layout, HFF sums applied)."""
+    lib = _lib.get_lib()
+    N, H, W, n = x.shape
+    if tuple(w_b33n.shape) != (4, 3, 3, n):
+        raise LednError('sesp_pyramid: weight shape')
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((N, Ho, Wo, 4 * n), dtype=x.dtype, device=x.device)
+    _check(lib, x, w_b33n, y)
+    d = _lib.PyrDesc()
+    d.x, d.w, d.y = _p(x), _p(_f32(w_b33n)), _p(y)
+    d.N, d.H, d.W, d.n, d.Ho, d.Wo, d.stride = N, H, W, n, Ho, Wo, stride
+    for i in range(4):
+        d.dil[i] = dil[i]
+    d.dtype_x = d.dtype_y = _dt(x)
+    _run(lib, 'ledn_sesp_pyramid', x, d, work=(f'pyr n{n} s{stride} {N}x{H}x{W}', _nb(x, y, w_b33n), 2 * y.numel() * 9))
+    return y
+
+
+def channel_stats(x, xadd=None, stats=None):
+    """x: [..., C] -> (sum[C], sqsum[C]) f32 (accumulated into `stats` when given)."""
+    lib = _lib.get_lib()
+    Cc = x.shape[-1]
+    P = x.numel() // Cc
+    if stats is None:
+        stats = (torch.zeros(Cc, dtype=torch.float32, device=x.device),
+                 torch.zeros(Cc, dtype=torch.float32, device=x.device))
+    _check(lib, x, xadd, stats[0], stats[1])
+    _run(lib, 'ledn_channel_stats', x, _p(x), _p(xadd), P, Cc, _dt(x), _p(_f32(stats[0], Cc)),
+         _p(_f32(stats[1], Cc)), work=(f'stats C{Cc} P{P}', _nb(x, xadd), 3 * x.numel()))
+    return stats
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """-> (scale, shift, mean, invstd); updates the running statistics in place."""
+    lib = _lib.get_lib()
+    Cc = stats[0].numel()
+    dev = stats[0].device
+    scale, shift, mean, invstd = (torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(4))
+    _check(lib, stats[0], stats[1], gamma, beta, running_mean, running_var)
+    _run(lib, 'ledn_bn_finalize', stats[0], _p(stats[0]), _p(stats[1]), float(count), _p(_f32(gamma, Cc)),
+         _p(_f32(beta, Cc)), _p(_f32(running_mean, Cc)), _p(_f32(running_var, Cc)), momentum, eps,
+         _p(scale), _p(shift), _p(mean), _p(invstd), Cc, work=(f'bnfin C{Cc}', 0, 0))
+    return scale, shift, mean, invstd
+
+
+def affine_act(x, scale=None, shift=None, *, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE,
+               xadd=None, out_dtype=None):
+    lib = _lib.get_lib()
+    Cc = x.shape[-1]
+    y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    if res is not None and (res.shape != y.shape or res.dtype != y.dtype):
+        raise LednError('affine_act: residual shape/dtype mismatch')
+    _check(lib, x, y, xadd, res, scale, shift, slope)
+    d = _lib.AffineDesc()
+    d.x, d.xadd, d.y, d.res = _p(x), _p(xadd), _p(y), _p(res)
+    d.scale, d.shift, d.slope = _p(_f32(scale, Cc)), _p(_f32(shift, Cc)), _p(_f32(slope, Cc))
+    d.P, d.C, d.act = x.numel() // Cc, Cc, act
+    d.res_mode = res_mode if res is not None else RES_NONE
+    d.dtype_x, d.dtype_y = _dt(x), _dt(y)
+    _run(lib, 'ledn_affine_act', x, d, work=(f'affine C{Cc} P{x.numel() // Cc}', _nb(x, xadd, y, res), 2 * x.numel()))
+    return y
+
+
+def nchw_to_nhwc(x, out_dtype, scale=None, shift=None, chan_map=None):
+    """x: [N,C,H,W] uint8/float32/bfloat16 -> [N,H,W,C] out_dtype, y = x[map[c]]*scale[c]+shift[c]."""
+    lib = _lib.get_lib()
+    N, Cc, H, W = x.shape
+    dtx = {torch.float32: F32, torch.bfloat16: BF16, torch.uint8: _lib.U8}.get(x.dtype)
+    if dtx is None:
+        raise LednError(f'nchw_to_nhwc: unsupported input dtype {x.dtype}')
+    y = torch.empty((N, H, W, Cc), dtype=out_dtype, device=x.device)
+    if chan_map is not None and (chan_map.dtype != torch.int32 or chan_map.numel() != Cc):
+        raise LednError('nchw_to_nhwc: chan_map must be int32[C]')
+    _check(lib, x, y, scale, shift, chan_map)
+    _run(lib, 'ledn_nchw_to_nhwc', x, _p(x), dtx, _p(y), _DT[out_dtype], N, Cc, H, W, _p(_f32(scale, Cc)),
+         _p(_f32(shift, Cc)), _p(chan_map), work=(f'nchw2nhwc {N}x{Cc}x{H}x{W}', _nb(x, y), 2 * x.numel()))
+    return y
+
+
+def bilinear(x, size, *, add=None, out_dtype=None, nchw=False, argmax=False):
+    """F.interpolate(bilinear, align_corners=False) of NHWC x to `size` (+ add)."""
+    lib = _lib.get_lib()
+    N, H, W, Cc = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    odt = torch.float32 if nchw else (out_dtype or x.dtype)
+    y = torch.empty((N, Cc, Ho, Wo) if nchw else (N, Ho, Wo, Cc), dtype=odt, device=x.device)
+    am = torch.empty((N, Ho, Wo), dtype=torch.uint8, device=x.device) if argmax else None
+    if add is not None and (tuple(add.shape) != (N, Ho, Wo, Cc) or add.dtype != odt):
+        raise LednError('bilinear: add shape/dtype mismatch')
+    _check(lib, x, y, add, am)
+    d = _lib.ResizeDesc()
+    d.x, d.add, d.y, d.argmax = _p(x), _p(add), _p(y), _p(am)
+    d.N, d.H, d.W, d.C, d.Ho, d.Wo = N, H, W, Cc, Ho, Wo
+    d.out_nchw, d.dtype_x, d.dtype_y = int(nchw), _dt(x), _DT[odt]
+    _run(lib, 'ledn_bilinear', x, d, work=(f'bilinear C{Cc} {H}x{W}->{Ho}x{Wo} N{N}', _nb(x, y, add, am), 8 * y.numel()))
+    return (y, am) if argmax else y
+
+
+def adaptive_avgpool(x, S, xadd=None):
+    lib = _lib.get_lib()
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, S, S, Cc), dtype=torch.float32, device=x.device)
+    _check(lib, x, xadd, y)
+    _run(lib, 'ledn_adaptive_avgpool', x, _p(x), _p(xadd), _p(y), N, H, W, Cc, S, _dt(x),
+         work=(f'apool S{S} C{Cc} {N}x{H}x{W}', _nb(x, xadd, y), x.numel()))
+    return y
+
+
+def avgpool3x3s2(x):
+    lib = _lib.get_lib()
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    _check(lib, x, y)
+    _run(lib, 'ledn_avgpool3x3s2', x, _p(x), _p(y), N, H, W, Cc, Ho, Wo, _dt(x),
+         work=(f'avgpool3s2 C{Cc} {N}x{H}x{W}', _nb(x, y), 9 * y.numel()))
+    return y
+
+
+def window_attn(qkv, biasT, heads, ws=8):
+    lib = _lib.get_lib()
+    N, H, W, C3 = qkv.shape
+    Cc = C3 // 3
+    if tuple(biasT.shape) != (heads, ws * ws, ws * ws):
+        raise LednError('window_attn: biasT shape')
+    out = torch.empty((N, H, W, Cc), dtype=qkv.dtype, device=qkv.device)
+    _check(lib, qkv, biasT, out)
+    nwin = N * ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
+    _run(lib, 'ledn_window_attn', qkv, _p(qkv), _p(_f32(biasT)), _p(out), N, H, W, Cc, heads, ws, _dt(qkv),
+         work=(f'wattn C{Cc} h{heads} {N}x{H}x{W}', _nb(qkv, out, biasT), 4 * nwin * (ws * ws) ** 2 * Cc))
+    return out
+
+
+def getb_pool(a, local, ws=8):
+    lib = _lib.get_lib()
+    N, H, W, Cc = a.shape
+    if local.shape != a.shape or local.dtype != a.dtype:
+        raise LednError('getb_pool: shape/dtype mismatch')
+    out = torch.empty_like(a)
+    _check(lib, a, local, out)
+    _run(lib, 'ledn_getb_pool', a, _p(a), _p(local), _p(out), N, H, W, Cc, ws, _dt(a),
+         work=(f'getbpool C{Cc} {N}x{H}x{W}', _nb(a, local, out), 17 * a.numel()))
+    return out
+
+
+def mfaf_gate(x, r, xl, ctx, affines, act=ACT_NONE):
+    """ctx: [c1 (N,4,4,C), c2 (N,8,8,C), c3 (N,16,16,C), xg (N,1,1,C)] f32;
+    affines: 5 (scale, shift) pairs for xl, c1, c2, c3, xg."""
+    lib = _lib.get_lib()
+    N, H, W, Cc = x.shape
+    if r.shape != x.shape or xl.shape != x.shape or r.dtype != x.dtype or xl.dtype != x.dtype:
+        raise LednError('mfaf_gate: shape/dtype mismatch')
+    out = torch.empty_like(x)
+    d = _lib.MfafDesc()
+    d.x, d.r, d.xl, d.out = _p(x), _p(r), _p(xl), _p(out)
+    keep = [x, r, xl, out]
+    for k, c in enumerate(ctx):
+        if c.shape[0] != N or c.shape[1] != c.shape[2] or c.shape[3] != Cc:
+            raise LednError('mfaf_gate: context map shape')
+        d.ctx[k] = _p(_f32(c))
+        d.ctx_size[k] = c.shape[1]
+        keep.append(c)
+    for k, (s, b) in enumerate(affines):
+        d.scale[k], d.shift[k] = _p(_f32(s, Cc)), _p(_f32(b, Cc))
+        keep += [s, b]
+    _check(lib, *keep)
+    d.N, d.H, d.W, d.C, d.dtype, d.act = N, H, W, Cc, _dt(x), act
+    _run(lib, 'ledn_mfaf_gate', x, d, work=(f'mfafgate C{Cc} {N}x{H}x{W}', _nb(x, r, xl, out), 20 * x.numel()))
+    return out
+
+
+def seam_edge(seg, percentile=0.8, thr=0.1, final_thr=0.1):
+    """seg: [N,h,w,1] f32 -> edge [N,h,w,1] f32 in {0,1}.  percentile=None: fixed `thr`."""
+    lib = _lib.get_lib()
+    N, h, w, one = seg.shape
+    if one != 1 or seg.dtype != torch.float32:
+        raise LednError('seam_edge: seg must be [N,h,w,1] float32')
+    edge = torch.empty_like(seg)
+    scratch = torch.empty((N, 3, h, w), dtype=torch.float32, device=seg.device)
+    kth = 0 if percentile is None else max(1, math.ceil(percentile * h * w))
+    _check(lib, seg, edge, scratch)
+    _run(lib, 'ledn_seam_edge', seg, _p(seg), _p(edge), _p(scratch), N, h, w, kth, thr, final_thr,
+         work=(f'seam {N}x{h}x{w}', _nb(seg, edge), 60 * seg.numel()))
+    return edge

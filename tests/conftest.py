@@ -49,3 +49,58 @@ def golden():
 def golden_names(prefix):
     return sorted(f[:-4] for f in os.listdir(GOLDEN)
                   if f.startswith(prefix) and f.endswith('.npz'))
+
+
+# --------------------------------------------------------------------------- #
+# CPU emulation build of the kernel sources (tests only; see csrc/emu.h)
+# --------------------------------------------------------------------------- #
+EMU_SO = os.path.join(ROOT, 'tests', 'emu', 'libledn_emu.so')
+_emu_lib = None
+
+
+def _build_emu():
+    import subprocess
+    subprocess.run(['make', '-s', '-j8', '-C', os.path.join(ROOT, 'led-net_amd', 'csrc'), 'emu'],
+                   check=True)
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def bind_emu():
+    global _emu_lib
+    import led_net_amd  # noqa: F401
+    from led_net_amd import _lib
+    if _emu_lib is None:
+        _build_emu()
+        _emu_lib = _lib.Library(EMU_SO, is_hip=False)
+    with _lib.use_library(_emu_lib):
+        yield _emu_lib
+
+
+@pytest.fixture
+def emu():
+    """Binds the CPU-emulated kernels for the duration of a test."""
+    with bind_emu() as lib:
+        yield lib
+
+
+class Backend:
+    def __init__(self, dev):
+        self.dev = torch.device(dev)
+
+    def __call__(self, t):
+        return t.to(self.dev) if torch.is_tensor(t) else t
+
+
+@pytest.fixture(params=['emu', pytest.param('hip', marks=pytest.mark.gpu)])
+def be(request):
+    """Backend under test: 'emu' = kernel sources on the CPU emulator (no GPU
+    needed), 'hip' = libledn_hip.so on cuda:0 through the same C ABI."""
+    if request.param == 'emu':
+        with bind_emu():
+            yield Backend('cpu')
+    else:
+        assert torch.cuda.is_available(), 'gpu-marked test needs a HIP device'
+        yield Backend('cuda:0')
