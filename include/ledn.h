@@ -248,6 +248,158 @@ int ledn_mfaf_gate(const ledn_mfaf_desc* d, void* stream);
 int ledn_seam_edge(const float* seg, float* edge, float* scratch, int N, int h, int w, int kth,
                    float thr, float final_thr, void* stream);
 
+/* ========================================================================= *
+ * Backward kernels (training path).  The reference gets all of these from
+ * torch.autograd over the ATen ops of its forward (tools/train.py:99-106 ->
+ * mmengine OptimWrapper.update_params -> loss.backward()).
+ * ========================================================================= */
+
+/* Backward of  y = act(res_mode((z*scale + shift), res))  where, for bn_mode=1,
+ * scale/shift are the batch-statistics affine of BatchNorm (x_hat = (z-mean)*invstd).
+ *   t = res_mode(v, res), g_t = dy * act'(t);  ADD: g_v = g_t, dres = g_t;
+ *   GATE (t = v*res + res): g_v = g_t*res, dres = g_t*(v+1).
+ * reduce pass : sum_g[c] += sum g_v, sum_gx[c] += sum g_v*x_hat  (= dbeta, dgamma),
+ *               dslope[c] += sum dy*min(t,0)                      (PReLU)
+ * apply pass  : bn_mode=1: dz = scale*(g_v - sum_g/count - x_hat*sum_gx/count)
+ *               bn_mode=0: dz = g_v*scale (scale NULL = 1);  dres written if given. */
+typedef struct {
+    const void* z;
+    const void* res;
+    const void* dy;
+    const float* scale;
+    const float* shift;
+    const float* slope;
+    const float* mean;
+    const float* invstd;
+    float* sum_g;
+    float* sum_gx;
+    float* dslope;
+    void* dz;
+    void* dres;
+    double count;
+    long long P;
+    int C, act, res_mode, bn_mode;
+    int dtype_z, dtype_y;
+} ledn_bnbwd_desc;
+int ledn_bn_act_bwd_reduce(const ledn_bnbwd_desc* d, void* stream);
+int ledn_bn_act_bwd_apply(const ledn_bnbwd_desc* d, void* stream);
+
+/* Depthwise convolution backward (geometry as ledn_dw_desc):
+ *   data  : dx[N,H,W,C]  = sum_taps dz[...] * w   (+ `add` if given; ext1 folds the
+ *           reflected row/column back onto H-2 / W-2)
+ *   weight: dw[KH][KW][C] += sum_pix x[pix@tap] * dz[pix]      (caller zeroes dw) */
+typedef struct {
+    const void* x;
+    const void* dz;
+    const float* w;
+    const void* add;
+    void* dx;
+    float* dw;
+    int N, H, W, C, Ho, Wo;
+    int KH, KW, stride, pad;
+    int dil[4], group_size;
+    int ext1;
+    int dtype;
+} ledn_dwbwd_desc;
+int ledn_dwconv2d_bwd_data(const ledn_dwbwd_desc* d, void* stream);
+int ledn_dwconv2d_bwd_weight(const ledn_dwbwd_desc* d, void* stream);
+
+/* SESP pyramid backward.  g = suffix sums of dy over the 4 branch groups
+ * (g_b = sum_{b'>=b} dy_b', the adjoint of the HFF adds, eesp.py:84-91):
+ *   ledn_sesp_pyramid_bwd_data  : gsum [N,Ho,Wo,4n] (scratch, written) and dx [N,H,W,n]
+ *   ledn_sesp_pyramid_bwd_weight: dw [4][3][3][n] += sum x[pix@tap,dil_b] * gsum_b[pix] */
+typedef struct {
+    const void* x;
+    const void* dy;
+    const float* w;
+    void* gsum;
+    void* dx;
+    float* dw;
+    int N, H, W, n, Ho, Wo, stride;
+    int dil[4];
+    int dtype;
+} ledn_pyrbwd_desc;
+int ledn_sesp_pyramid_bwd_data(const ledn_pyrbwd_desc* d, void* stream);
+int ledn_sesp_pyramid_bwd_weight(const ledn_pyrbwd_desc* d, void* stream);
+
+/* dx[N,H,W,C] = adjoint of ledn_bilinear (gather form, deterministic); dy [N,Ho,Wo,C]. */
+int ledn_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo,
+                      int dtype_dy, int dtype_dx, void* stream);
+/* dx = (add ? add : 0) + adjoint of ledn_avgpool3x3s2 applied to dy [N,Ho,Wo,C]. */
+int ledn_avgpool3x3s2_bwd(const void* dy, const void* add, void* dx, int N, int H, int W, int C,
+                          int Ho, int Wo, int dtype, void* stream);
+
+/* Window attention backward.  dqkv [N,H,W,3C] f32 MUST be zeroed by the caller when
+ * the map is reflect-padded (H or W not a multiple of ws): padded tokens add into
+ * their source pixel.  dbiasT [heads][ws^2][ws^2] f32 is accumulated (caller zeroes). */
+int ledn_window_attn_bwd(const void* qkv, const float* biasT, const void* dout, float* dqkv,
+                         float* dbiasT, int N, int H, int W, int C, int heads, int ws, int dtype,
+                         void* stream);
+/* da = adjoint of ledn_getb_pool wrt `a` (dlocal = dout needs no kernel). */
+int ledn_getb_pool_bwd(const void* dout, void* da, int N, int H, int W, int C, int ws, int dtype,
+                       void* stream);
+
+/* MFAF gate backward (forward quantities recomputed from x, r, xl, ctx, affines):
+ *   dx_b = 2*w*dout, dr_b = 2*(1-w)*dout, ds = 2*(x-r)*dout*w*(1-w)   [N,H,W,C]
+ *   dctx[k][n,sy,sx,c] += sum of ds over the pixels that read that cell (caller zeroes). */
+typedef struct {
+    const void* x;
+    const void* r;
+    const void* xl;
+    const float* ctx[4];
+    int ctx_size[4];
+    const float* scale[5];
+    const float* shift[5];
+    const void* dout;
+    void* dx;
+    void* dr;
+    void* ds;
+    float* dctx[4];
+    int N, H, W, C;
+    int dtype;
+    int act;               /* forward applied ReLU to out */
+} ledn_mfafbwd_desc;
+int ledn_mfaf_gate_bwd(const ledn_mfafbwd_desc* d, void* stream);
+/* dx = dx_b + dxa, dr = dr_b + dxa with dxa = dxl + sum_k adaptive-avg-pool adjoint of dpool[k]
+ * (dpool[k]: [N,S_k,S_k,C] f32).  In place on dx/dr (dr may be NULL). */
+int ledn_mfaf_bwd_combine(void* dx, void* dr, const void* dxl, const float* const* dpool,
+                          const int* sizes, int npool, int N, int H, int W, int C, int dtype,
+                          void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * OHEM cross-entropy + accuracy (mmseg/models/losses/ohem_cross_entropy_loss.py:52-90,
+ * losses/accuracy.py:6-60), fused: softmax prob of the target class, per-pixel CE,
+ * exact k-th smallest prob by 3-pass radix select on the f32 bit patterns,
+ * thr = max(kth, thres), masked mean.  logits [P][C] f32 (NHWC), target [P] int64.
+ *   work: float[2*P] + 4096 words of scratch (prob | loss | histograms | state).
+ *   out[0] = loss_weight * mean(loss[valid & prob < thr])  (0 if no valid pixel)
+ *   out[1] = top-1 accuracy in percent over valid pixels;  out[2] = thr; out[3] = #selected
+ * ledn_ohem_ce_bwd: dlogits[p][c] = dloss*loss_weight/#selected * (softmax_c - onehot_c)
+ * for selected pixels, 0 elsewhere. */
+int ledn_ohem_ce_fwd(const float* logits, const long long* target, long long P, int C, float thres,
+                     long long min_kept, float loss_weight, int ignore_label, float* work,
+                     float* out, void* stream);
+int ledn_ohem_ce_bwd(const float* logits, const long long* target, long long P, int C,
+                     int ignore_label, const float* work, const float* out, const float* dloss,
+                     float loss_weight, float* dlogits, void* stream);
+long long ledn_ohem_work_floats(long long P);
+
+/* ------------------------------------------------------------------------- *
+ * SGD with momentum and weight decay over a table of tensors (torch.optim.SGD
+ * semantics; config optimizer = dict(type='SGD', lr, momentum, weight_decay)):
+ *   g' = grad_scale*g + wd*p;  m = momentum*m + g';  p -= lr*m;  g = 0.
+ * (grad_scale = 1/world_size turns the all-reduced gradient SUM into DDP's mean.)
+ * table: n_tensors x {p, g, m} device pointers followed by element counts
+ * (see ledn_sgd_entry); one launch for the whole model. */
+typedef struct {
+    float* p;
+    float* g;
+    float* m;
+    long long n;
+} ledn_sgd_entry;
+int ledn_sgd_step(const ledn_sgd_entry* table_dev, int n_tensors, long long max_n, float lr,
+                  float momentum, float weight_decay, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,9 +11,10 @@ from .led_head import LEDHead
 from .losses import OhemCrossEntropy  # noqa: F401
 from .segmentor import EncoderDecoder, SegDataSample  # noqa: F401
 from .config import load_config  # noqa: F401
+from .train import Trainer  # noqa: F401
 
 MODELS.register_module(module=LEDNet)
 MODELS.register_module(module=LEDHead)
 
 __all__ = ['MODELS', 'LEDNet', 'LEDHead', 'OhemCrossEntropy', 'EncoderDecoder', 'SegDataSample',
-           'load_config', 'ops', 'register_into_mmseg']
+           'load_config', 'ops', 'register_into_mmseg', 'Trainer']

@@ -73,7 +73,54 @@ class MfafDesc(C.Structure):
                 ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('dtype', i32), ('act', i32)]
 
 
+class BnBwdDesc(C.Structure):
+    _fields_ = [('z', vp), ('res', vp), ('dy', vp), ('scale', fp), ('shift', fp), ('slope', fp),
+                ('mean', fp), ('invstd', fp), ('sum_g', fp), ('sum_gx', fp), ('dslope', fp),
+                ('dz', vp), ('dres', vp), ('count', C.c_double), ('P', i64),
+                ('C', i32), ('act', i32), ('res_mode', i32), ('bn_mode', i32),
+                ('dtype_z', i32), ('dtype_y', i32)]
+
+
+class DwBwdDesc(C.Structure):
+    _fields_ = [('x', vp), ('dz', vp), ('w', fp), ('add', vp), ('dx', vp), ('dw', fp),
+                ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('Ho', i32), ('Wo', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
+                ('dil', i32 * 4), ('group_size', i32), ('ext1', i32), ('dtype', i32)]
+
+
+class PyrBwdDesc(C.Structure):
+    _fields_ = [('x', vp), ('dy', vp), ('w', fp), ('gsum', vp), ('dx', vp), ('dw', fp),
+                ('N', i32), ('H', i32), ('W', i32), ('n', i32), ('Ho', i32), ('Wo', i32), ('stride', i32),
+                ('dil', i32 * 4), ('dtype', i32)]
+
+
+class MfafBwdDesc(C.Structure):
+    _fields_ = [('x', vp), ('r', vp), ('xl', vp), ('ctx', fp * 4), ('ctx_size', i32 * 4),
+                ('scale', fp * 5), ('shift', fp * 5), ('dout', vp), ('dx', vp), ('dr', vp), ('ds', vp),
+                ('dctx', fp * 4), ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('dtype', i32), ('act', i32)]
+
+
+class SgdEntry(C.Structure):
+    _fields_ = [('p', fp), ('g', fp), ('m', fp), ('n', i64)]
+
+
 _PROTOS = {
+    'ledn_bn_act_bwd_reduce': ([C.POINTER(BnBwdDesc), vp], i32),
+    'ledn_bn_act_bwd_apply': ([C.POINTER(BnBwdDesc), vp], i32),
+    'ledn_dwconv2d_bwd_data': ([C.POINTER(DwBwdDesc), vp], i32),
+    'ledn_dwconv2d_bwd_weight': ([C.POINTER(DwBwdDesc), vp], i32),
+    'ledn_sesp_pyramid_bwd_data': ([C.POINTER(PyrBwdDesc), vp], i32),
+    'ledn_sesp_pyramid_bwd_weight': ([C.POINTER(PyrBwdDesc), vp], i32),
+    'ledn_bilinear_bwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_avgpool3x3s2_bwd': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_window_attn_bwd': ([vp, fp, vp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_getb_pool_bwd': ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_mfaf_gate_bwd': ([C.POINTER(MfafBwdDesc), vp], i32),
+    'ledn_mfaf_bwd_combine': ([vp, vp, vp, C.POINTER(fp), C.POINTER(i32), i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_ohem_work_floats': ([i64], i64),
+    'ledn_ohem_ce_fwd': ([fp, vp, i64, i32, C.c_float, i64, C.c_float, i32, fp, fp, vp], i32),
+    'ledn_ohem_ce_bwd': ([fp, vp, i64, i32, i32, fp, fp, fp, C.c_float, fp, vp], i32),
+    'ledn_sgd_step': ([vp, i32, i64, C.c_float, C.c_float, C.c_float, C.c_float, vp], i32),
     'ledn_abi_version': ([], i32),
     'ledn_conv2d': ([C.POINTER(ConvDesc), vp], i32),
     'ledn_conv2d_wgrad': ([C.POINTER(WgradDesc), vp], i32),

@@ -1,0 +1,402 @@
+// attn_loss_opt.hip -- window-attention backward, fused OHEM cross-entropy
+// (radix-select threshold instead of the reference's full sort), multi-tensor SGD.
+#include "ledn_rt.h"
+
+namespace ledn {
+
+// ===========================================================================
+// Window attention backward.  One wavefront per (window, head); lane = token.
+// Phase A (lane = query i): recompute P[i][:], dP = dO.V^T, dS = P*(dP - rowsum(P*dP)),
+//   dQ[i] = scale * dS[i][:] . K ; dS kept in LDS (64x64 f32) and added to dbiasT.
+// Phase B (lane = key j): dK[j] = scale * dS[:][j]^T . Q,  dV[j] = P[:][j]^T . dO.
+// LDS: K, V, Q, dO (4 x 64 x D f32) + dS + P (2 x 16 KiB) = 48 KiB at D = 16.
+// ===========================================================================
+template <typename T, int D, bool PADDED>
+__global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T* qkv, const float* biasT, const T* dout,
+                                                             float* dqkv, float* dbiasT, int N, int H,
+                                                             int W, int C, int heads, int hh, int ww) {
+    constexpr int WS = 8, T2 = 64;
+    __shared__ float s_k[T2 * D], s_v[T2 * D], s_q[T2 * D], s_do[T2 * D];
+    __shared__ float s_ds[T2 * T2], s_p[T2 * T2];
+    const int win = blockIdx.x, head = blockIdx.y;
+    const int wx = win % ww, wy = (win / ww) % hh, n = win / (ww * hh);
+    const int t = threadIdx.x;
+    const int y = wy * WS + t / WS, x = wx * WS + t % WS;
+    const bool inside = y < H && x < W;
+    const int ys = y < H ? y : 2 * H - 2 - y;
+    const int xs = x < W ? x : 2 * W - 2 - x;
+    const long src = ((long)n * H + ys) * W + xs;
+    const T* p = qkv + src * (3L * C) + head * D;
+    float q[D], go[D];
+#pragma unroll
+    for (int j = 0; j < D; j += 4) {
+        float kv[4], vv[4];
+        ldv<4>(p + j, q + j);
+        ldv<4>(p + C + j, kv);
+        ldv<4>(p + 2 * C + j, vv);
+        if (inside) ldv<4>(dout + src * C + head * D + j, go + j);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) go[j + i] = 0.f;  // cropped outputs carry no gradient
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s_k[t * D + j + i] = kv[i];
+            s_v[t * D + j + i] = vv[i];
+            s_q[t * D + j + i] = q[j + i];
+            s_do[t * D + j + i] = go[j + i];
+        }
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)D);
+    const float* b = biasT + (long)head * T2 * T2 + t;
+    float m = -3.0e38f;
+    for (int k = 0; k < T2; ++k) {
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) dot = fmaf(q[j], s_k[k * D + j], dot);
+        const float sc = dot * scale + b[k * T2];
+        s_p[t * T2 + k] = sc;      // row t is private to lane t in phase A
+        m = fmaxf(m, sc);
+    }
+    float l = 0.f;
+    for (int k = 0; k < T2; ++k) {
+        const float e = __expf(s_p[t * T2 + k] - m);
+        s_p[t * T2 + k] = e;
+        l += e;
+    }
+    const float inv = 1.f / l;
+    float rs = 0.f;  // sum_k P*dP
+    for (int k = 0; k < T2; ++k) {
+        const float pk = s_p[t * T2 + k] * inv;
+        float dp = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) dp = fmaf(go[j], s_v[k * D + j], dp);
+        s_p[t * T2 + k] = pk;
+        s_ds[t * T2 + k] = dp;
+        rs = fmaf(pk, dp, rs);
+    }
+    float dq[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) dq[j] = 0.f;
+    float* db = dbiasT + (long)head * T2 * T2 + t;
+    for (int k = 0; k < T2; ++k) {
+        const float ds = s_p[t * T2 + k] * (s_ds[t * T2 + k] - rs);
+        s_ds[t * T2 + k] = ds;
+        atomicAdd(db + k * T2, ds);
+#pragma unroll
+        for (int j = 0; j < D; ++j) dq[j] = fmaf(ds, s_k[k * D + j], dq[j]);
+    }
+    __syncthreads();
+    // phase B: lane = key t
+    float dk[D], dv[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) dk[j] = dv[j] = 0.f;
+    for (int i = 0; i < T2; ++i) {
+        const float ds = s_ds[i * T2 + t], pk = s_p[i * T2 + t];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            dk[j] = fmaf(ds, s_q[i * D + j], dk[j]);
+            dv[j] = fmaf(pk, s_do[i * D + j], dv[j]);
+        }
+    }
+    float* o = dqkv + src * (3L * C) + head * D;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        if (PADDED) {
+            atomicAdd(o + j, dq[j] * scale);
+            atomicAdd(o + C + j, dk[j] * scale);
+            atomicAdd(o + 2 * C + j, dv[j]);
+        } else {
+            o[j] = dq[j] * scale;
+            o[C + j] = dk[j] * scale;
+            o[2 * C + j] = dv[j];
+        }
+    }
+}
+
+int window_attn_bwd_impl(const void* qkv, const float* biasT, const void* dout, float* dqkv, float* dbiasT,
+                         int N, int H, int W, int C, int heads, int ws, int dtype, hipStream_t s) {
+    LEDN_REQUIRE(qkv && biasT && dout && dqkv && dbiasT && N > 0 && H > 0 && W > 0 && C > 0 && heads > 0);
+    LEDN_REQUIRE(ws == 8 && C % heads == 0);
+    const int D = C / heads;
+    const int hh = (H + ws - 1) / ws, ww = (W + ws - 1) / ws;
+    LEDN_REQUIRE(hh * ws - H < H && ww * ws - W < W);
+    const bool padded = (H % ws) || (W % ws);
+    const dim3 grid((unsigned)(N * hh * ww), (unsigned)heads);
+#define LEDN_WB(T, DD)                                                                                  \
+    do {                                                                                                \
+        if (padded)                                                                                     \
+            LEDN_LAUNCH((window_attn_bwd_kernel<T, DD, true>), grid, dim3(64), 0, s, (const T*)qkv, biasT, \
+                        (const T*)dout, dqkv, dbiasT, N, H, W, C, heads, hh, ww);                       \
+        else                                                                                            \
+            LEDN_LAUNCH((window_attn_bwd_kernel<T, DD, false>), grid, dim3(64), 0, s, (const T*)qkv, biasT, \
+                        (const T*)dout, dqkv, dbiasT, N, H, W, C, heads, hh, ww);                       \
+    } while (0)
+#define LEDN_WBD(T)                        \
+    do {                                   \
+        if (D == 8) LEDN_WB(T, 8);         \
+        else if (D == 16) LEDN_WB(T, 16);  \
+        else if (D == 32) LEDN_WB(T, 32);  \
+        else return LEDN_EINVAL;           \
+    } while (0)
+    if (dtype == LEDN_F32) LEDN_WBD(float);
+    else if (dtype == LEDN_BF16) LEDN_WBD(bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_WBD
+#undef LEDN_WB
+    return check_launch();
+}
+
+// ===========================================================================
+// OHEM cross-entropy.
+// work layout (floats): prob[P] | loss[P] | u32 hist[3][2048] | u32 state[16]
+// state: 0 n_valid, 1 n_correct, 2 rank (remaining), 3 prefix bits, 4 thr bits,
+//        5 n_selected, 6 (float) loss_sum
+// ===========================================================================
+constexpr int OH_BINS = 2048;
+struct OhemWork {
+    float* prob;
+    float* loss;
+    unsigned* hist;
+    unsigned* state;
+};
+__host__ __device__ inline OhemWork ohem_work(float* work, long long P) {
+    OhemWork w;
+    w.prob = work;
+    w.loss = work + P;
+    w.hist = reinterpret_cast<unsigned*>(work + 2 * P);
+    w.state = w.hist + 3 * OH_BINS;
+    return w;
+}
+long long ohem_work_floats(long long P) { return 2 * P + 3 * OH_BINS + 16; }
+
+__device__ __forceinline__ int oh_bin(unsigned u, int pass) {
+    return pass == 0 ? (int)(u >> 21) : (pass == 1 ? (int)((u >> 10) & 2047u) : (int)(u & 1023u));
+}
+
+// pass over the pixels: prob of the target class, CE, validity, accuracy, level-0 histogram
+template <int CT>
+__global__ void __launch_bounds__(256) ohem_prob_kernel(const float* logits, const long long* target, long P,
+                                                        int C, int ignore_label, float* work) {
+    __shared__ unsigned s_hist[OH_BINS];
+    __shared__ unsigned s_cnt[2];
+    const OhemWork w = ohem_work(work, P);
+    for (int i = threadIdx.x; i < OH_BINS; i += blockDim.x) s_hist[i] = 0u;
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const long long tg = target[p];
+        if (tg == ignore_label) {
+            w.prob[p] = 2.0f;   // > any probability: never selected
+            w.loss[p] = 0.f;
+            continue;
+        }
+        const float* lg = logits + p * C;
+        float mx = lg[0];
+        int am = 0;
+        const int cc = CT > 0 ? CT : C;
+#pragma unroll
+        for (int c = 1; c < cc; ++c)
+            if (lg[c] > mx) { mx = lg[c]; am = c; }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < cc; ++c) se += __expf(lg[c] - mx);
+        const float lt = lg[(int)tg] - mx;
+        const float pr = __expf(lt) / se;
+        w.prob[p] = pr;
+        w.loss[p] = __logf(se) - lt;
+        atomicAdd(&s_hist[oh_bin(__float_as_uint(pr), 0)], 1u);
+        atomicAdd(&s_cnt[0], 1u);
+        if (am == (int)tg) atomicAdd(&s_cnt[1], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < OH_BINS; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&w.hist[i], s_hist[i]);
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&w.state[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+// single workgroup: locate the bucket holding the wanted rank at this level
+__global__ void __launch_bounds__(256) ohem_scan_kernel(float* work, long P, int pass, long long min_kept,
+                                                        float thres) {
+    const OhemWork w = ohem_work(work, P);
+    if (threadIdx.x != 0) return;
+    unsigned rank;
+    if (pass == 0) {
+        const unsigned nv = w.state[0];
+        if (nv == 0u) { w.state[4] = __float_as_uint(thres); w.state[2] = 0u; w.state[3] = 0u; return; }
+        const long long k = min_kept < (long long)nv - 1 ? min_kept : (long long)nv - 1;
+        rank = (unsigned)k;
+        w.state[3] = 0u;
+    } else {
+        if (w.state[0] == 0u) return;
+        rank = w.state[2];
+    }
+    const unsigned* h = w.hist + pass * OH_BINS;
+    const int nb = pass == 2 ? 1024 : 2048;
+    int b = 0;
+    for (; b < nb; ++b) {
+        if (rank < h[b]) break;
+        rank -= h[b];
+    }
+    if (b >= nb) b = nb - 1;
+    const unsigned bits = pass == 0 ? ((unsigned)b << 21) : (pass == 1 ? ((unsigned)b << 10) : (unsigned)b);
+    w.state[3] |= bits;
+    w.state[2] = rank;
+    if (pass == 2) {
+        const float kth = __uint_as_float(w.state[3]);
+        w.state[4] = __float_as_uint(kth > thres ? kth : thres);   // threshold = max(min_value, thresh)
+    }
+}
+
+__global__ void __launch_bounds__(256) ohem_hist_kernel(float* work, long P, int pass) {
+    __shared__ unsigned s_hist[OH_BINS];
+    const OhemWork w = ohem_work(work, P);
+    for (int i = threadIdx.x; i < OH_BINS; i += blockDim.x) s_hist[i] = 0u;
+    __syncthreads();
+    const unsigned prefix = w.state[3];
+    const unsigned mask = pass == 1 ? 0xffe00000u : 0xfffffc00u;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const unsigned u = __float_as_uint(w.prob[p]);
+        if ((u & mask) == prefix) atomicAdd(&s_hist[oh_bin(u, pass)], 1u);
+    }
+    __syncthreads();
+    unsigned* h = w.hist + pass * OH_BINS;
+    for (int i = threadIdx.x; i < OH_BINS; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&h[i], s_hist[i]);
+}
+
+__global__ void __launch_bounds__(256) ohem_reduce_kernel(float* work, long P) {
+    __shared__ float s_sum[4];
+    __shared__ unsigned s_cnt[4];
+    const OhemWork w = ohem_work(work, P);
+    const float thr = __uint_as_float(w.state[4]);
+    float sum = 0.f;
+    unsigned cnt = 0u;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        if (w.prob[p] < thr) {
+            sum += w.loss[p];
+            ++cnt;
+        }
+    }
+    sum = wave_sum(sum);
+    float cf = wave_sum((float)cnt);   // exact below 2^24 per wave
+    if ((threadIdx.x & 63) == 0) {
+        s_sum[threadIdx.x >> 6] = sum;
+        s_cnt[threadIdx.x >> 6] = (unsigned)cf;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(reinterpret_cast<float*>(&w.state[6]), s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        atomicAdd(&w.state[5], s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+    }
+}
+
+__global__ void ohem_final_kernel(float* work, long P, float loss_weight, float* out) {
+    const OhemWork w = ohem_work(work, P);
+    const unsigned nv = w.state[0], nsel = w.state[5];
+    const float sum = __uint_as_float(w.state[6]);
+    out[0] = nv == 0u ? 0.f : loss_weight * (sum / (float)nsel);   // 0/0 -> NaN like the reference
+    const float eps = 1.1920929e-07f;
+    out[1] = ((float)w.state[1] + eps) * (100.0f / ((float)nv + eps));
+    out[2] = __uint_as_float(w.state[4]);
+    out[3] = (float)nsel;
+}
+
+int ohem_ce_fwd_impl(const float* logits, const long long* target, long long P, int C, float thres,
+                     long long min_kept, float loss_weight, int ignore_label, float* work, float* out,
+                     hipStream_t s) {
+    LEDN_REQUIRE(logits && target && work && out && P > 0 && C > 1 && min_kept >= 1);
+    LEDN_REQUIRE(P < (1LL << 31));
+    const OhemWork w = ohem_work(work, P);
+    if (hipMemsetAsync(w.hist, 0, sizeof(unsigned) * (3 * OH_BINS + 16), s) != hipSuccess) return LEDN_ELAUNCH;
+    const dim3 grid((unsigned)(cdiv(P, 256) < 2048 ? cdiv(P, 256) : 2048));
+    if (C == 2) LEDN_LAUNCH(ohem_prob_kernel<2>, grid, dim3(256), 0, s, logits, target, (long)P, C, ignore_label, work);
+    else LEDN_LAUNCH(ohem_prob_kernel<0>, grid, dim3(256), 0, s, logits, target, (long)P, C, ignore_label, work);
+    LEDN_LAUNCH(ohem_scan_kernel, dim3(1), dim3(256), 0, s, work, (long)P, 0, min_kept, thres);
+    LEDN_LAUNCH(ohem_hist_kernel, grid, dim3(256), 0, s, work, (long)P, 1);
+    LEDN_LAUNCH(ohem_scan_kernel, dim3(1), dim3(256), 0, s, work, (long)P, 1, min_kept, thres);
+    LEDN_LAUNCH(ohem_hist_kernel, grid, dim3(256), 0, s, work, (long)P, 2);
+    LEDN_LAUNCH(ohem_scan_kernel, dim3(1), dim3(256), 0, s, work, (long)P, 2, min_kept, thres);
+    LEDN_LAUNCH(ohem_reduce_kernel, grid, dim3(256), 0, s, work, (long)P);
+    LEDN_LAUNCH(ohem_final_kernel, dim3(1), dim3(1), 0, s, work, (long)P, loss_weight, out);
+    return check_launch();
+}
+
+template <int CT>
+__global__ void __launch_bounds__(256) ohem_bwd_kernel(const float* logits, const long long* target, long P,
+                                                       int C, int ignore_label, const float* work,
+                                                       const float* out, const float* dloss,
+                                                       float loss_weight, float* dlogits) {
+    const float* prob = work;
+    const float thr = out[2];
+    const float coef = dloss[0] * loss_weight / out[3];
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int cc = CT > 0 ? CT : C;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const long long tg = target[p];
+        float* dl = dlogits + p * C;
+        if (tg == ignore_label || !(prob[p] < thr)) {
+#pragma unroll
+            for (int c = 0; c < cc; ++c) dl[c] = 0.f;
+            continue;
+        }
+        const float* lg = logits + p * C;
+        float mx = lg[0];
+#pragma unroll
+        for (int c = 1; c < cc; ++c) mx = fmaxf(mx, lg[c]);
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < cc; ++c) se += __expf(lg[c] - mx);
+        const float inv = 1.f / se;
+#pragma unroll
+        for (int c = 0; c < cc; ++c)
+            dl[c] = coef * (__expf(lg[c] - mx) * inv - (c == (int)tg ? 1.f : 0.f));
+    }
+}
+
+int ohem_ce_bwd_impl(const float* logits, const long long* target, long long P, int C, int ignore_label,
+                     const float* work, const float* out, const float* dloss, float loss_weight,
+                     float* dlogits, hipStream_t s) {
+    LEDN_REQUIRE(logits && target && work && out && dloss && dlogits && P > 0 && C > 1);
+    const dim3 grid((unsigned)(cdiv(P, 256) < 4096 ? cdiv(P, 256) : 4096));
+    if (C == 2)
+        LEDN_LAUNCH(ohem_bwd_kernel<2>, grid, dim3(256), 0, s, logits, target, (long)P, C, ignore_label, work,
+                    out, dloss, loss_weight, dlogits);
+    else
+        LEDN_LAUNCH(ohem_bwd_kernel<0>, grid, dim3(256), 0, s, logits, target, (long)P, C, ignore_label, work,
+                    out, dloss, loss_weight, dlogits);
+    return check_launch();
+}
+
+// ===========================================================================
+// multi-tensor SGD: grid = (chunks, tensors)
+// ===========================================================================
+__global__ void __launch_bounds__(256) sgd_kernel(const ledn_sgd_entry* table, float lr, float momentum,
+                                                  float wd, float gscale) {
+    const ledn_sgd_entry e = table[blockIdx.y];
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < e.n; i += stride) {
+        const float p = e.p[i];
+        const float g = e.g[i] * gscale + wd * p;
+        const float m = momentum * e.m[i] + g;
+        e.m[i] = m;
+        e.p[i] = p - lr * m;
+        e.g[i] = 0.f;
+    }
+}
+
+int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_n, float lr, float momentum,
+                  float weight_decay, float grad_scale, hipStream_t s) {
+    LEDN_REQUIRE(table_dev && n_tensors > 0 && max_n > 0);
+    long chunks = cdiv(max_n, 256 * 8);
+    if (chunks > 64) chunks = 64;
+    LEDN_LAUNCH(sgd_kernel, dim3((unsigned)chunks, (unsigned)n_tensors), dim3(256), 0, s, table_dev, lr,
+                momentum, weight_decay, grad_scale);
+    return check_launch();
+}
+
+}  // namespace ledn

@@ -1,0 +1,844 @@
+// backward.hip -- adjoint kernels of the streaming (HBM-bound) forward ops:
+// BatchNorm/activation, depthwise + SESP pyramid, bilinear, pools, GETB mixing,
+// MFAF gate.  Gradients wrt activations are written in gather form (one store
+// per element, deterministic); only per-channel / per-tap reductions use f32
+// atomics (one per workgroup after an LDS reduction).
+#include "ledn_rt.h"
+
+namespace ledn {
+
+// ===========================================================================
+// BatchNorm (+ residual / gate) + activation backward
+// ===========================================================================
+template <typename TZ, typename TY, int V>
+__device__ __forceinline__ void bn_g(const ledn_bnbwd_desc& d, long off, int c, float* gv, float* xh,
+                                     float* gres, float* dsl) {
+    float z[V], dy[V], r[V];
+    ldv<V>(reinterpret_cast<const TZ*>(d.z) + off, z);
+    ldv<V>(reinterpret_cast<const TY*>(d.dy) + off, dy);
+    if (d.res_mode != LEDN_RES_NONE) ldv<V>(reinterpret_cast<const TY*>(d.res) + off, r);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const float sc = d.scale ? d.scale[c + i] : 1.f, sh = d.shift ? d.shift[c + i] : 0.f;
+        const float v = z[i] * sc + sh;
+        float t = v;
+        if (d.res_mode == LEDN_RES_ADD) t = v + r[i];
+        else if (d.res_mode == LEDN_RES_GATE) t = v * r[i] + r[i];
+        const float sl = d.slope ? d.slope[c + i] : 0.f;
+        const float gt = dy[i] * act_grad(d.act, t, sl);
+        dsl[i] = (d.act == LEDN_ACT_PRELU && t <= 0.f) ? dy[i] * t : 0.f;
+        if (d.res_mode == LEDN_RES_GATE) {
+            gv[i] = gt * r[i];
+            gres[i] = gt * (v + 1.f);
+        } else {
+            gv[i] = gt;
+            gres[i] = gt;
+        }
+        xh[i] = d.bn_mode ? (z[i] - d.mean[c + i]) * d.invstd[c + i] : 0.f;
+    }
+}
+
+template <typename TZ, typename TY, int V>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(ledn_bnbwd_desc d, int pix_per_block) {
+    __shared__ float s_part[3][256 * 4];
+    const int cvn = d.C / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    float a[V], b[V], e[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) a[v] = b[v] = e[v] = 0.f;
+    if (r < rows) {
+        const long p0 = (long)blockIdx.x * pix_per_block;
+        const long p1 = min((long)d.P, p0 + (long)pix_per_block);
+        for (long p = p0 + r; p < p1; p += rows) {
+            float gv[V], xh[V], gres[V], dsl[V];
+            bn_g<TZ, TY, V>(d, p * d.C + cv * V, cv * V, gv, xh, gres, dsl);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                a[v] += gv[v];
+                b[v] = fmaf(gv[v], xh[v], b[v]);
+                e[v] += dsl[v];
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        s_part[0][threadIdx.x * V + v] = a[v];
+        s_part[1][threadIdx.x * V + v] = b[v];
+        s_part[2][threadIdx.x * V + v] = e[v];
+    }
+    __syncthreads();
+    if (threadIdx.x < cvn) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float sa = 0.f, sb = 0.f, se = 0.f;
+            for (int rr = 0; rr < rows; ++rr) {
+                sa += s_part[0][(rr * cvn + cv) * V + v];
+                sb += s_part[1][(rr * cvn + cv) * V + v];
+                se += s_part[2][(rr * cvn + cv) * V + v];
+            }
+            atomicAdd(d.sum_g + cv * V + v, sa);
+            if (d.sum_gx) atomicAdd(d.sum_gx + cv * V + v, sb);
+            if (d.dslope) atomicAdd(d.dslope + cv * V + v, se);
+        }
+    }
+}
+
+template <typename TZ, typename TY, int V>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(ledn_bnbwd_desc d) {
+    const long total = d.P * (d.C / V);
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % (d.C / V)) * V;
+    const long off = idx * V;
+    float gv[V], xh[V], gres[V], dsl[V], dz[V];
+    bn_g<TZ, TY, V>(d, off, c, gv, xh, gres, dsl);
+    const float invn = (float)(1.0 / d.count);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const float sc = d.scale ? d.scale[c + i] : 1.f;
+        dz[i] = d.bn_mode ? sc * (gv[i] - d.sum_g[c + i] * invn - xh[i] * d.sum_gx[c + i] * invn)
+                          : gv[i] * sc;
+    }
+    stv<V>(reinterpret_cast<TZ*>(d.dz) + off, dz);
+    if (d.dres) stv<V>(reinterpret_cast<TY*>(d.dres) + off, gres);
+}
+
+static int bnbwd_validate(const ledn_bnbwd_desc& d, bool apply) {
+    LEDN_REQUIRE(d.z && d.dy && d.P > 0 && d.C > 0);
+    LEDN_REQUIRE((d.scale == nullptr) == (d.shift == nullptr));
+    LEDN_REQUIRE(d.res_mode == LEDN_RES_NONE || d.res != nullptr);
+    LEDN_REQUIRE(d.act != LEDN_ACT_PRELU || d.slope != nullptr);
+    LEDN_REQUIRE(!d.bn_mode || (d.mean && d.invstd && d.scale && d.sum_g && d.sum_gx && d.count > 0));
+    if (apply) LEDN_REQUIRE(d.dz != nullptr);
+    else LEDN_REQUIRE(d.sum_g != nullptr);
+    const int V = d.C % 4 == 0 ? 4 : 1;
+    LEDN_REQUIRE(d.C / V <= 256);
+    return LEDN_OK;
+}
+
+#define LEDN_BNB_DISPATCH(KERNEL, ...)                                                                   \
+    do {                                                                                                 \
+        const bool v4 = d.C % 4 == 0;                                                                    \
+        if (d.dtype_z == LEDN_F32 && d.dtype_y == LEDN_F32) {                                            \
+            if (v4) LEDN_LAUNCH((KERNEL<float, float, 4>), grid, dim3(256), 0, s, __VA_ARGS__);          \
+            else LEDN_LAUNCH((KERNEL<float, float, 1>), grid, dim3(256), 0, s, __VA_ARGS__);             \
+        } else if (d.dtype_z == LEDN_BF16 && d.dtype_y == LEDN_BF16) {                                   \
+            if (v4) LEDN_LAUNCH((KERNEL<bf16_t, bf16_t, 4>), grid, dim3(256), 0, s, __VA_ARGS__);        \
+            else LEDN_LAUNCH((KERNEL<bf16_t, bf16_t, 1>), grid, dim3(256), 0, s, __VA_ARGS__);           \
+        } else if (d.dtype_z == LEDN_BF16 && d.dtype_y == LEDN_F32) {                                    \
+            if (v4) LEDN_LAUNCH((KERNEL<bf16_t, float, 4>), grid, dim3(256), 0, s, __VA_ARGS__);         \
+            else LEDN_LAUNCH((KERNEL<bf16_t, float, 1>), grid, dim3(256), 0, s, __VA_ARGS__);            \
+        } else if (d.dtype_z == LEDN_F32 && d.dtype_y == LEDN_BF16) {                                    \
+            if (v4) LEDN_LAUNCH((KERNEL<float, bf16_t, 4>), grid, dim3(256), 0, s, __VA_ARGS__);         \
+            else LEDN_LAUNCH((KERNEL<float, bf16_t, 1>), grid, dim3(256), 0, s, __VA_ARGS__);            \
+        } else return LEDN_EINVAL;                                                                       \
+    } while (0)
+
+int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
+    const int rc = bnbwd_validate(d, false);
+    if (rc != LEDN_OK) return rc;
+    long ppb = cdiv(d.P, 2048);
+    if (ppb < 256) ppb = 256;
+    const dim3 grid((unsigned)cdiv(d.P, ppb));
+    LEDN_BNB_DISPATCH(bn_bwd_reduce_kernel, d, (int)ppb);
+    return check_launch();
+}
+
+int bn_act_bwd_apply_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
+    const int rc = bnbwd_validate(d, true);
+    if (rc != LEDN_OK) return rc;
+    const long total = d.P * (d.C % 4 == 0 ? d.C / 4 : d.C);
+    const dim3 grid((unsigned)cdiv(total, 256));
+    LEDN_BNB_DISPATCH(bn_bwd_apply_kernel, d);
+    return check_launch();
+}
+
+// ===========================================================================
+// depthwise convolution backward
+// ===========================================================================
+template <typename T, int V>
+__global__ void __launch_bounds__(256) dw_bwd_data_kernel(ledn_dwbwd_desc d) {
+    const int cv = d.C / V;
+    const long total = (long)d.N * d.H * d.W * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int x = (int)(pix % d.W);
+    const int y = (int)((pix / d.W) % d.H);
+    const int n = (int)(pix / ((long)d.W * d.H));
+    const int dl = d.dil[c / d.group_size];
+    const int padh = d.pad >= 0 ? d.pad : dl * (d.KH - 1) / 2;
+    const int padw = d.pad >= 0 ? d.pad : dl * (d.KW - 1) / 2;
+    const T* dz = reinterpret_cast<const T*>(d.dz);
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    // virtual source positions: (y,x) itself plus the reflected row H / column W it feeds
+    const int ny = (d.ext1 && y == d.H - 2) ? 2 : 1, nx = (d.ext1 && x == d.W - 2) ? 2 : 1;
+    for (int iy = 0; iy < ny; ++iy) {
+        const int yy = iy ? d.H : y;
+        for (int ix = 0; ix < nx; ++ix) {
+            const int xx = ix ? d.W : x;
+            for (int kh = 0; kh < d.KH; ++kh) {
+                const int th = yy + padh - kh * dl;
+                if (th < 0 || th % d.stride) continue;
+                const int ho = th / d.stride;
+                if (ho >= d.Ho) continue;
+                for (int kw = 0; kw < d.KW; ++kw) {
+                    const int tw = xx + padw - kw * dl;
+                    if (tw < 0 || tw % d.stride) continue;
+                    const int wo = tw / d.stride;
+                    if (wo >= d.Wo) continue;
+                    float g[V], wv[V];
+                    ldv<V>(dz + (((long)n * d.Ho + ho) * d.Wo + wo) * d.C + c, g);
+                    ldv<V>(d.w + (long)(kh * d.KW + kw) * d.C + c, wv);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[v] = fmaf(g[v], wv[v], acc[v]);
+                }
+            }
+        }
+    }
+    if (d.add) {
+        float a[V];
+        ldv<V>(reinterpret_cast<const T*>(d.add) + pix * d.C + c, a);
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] += a[v];
+    }
+    stv<V>(reinterpret_cast<T*>(d.dx) + pix * d.C + c, acc);
+}
+
+// one workgroup = one tap x a chunk of output pixels; thread (row r, channel vector cv)
+template <typename T, int V>
+__global__ void __launch_bounds__(256) dw_bwd_weight_kernel(ledn_dwbwd_desc d, int pix_per_block) {
+    __shared__ float s_part[256 * 4];
+    const int tap = blockIdx.y;
+    const int kh = tap / d.KW, kw = tap % d.KW;
+    const int cvn = d.C / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    const int c = cv * V;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    if (r < rows) {
+        const int dl = d.dil[c / d.group_size];
+        const int padh = d.pad >= 0 ? d.pad : dl * (d.KH - 1) / 2;
+        const int padw = d.pad >= 0 ? d.pad : dl * (d.KW - 1) / 2;
+        const int Hx = d.H + (d.ext1 ? 1 : 0), Wx = d.W + (d.ext1 ? 1 : 0);
+        const T* x = reinterpret_cast<const T*>(d.x);
+        const T* dz = reinterpret_cast<const T*>(d.dz);
+        const long npix = (long)d.N * d.Ho * d.Wo;
+        const long p0 = (long)blockIdx.x * pix_per_block;
+        const long p1 = min(npix, p0 + (long)pix_per_block);
+        for (long p = p0 + r; p < p1; p += rows) {
+            const int wo = (int)(p % d.Wo);
+            const int ho = (int)((p / d.Wo) % d.Ho);
+            const int n = (int)(p / ((long)d.Wo * d.Ho));
+            int hi = ho * d.stride - padh + kh * dl, wi = wo * d.stride - padw + kw * dl;
+            if (hi < 0 || hi >= Hx || wi < 0 || wi >= Wx) continue;
+            if (hi == d.H) hi = d.H - 2;
+            if (wi == d.W) wi = d.W - 2;
+            float xv[V], g[V];
+            ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.C + c, xv);
+            ldv<V>(dz + p * d.C + c, g);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fmaf(xv[v], g[v], acc[v]);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) s_part[threadIdx.x * V + v] = acc[v];
+    __syncthreads();
+    if (threadIdx.x < cvn) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float t = 0.f;
+            for (int rr = 0; rr < rows; ++rr) t += s_part[(rr * cvn + cv) * V + v];
+            atomicAdd(d.dw + (long)tap * d.C + c + v, t);
+        }
+    }
+}
+
+static int dwbwd_validate(const ledn_dwbwd_desc& d) {
+    LEDN_REQUIRE(d.dz && d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.Ho > 0 && d.Wo > 0);
+    LEDN_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.group_size > 0 && d.C <= 4 * d.group_size);
+    LEDN_REQUIRE(!d.ext1 || (d.H >= 2 && d.W >= 2));
+    for (int g = 0; g * d.group_size < d.C; ++g) {
+        LEDN_REQUIRE(d.dil[g] > 0);
+        const int Hx = d.H + (d.ext1 ? 1 : 0), Wx = d.W + (d.ext1 ? 1 : 0);
+        const int ph = d.pad >= 0 ? d.pad : d.dil[g] * (d.KH - 1) / 2;
+        const int pw = d.pad >= 0 ? d.pad : d.dil[g] * (d.KW - 1) / 2;
+        LEDN_REQUIRE(d.Ho == (Hx + 2 * ph - ((d.KH - 1) * d.dil[g] + 1)) / d.stride + 1);
+        LEDN_REQUIRE(d.Wo == (Wx + 2 * pw - ((d.KW - 1) * d.dil[g] + 1)) / d.stride + 1);
+    }
+    return LEDN_OK;
+}
+
+int dw_bwd_data_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
+    int rc = dwbwd_validate(d);
+    if (rc != LEDN_OK) return rc;
+    LEDN_REQUIRE(d.w && d.dx);
+    const bool v4 = d.C % 4 == 0 && d.group_size % 4 == 0;
+    const long total = (long)d.N * d.H * d.W * (v4 ? d.C / 4 : d.C);
+    const dim3 grid((unsigned)cdiv(total, 256));
+#define LEDN_K(T)                                                                     \
+    do {                                                                              \
+        if (v4) LEDN_LAUNCH((dw_bwd_data_kernel<T, 4>), grid, dim3(256), 0, s, d);    \
+        else LEDN_LAUNCH((dw_bwd_data_kernel<T, 1>), grid, dim3(256), 0, s, d);       \
+    } while (0)
+    if (d.dtype == LEDN_F32) LEDN_K(float);
+    else if (d.dtype == LEDN_BF16) LEDN_K(bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_K
+    return check_launch();
+}
+
+int dw_bwd_weight_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
+    int rc = dwbwd_validate(d);
+    if (rc != LEDN_OK) return rc;
+    LEDN_REQUIRE(d.x && d.dw);
+    const bool v4 = d.C % 4 == 0 && d.group_size % 4 == 0;
+    LEDN_REQUIRE((v4 ? d.C / 4 : d.C) <= 256);
+    const long npix = (long)d.N * d.Ho * d.Wo;
+    long ppb = cdiv(npix * d.KH * d.KW, 2048);
+    if (ppb < 128) ppb = 128;
+    const dim3 grid((unsigned)cdiv(npix, ppb), (unsigned)(d.KH * d.KW));
+#define LEDN_K(T)                                                                                 \
+    do {                                                                                          \
+        if (v4) LEDN_LAUNCH((dw_bwd_weight_kernel<T, 4>), grid, dim3(256), 0, s, d, (int)ppb);    \
+        else LEDN_LAUNCH((dw_bwd_weight_kernel<T, 1>), grid, dim3(256), 0, s, d, (int)ppb);       \
+    } while (0)
+    if (d.dtype == LEDN_F32) LEDN_K(float);
+    else if (d.dtype == LEDN_BF16) LEDN_K(bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_K
+    return check_launch();
+}
+
+// ===========================================================================
+// SESP pyramid backward
+// ===========================================================================
+template <typename T, int V>
+__global__ void __launch_bounds__(256) pyr_suffix_kernel(const T* dy, T* g, long npix, int n) {
+    const int cv = n / V;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * cv) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    float run[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) run[v] = 0.f;
+    for (int b = 3; b >= 0; --b) {
+        float t[V];
+        ldv<V>(dy + pix * 4L * n + (long)b * n + c, t);
+#pragma unroll
+        for (int v = 0; v < V; ++v) run[v] += t[v];
+        stv<V>(g + pix * 4L * n + (long)b * n + c, run);
+    }
+}
+
+template <typename T, int V>
+__global__ void __launch_bounds__(256) pyr_bwd_data_kernel(ledn_pyrbwd_desc d) {
+    const int cv = d.n / V;
+    const long total = (long)d.N * d.H * d.W * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int x = (int)(pix % d.W);
+    const int y = (int)((pix / d.W) % d.H);
+    const int n = (int)(pix / ((long)d.W * d.H));
+    const T* g = reinterpret_cast<const T*>(d.gsum);
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    for (int b = 0; b < 4; ++b) {
+        const int dl = d.dil[b];
+        for (int kh = 0; kh < 3; ++kh) {
+            const int th = y - (kh - 1) * dl;
+            if (th < 0 || th % d.stride) continue;
+            const int ho = th / d.stride;
+            if (ho >= d.Ho) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tw = x - (kw - 1) * dl;
+                if (tw < 0 || tw % d.stride) continue;
+                const int wo = tw / d.stride;
+                if (wo >= d.Wo) continue;
+                float gv[V], wv[V];
+                ldv<V>(g + (((long)n * d.Ho + ho) * d.Wo + wo) * 4L * d.n + (long)b * d.n + c, gv);
+                ldv<V>(d.w + (long)((b * 3 + kh) * 3 + kw) * d.n + c, wv);
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[v] = fmaf(gv[v], wv[v], acc[v]);
+            }
+        }
+    }
+    stv<V>(reinterpret_cast<T*>(d.dx) + pix * d.n + c, acc);
+}
+
+// blockIdx.y = branch*9 + tap
+template <typename T, int V>
+__global__ void __launch_bounds__(256) pyr_bwd_weight_kernel(ledn_pyrbwd_desc d, int pix_per_block) {
+    __shared__ float s_part[256 * 4];
+    const int b = blockIdx.y / 9, tap = blockIdx.y % 9;
+    const int kh = tap / 3, kw = tap % 3;
+    const int dl = d.dil[b];
+    const int cvn = d.n / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    const int c = cv * V;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    if (r < rows) {
+        const T* x = reinterpret_cast<const T*>(d.x);
+        const T* g = reinterpret_cast<const T*>(d.gsum);
+        const long npix = (long)d.N * d.Ho * d.Wo;
+        const long p0 = (long)blockIdx.x * pix_per_block;
+        const long p1 = min(npix, p0 + (long)pix_per_block);
+        for (long p = p0 + r; p < p1; p += rows) {
+            const int wo = (int)(p % d.Wo);
+            const int ho = (int)((p / d.Wo) % d.Ho);
+            const int n = (int)(p / ((long)d.Wo * d.Ho));
+            const int hi = ho * d.stride + (kh - 1) * dl, wi = wo * d.stride + (kw - 1) * dl;
+            if (hi < 0 || hi >= d.H || wi < 0 || wi >= d.W) continue;
+            float xv[V], gv[V];
+            ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.n + c, xv);
+            ldv<V>(g + p * 4L * d.n + (long)b * d.n + c, gv);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fmaf(xv[v], gv[v], acc[v]);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) s_part[threadIdx.x * V + v] = acc[v];
+    __syncthreads();
+    if (threadIdx.x < cvn) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float t = 0.f;
+            for (int rr = 0; rr < rows; ++rr) t += s_part[(rr * cvn + cv) * V + v];
+            atomicAdd(d.dw + (long)blockIdx.y * d.n + c + v, t);
+        }
+    }
+}
+
+static int pyrbwd_validate(const ledn_pyrbwd_desc& d) {
+    LEDN_REQUIRE(d.gsum && d.N > 0 && d.H > 0 && d.W > 0 && d.n > 0 && (d.stride == 1 || d.stride == 2));
+    LEDN_REQUIRE(d.Ho == (d.H - 1) / d.stride + 1 && d.Wo == (d.W - 1) / d.stride + 1);
+    for (int b = 0; b < 4; ++b) LEDN_REQUIRE(d.dil[b] > 0);
+    LEDN_REQUIRE(d.dtype == LEDN_F32 || d.dtype == LEDN_BF16);
+    return LEDN_OK;
+}
+
+int pyr_bwd_data_impl(const ledn_pyrbwd_desc& d, hipStream_t s) {
+    int rc = pyrbwd_validate(d);
+    if (rc != LEDN_OK) return rc;
+    LEDN_REQUIRE(d.dy && d.w && d.dx);
+    const bool v4 = d.n % 4 == 0;
+    const int cvn = v4 ? d.n / 4 : d.n;
+    const long npo = (long)d.N * d.Ho * d.Wo;
+    const dim3 g1((unsigned)cdiv(npo * cvn, 256)), g2((unsigned)cdiv((long)d.N * d.H * d.W * cvn, 256));
+#define LEDN_K(T)                                                                                          \
+    do {                                                                                                   \
+        if (v4) {                                                                                          \
+            LEDN_LAUNCH((pyr_suffix_kernel<T, 4>), g1, dim3(256), 0, s, (const T*)d.dy, (T*)d.gsum, npo, d.n); \
+            LEDN_LAUNCH((pyr_bwd_data_kernel<T, 4>), g2, dim3(256), 0, s, d);                              \
+        } else {                                                                                           \
+            LEDN_LAUNCH((pyr_suffix_kernel<T, 1>), g1, dim3(256), 0, s, (const T*)d.dy, (T*)d.gsum, npo, d.n); \
+            LEDN_LAUNCH((pyr_bwd_data_kernel<T, 1>), g2, dim3(256), 0, s, d);                              \
+        }                                                                                                  \
+    } while (0)
+    if (d.dtype == LEDN_F32) LEDN_K(float);
+    else LEDN_K(bf16_t);
+#undef LEDN_K
+    return check_launch();
+}
+
+int pyr_bwd_weight_impl(const ledn_pyrbwd_desc& d, hipStream_t s) {
+    int rc = pyrbwd_validate(d);
+    if (rc != LEDN_OK) return rc;
+    LEDN_REQUIRE(d.x && d.dw);
+    const bool v4 = d.n % 4 == 0;
+    LEDN_REQUIRE((v4 ? d.n / 4 : d.n) <= 256);
+    const long npix = (long)d.N * d.Ho * d.Wo;
+    long ppb = cdiv(npix * 36, 2048);
+    if (ppb < 128) ppb = 128;
+    const dim3 grid((unsigned)cdiv(npix, ppb), 36u);
+#define LEDN_K(T)                                                                                  \
+    do {                                                                                           \
+        if (v4) LEDN_LAUNCH((pyr_bwd_weight_kernel<T, 4>), grid, dim3(256), 0, s, d, (int)ppb);    \
+        else LEDN_LAUNCH((pyr_bwd_weight_kernel<T, 1>), grid, dim3(256), 0, s, d, (int)ppb);       \
+    } while (0)
+    if (d.dtype == LEDN_F32) LEDN_K(float);
+    else LEDN_K(bf16_t);
+#undef LEDN_K
+    return check_launch();
+}
+
+// ===========================================================================
+// bilinear backward (gather): dx[src] = sum over destinations that read src
+// ===========================================================================
+struct LerpB {
+    int i0, i1;
+    float w0, w1;
+};
+__device__ __forceinline__ LerpB lerp_coord_b(int dst, int in, int out) {
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    LerpB l;
+    l.i0 = (int)src;
+    if (l.i0 > in - 1) l.i0 = in - 1;
+    l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+__device__ __forceinline__ void dst_range(int s, int in, int out, int& lo, int& hi) {
+    // destinations d whose source coordinate lies in (s-1, s+1): d in ((s-0.5)/scale-0.5, (s+1.5)/scale-0.5)
+    const float inv = (float)out / (float)in;
+    lo = (int)floorf(((float)s - 0.5f) * inv - 0.5f) - 1;
+    hi = (int)ceilf(((float)s + 1.5f) * inv - 0.5f) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+    if (s == 0) lo = 0;              // clamped sources (src < 0 -> 0)
+}
+
+template <typename TY, typename TX, int V>
+__global__ void __launch_bounds__(256) bilinear_bwd_kernel(const TY* dy, TX* dx, int N, int H, int W, int C,
+                                                           int Ho, int Wo) {
+    const int cv = C / V;
+    const long total = (long)N * H * W * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long)W * H));
+    int ylo, yhi, xlo, xhi;
+    dst_range(y, H, Ho, ylo, yhi);
+    dst_range(x, W, Wo, xlo, xhi);
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    for (int dyy = ylo; dyy <= yhi; ++dyy) {
+        const LerpB ly = lerp_coord_b(dyy, H, Ho);
+        const float wy = (ly.i0 == y ? ly.w0 : 0.f) + (ly.i1 == y ? ly.w1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int dxx = xlo; dxx <= xhi; ++dxx) {
+            const LerpB lx = lerp_coord_b(dxx, W, Wo);
+            const float wx = (lx.i0 == x ? lx.w0 : 0.f) + (lx.i1 == x ? lx.w1 : 0.f);
+            if (wx == 0.f) continue;
+            float g[V];
+            ldv<V>(dy + (((long)n * Ho + dyy) * Wo + dxx) * C + c, g);
+            const float wgt = wy * wx;
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fmaf(wgt, g[v], acc[v]);
+        }
+    }
+    stv<V>(dx + pix * C + c, acc);
+}
+
+int bilinear_bwd_impl(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int dtype_dy,
+                      int dtype_dx, hipStream_t s) {
+    LEDN_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0);
+    const bool v4 = C % 4 == 0;
+    const bool v2 = !v4 && C % 2 == 0;
+    const long total = (long)N * H * W * (v4 ? C / 4 : (v2 ? C / 2 : C));
+    const dim3 grid((unsigned)cdiv(total, 256));
+#define LEDN_K(TY, TX)                                                                                          \
+    do {                                                                                                        \
+        if (v4) LEDN_LAUNCH((bilinear_bwd_kernel<TY, TX, 4>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C, Ho, Wo); \
+        else if (v2) LEDN_LAUNCH((bilinear_bwd_kernel<TY, TX, 2>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C, Ho, Wo); \
+        else LEDN_LAUNCH((bilinear_bwd_kernel<TY, TX, 1>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C, Ho, Wo); \
+    } while (0)
+    if (dtype_dy == LEDN_F32 && dtype_dx == LEDN_F32) LEDN_K(float, float);
+    else if (dtype_dy == LEDN_BF16 && dtype_dx == LEDN_BF16) LEDN_K(bf16_t, bf16_t);
+    else if (dtype_dy == LEDN_F32 && dtype_dx == LEDN_BF16) LEDN_K(float, bf16_t);
+    else if (dtype_dy == LEDN_BF16 && dtype_dx == LEDN_F32) LEDN_K(bf16_t, float);
+    else return LEDN_EINVAL;
+#undef LEDN_K
+    return check_launch();
+}
+
+// ===========================================================================
+// 3x3/s2 average pool backward:  dx[y,x] = add + 1/9 * sum_{taps} dy[(y+1-kh)/2, (x+1-kw)/2]
+// ===========================================================================
+template <typename T, int V>
+__global__ void __launch_bounds__(256) avgpool3x3s2_bwd_kernel(const T* dy, const T* add, T* dx, int N, int H,
+                                                               int W, int C, int Ho, int Wo) {
+    const int cv = C / V;
+    const long total = (long)N * H * W * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long)W * H));
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int th = y + 1 - kh;
+        if (th < 0 || (th & 1)) continue;
+        const int ho = th >> 1;
+        if (ho >= Ho) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int tw = x + 1 - kw;
+            if (tw < 0 || (tw & 1)) continue;
+            const int wo = tw >> 1;
+            if (wo >= Wo) continue;
+            float g[V];
+            ldv<V>(dy + (((long)n * Ho + ho) * Wo + wo) * C + c, g);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] += g[v];
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] *= (1.f / 9.f);
+    if (add) {
+        float a[V];
+        ldv<V>(add + pix * C + c, a);
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] += a[v];
+    }
+    stv<V>(dx + pix * C + c, acc);
+}
+
+int avgpool3x3s2_bwd_impl(const void* dy, const void* add, void* dx, int N, int H, int W, int C, int Ho,
+                          int Wo, int dtype, hipStream_t s) {
+    LEDN_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0);
+    LEDN_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1);
+    const bool v4 = C % 4 == 0;
+    const long total = (long)N * H * W * (v4 ? C / 4 : C);
+    const dim3 grid((unsigned)cdiv(total, 256));
+#define LEDN_K(T)                                                                                            \
+    do {                                                                                                     \
+        if (v4) LEDN_LAUNCH((avgpool3x3s2_bwd_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)dy, (const T*)add, (T*)dx, N, H, W, C, Ho, Wo); \
+        else LEDN_LAUNCH((avgpool3x3s2_bwd_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)dy, (const T*)add, (T*)dx, N, H, W, C, Ho, Wo);    \
+    } while (0)
+    if (dtype == LEDN_F32) LEDN_K(float);
+    else if (dtype == LEDN_BF16) LEDN_K(bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_K
+    return check_launch();
+}
+
+// ===========================================================================
+// GETB mixing backward:  da[y,x] = 1/ws * ( sum_{y' in [y-ws/2, y+ws/2-1]} dout[y',x]
+//     + [y == H-2] sum_{y' in [H-ws/2, H-1]} dout[y',x] + same along x )
+// (forward window of output y' covers rows y'-p .. y'-p+ws-1, p = ws/2-1; row H is the
+//  reflection of row H-2.)
+// ===========================================================================
+template <typename T, int V>
+__global__ void __launch_bounds__(256) getb_pool_bwd_kernel(const T* dout, T* da, int N, int H, int W, int C,
+                                                            int ws) {
+    const int cv = C / V;
+    const long total = (long)N * H * W * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long)W * H));
+    const T* base = dout + (long)n * H * W * C + c;
+    const int p = ws / 2 - 1;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    // rows: source row r feeds outputs y' with y'-p <= r <= y'-p+ws-1  <=>  r-ws+1+p <= y' <= r+p
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && y != H - 2) break;
+        const int r = pass ? H : y;
+        for (int yo = r - ws + 1 + p; yo <= r + p; ++yo) {
+            if (yo < 0 || yo >= H) continue;
+            float t[V];
+            ldv<V>(base + ((long)yo * W + x) * C, t);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] += t[v];
+        }
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && x != W - 2) break;
+        const int q = pass ? W : x;
+        for (int xo = q - ws + 1 + p; xo <= q + p; ++xo) {
+            if (xo < 0 || xo >= W) continue;
+            float t[V];
+            ldv<V>(base + ((long)y * W + xo) * C, t);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] += t[v];
+        }
+    }
+    const float inv = 1.f / (float)ws;
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] *= inv;
+    stv<V>(da + pix * C + c, acc);
+}
+
+int getb_pool_bwd_impl(const void* dout, void* da, int N, int H, int W, int C, int ws, int dtype,
+                       hipStream_t s) {
+    LEDN_REQUIRE(dout && da && N > 0 && H >= 2 && W >= 2 && C > 0 && ws >= 2 && C % 4 == 0);
+    const long total = (long)N * H * W * (C / 4);
+    const dim3 grid((unsigned)cdiv(total, 256));
+    if (dtype == LEDN_F32)
+        LEDN_LAUNCH((getb_pool_bwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)dout, (float*)da, N,
+                    H, W, C, ws);
+    else if (dtype == LEDN_BF16)
+        LEDN_LAUNCH((getb_pool_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)dout,
+                    (bf16_t*)da, N, H, W, C, ws);
+    else return LEDN_EINVAL;
+    return check_launch();
+}
+
+// ===========================================================================
+// MFAF gate backward + combine
+// ===========================================================================
+template <typename T, int V>
+__global__ void __launch_bounds__(256) mfaf_gate_bwd_kernel(ledn_mfafbwd_desc d) {
+    const int cv = d.C / V;
+    const long total = (long)d.N * d.H * d.W * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int x = (int)(pix % d.W);
+    const int y = (int)((pix / d.W) % d.H);
+    const int n = (int)(pix / ((long)d.W * d.H));
+    float s[V], t[V];
+    ldv<V>(reinterpret_cast<const T*>(d.xl) + pix * d.C + c, t);
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = t[v] * d.scale[0][c + v] + d.shift[0][c + v];
+    long cell[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int S = d.ctx_size[k];
+        int sy = (int)((float)y * ((float)S / (float)d.H));
+        int sx = (int)((float)x * ((float)S / (float)d.W));
+        if (sy > S - 1) sy = S - 1;
+        if (sx > S - 1) sx = S - 1;
+        cell[k] = (((long)n * S + sy) * S + sx) * d.C + c;
+        ldv<V>(d.ctx[k] + cell[k], t);
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[v] += t[v] * d.scale[k + 1][c + v] + d.shift[k + 1][c + v];
+    }
+    float xv[V], rv[V], g[V], dxv[V], drv[V], dsv[V];
+    ldv<V>(reinterpret_cast<const T*>(d.x) + pix * d.C + c, xv);
+    ldv<V>(reinterpret_cast<const T*>(d.r) + pix * d.C + c, rv);
+    ldv<V>(reinterpret_cast<const T*>(d.dout) + pix * d.C + c, g);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const float w = 1.f / (1.f + __expf(-s[v]));
+        float go = g[v];
+        if (d.act == LEDN_ACT_RELU) {
+            const float o = 2.f * xv[v] * w + 2.f * rv[v] * (1.f - w);
+            if (o <= 0.f) go = 0.f;
+        }
+        dxv[v] = 2.f * w * go;
+        drv[v] = 2.f * (1.f - w) * go;
+        dsv[v] = 2.f * (xv[v] - rv[v]) * go * w * (1.f - w);
+    }
+    stv<V>(reinterpret_cast<T*>(d.dx) + pix * d.C + c, dxv);
+    stv<V>(reinterpret_cast<T*>(d.dr) + pix * d.C + c, drv);
+    stv<V>(reinterpret_cast<T*>(d.ds) + pix * d.C + c, dsv);
+    // context gradients: sum of ds over the pixels of each cell (the value stored to ds
+    // is what the local branch sees; the same un-rounded ds goes to the cells)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int v = 0; v < V; ++v) atomicAdd(d.dctx[k] + cell[k] + v, dsv[v]);
+}
+
+int mfaf_gate_bwd_impl(const ledn_mfafbwd_desc& d, hipStream_t s) {
+    LEDN_REQUIRE(d.x && d.r && d.xl && d.dout && d.dx && d.dr && d.ds);
+    LEDN_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.C % 4 == 0);
+    for (int k = 0; k < 4; ++k) LEDN_REQUIRE(d.ctx[k] && d.dctx[k] && d.ctx_size[k] > 0);
+    for (int k = 0; k < 5; ++k) LEDN_REQUIRE(d.scale[k] && d.shift[k]);
+    const long total = (long)d.N * d.H * d.W * (d.C / 4);
+    const dim3 grid((unsigned)cdiv(total, 256));
+    if (d.dtype == LEDN_F32) LEDN_LAUNCH((mfaf_gate_bwd_kernel<float, 4>), grid, dim3(256), 0, s, d);
+    else if (d.dtype == LEDN_BF16) LEDN_LAUNCH((mfaf_gate_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, d);
+    else return LEDN_EINVAL;
+    return check_launch();
+}
+
+struct PoolSet {
+    const float* p[4];
+    int S[4];
+    int n;
+};
+
+template <typename T, int V>
+__global__ void __launch_bounds__(256) mfaf_combine_kernel(T* dx, T* dr, const T* dxl, PoolSet ps, int N, int H,
+                                                           int W, int C) {
+    const int cv = C / V;
+    const long total = (long)N * H * W * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long)W * H));
+    float a[V];
+    if (dxl) ldv<V>(dxl + pix * C + c, a);
+    else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) a[v] = 0.f;
+    }
+    for (int k = 0; k < ps.n; ++k) {
+        const int S = ps.S[k];
+        // adaptive windows [floor(i*H/S), ceil((i+1)*H/S)) may overlap: visit every cell containing (y,x)
+        int oy0 = (y * S) / H - 1, ox0 = (x * S) / W - 1;
+        for (int oy = max(oy0, 0); oy <= min(oy0 + 2, S - 1); ++oy) {
+            const int h0 = (oy * H) / S, h1 = ((oy + 1) * H + S - 1) / S;
+            if (y < h0 || y >= h1) continue;
+            for (int ox = max(ox0, 0); ox <= min(ox0 + 2, S - 1); ++ox) {
+                const int w0 = (ox * W) / S, w1 = ((ox + 1) * W + S - 1) / S;
+                if (x < w0 || x >= w1) continue;
+                const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+                float t[V];
+                ldv<V>(ps.p[k] + (((long)n * S + oy) * S + ox) * C + c, t);
+#pragma unroll
+                for (int v = 0; v < V; ++v) a[v] = fmaf(t[v], inv, a[v]);
+            }
+        }
+    }
+    float u[V];
+    ldv<V>(dx + pix * C + c, u);
+#pragma unroll
+    for (int v = 0; v < V; ++v) u[v] += a[v];
+    stv<V>(dx + pix * C + c, u);
+    if (dr) {
+        ldv<V>(dr + pix * C + c, u);
+#pragma unroll
+        for (int v = 0; v < V; ++v) u[v] += a[v];
+        stv<V>(dr + pix * C + c, u);
+    }
+}
+
+int mfaf_bwd_combine_impl(void* dx, void* dr, const void* dxl, const float* const* dpool, const int* sizes,
+                          int npool, int N, int H, int W, int C, int dtype, hipStream_t s) {
+    LEDN_REQUIRE(dx && npool >= 0 && npool <= 4 && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    PoolSet ps;
+    ps.n = npool;
+    for (int k = 0; k < npool; ++k) {
+        LEDN_REQUIRE(dpool[k] && sizes[k] > 0);
+        ps.p[k] = dpool[k];
+        ps.S[k] = sizes[k];
+    }
+    const long total = (long)N * H * W * (C / 4);
+    const dim3 grid((unsigned)cdiv(total, 256));
+    if (dtype == LEDN_F32)
+        LEDN_LAUNCH((mfaf_combine_kernel<float, 4>), grid, dim3(256), 0, s, (float*)dx, (float*)dr,
+                    (const float*)dxl, ps, N, H, W, C);
+    else if (dtype == LEDN_BF16)
+        LEDN_LAUNCH((mfaf_combine_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (bf16_t*)dx, (bf16_t*)dr,
+                    (const bf16_t*)dxl, ps, N, H, W, C);
+    else return LEDN_EINVAL;
+    return check_launch();
+}
+
+}  // namespace ledn

@@ -30,6 +30,32 @@ int getb_pool_impl(const void* a, const void* local, void* out, int N, int H, in
 int mfaf_gate_impl(const ledn_mfaf_desc& d, hipStream_t s);
 int seam_edge_impl(const float* seg, float* edge, float* scratch, int N, int h, int w, int kth, float thr,
                    float final_thr, hipStream_t s);
+int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d, hipStream_t s);
+int bn_act_bwd_apply_impl(const ledn_bnbwd_desc& d, hipStream_t s);
+int dw_bwd_data_impl(const ledn_dwbwd_desc& d, hipStream_t s);
+int dw_bwd_weight_impl(const ledn_dwbwd_desc& d, hipStream_t s);
+int pyr_bwd_data_impl(const ledn_pyrbwd_desc& d, hipStream_t s);
+int pyr_bwd_weight_impl(const ledn_pyrbwd_desc& d, hipStream_t s);
+int bilinear_bwd_impl(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int dtype_dy,
+                      int dtype_dx, hipStream_t s);
+int avgpool3x3s2_bwd_impl(const void* dy, const void* add, void* dx, int N, int H, int W, int C, int Ho,
+                          int Wo, int dtype, hipStream_t s);
+int window_attn_bwd_impl(const void* qkv, const float* biasT, const void* dout, float* dqkv, float* dbiasT,
+                         int N, int H, int W, int C, int heads, int ws, int dtype, hipStream_t s);
+int getb_pool_bwd_impl(const void* dout, void* da, int N, int H, int W, int C, int ws, int dtype,
+                       hipStream_t s);
+int mfaf_gate_bwd_impl(const ledn_mfafbwd_desc& d, hipStream_t s);
+int mfaf_bwd_combine_impl(void* dx, void* dr, const void* dxl, const float* const* dpool, const int* sizes,
+                          int npool, int N, int H, int W, int C, int dtype, hipStream_t s);
+long long ohem_work_floats(long long P);
+int ohem_ce_fwd_impl(const float* logits, const long long* target, long long P, int C, float thres,
+                     long long min_kept, float loss_weight, int ignore_label, float* work, float* out,
+                     hipStream_t s);
+int ohem_ce_bwd_impl(const float* logits, const long long* target, long long P, int C, int ignore_label,
+                     const float* work, const float* out, const float* dloss, float loss_weight,
+                     float* dlogits, hipStream_t s);
+int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_n, float lr, float momentum,
+                  float weight_decay, float grad_scale, hipStream_t s);
 }  // namespace ledn
 
 using namespace ledn;
@@ -97,6 +123,65 @@ int ledn_mfaf_gate(const ledn_mfaf_desc* d, void* stream) { return d ? mfaf_gate
 int ledn_seam_edge(const float* seg, float* edge, float* scratch, int N, int h, int w, int kth, float thr,
                    float final_thr, void* stream) {
     return seam_edge_impl(seg, edge, scratch, N, h, w, kth, thr, final_thr, S(stream));
+}
+
+int ledn_bn_act_bwd_reduce(const ledn_bnbwd_desc* d, void* stream) {
+    return d ? bn_act_bwd_reduce_impl(*d, S(stream)) : LEDN_EINVAL;
+}
+int ledn_bn_act_bwd_apply(const ledn_bnbwd_desc* d, void* stream) {
+    return d ? bn_act_bwd_apply_impl(*d, S(stream)) : LEDN_EINVAL;
+}
+int ledn_dwconv2d_bwd_data(const ledn_dwbwd_desc* d, void* stream) {
+    return d ? dw_bwd_data_impl(*d, S(stream)) : LEDN_EINVAL;
+}
+int ledn_dwconv2d_bwd_weight(const ledn_dwbwd_desc* d, void* stream) {
+    return d ? dw_bwd_weight_impl(*d, S(stream)) : LEDN_EINVAL;
+}
+int ledn_sesp_pyramid_bwd_data(const ledn_pyrbwd_desc* d, void* stream) {
+    return d ? pyr_bwd_data_impl(*d, S(stream)) : LEDN_EINVAL;
+}
+int ledn_sesp_pyramid_bwd_weight(const ledn_pyrbwd_desc* d, void* stream) {
+    return d ? pyr_bwd_weight_impl(*d, S(stream)) : LEDN_EINVAL;
+}
+int ledn_bilinear_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int dtype_dy,
+                      int dtype_dx, void* stream) {
+    return bilinear_bwd_impl(dy, dx, N, H, W, C, Ho, Wo, dtype_dy, dtype_dx, S(stream));
+}
+int ledn_avgpool3x3s2_bwd(const void* dy, const void* add, void* dx, int N, int H, int W, int C, int Ho,
+                          int Wo, int dtype, void* stream) {
+    return avgpool3x3s2_bwd_impl(dy, add, dx, N, H, W, C, Ho, Wo, dtype, S(stream));
+}
+int ledn_window_attn_bwd(const void* qkv, const float* biasT, const void* dout, float* dqkv, float* dbiasT,
+                         int N, int H, int W, int C, int heads, int ws, int dtype, void* stream) {
+    return window_attn_bwd_impl(qkv, biasT, dout, dqkv, dbiasT, N, H, W, C, heads, ws, dtype, S(stream));
+}
+int ledn_getb_pool_bwd(const void* dout, void* da, int N, int H, int W, int C, int ws, int dtype,
+                       void* stream) {
+    return getb_pool_bwd_impl(dout, da, N, H, W, C, ws, dtype, S(stream));
+}
+int ledn_mfaf_gate_bwd(const ledn_mfafbwd_desc* d, void* stream) {
+    return d ? mfaf_gate_bwd_impl(*d, S(stream)) : LEDN_EINVAL;
+}
+int ledn_mfaf_bwd_combine(void* dx, void* dr, const void* dxl, const float* const* dpool, const int* sizes,
+                          int npool, int N, int H, int W, int C, int dtype, void* stream) {
+    return mfaf_bwd_combine_impl(dx, dr, dxl, dpool, sizes, npool, N, H, W, C, dtype, S(stream));
+}
+long long ledn_ohem_work_floats(long long P) { return ohem_work_floats(P); }
+int ledn_ohem_ce_fwd(const float* logits, const long long* target, long long P, int C, float thres,
+                     long long min_kept, float loss_weight, int ignore_label, float* work, float* out,
+                     void* stream) {
+    return ohem_ce_fwd_impl(logits, target, P, C, thres, min_kept, loss_weight, ignore_label, work, out,
+                            S(stream));
+}
+int ledn_ohem_ce_bwd(const float* logits, const long long* target, long long P, int C, int ignore_label,
+                     const float* work, const float* out, const float* dloss, float loss_weight,
+                     float* dlogits, void* stream) {
+    return ohem_ce_bwd_impl(logits, target, P, C, ignore_label, work, out, dloss, loss_weight, dlogits,
+                            S(stream));
+}
+int ledn_sgd_step(const ledn_sgd_entry* table_dev, int n_tensors, long long max_n, float lr, float momentum,
+                  float weight_decay, float grad_scale, void* stream) {
+    return sgd_step_impl(table_dev, n_tensors, max_n, lr, momentum, weight_decay, grad_scale, S(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,240 @@
+"""Tensor-level wrappers for the backward / loss / optimizer entry points of the
+C ABI (second half of include/ledn.h).  Same conventions as ops.py."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .ops import (ACT_NONE, RES_NONE, _DT, LednError, _check, _dt, _f32, _nb, _p, _run,  # noqa: F401
+                  conv_out_size)
+
+
+def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
+               res=None, res_mode=RES_NONE, count=None, want_dres=False, sync=None):
+    """Backward of y = act(res_mode(z*scale+shift, res)).
+    BN mode (mean/invstd given): returns (dz, dres, dgamma, dbeta, dslope).
+    Plain mode: returns (dz, dres, None, None, dslope).
+    sync: optional callable all-reducing the [2,C] (sum_g, sum_gx) buffer (SyncBN)."""
+    lib = _lib.get_lib()
+    Cc = z.shape[-1]
+    P = z.numel() // Cc
+    bn = mean is not None
+    d = _lib.BnBwdDesc()
+    sums = torch.zeros((2, Cc), dtype=torch.float32, device=z.device)
+    dslope = torch.zeros(Cc, dtype=torch.float32, device=z.device) if slope is not None else None
+    dz = torch.empty_like(z)
+    dres = torch.empty_like(dy) if (want_dres and res_mode != RES_NONE) else None
+    _check(lib, z, dy, res, scale, shift, slope, mean, invstd)
+    d.z, d.res, d.dy = _p(z), _p(res), _p(dy)
+    d.scale, d.shift, d.slope = _p(_f32(scale, Cc)), _p(_f32(shift, Cc)), _p(_f32(slope, Cc))
+    d.mean, d.invstd = _p(_f32(mean, Cc)), _p(_f32(invstd, Cc))
+    d.sum_g, d.sum_gx = sums[0].data_ptr(), sums[1].data_ptr()
+    d.dslope, d.dz, d.dres = _p(dslope), _p(dz), _p(dres)
+    d.count = float(count if count is not None else P)
+    d.P, d.C, d.act = P, Cc, act
+    d.res_mode = res_mode if res is not None else RES_NONE
+    d.bn_mode, d.dtype_z, d.dtype_y = int(bn), _dt(z), _dt(dy)
+    if bn or slope is not None:
+        _run(lib, 'ledn_bn_act_bwd_reduce', z, d, work=(f'bnbwd_reduce C{Cc} P{P}', _nb(z, dy, res), 6 * z.numel()))
+        if bn and sync is not None:
+            sync(sums)
+    _run(lib, 'ledn_bn_act_bwd_apply', z, d, work=(f'bnbwd_apply C{Cc} P{P}', _nb(z, dy, res, dz, dres), 8 * z.numel()))
+    return dz, dres, (sums[1] if bn else None), (sums[0] if bn else None), dslope
+
+
+def _dw_desc(x_shape, dz, w_khwc, stride, pad, dil, group_size, ext1, dtype):
+    N, H, W, Cc = x_shape
+    KH, KW, _ = w_khwc.shape
+    d = _lib.DwBwdDesc()
+    d.N, d.H, d.W, d.C, d.Ho, d.Wo = N, H, W, Cc, dz.shape[1], dz.shape[2]
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    for i in range(4):
+        d.dil[i] = dil[i] if i < len(dil) else dil[-1]
+    d.group_size, d.ext1, d.dtype = group_size or Cc, int(ext1), dtype
+    return d
+
+
+def dwconv2d_bwd(x, dz, w_khwc, *, stride=1, pad=-1, dil=(1, 1, 1, 1), group_size=None, ext1=False,
+                 add=None, need_dx=True, need_dw=True):
+    """-> (dx or None, dw [KH,KW,C] or None)."""
+    lib = _lib.get_lib()
+    if dz.dtype != x.dtype:
+        raise LednError('dwconv2d_bwd: dz dtype must match x')
+    dx = dw = None
+    d = _dw_desc(x.shape, dz, w_khwc, stride, pad, dil, group_size, ext1, _dt(x))
+    _check(lib, x, dz, w_khwc, add)
+    d.x, d.dz, d.w, d.add = _p(x), _p(dz), _p(_f32(w_khwc)), _p(add)
+    KH, KW, Cc = w_khwc.shape
+    if need_dx:
+        dx = torch.empty_like(x)
+        d.dx = _p(dx)
+        _run(lib, 'ledn_dwconv2d_bwd_data', x, d, work=(f'dwbwd_data{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(dz, dx, add), 2 * dz.numel() * KH * KW))
+    if need_dw:
+        dw = torch.zeros_like(w_khwc)
+        d.dw = _p(dw)
+        _run(lib, 'ledn_dwconv2d_bwd_weight', x, d, work=(f'dwbwd_w{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(x, dz) , 2 * dz.numel() * KH * KW))
+    return dx, dw
+
+
+def sesp_pyramid_bwd(x, dy, w_b33n, dil, stride):
+    """-> (dx [N,H,W,n], dw [4,3,3,n])."""
+    lib = _lib.get_lib()
+    N, H, W, n = x.shape
+    if dy.dtype != x.dtype:
+        raise LednError('sesp_pyramid_bwd: dtype mismatch')
+    d = _lib.PyrBwdDesc()
+    gsum = torch.empty_like(dy)
+    dx = torch.empty_like(x)
+    dw = torch.zeros_like(w_b33n)
+    _check(lib, x, dy, w_b33n)
+    d.x, d.dy, d.w, d.gsum, d.dx, d.dw = _p(x), _p(dy), _p(_f32(w_b33n)), _p(gsum), _p(dx), _p(dw)
+    d.N, d.H, d.W, d.n, d.Ho, d.Wo, d.stride = N, H, W, n, dy.shape[1], dy.shape[2], stride
+    for i in range(4):
+        d.dil[i] = dil[i]
+    d.dtype = _dt(x)
+    _run(lib, 'ledn_sesp_pyramid_bwd_data', x, d, work=(f'pyrbwd_data n{n} {tuple(x.shape)}', _nb(dy, gsum, gsum, dx), 2 * dy.numel() * 9))
+    _run(lib, 'ledn_sesp_pyramid_bwd_weight', x, d, work=(f'pyrbwd_w n{n} {tuple(x.shape)}', _nb(x, gsum), 2 * dy.numel() * 9))
+    return dx, dw
+
+
+def bilinear_bwd(dy, in_hw, out_dtype=None):
+    lib = _lib.get_lib()
+    N, Ho, Wo, Cc = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, H, W, Cc), dtype=out_dtype or dy.dtype, device=dy.device)
+    _check(lib, dy, dx)
+    _run(lib, 'ledn_bilinear_bwd', dy, _p(dy), _p(dx), N, H, W, Cc, Ho, Wo, _dt(dy), _dt(dx),
+         work=(f'bilinear_bwd C{Cc} {Ho}x{Wo}->{H}x{W} N{N}', _nb(dy, dx), 8 * dy.numel()))
+    return dx
+
+
+def avgpool3x3s2_bwd(dy, in_hw, add=None):
+    lib = _lib.get_lib()
+    N, Ho, Wo, Cc = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device)
+    if add is not None and (add.shape != dx.shape or add.dtype != dx.dtype):
+        raise LednError('avgpool3x3s2_bwd: add mismatch')
+    _check(lib, dy, dx, add)
+    _run(lib, 'ledn_avgpool3x3s2_bwd', dy, _p(dy), _p(add), _p(dx), N, H, W, Cc, Ho, Wo, _dt(dy),
+         work=(f'avgpool_bwd C{Cc} {N}x{H}x{W}', _nb(dy, dx, add), 3 * dx.numel()))
+    return dx
+
+
+def window_attn_bwd(qkv, biasT, dout, heads, ws=8):
+    """-> (dqkv in qkv.dtype, dbiasT f32 [heads, ws^2, ws^2])."""
+    lib = _lib.get_lib()
+    N, H, W, C3 = qkv.shape
+    Cc = C3 // 3
+    padded = (H % ws != 0) or (W % ws != 0)
+    dq32 = (torch.zeros if padded else torch.empty)((N, H, W, C3), dtype=torch.float32, device=qkv.device)
+    dbias = torch.zeros_like(biasT)
+    _check(lib, qkv, biasT, dout)
+    nwin = N * ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
+    _run(lib, 'ledn_window_attn_bwd', qkv, _p(qkv), _p(_f32(biasT)), _p(dout), _p(dq32), _p(dbias), N, H, W,
+         Cc, heads, ws, _dt(qkv), work=(f'wattn_bwd C{Cc} h{heads} {N}x{H}x{W}', _nb(qkv, dout, dq32), 10 * nwin * (ws * ws) ** 2 * Cc))
+    if qkv.dtype != torch.float32:
+        from .ops import affine_act
+        dq32 = affine_act(dq32, out_dtype=qkv.dtype)
+    return dq32, dbias
+
+
+def getb_pool_bwd(dout, ws=8):
+    lib = _lib.get_lib()
+    N, H, W, Cc = dout.shape
+    da = torch.empty_like(dout)
+    _check(lib, dout, da)
+    _run(lib, 'ledn_getb_pool_bwd', dout, _p(dout), _p(da), N, H, W, Cc, ws, _dt(dout),
+         work=(f'getbpool_bwd C{Cc} {N}x{H}x{W}', _nb(dout, da), 18 * da.numel()))
+    return da
+
+
+def mfaf_gate_bwd(x, r, xl, ctx, affines, dout, act=ACT_NONE):
+    """-> (dx_b, dr_b, ds, [dctx_k f32])."""
+    lib = _lib.get_lib()
+    N, H, W, Cc = x.shape
+    d = _lib.MfafBwdDesc()
+    dx, dr, ds = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    dctx = [torch.zeros_like(c) for c in ctx]
+    keep = [x, r, xl, dout]
+    d.x, d.r, d.xl, d.dout, d.dx, d.dr, d.ds = _p(x), _p(r), _p(xl), _p(dout), _p(dx), _p(dr), _p(ds)
+    for k, c in enumerate(ctx):
+        d.ctx[k], d.ctx_size[k], d.dctx[k] = _p(_f32(c)), c.shape[1], _p(dctx[k])
+        keep.append(c)
+    for k, (s, b) in enumerate(affines):
+        d.scale[k], d.shift[k] = _p(_f32(s, Cc)), _p(_f32(b, Cc))
+        keep += [s, b]
+    _check(lib, *keep)
+    d.N, d.H, d.W, d.C, d.dtype, d.act = N, H, W, Cc, _dt(x), act
+    _run(lib, 'ledn_mfaf_gate_bwd', x, d, work=(f'mfafgate_bwd C{Cc} {N}x{H}x{W}', _nb(x, r, xl, dout, dx, dr, ds), 30 * x.numel()))
+    return dx, dr, ds, dctx
+
+
+def mfaf_bwd_combine(dx, dr, dxl, dpools):
+    """in place: dx += dxa, dr += dxa, dxa = dxl + sum_k adjoint-adaptive-pool(dpools[k])."""
+    lib = _lib.get_lib()
+    N, H, W, Cc = dx.shape
+    n = len(dpools)
+    ptrs = (C.c_void_p * max(n, 1))(*[p.data_ptr() for p in dpools])
+    sizes = (C.c_int * max(n, 1))(*[p.shape[1] for p in dpools])
+    _check(lib, dx, dr, dxl, *dpools)
+    _run(lib, 'ledn_mfaf_bwd_combine', dx, _p(dx), _p(dr), _p(dxl), ptrs, sizes, n, N, H, W, Cc, _dt(dx),
+         work=(f'mfaf_combine C{Cc} {N}x{H}x{W}', _nb(dx, dr, dxl) * 2, 8 * dx.numel()))
+    return dx, dr
+
+
+def ohem_ce_fwd(logits, target, thres, min_kept, loss_weight, ignore_label=255):
+    """logits [N,H,W,C] f32, target [N,H,W] int64 -> (out[4] = loss, acc, thr, nsel ; work)."""
+    lib = _lib.get_lib()
+    if logits.dtype != torch.float32 or target.dtype != torch.int64:
+        raise LednError('ohem_ce: logits f32 NHWC and int64 target required')
+    Cc = logits.shape[-1]
+    P = logits.numel() // Cc
+    if target.numel() != P:
+        raise LednError('ohem_ce: target shape')
+    work = torch.empty(lib.cdll.ledn_ohem_work_floats(P), dtype=torch.float32, device=logits.device)
+    out = torch.empty(4, dtype=torch.float32, device=logits.device)
+    _check(lib, logits, target, work, out)
+    _run(lib, 'ledn_ohem_ce_fwd', logits, _p(logits), _p(target), P, Cc, thres, int(min_kept), loss_weight,
+         ignore_label, _p(work), _p(out), work=(f'ohem_fwd P{P} C{Cc}', _nb(logits, target) + 5 * 8 * P, 30 * P))
+    return out, work
+
+
+def ohem_ce_bwd(logits, target, work, out, dloss, loss_weight, ignore_label=255):
+    lib = _lib.get_lib()
+    Cc = logits.shape[-1]
+    P = logits.numel() // Cc
+    dl = torch.empty_like(logits)
+    dloss = dloss.reshape(1).to(torch.float32).contiguous()
+    _check(lib, logits, target, work, out, dloss, dl)
+    _run(lib, 'ledn_ohem_ce_bwd', logits, _p(logits), _p(target), P, Cc, ignore_label, _p(work), _p(out),
+         _p(dloss), loss_weight, _p(dl), work=(f'ohem_bwd P{P} C{Cc}', _nb(logits, target, dl) + 4 * P, 20 * P))
+    return dl
+
+
+class SgdTable:
+    """Device table of (param, grad, momentum) pointers for ledn_sgd_step."""
+
+    def __init__(self, params, grads, moms):
+        lib = _lib.get_lib()
+        n = len(params)
+        host = (_lib.SgdEntry * n)()
+        self.max_n = 0
+        for i, (p, g, m) in enumerate(zip(params, grads, moms)):
+            for t in (p, g, m):
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise LednError('SGD tensors must be contiguous float32')
+            _check(lib, p, g, m)
+            host[i].p, host[i].g, host[i].m, host[i].n = p.data_ptr(), g.data_ptr(), m.data_ptr(), p.numel()
+            self.max_n = max(self.max_n, p.numel())
+        raw = bytes(host)
+        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        self.table = t.to(params[0].device)
+        self.n = n
+        self.ref = params[0]
+        self.keep = (params, grads, moms)
+
+    def step(self, lr, momentum, weight_decay, grad_scale=1.0):
+        lib = _lib.get_lib()
+        _run(lib, 'ledn_sgd_step', self.ref, self.table.data_ptr(), self.n, self.max_n, lr, momentum,
+             weight_decay, grad_scale, work=(f'sgd {self.n} tensors', 16 * sum(p.numel() for p in self.keep[0]), 0))

@@ -1,0 +1,581 @@
+"""Training path: forward with batch-statistics BatchNorm, hand-written backward
+kernels wired through ``torch.autograd.Function`` (torch only routes tensors and
+owns the tape), OHEM-CE loss, SGD + PolyLR, data-parallel gradient exchange.
+
+Reference call stack: tools/train.py:99-106 -> mmengine IterBasedTrainLoop ->
+model.train_step -> EncoderDecoder.loss (segmentors/encoder_decoder.py:161-185)
+-> LEDHead.loss (decode_heads/decode_head.py:248-264, led_head.py:101-146) ->
+OptimWrapper.update_params (backward + SGD step); SyncBN / DDP collectives are
+implicit there and explicit here (RCCL via
+torch.distributed on the [2,C] statistic buffers and the flat gradient buffer).
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import ops, ops_train as T
+from .ops import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_RELU6, RES_ADD, RES_GATE, RES_NONE
+
+BN_MOMENTUM = 0.1
+
+
+class _Env:
+    """Process-wide training environment (SyncBN collective, world size)."""
+    sync_bn = None      # callable(tensor[2,C]) all-reducing in place, or None
+    world = 1
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------- #
+# autograd Functions (forward/backward = C-ABI kernels)
+# --------------------------------------------------------------------------- #
+class ConvFn(Function):
+    """z = conv2d(x [+ xadd], w) + b, with per-channel sum/sumsq of z accumulated
+    into `stats` ([2,Cout] f32, zeroed by the caller) by the kernel's epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, xadd, stride, pad, groups, stats, out_dtype):
+        st = (stats[0], stats[1]) if stats is not None else None
+        z = ops.conv2d(x, w, stride=stride, pad=pad, groups=groups, xadd=xadd, out_shift=b, stats=st,
+                       out_dtype=out_dtype)
+        ctx.save_for_backward(x, w, xadd)
+        ctx.cfg = (stride, pad, groups, b is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w, xadd = ctx.saved_tensors
+        stride, pad, groups, has_b = ctx.cfg
+        dz = _c(dz)
+        dx = None
+        if ctx.needs_input_grad[0] or (xadd is not None and ctx.needs_input_grad[3]):
+            dx = ops.conv2d(dz, w, stride=stride, pad=pad, groups=groups, transposed=True,
+                            out_hw=(x.shape[1], x.shape[2]), out_dtype=x.dtype)
+        dw, db = ops.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, pad=pad, groups=groups, xadd=xadd,
+                                  bias=has_b)
+        return (dx if ctx.needs_input_grad[0] else None, dw, db,
+                dx if (xadd is not None and ctx.needs_input_grad[3]) else None, None, None, None, None, None)
+
+
+class BNActFn(Function):
+    """y = act(res_mode(BN_train(z), res)); statistics come from `stats` (filled by
+    the producing kernel) or are reduced here; running stats updated in place."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, slope, res, stats, bn, act, res_mode, out_dtype):
+        Cc = z.shape[-1]
+        count = z.numel() // Cc
+        if stats is None:
+            stats = torch.zeros((2, Cc), dtype=torch.float32, device=z.device)
+            ops.channel_stats(z, stats=(stats[0], stats[1]))
+        if _Env.sync_bn is not None:
+            _Env.sync_bn(stats)
+            count *= _Env.world
+        scale, shift, mean, invstd = ops.bn_finalize((stats[0], stats[1]), count, gamma, beta,
+                                                     bn.running_mean, bn.running_var, BN_MOMENTUM, bn.eps)
+        y = ops.affine_act(z, scale, shift, act=act, slope=slope, res=res, res_mode=res_mode,
+                           out_dtype=out_dtype)
+        ctx.save_for_backward(z, res, scale, shift, mean, invstd, slope)
+        ctx.cfg = (act, res_mode, count)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, res, scale, shift, mean, invstd, slope = ctx.saved_tensors
+        act, res_mode, count = ctx.cfg
+        dz, dres, dgamma, dbeta, dslope = T.bn_act_bwd(
+            z, _c(dy), scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, slope=slope, res=res,
+            res_mode=res_mode, count=count, want_dres=res is not None and ctx.needs_input_grad[4],
+            sync=_Env.sync_bn)
+        return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None
+
+
+class ActFn(Function):
+    """y = act(x [+ xadd]) without normalisation (stage ReLUs, xa = x + r)."""
+
+    @staticmethod
+    def forward(ctx, x, xadd, act):
+        y = ops.affine_act(x, act=act, xadd=xadd)
+        ctx.save_for_backward(x, xadd)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xadd = ctx.saved_tensors
+        dy = _c(dy)
+        if ctx.act == ACT_NONE:
+            return dy, (dy if xadd is not None else None), None
+        assert xadd is None
+        dz, _, _, _, _ = T.bn_act_bwd(x, dy, act=ctx.act)
+        return dz, None, None
+
+
+class DwFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, pad, dil, group_size, ext1, stats):
+        st = (stats[0], stats[1]) if stats is not None else None
+        z = ops.dwconv2d(x, w, stride=stride, pad=pad, dil=dil, group_size=group_size, ext1=ext1, stats=st)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, tuple(dil), group_size, ext1)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        stride, pad, dil, gs, ext1 = ctx.cfg
+        dx, dw = T.dwconv2d_bwd(x, _c(dz), w, stride=stride, pad=pad, dil=dil, group_size=gs, ext1=ext1,
+                                need_dx=ctx.needs_input_grad[0])
+        return dx, dw, None, None, None, None, None, None
+
+
+class PyrFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, dil, stride):
+        y = ops.sesp_pyramid(x, w, dil, stride)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (tuple(dil), stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw = T.sesp_pyramid_bwd(x, _c(dy), w, ctx.cfg[0], ctx.cfg[1])
+        return dx, dw, None, None
+
+
+class BilinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, add, size, out_dtype):
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        ctx.x_dtype = x.dtype
+        ctx.has_add = add is not None
+        return ops.bilinear(x, size, add=add, out_dtype=out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = T.bilinear_bwd(dy, ctx.in_hw, out_dtype=ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        return dx, (dy if ctx.has_add else None), None, None
+
+
+class AvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        return ops.avgpool3x3s2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return T.avgpool3x3s2_bwd(_c(dy), ctx.in_hw)
+
+
+class MultiPoolFn(Function):
+    """adaptive average pools of xa to 4x4, 8x8, 16x16, 1x1 (f32)."""
+    SIZES = (4, 8, 16, 1)
+
+    @staticmethod
+    def forward(ctx, xa):
+        ctx.shape, ctx.dtype = xa.shape, xa.dtype
+        return tuple(ops.adaptive_avgpool(xa, S) for S in MultiPoolFn.SIZES)
+
+    @staticmethod
+    def backward(ctx, *dps):
+        dxa = torch.zeros(ctx.shape, dtype=ctx.dtype, device=dps[0].device)
+        T.mfaf_bwd_combine(dxa, None, None, [_c(d) for d in dps])
+        return dxa
+
+
+class WindowAttnFn(Function):
+    @staticmethod
+    def forward(ctx, qkv, biasT, heads, ws):
+        ctx.save_for_backward(qkv, biasT)
+        ctx.cfg = (heads, ws)
+        return ops.window_attn(qkv, biasT, heads, ws)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, biasT = ctx.saved_tensors
+        dqkv, dbias = T.window_attn_bwd(qkv, biasT, _c(dout), *ctx.cfg)
+        return dqkv, dbias, None, None
+
+
+class GetbPoolFn(Function):
+    @staticmethod
+    def forward(ctx, a, local, ws):
+        ctx.ws = ws
+        return ops.getb_pool(a, local, ws)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _c(dout)
+        return T.getb_pool_bwd(dout, ctx.ws), dout, None
+
+
+class MfafTailFn(Function):
+    """The five trailing BatchNorms (batch statistics) + sigmoid gate + blend of
+    Muti_AFF (classification/model_utils.py:377-400,425-428) in one kernel."""
+
+    @staticmethod
+    def forward(ctx, x, r, xl, c1, c2, c3, xg, bns, out_relu, *gb):
+        raws = [xl, c1, c2, c3, xg]
+        affs, saved, counts = [], [], []
+        for k, raw in enumerate(raws):
+            Cc = raw.shape[-1]
+            count = raw.numel() // Cc
+            stats = torch.zeros((2, Cc), dtype=torch.float32, device=raw.device)
+            ops.channel_stats(raw, stats=(stats[0], stats[1]))
+            if _Env.sync_bn is not None:
+                _Env.sync_bn(stats)
+                count *= _Env.world
+            bn = bns[k]
+            scale, shift, mean, invstd = ops.bn_finalize((stats[0], stats[1]), count, gb[2 * k], gb[2 * k + 1],
+                                                         bn.running_mean, bn.running_var, BN_MOMENTUM, bn.eps)
+            affs.append((scale, shift))
+            saved += [scale, shift, mean, invstd]
+            counts.append(count)
+        act = ACT_RELU if out_relu else ACT_NONE
+        out = ops.mfaf_gate(x, r, xl, [c1, c2, c3, xg], affs, act=act)
+        ctx.save_for_backward(x, r, xl, c1, c2, c3, xg, *saved)
+        ctx.act, ctx.counts = act, counts
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, r, xl, c1, c2, c3, xg = ctx.saved_tensors[:7]
+        sv = ctx.saved_tensors[7:]
+        raws = [xl, c1, c2, c3, xg]
+        affs = [(sv[4 * k], sv[4 * k + 1]) for k in range(5)]
+        dx, dr, ds, dctx = T.mfaf_gate_bwd(x, r, xl, [c1, c2, c3, xg], affs, _c(dout), act=ctx.act)
+        gys = [ds] + dctx
+        draws, dgb = [], []
+        for k in range(5):
+            dz, _, dgamma, dbeta, _ = T.bn_act_bwd(raws[k], gys[k], scale=sv[4 * k], shift=sv[4 * k + 1],
+                                                    mean=sv[4 * k + 2], invstd=sv[4 * k + 3],
+                                                    count=ctx.counts[k], sync=_Env.sync_bn)
+            draws.append(dz)
+            dgb += [dgamma, dbeta]
+        return (dx, dr, *draws, None, None, *dgb)
+
+
+class OhemFn(Function):
+    @staticmethod
+    def forward(ctx, logits, target, thres, min_kept, loss_weight, ignore_label):
+        out, work = T.ohem_ce_fwd(logits, target, thres, min_kept, loss_weight, ignore_label)
+        ctx.save_for_backward(logits, target, work, out)
+        ctx.cfg = (loss_weight, ignore_label)
+        ctx.mark_non_differentiable(out)
+        loss = out[0].clone()   # 0-dim view copy (4 bytes)
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, dloss, _dout):
+        logits, target, work, out = ctx.saved_tensors
+        dl = T.ohem_ce_bwd(logits, target, work, out, dloss, ctx.cfg[0], ctx.cfg[1])
+        return dl, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------- #
+# train-mode forward of the blocks (mirrors blocks.py; BatchNorm on batch statistics)
+# --------------------------------------------------------------------------- #
+def _stats(c, ref):
+    return torch.zeros((2, c), dtype=torch.float32, device=ref.device)
+
+
+def relu(x):
+    return ActFn.apply(x, None, ACT_RELU)
+
+
+def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE, xadd=None, out_dtype=None):
+    st = _stats(conv.out_channels, x) if bn is not None else None
+    z = ConvFn.apply(x, conv.weight, conv.bias, xadd, conv.stride[0], conv.padding[0], conv.groups, st,
+                     out_dtype if bn is None else None)
+    if bn is None:
+        assert act == ACT_NONE and res is None
+        return z
+    return BNActFn.apply(z, bn.weight, bn.bias, slope, res, st, bn, act, res_mode, out_dtype)
+
+
+def bn_act(x, bn, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE, stats=None, out_dtype=None):
+    return BNActFn.apply(x, bn.weight, bn.bias, slope, res, stats, bn, act, res_mode, out_dtype)
+
+
+_ACT = {None: ACT_NONE, 'relu': ACT_RELU, 'relu6': ACT_RELU6}
+
+
+def conv_module(m, x, act_override=None, res=None, res_mode=RES_NONE, out_dtype=None):
+    """blocks.ConvModule in training mode."""
+    act = _ACT[m.act] if act_override is None else act_override
+    if m.norm_first:
+        y = bn_act(x, m.bn, act)
+        return ConvFn.apply(y, m.conv.weight, m.conv.bias, None, m.stride, m.padding, 1, None, out_dtype)
+    return conv_bn_act(x, m.conv, m.bn if m.with_norm else None, act, res=res, res_mode=res_mode,
+                       out_dtype=out_dtype)
+
+
+def basic_block(m, x, final_relu=False):
+    out = conv_module(m.conv1, x)
+    if m.downsample is not None:
+        res = conv_bn_act(x, m.downsample[0], m.downsample[1])
+    else:
+        res = x
+    act = ACT_RELU if (m.act_out or final_relu) else ACT_NONE
+    return conv_module(m.conv2, out, act_override=act, res=res, res_mode=RES_ADD)
+
+
+def sesp(m, x):
+    o1 = conv_bn_act(x, m.proj_1x1.conv, m.proj_1x1.bn, ACT_PRELU, slope=m.proj_1x1.act.weight)
+    w1 = torch.stack([d.conv.weight[:, 0].permute(1, 2, 0) for d in m.spp_dw]).contiguous()
+    p = PyrFn.apply(o1, w1, m.dil, m.stride)
+    w2 = torch.cat([d.conv.weight[:, 0].permute(1, 2, 0) for d in m.spp_dw_v2], dim=2).contiguous()
+    st = _stats(m.nOut, x)
+    z = DwFn.apply(p, w2, 1, -1, [d + 1 for d in m.dil], m.n, False, st)
+    cat = bn_act(z, m.br_after_cat.bn, ACT_PRELU, slope=m.br_after_cat.act.weight, stats=st)
+    if m.stride == 2 and not m.spatial:
+        return conv_bn_act(cat, m.conv_1x1_exp.conv, m.conv_1x1_exp.bn, res=AvgPoolFn.apply(x), res_mode=RES_ADD)
+    res = x if (m.stride == 1 and m.nIn == m.nOut) else None
+    return conv_bn_act(cat, m.conv_1x1_exp.conv, m.conv_1x1_exp.bn, ACT_PRELU, slope=m.module_act.weight,
+                       res=res, res_mode=RES_ADD if res is not None else RES_NONE)
+
+
+def cespb(m, x):
+    return sesp(m[1], sesp(m[0], x))
+
+
+def getb(m, x):
+    a = m.attn
+    n1 = bn_act(x, m.norm1)
+    qkv = ConvFn.apply(n1, a.qkv[0].weight, None, None, 1, 0, 1, None, None)
+    att = WindowAttnFn.apply(qkv, a.bias_t(), m.heads, m.ws)
+    mix = GetbPoolFn.apply(att, n1, m.ws)
+    wdw = a.proj[0].weight[:, 0].permute(1, 2, 0).contiguous()
+    st = _stats(m.dim, x)
+    z = DwFn.apply(mix, wdw, 1, (m.ws - 1) // 2, [1, 1, 1, 1], m.dim, True, st)
+    pj = bn_act(z, a.proj[1], stats=st)
+    x1 = ActFn.apply(ConvFn.apply(pj, a.proj[2].weight, None, None, 1, 0, 1, None, None), x, ACT_NONE)
+    n2 = bn_act(x1, m.norm2)
+    h = ActFn.apply(ConvFn.apply(n2, m.mlp.fc1.weight, m.mlp.fc1.bias, None, 1, 0, 1, None, None), None, ACT_RELU6)
+    y = ConvFn.apply(h, m.mlp.fc2.weight, m.mlp.fc2.bias, None, 1, 0, 1, None, None)
+    return ActFn.apply(y, x1, ACT_NONE)
+
+
+def mfaf(m, x, r, out_relu=False):
+    xa = ActFn.apply(x, r, ACT_NONE)
+
+    def mlp(seq, off, inp, out_dtype=None):
+        mid = conv_bn_act(inp, seq[off], seq[off + 1], ACT_RELU)
+        c1 = seq[off + 3]
+        return ConvFn.apply(mid, c1.weight, c1.bias, None, 1, 0, 1, None, out_dtype), seq[off + 4]
+    xl, bn_l = mlp(m.local_att, 0, xa)
+    pooled = MultiPoolFn.apply(xa)
+    raws, bns = [xl], [bn_l]
+    for (name, _), pz in zip(m.POOLS, pooled):
+        c, bn = mlp(getattr(m, name), 1, pz)
+        raws.append(c)
+        bns.append(bn)
+    gb = []
+    for bn in bns:
+        gb += [bn.weight, bn.bias]
+    return MfafTailFn.apply(x, r, *raws, bns, out_relu, *gb)
+
+
+def lednet_forward_train(m, x, pre=None):
+    """LEDNet.forward in training mode -> (c3, c5, x1, x2) NCHW views."""
+    from .lednet import to_nchw_view
+    H, W = x.shape[2:]
+    out_size = (math.ceil(H / 8), math.ceil(W / 8))
+    s, b, mp = pre if pre is not None else (None, None, None)
+    xin = ops.nchw_to_nhwc(x.contiguous(), m.act_dtype, s, b, mp)
+    x1 = conv_module(m.stem['0'], xin)
+    x2 = conv_module(m.stem['1'], x1)
+    y = basic_block(m.stem['2'][1], basic_block(m.stem['2'][0], x2), final_relu=True)
+    y = basic_block(m.stem['4'][1], basic_block(m.stem['4'][0], y), final_relu=True)
+    with torch.no_grad():   # the binarised edge map is piecewise constant: no gradient (ddrnet_speed.py:290-338)
+        seg = conv_module(m.seam.conv_1, y.detach(), out_dtype=torch.float32)
+        edge = ops.seam_edge(seg, m.seam.percentile, m.seam.fixed_threshold, 0.1)
+    # stage 3
+    x_s = cespb(m.layer3_, y)
+    x_c = getb(m.getb1, cespb(m.layer3, y))
+    comp = conv_module(m.compression_1, relu(x_c))
+    x_c = conv_module(m.down_1, relu(x_s), res=x_c, res_mode=RES_ADD)
+    x_s = mfaf(m.aff1, x_s, BilinearFn.apply(comp, None, out_size, None))
+    c3 = x_s
+    # stage 4
+    x_c = cespb(m.layer4, relu(x_c))
+    x_s = cespb(m.layer4_, relu(x_s))
+    comp = conv_module(m.compression_2, relu(x_c))
+    d = conv_module(m.down_2[0], relu(x_s))
+    x_c = conv_module(m.down_2[1], d, res=x_c, res_mode=RES_ADD)
+    x_s = mfaf(m.aff2, x_s, BilinearFn.apply(comp, None, out_size, None))
+    x_s = conv_module(m.seam.conv_2, edge, res=x_s, res_mode=RES_GATE, out_dtype=x_s.dtype)
+    # stage 5
+    x_s = sesp(m.layer5_, relu(x_s))
+    x_c = cespb(m.layer5, relu(x_c))
+    x_c = getb(m.getb2, conv_module(m.spp, x_c))
+    c5 = BilinearFn.apply(x_c, x_s, out_size, None)
+    return tuple(to_nchw_view(t) for t in (c3, c5, x1, x2))
+
+
+# --------------------------------------------------------------------------- #
+# LEDHead training forward + loss (led_head.py:62-75,101-146)
+# --------------------------------------------------------------------------- #
+def _base_head(seq, x, out_dtype=None):
+    z = conv_module(seq[0], x)
+    return bn_act(z, seq[1], ACT_RELU, out_dtype=out_dtype)
+
+
+def led_head_forward_train(h, inputs):
+    from .lednet import to_nhwc
+    c3, c5, x1, x2 = (to_nhwc(t) for t in inputs)
+    f32 = torch.float32
+    xc = _base_head(h.head, c5)
+    xc = ConvFn.apply(xc, h.conv_seg.weight, h.conv_seg.bias, None, 1, 0, 1, None, f32)
+    xs = _base_head(h.aux_head, c3)
+    xs = ConvFn.apply(xs, h.aux_cls_seg.weight, h.aux_cls_seg.bias, None, 1, 0, 1, None, f32)
+    h1 = _base_head(h.head_x1, x1, f32)
+    h2 = _base_head(h.head_x2, x2, f32)
+    return xc, xs, h1, h2
+
+
+def fuse_loss(logit, h1, h2, hw):
+    """led_head.py:106-138: floor(size/4), floor(size/2), size; NHWC f32."""
+    H, W = hw
+    r = BilinearFn.apply(logit, h2, (H // 4, W // 4), None)
+    r = BilinearFn.apply(r, h1, (H // 2, W // 2), None)
+    return BilinearFn.apply(r, None, (H, W), None)
+
+
+def ohem_loss(crit, score, target):
+    """OhemCrossEntropy.forward on NCHW(-view) logits."""
+    from .lednet import to_nhwc
+    lg = to_nhwc(score, torch.float32)
+    loss, _ = OhemFn.apply(lg, target.contiguous(), crit.thresh, crit.min_kept, crit.loss_weight,
+                           crit.ignore_label)
+    return loss
+
+
+def led_head_loss(h, inputs, batch_data_samples):
+    xc, xs, h1, h2 = led_head_forward_train(h, inputs)
+    label = torch.stack([ds.gt_sem_seg.data for ds in batch_data_samples], dim=0)   # N x 1 x H x W
+    hw = label.shape[2:]
+    y = label.squeeze(1).contiguous()
+    ctx = fuse_loss(xc, h1, h2, hw)
+    spa = fuse_loss(xs, h1, h2, hw)
+    c0, c1 = h.loss_decode[0], h.loss_decode[1]
+    l0, out0 = OhemFn.apply(ctx, y, c0.thresh, c0.min_kept, c0.loss_weight, c0.ignore_label)
+    l1, _ = OhemFn.apply(spa, y, c1.thresh, c1.min_kept, c1.loss_weight, c1.ignore_label)
+    return {'loss_context': l0, 'loss_spatial': l1, 'acc_seg': out0[1:2]}
+
+
+# --------------------------------------------------------------------------- #
+# Trainer: SGD(momentum, wd) + PolyLR + data-parallel gradient all-reduce
+# --------------------------------------------------------------------------- #
+class Trainer:
+    """One process per GPU.  Gradients live in ONE flat f32 buffer (parameter
+    ``.grad`` tensors are views of it): a single multi-tensor SGD launch updates
+    the model and re-zeroes the buffer, and the data-parallel exchange is a few
+    large RCCL all-reduces over contiguous slices instead of one per tensor."""
+
+    def __init__(self, model, cfg=None, world_size=1, lr=None, momentum=None, weight_decay=None,
+                 max_iters=None, power=0.9, eta_min=0.0, bucket_mb=2.0):
+        opt = dict((cfg or {}).get('optimizer', {}))
+        self.model = model
+        self.base_lr = lr if lr is not None else opt.get('lr', 0.01)
+        self.momentum = momentum if momentum is not None else opt.get('momentum', 0.9)
+        self.wd = weight_decay if weight_decay is not None else opt.get('weight_decay', 5e-4)
+        sched = ((cfg or {}).get('param_scheduler') or [dict(power=0.9, eta_min=0, end=80000)])[0]
+        self.max_iters = max_iters or sched.get('end', 80000)
+        self.power, self.eta_min = sched.get('power', power), sched.get('eta_min', eta_min)
+        self.iter = 0
+        self.world = world_size
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_mom = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views, self.moms, off = [], [], 0
+        for p in self.params:
+            k = p.numel()
+            self.views.append(self.flat_grad[off:off + k].view_as(p))
+            self.moms.append(self.flat_mom[off:off + k].view_as(p))
+            off += k
+        self.table = None
+        self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
+        sync = getattr(model.backbone, 'sync_bn', False) or getattr(model.decode_head, 'sync_bn', False)
+        _Env.world = world_size
+        if world_size > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            for p in self.params:                       # DDP init: rank-0 weights everywhere
+                dist.broadcast(p.data, 0)
+            for b in model.buffers():
+                if b.is_floating_point():
+                    dist.broadcast(b.data, 0)
+            _Env.sync_bn = (lambda t: dist.all_reduce(t)) if sync else None
+        else:
+            self.dist = None
+            _Env.sync_bn = None
+
+    def lr(self):
+        """mmengine PolyLR (by iteration): (base-eta_min)*(1-it/max)^power + eta_min."""
+        t = min(self.iter, self.max_iters) / self.max_iters
+        return (self.base_lr - self.eta_min) * (1.0 - t) ** self.power + self.eta_min
+
+    def _attach_grads(self):
+        for p, v in zip(self.live, self.live_views):
+            p.grad = v
+
+    def train_step(self, inputs, data_samples):
+        """forward + loss + backward + gradient all-reduce + SGD; returns the loss dict
+        (device scalars; no host synchronisation)."""
+        self.model.train()
+        first = self.table is None
+        if first:
+            for p in self.params:
+                p.grad = None
+        else:
+            self._attach_grads()
+        losses = self.model(inputs, data_samples, mode='loss')
+        total = None
+        for k, v in losses.items():
+            if 'loss' in k:
+                total = v if total is None else total + v
+        total.backward()
+        if first:
+            # Parameters that never receive a gradient (SEAM conv_1: the binarised edge
+            # map is non-differentiable) are skipped, as torch.optim.SGD skips grad=None.
+            idx = [i for i, p in enumerate(self.params) if p.grad is not None]
+            self.live = [self.params[i] for i in idx]
+            self.live_views = [self.views[i] for i in idx]
+            for p, v in zip(self.live, self.live_views):
+                v.copy_(p.grad)
+            self._attach_grads()
+            self.table = T.SgdTable(self.live, self.live_views, [self.moms[i] for i in idx])
+        if self.dist is not None:
+            n = self.flat_grad.numel()
+            for off in range(0, n, self.bucket_elems):
+                self.dist.all_reduce(self.flat_grad[off:off + self.bucket_elems])
+        self.table.step(self.lr(), self.momentum, self.wd, 1.0 / self.world)
+        self.iter += 1
+        return losses
+
+
+def smoke_train_step(model, dev):
+    """one tiny train step on the device, loss compared with the CPU oracle by the caller's tests"""
+    import led_net_amd as L
+    model.train()
+    g = torch.Generator().manual_seed(7)
+    img = torch.randint(0, 256, (2, 3, 320, 320), dtype=torch.uint8, generator=g).to(dev)
+    lab = torch.randint(0, 2, (2, 1, 320, 320), dtype=torch.int64, generator=g)
+    lab[:, :, :8] = 255
+    samples = [L.SegDataSample(gt=lab[i].to(dev)) for i in range(2)]
+    tr = Trainer(model, max_iters=100)
+    out = tr.train_step(img, samples)
+    vals = {k: float(v.float().reshape(-1)[0]) for k, v in out.items()}
+    print('smoke train step:', vals)
+    assert all(math.isfinite(v) for v in vals.values())

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     src = open(os.path.join(ROOT, 'include', 'ledn.h')).read()
-    return sorted(set(re.findall(r'^int (ledn_\w+)\(', src, flags=re.M)))
+    return sorted(set(re.findall(r'^(?:int|long long) (ledn_\w+)\(', src, flags=re.M)))
 
 
 def test_header_and_binding_agree():

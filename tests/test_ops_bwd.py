@@ -1,0 +1,252 @@
+"""Backward / loss / optimizer kernels vs torch autograd on the same inputs
+(emulator on CPU; the same tests run on the MI355X with -m gpu)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import spec
+
+torch.manual_seed(1)
+_DEV = [torch.device('cpu')]
+
+
+@pytest.fixture(autouse=True)
+def _track_device(request):
+    _DEV[0] = request.getfixturevalue('be').dev if 'be' in request.fixturenames else torch.device('cpu')
+    yield
+
+
+def D(t):
+    return t.to(_DEV[0])
+
+
+def nhwc(t):
+    return D(t.detach().permute(0, 2, 3, 1).contiguous())
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def close(a, b, rt=2e-4, at=2e-5):
+    torch.testing.assert_close(a.cpu(), b.cpu(), rtol=rt, atol=at)
+
+
+@pytest.mark.parametrize('act,res_mode,c', [('relu', 'add', 8), ('prelu', 'add', 8), (None, 'gate', 8),
+                                            ('relu6', None, 3), ('prelu', None, 64), ('relu', None, 2)])
+def test_bn_act_bwd(be, act, res_mode, c):
+    from led_net_amd import ops, ops_train as T
+    z = (torch.randn(2, c, 7, 9) * 2 + 0.5).requires_grad_(True)
+    res = torch.randn(2, c, 7, 9, requires_grad=True)
+    g, b = (torch.rand(c) + 0.5).requires_grad_(True), torch.randn(c, requires_grad=True)
+    slope = (torch.rand(c) * 0.3).requires_grad_(True)
+    v = F.batch_norm(z, None, None, g, b, True, 0.1, 1e-5)
+    t = v + res if res_mode == 'add' else (v * res + res if res_mode == 'gate' else v)
+    y = {'relu': F.relu, 'relu6': F.relu6, None: lambda a: a, 'prelu': lambda a: F.prelu(a, slope)}[act](t)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    zs = nhwc(z)
+    st = ops.channel_stats(zs)
+    scale, shift, mean, invstd = ops.bn_finalize(st, z.numel() // c, D(g.detach()), D(b.detach()))
+    A = {'relu': ops.ACT_RELU, 'relu6': ops.ACT_RELU6, None: ops.ACT_NONE, 'prelu': ops.ACT_PRELU}[act]
+    R = {'add': ops.RES_ADD, 'gate': ops.RES_GATE, None: ops.RES_NONE}[res_mode]
+    dz, dres, dgamma, dbeta, dslope = T.bn_act_bwd(
+        zs, nhwc(dy), scale=scale, shift=shift, mean=mean, invstd=invstd, act=A,
+        slope=D(slope.detach()) if act == 'prelu' else None, res=nhwc(res) if res_mode else None,
+        res_mode=R, want_dres=True)
+    close(nchw(dz), z.grad, 1e-3, 1e-4)
+    close(dgamma, g.grad, 1e-3, 1e-4)
+    close(dbeta, b.grad, 1e-3, 1e-4)
+    if res_mode:
+        close(nchw(dres), res.grad, 1e-3, 1e-4)
+    if act == 'prelu':
+        close(dslope, slope.grad, 1e-3, 1e-4)
+
+
+def test_plain_relu_bwd(be):
+    from led_net_amd import ops, ops_train as T
+    z = torch.randn(2, 8, 5, 6, requires_grad=True)
+    dy = torch.randn(2, 8, 5, 6)
+    F.relu(z).backward(dy)
+    dz, _, _, _, _ = T.bn_act_bwd(nhwc(z), nhwc(dy), act=ops.ACT_RELU)
+    close(nchw(dz), z.grad)
+
+
+@pytest.mark.parametrize('stride,dil,k,ext1', [(1, [1, 2, 3, 4], 3, False), (2, [2, 3, 4, 5], 3, False),
+                                              (1, [1, 1, 1, 1], 8, True)])
+def test_dwconv_bwd(be, stride, dil, k, ext1):
+    from led_net_amd import ops_train as T
+    n = 8
+    c = 4 * n if k == 3 else 8
+    x = torch.randn(2, c, 13, 11, requires_grad=True)
+    if k == 3:
+        ws = [(torch.randn(n, 1, 3, 3) * 0.3).requires_grad_(True) for _ in range(4)]
+        y = torch.cat([F.conv2d(x[:, i * n:(i + 1) * n], ws[i], stride=stride, padding=dil[i],
+                                dilation=dil[i], groups=n) for i in range(4)], 1)
+        wp = torch.cat([w[:, 0].permute(1, 2, 0) for w in ws], 2).detach().contiguous()
+        pad, gs = -1, n
+    else:
+        ws = [(torch.randn(c, 1, 8, 8) * 0.1).requires_grad_(True)]
+        y = F.conv2d(F.pad(x, (0, 1, 0, 1), mode='reflect'), ws[0], padding=3, groups=c)
+        wp = ws[0][:, 0].permute(1, 2, 0).detach().contiguous()
+        pad, gs = 3, c
+    dy = torch.randn_like(y)
+    add = torch.randn_like(x)
+    y.backward(dy)
+    dx, dw = T.dwconv2d_bwd(nhwc(x), nhwc(dy), D(wp), stride=stride, pad=pad, dil=dil, group_size=gs,
+                            ext1=ext1, add=nhwc(add))
+    close(nchw(dx), x.grad + add, 1e-3, 1e-4)
+    want_dw = torch.cat([w.grad[:, 0].permute(1, 2, 0) for w in ws], 2)
+    close(dw, want_dw, 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+def test_sesp_pyramid_bwd(be, stride):
+    from led_net_amd import ops_train as T
+    n, dil = 8, [1, 2, 3, 4]
+    x = torch.randn(2, n, 13, 10, requires_grad=True)
+    ws = [(torch.randn(n, 1, 3, 3) * 0.3).requires_grad_(True) for _ in range(4)]
+    outs = []
+    for i in range(4):
+        o = F.conv2d(x, ws[i], stride=stride, padding=dil[i], dilation=dil[i], groups=n)
+        outs.append(o if i == 0 else o + outs[-1])
+    y = torch.cat(outs, 1)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    wp = torch.stack([w[:, 0].permute(1, 2, 0) for w in ws]).detach().contiguous()
+    dx, dw = T.sesp_pyramid_bwd(nhwc(x), nhwc(dy), D(wp), dil, stride)
+    close(nchw(dx), x.grad, 1e-3, 1e-4)
+    close(dw, torch.stack([w.grad[:, 0].permute(1, 2, 0) for w in ws]), 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize('src,dst,c', [((9, 17), (18, 34), 4), ((9, 17), (35, 67), 2), ((5, 7), (5, 7), 4),
+                                       ((8, 8), (64, 64), 4), ((16, 12), (7, 5), 1)])
+def test_bilinear_bwd(be, src, dst, c):
+    from led_net_amd import ops_train as T
+    x = torch.randn(2, c, *src, requires_grad=True)
+    y = F.interpolate(x, size=dst, mode='bilinear', align_corners=False)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    close(nchw(T.bilinear_bwd(nhwc(dy), src)), x.grad, 1e-4, 1e-5)
+
+
+def test_avgpool_bwd(be):
+    from led_net_amd import ops_train as T
+    x = torch.randn(2, 8, 13, 10, requires_grad=True)
+    y = F.avg_pool2d(x, 3, 2, 1)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    add = torch.randn_like(x)
+    close(nchw(T.avgpool3x3s2_bwd(nhwc(dy), (13, 10), add=nhwc(add))), x.grad + add)
+
+
+@pytest.mark.parametrize('hw', [(16, 8), (13, 11)])
+def test_window_attn_and_pool_bwd(be, hw):
+    from led_net_amd import ops, ops_train as T
+    Cc, heads, ws = 32, 2, 8
+    d = Cc // heads
+    H, W = hw
+    qkv = torch.randn(1, 3 * Cc, H, W, requires_grad=True)
+    bias = (torch.randn(heads, 64, 64) * 0.5).requires_grad_(True)   # [h][i][j]
+    x = qkv
+    if W % ws:
+        x = F.pad(x, (0, ws - W % ws, 0, 0), mode='reflect')
+    if H % ws:
+        x = F.pad(x, (0, 0, 0, ws - H % ws), mode='reflect')
+    Hp, Wp = x.shape[2:]
+    hh, ww = Hp // ws, Wp // ws
+    t = x.view(1, 3, heads, d, hh, ws, ww, ws).permute(1, 0, 4, 6, 2, 5, 7, 3).reshape(3, hh * ww, heads, 64, d)
+    att = ((t[0] @ t[1].transpose(-2, -1)) * d ** -0.5 + bias.unsqueeze(0)).softmax(-1) @ t[2]
+    att = att.view(1, hh, ww, heads, ws, ws, d).permute(0, 3, 6, 1, 4, 2, 5).reshape(1, Cc, Hp, Wp)[:, :, :H, :W]
+    local = torch.randn(1, Cc, H, W)
+    out = F.avg_pool2d(F.pad(att, (0, 0, 0, 1), mode='reflect'), (ws, 1), 1, (ws // 2 - 1, 0)) + \
+        F.avg_pool2d(F.pad(att, (0, 1, 0, 0), mode='reflect'), (1, ws), 1, (0, ws // 2 - 1)) + local
+    dout = torch.randn_like(out)
+    att.retain_grad()
+    out.backward(dout)
+    biasT = D(bias.detach().permute(0, 2, 1).contiguous())
+    got_att = ops.window_attn(nhwc(qkv), biasT, heads, ws)
+    close(nchw(got_att), att.detach(), 1e-4, 1e-5)
+    da = T.getb_pool_bwd(nhwc(dout), ws)
+    close(nchw(da), att.grad, 1e-4, 1e-5)
+    dqkv, dbT = T.window_attn_bwd(nhwc(qkv), biasT, da, heads, ws)
+    close(nchw(dqkv), qkv.grad, 1e-3, 1e-4)
+    close(dbT.permute(0, 2, 1), bias.grad, 1e-3, 1e-4)
+
+
+def test_mfaf_gate_bwd_and_combine(be):
+    from led_net_amd import ops, ops_train as T
+    N, Cc, H, W = 2, 8, 19, 21
+    x, r, xl = (torch.randn(N, Cc, H, W, requires_grad=True) for _ in range(3))
+    sizes = [4, 8, 16, 1]
+    ctx = [torch.randn(N, Cc, s, s, requires_grad=True) for s in sizes]
+    aff = [(torch.rand(Cc) + 0.5, torch.randn(Cc) * 0.1) for _ in range(5)]
+
+    def a(t, k):
+        return t * aff[k][0].view(1, -1, 1, 1) + aff[k][1].view(1, -1, 1, 1)
+    s = a(xl, 0)
+    for k in range(4):
+        s = s + F.interpolate(a(ctx[k], k + 1), size=[H, W], mode='nearest')
+    w = torch.sigmoid(s)
+    out = F.relu(2 * x * w + 2 * r * (1 - w))
+    dout = torch.randn_like(out)
+    out.backward(dout)
+    affd = [(D(p), D(q)) for p, q in aff]
+    ctxd = [nhwc(c) for c in ctx]
+    got = ops.mfaf_gate(nhwc(x), nhwc(r), nhwc(xl), ctxd, affd, act=ops.ACT_RELU)
+    close(nchw(got), out.detach())
+    dx, dr, ds, dctx = T.mfaf_gate_bwd(nhwc(x), nhwc(r), nhwc(xl), ctxd, affd, nhwc(dout), act=ops.ACT_RELU)
+    close(nchw(dx), x.grad, 1e-3, 1e-5)
+    close(nchw(dr), r.grad, 1e-3, 1e-5)
+    close(nchw(ds) * aff[0][0].view(1, -1, 1, 1), xl.grad, 1e-3, 1e-5)
+    for k in range(4):
+        close(nchw(dctx[k]) * aff[k + 1][0].view(1, -1, 1, 1), ctx[k].grad, 1e-3, 1e-4)
+    # combine: dx += dxa, dr += dxa with dxa = dxl + sum adjoint-pools
+    xa = torch.randn(N, Cc, H, W, requires_grad=True)
+    dpool = [torch.randn(N, Cc, sz, sz) for sz in sizes]
+    dxl = torch.randn(N, Cc, H, W)
+    tot = sum((F.adaptive_avg_pool2d(xa, sz) * dp).sum() for sz, dp in zip(sizes, dpool)) + (xa * dxl).sum()
+    tot.backward()
+    dxc, drc = T.mfaf_bwd_combine(dx.clone(), dr.clone(), nhwc(dxl), [nhwc(p) for p in dpool])
+    close(nchw(dxc), x.grad + xa.grad, 1e-3, 1e-5)
+    close(nchw(drc), r.grad + xa.grad, 1e-3, 1e-5)
+
+
+@pytest.mark.parametrize('name', ['g7_ohem_k1000', 'g7_ohem_k131072', 'g7_ohem_k100_confident', 'g7_ohem_c5',
+                                  'g7_ohem_all_ignored'])
+def test_ohem_golden(be, name):
+    from conftest import Fixture
+    from led_net_amd import ops_train as T
+    fx = Fixture(name)
+    kw = fx.meta['kwargs']
+    score, tgt = fx.ins['score'], fx.ins['target']
+    lg = nhwc(score)
+    out, work = T.ohem_ce_fwd(lg, D(tgt.contiguous()), kw['thres'], max(1, kw['min_kept']), kw['loss_weight'])
+    close(out[0], fx.outs['loss'].reshape(()), 1e-4, 1e-6)
+    close(out[1], fx.outs['acc'].reshape(()), 1e-5, 1e-4)
+    if 'score' in fx.gin:
+        dl = T.ohem_ce_bwd(lg, D(tgt.contiguous()), work, out, D(torch.ones(1)), kw['loss_weight'])
+        close(nchw(dl), fx.gin['score'], 1e-3, 1e-8)
+
+
+def test_sgd_step(be):
+    from led_net_amd import ops_train as T
+    ps = [torch.randn(s) for s in ((5,), (3, 4), (1000,), (7, 3, 3, 3))]
+    gs = [torch.randn_like(p) for p in ps]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.SGD(ref, lr=0.01, momentum=0.9, weight_decay=5e-4)
+    pd, gd = [D(p.clone()) for p in ps], [D(g.clone()) for g in gs]
+    md = [torch.zeros_like(p) for p in pd]
+    tab = T.SgdTable(pd, gd, md)
+    for it in range(3):
+        for r_, g in zip(ref, gs):
+            r_.grad = g.clone() * (it + 1)
+        opt.step()
+        for g, g0 in zip(gd, gs):
+            g.copy_(D(g0 * (it + 1)))
+        tab.step(0.01, 0.9, 5e-4)
+    for p, r_ in zip(pd, ref):
+        close(p, r_.detach(), 1e-5, 1e-6)
+    assert all(float(g.abs().max()) == 0.0 for g in gd)

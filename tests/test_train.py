@@ -1,0 +1,206 @@
+"""Training path: blocks in train mode (batch-statistics BN, hand-written backward
+kernels through autograd) against the golden vectors from the reference modules
+(outputs, input grads, parameter grads, running-stat updates), then the whole
+LED-Net train step against the CPU oracle."""
+import math
+import os
+
+import pytest
+import torch
+
+from conftest import Fixture, golden_names
+from oracle import spec
+
+_DEV = [torch.device('cpu')]
+
+
+@pytest.fixture(autouse=True)
+def _track_device(request):
+    _DEV[0] = request.getfixturevalue('be').dev if 'be' in request.fixturenames else torch.device('cpu')
+    yield
+
+
+def D(t):
+    return t.to(_DEV[0])
+
+
+def nhwc(t):
+    return D(t.detach().permute(0, 2, 3, 1).contiguous())
+
+
+def nchw(t):
+    return t.detach().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def close(a, b, rt=1e-3, at=1e-4, what=''):
+    """Elementwise tolerance, OR (for gradients) a relative-L2 bound of 1%: a ReLU /
+    ReLU6 / PReLU kink whose pre-activation is ~1e-7 can flip between two fp32
+    summation orders, which moves a handful of gradient elements by O(1) while a
+    genuine chain-rule error moves the whole tensor (rel-L2 ~ 1)."""
+    a, b = a.detach().cpu().float(), b.cpu().float()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if torch.allclose(a, b, rtol=rt, atol=at):
+        return
+    rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+    assert rel < 1e-2, f'{what}: rel-L2 {rel:.3e}, max abs diff {(a - b).abs().max().item():.3e}'
+
+
+def train_names(prefix):
+    return [n for n in golden_names(prefix) if n.endswith('_train')]
+
+
+def _check_block(fx, m, fn, n_in=1):
+    """fn(module, *nhwc inputs) -> nhwc output; compares y, dx, param grads, running stats."""
+    m.load_state_dict(fx.sd, strict=True)
+    m.to(_DEV[0]).train()
+    ins = [nhwc(v).requires_grad_(True) for v in fx.ins.values()]
+    y = fn(m, *ins)
+    close(nchw(y), fx.outs['y'], 5e-4, 5e-5, fx.name + ' y')
+    (y * nhwc(fx.outs['cot'])).sum().backward()
+    for t, (k, g) in zip(ins, fx.gin.items()):
+        close(nchw(t.grad), g, 2e-3, 2e-4, f'{fx.name} d/d{k}')
+    params = dict(m.named_parameters())
+    for k, g in fx.gp.items():
+        got = params[k].grad
+        assert got is not None, k
+        scale = max(1.0, float(g.abs().max()))
+        close(got, g, 3e-3, 1e-3 * scale, f'{fx.name} grad {k}')   # atol: grads that are analytically 0 (bias before BN) are fp32 noise ~1e-4
+    sd = m.state_dict()
+    for k, v in fx.outs.items():
+        if k.startswith('post/'):
+            close(sd[k[5:]], v, 1e-3, 1e-4, f'{fx.name} {k}')
+
+
+@pytest.mark.parametrize('name', train_names('g1_') + train_names('g2_') + train_names('g3_') + train_names('g4'))
+def test_sesp_train_golden(be, name):
+    from led_net_amd.blocks import SESP
+    from led_net_amd import train as TR
+    fx = Fixture(name)
+    kw = fx.meta['kwargs']
+    m = SESP(kw['nIn'], kw['nOut'], kw['stride'], 4, kw.get('r_lim', 7), kw['Spatial'])
+    _check_block(fx, m, TR.sesp)
+
+
+@pytest.mark.parametrize('name', train_names('g5_'))
+def test_getb_train_golden(be, name):
+    from led_net_amd.blocks import GETB
+    from led_net_amd import train as TR
+    fx = Fixture(name)
+    _check_block(fx, GETB(128, 8, 8), TR.getb)
+
+
+@pytest.mark.parametrize('name', train_names('g6_'))
+def test_mfaf_train_golden(be, name):
+    from led_net_amd.blocks import MFAF
+    from led_net_amd import train as TR
+    fx = Fixture(name)
+    _check_block(fx, MFAF(64, 4), TR.mfaf)
+
+
+@pytest.mark.parametrize('name', train_names('g11_'))
+def test_basic_block_train_golden(be, name):
+    from led_net_amd.blocks import BasicBlock
+    from led_net_amd import train as TR
+    fx = Fixture(name)
+    kw = fx.meta['kwargs']
+    m = BasicBlock(kw['in_channels'], kw['channels'], kw['stride'], kw.get('downsample', False),
+                   kw.get('act_out', True))
+    _check_block(fx, m, TR.basic_block)
+
+
+def test_led_head_train_golden(be):
+    """LEDHead.forward (train) + loss_by_feat: logits, losses, accuracy, grads wrt the
+    four backbone features and every head parameter (fixture g10, mmcv shim)."""
+    import led_net_amd as L
+    fx = Fixture('g10_ledhead_train')
+    kw = fx.meta['kwargs']
+    m = L.LEDHead(**kw)
+    m.load_state_dict(fx.sd, strict=True)
+    m.to(_DEV[0]).train()
+    # backbone features arrive as NCHW *views* of NHWC storage (what LEDNet returns)
+    ins = {k: nhwc(fx.ins[k]).requires_grad_(True) for k in ('c3', 'c5', 'x1', 'x2')}
+    label = D(fx.ins['label'])
+    samples = [L.SegDataSample(gt=label[i]) for i in range(label.shape[0])]
+    out = m.loss(tuple(ins[k].permute(0, 3, 1, 2) for k in ('c3', 'c5', 'x1', 'x2')), samples)
+    for k in ('loss_context', 'loss_spatial', 'acc_seg'):
+        close(out[k].reshape(-1), fx.outs[k].reshape(-1), 1e-4, 1e-6, k)
+    (out['loss_context'] + out['loss_spatial']).backward()
+    for k, g in fx.gin.items():
+        close(nchw(ins[k].grad), g, 2e-3, 1e-7, f'd/d{k}')
+    params = dict(m.named_parameters())
+    for k, g in fx.gp.items():
+        close(params[k].grad, g, 3e-3, 1e-6, f'grad {k}')
+
+
+def _randomize(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and n.endswith('weight') and 'act' not in n:
+                p.copy_(0.7 + 0.6 * torch.rand(p.shape, generator=g))
+            elif p.dim() == 1 and n.endswith('bias'):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif 'relative_position_bias_table' in n:
+                p.copy_(0.5 * torch.randn(p.shape, generator=g))
+
+
+def test_whole_train_step_vs_oracle(be):
+    """mode='loss' + backward + one SGD step on 2 x 3 x 320 x 320 vs oracle.spec.loss
+    autograd + torch.optim.SGD: losses, accuracy, updated weights, running stats."""
+    import led_net_amd as L
+    torch.manual_seed(304)
+    cfg = L.load_config(os.path.join(os.path.dirname(__file__), 'data', 'lednet_test_config.py'))
+    cfg['model']['decode_head']['loss_decode'][0]['min_kept'] = 20000
+    cfg['model']['decode_head']['loss_decode'][1]['min_kept'] = 20000
+    model = L.MODELS.build(cfg['model'])
+    _randomize(model, 3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(_DEV[0])
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (2, 3, 320, 320), dtype=torch.uint8, generator=g)
+    lab = torch.randint(0, 2, (2, 1, 320, 320), dtype=torch.int64, generator=g)
+    lab[:, :, :6, :] = 255
+    lab[:, :, :, -5:] = 255
+
+    # ---- oracle
+    init = {k: v.clone() for k, v in sd.items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items()
+              if v.is_floating_point() and 'running_' not in k}
+    want = spec.loss(spec.preprocess(img), lab, sd, loss_cfg=((0.9, 20000, 1.0), (0.9, 20000, 0.4)))
+    (want['decode.loss_context'] + want['decode.loss_spatial']).backward()
+    used = [k for k, v in leaves.items() if v.grad is not None]
+    opt = torch.optim.SGD([leaves[k] for k in used], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    opt.step()
+
+    # ---- product
+    tr = L.Trainer(model, cfg, max_iters=80000)
+    samples = [L.SegDataSample(gt=D(lab[i])) for i in range(2)]
+    got = tr.train_step(D(img), samples)
+    for k in ('decode.loss_context', 'decode.loss_spatial', 'decode.acc_seg'):
+        close(got[k].reshape(-1), want[k].detach().reshape(-1), 2e-3, 1e-4, k)
+    new = model.state_dict()
+    worst = 0.0
+    for k in used:
+        key = k
+        a, b = new[key].detach().cpu(), leaves[k].detach()
+        upd = (b - init[k]).norm().item()
+        err = (a - b).norm().item()
+        worst = max(worst, err / (upd + 1e-7))
+        # the update itself (lr * (grad + wd*p)) must agree to a few %: kink flips and
+        # fp32 summation order move individual gradient elements, a wrong chain rule
+        # moves the whole update
+        # (+2e-5: biases in front of a BatchNorm have an analytically zero gradient,
+        #  what is left is lr * fp32 noise)
+        assert err <= 0.05 * upd + 2e-5, (k, err, upd)
+    # parameters without gradient: SEAM conv_1 (non-differentiable edge map) and the unused
+    # module_act of stride-2 context SESP blocks (eesp.py:110-111 returns before it);
+    # the product must skip exactly the same set (torch.optim.SGD skips grad=None)
+    dead = sorted(k for k in leaves if k not in used)
+    assert all('seam.conv_1' in k or k.endswith('.1.module_act.weight') for k in dead), dead
+    live_names = {n for n, p in model.named_parameters() if any(p is q for q in tr.live)}
+    assert live_names == set(used)
+    for k in dead:
+        close(new[k], init[k], 0, 0, k)
+    for k, v in sd.items():
+        if 'running_' in k:
+            close(new[k], v, 2e-3, 2e-4, k)
