@@ -131,39 +131,81 @@ int bilinear_impl(const ledn_resize_desc& d, hipStream_t s) {
 }
 
 // ---- adaptive average pool to S x S (PyTorch window: [floor(i*H/S), ceil((i+1)*H/S)) )
-template <typename T>
-__global__ void adaptive_avgpool_kernel(const T* x, const T* xadd, float* y, int N, int H, int W,
-                                        int C, int S) {
+// grid = (cells, row-chunks): a workgroup sums a slab of rows of one cell, lanes run
+// along (pixel-in-row, channel-vector) so a wave reads whole NHWC row segments, then
+// an LDS reduction over the pixel lanes and one f32 atomic per channel (y pre-zeroed).
+template <typename T, int V>
+__global__ void __launch_bounds__(256) adaptive_avgpool_kernel(const T* x, const T* xadd, float* y, int N,
+                                                               int H, int W, int C, int S,
+                                                               int rows_per_block) {
+    __shared__ float s_acc[256 * V];
     const int cell = blockIdx.x;
     const int ox = cell % S, oy = (cell / S) % S, n = cell / (S * S);
     const int h0 = (oy * H) / S, h1 = ((oy + 1) * H + S - 1) / S;
     const int w0 = (ox * W) / S, w1 = ((ox + 1) * W + S - 1) / S;
-    const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float acc = 0.f;
-        for (int h = h0; h < h1; ++h)
-            for (int w = w0; w < w1; ++w) {
-                const long off = (((long)n * H + h) * W + w) * C + c;
-                float v = ld(x + off);
-                if (xadd) v += ld(xadd + off);
-                acc += v;
+    const int r0 = h0 + blockIdx.y * rows_per_block;
+    const int r1 = min(h1, r0 + rows_per_block);
+    const int cvn = C / V;
+    const int lanes = 256 / cvn;  // pixel lanes per row sweep
+    const int pl = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    if (pl < lanes) {
+        for (int h = r0; h < r1; ++h)
+            for (int w = w0 + pl; w < w1; w += lanes) {
+                const long off = (((long)n * H + h) * W + w) * C + cv * V;
+                float t[V];
+                ldv<V>(x + off, t);
+                if (xadd) {
+                    float u[V];
+                    ldv<V>(xadd + off, u);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) t[v] += u[v];
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[v] += t[v];
             }
-        y[(long)cell * C + c] = acc * inv;
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) s_acc[threadIdx.x * V + v] = acc[v];
+    __syncthreads();
+    if (r0 < r1 && threadIdx.x < cvn) {
+        const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float t = 0.f;
+            for (int p = 0; p < lanes; ++p) t += s_acc[(p * cvn + cv) * V + v];
+            atomicAdd(y + (long)cell * C + cv * V + v, t * inv);
+        }
     }
 }
 
 int adaptive_avgpool_impl(const void* x, const void* xadd, float* y, int N, int H, int W, int C, int S,
                           int dtype, hipStream_t s) {
     LEDN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && S > 0);
-    const dim3 grid((unsigned)(N * S * S));
-    const int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
-    if (dtype == LEDN_F32)
-        LEDN_LAUNCH(adaptive_avgpool_kernel<float>, grid, dim3(threads), 0, s, (const float*)x,
-                    (const float*)xadd, y, N, H, W, C, S);
-    else if (dtype == LEDN_BF16)
-        LEDN_LAUNCH(adaptive_avgpool_kernel<bf16_t>, grid, dim3(threads), 0, s, (const bf16_t*)x,
-                    (const bf16_t*)xadd, y, N, H, W, C, S);
+    const int V = C % 4 == 0 ? 4 : 1;
+    LEDN_REQUIRE(C / V <= 256);
+    const int max_rows = (H + S - 1) / S + 1;                      // tallest adaptive window
+    int chunks = (int)cdiv(2048, (long)N * S * S);                 // aim for >= ~2k workgroups
+    if (chunks < 1) chunks = 1;
+    if (chunks > max_rows) chunks = max_rows;
+    const int rpb = (int)cdiv(max_rows, chunks);
+    const dim3 grid((unsigned)(N * S * S), (unsigned)cdiv(max_rows, rpb));
+    if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * S * S * C, s) != hipSuccess) return LEDN_ELAUNCH;
+#define LEDN_AA(T)                                                                                    \
+    do {                                                                                              \
+        if (V == 4)                                                                                   \
+            LEDN_LAUNCH((adaptive_avgpool_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x,          \
+                        (const T*)xadd, y, N, H, W, C, S, rpb);                                       \
+        else                                                                                          \
+            LEDN_LAUNCH((adaptive_avgpool_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x,          \
+                        (const T*)xadd, y, N, H, W, C, S, rpb);                                       \
+    } while (0)
+    if (dtype == LEDN_F32) LEDN_AA(float);
+    else if (dtype == LEDN_BF16) LEDN_AA(bf16_t);
     else return LEDN_EINVAL;
+#undef LEDN_AA
     return check_launch();
 }
 
