@@ -22,7 +22,7 @@ vp, fp, i32, i64 = C.c_void_p, C.c_void_p, C.c_int, C.c_longlong
 
 
 class ConvDesc(C.Structure):
-    _fields_ = [('x', vp), ('xadd', vp), ('w', fp), ('y', vp), ('res', vp),
+    _fields_ = [('x', vp), ('xadd', vp), ('w', fp), ('w_bf16', vp), ('y', vp), ('res', vp),
                 ('in_scale', fp), ('in_shift', fp), ('out_scale', fp), ('out_shift', fp),
                 ('slope', fp), ('stat_sum', fp), ('stat_sqsum', fp),
                 ('ws_co', i64), ('ws_ci', i64), ('ws_tap', i64),
@@ -123,6 +123,7 @@ _PROTOS = {
     'ledn_sgd_step': ([vp, i32, i64, C.c_float, C.c_float, C.c_float, C.c_float, vp], i32),
     'ledn_abi_version': ([], i32),
     'ledn_conv2d': ([C.POINTER(ConvDesc), vp], i32),
+    'ledn_pack_conv_weights': ([fp, vp, i32, i32, i32, i32, i32, vp], i32),
     'ledn_conv2d_wgrad': ([C.POINTER(WgradDesc), vp], i32),
     'ledn_dwconv2d': ([C.POINTER(DwDesc), vp], i32),
     'ledn_sesp_pyramid': ([C.POINTER(PyrDesc), vp], i32),

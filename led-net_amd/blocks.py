@@ -59,6 +59,14 @@ def fold_bn(bn, conv_bias=None):
     return scale.contiguous(), shift.contiguous()
 
 
+def packed(block, w, x, mode=0):
+    """bf16 weight pack for the MFMA conv path (None when the layer runs on the direct
+    kernel): cached per block in eval mode, rebuilt per call in training."""
+    if x.dtype != torch.bfloat16 or not ops.mfma_weight_ok(w):
+        return None
+    return block.cached(('wp', id(w), mode), lambda: ops.pack_conv_weights(w.detach(), mode))
+
+
 def pack_dw(weights):
     """list of [n,1,KH,KW] depthwise filters -> [KH,KW,sum n] f32."""
     return torch.cat([w[:, 0].permute(1, 2, 0) for w in weights], dim=2).contiguous()
@@ -95,14 +103,15 @@ class ConvModule(Block):
             s, b = self.cached('fold', lambda: fold_bn(self.bn))
             ps, pb, pact = post if post is not None else (None, self.conv.bias, ACT_NONE)
             return ops.conv2d(x, w, stride=self.stride, pad=self.padding, in_scale=s, in_shift=b,
-                              in_act=act, out_scale=ps, out_shift=pb, act=pact, out_dtype=out_dtype)
+                              in_act=act, out_scale=ps, out_shift=pb, act=pact, out_dtype=out_dtype,
+                              w_bf16=packed(self, w, x))
         if self.with_norm:
             s, b = self.cached('fold', lambda: fold_bn(self.bn, self.conv.bias))
         else:
             s, b = None, self.conv.bias
         return ops.conv2d(x, w, stride=self.stride, pad=self.padding, in_act=in_act, xadd=xadd,
                           out_scale=s, out_shift=b, act=act, res=res, res_mode=res_mode,
-                          out_dtype=out_dtype)
+                          out_dtype=out_dtype, w_bf16=packed(self, w, x))
 
 
 class BasicBlock(Block):
@@ -127,7 +136,8 @@ class BasicBlock(Block):
         out = self.conv1(x)
         if self.downsample is not None:
             s, b = self.cached('ds', lambda: fold_bn(self.downsample[1]))
-            res = ops.conv2d(x, self.downsample[0].weight, stride=self.stride, out_scale=s, out_shift=b)
+            wd = self.downsample[0].weight
+            res = ops.conv2d(x, wd, stride=self.stride, out_scale=s, out_shift=b, w_bf16=packed(self, wd, x))
         else:
             res = x
         act = ACT_RELU if (self.act_out or final_relu) else ACT_NONE
@@ -274,17 +284,18 @@ class GETB(Block):
         a = self.attn
         s1, b1 = self.cached('n1', lambda: fold_bn(self.norm1))
         n1 = ops.affine_act(x, s1, b1)                                   # norm1(x): also `local`
-        qkv = ops.conv2d(n1, a.qkv[0].weight)
+        qkv = ops.conv2d(n1, a.qkv[0].weight, w_bf16=packed(self, a.qkv[0].weight, n1))
         att = ops.window_attn(qkv, self.cached('bias', a.bias_t), self.heads, self.ws)
         mix = ops.getb_pool(att, n1, self.ws)
         sp, bp = self.cached('proj', lambda: fold_bn(a.proj[1]))
         wdw = self.cached('dw', lambda: pack_dw([a.proj[0].weight]))
         pj = ops.dwconv2d(mix, wdw, pad=(self.ws - 1) // 2, ext1=True, out_scale=sp, out_shift=bp)
-        x1 = ops.conv2d(pj, a.proj[2].weight, res=x, res_mode=RES_ADD)
+        x1 = ops.conv2d(pj, a.proj[2].weight, res=x, res_mode=RES_ADD, w_bf16=packed(self, a.proj[2].weight, pj))
         s2, b2 = self.cached('n2', lambda: fold_bn(self.norm2))
         h = ops.conv2d(x1, self.mlp.fc1.weight, in_scale=s2, in_shift=b2, out_shift=self.mlp.fc1.bias,
-                       act=ACT_RELU6)
-        return ops.conv2d(h, self.mlp.fc2.weight, out_shift=self.mlp.fc2.bias, res=x1, res_mode=RES_ADD)
+                       act=ACT_RELU6, w_bf16=packed(self, self.mlp.fc1.weight, x1))
+        return ops.conv2d(h, self.mlp.fc2.weight, out_shift=self.mlp.fc2.bias, res=x1, res_mode=RES_ADD,
+                          w_bf16=packed(self, self.mlp.fc2.weight, h))
 
 
 # --------------------------------------------------------------------------- #

@@ -5,6 +5,12 @@
 namespace ledn {
 int conv_validate(const ledn_conv_desc& d);
 int conv_direct(const ledn_conv_desc& d, hipStream_t s);
+bool conv_mfma_supported(const ledn_conv_desc& d);
+int conv_mfma(const ledn_conv_desc& d, hipStream_t s);
+bool wgrad_mfma_supported(const ledn_wgrad_desc& d);
+int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s);
+int pack_conv_weights_impl(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode,
+                           hipStream_t s);
 int wgrad_validate(const ledn_wgrad_desc& d);
 int conv_wgrad_direct(const ledn_wgrad_desc& d, hipStream_t s);
 int dwconv_impl(const ledn_dw_desc& d, hipStream_t s);
@@ -69,13 +75,25 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
     if (!d) return LEDN_EINVAL;
     const int rc = conv_validate(*d);
     if (rc != LEDN_OK) return rc;
+    if (conv_mfma_supported(*d)) return conv_mfma(*d, S(stream));
     return conv_direct(*d, S(stream));
+}
+
+int ledn_pack_conv_weights(const float* w, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode,
+                           void* stream) {
+    return pack_conv_weights_impl(w, out_bf16, Cout, Cin, KH, KW, mode, S(stream));
 }
 
 int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream) {
     if (!d) return LEDN_EINVAL;
     const int rc = wgrad_validate(*d);
     if (rc != LEDN_OK) return rc;
+    if (wgrad_mfma_supported(*d)) {
+        const int r2 = conv_wgrad_mfma(*d, S(stream));
+        if (r2 != LEDN_OK || !d->db) return r2;
+        return channel_stats_impl(d->dz, nullptr, (long long)d->N * d->Ho * d->Wo, d->Cout, d->dtype_dz, d->db,
+                                  nullptr, S(stream));
+    }
     return conv_wgrad_direct(*d, S(stream));
 }
 

@@ -350,5 +350,27 @@ inline emu_f32x16 mfma_32x32x2_f32(float a, float b, emu_f32x16 c) {
 }
 }  // namespace emu
 
+typedef short emu_s4 __attribute__((ext_vector_type(4)));
+namespace emu {
+// ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per 16-lane group, lane 4q+p supplies the
+// address of row q, columns 4p..4p+3; lane i receives column i of the 4 rows (row q in element q).
+inline emu_s4 lds_read_tr16(const void* p) {
+    Ctx& cx = *g_sched.cur;
+    std::memcpy(cx.xchg + cx.lane * 64, &p, sizeof(p));
+    barrier_wait(cx.wave_bar);
+    const int g = cx.lane >> 4, i = cx.lane & 15;
+    emu_s4 r;
+    for (int q = 0; q < 4; ++q) {
+        const unsigned char* base;
+        std::memcpy(&base, cx.xchg + (g * 16 + 4 * q + (i >> 2)) * 64, sizeof(base));
+        short v;
+        std::memcpy(&v, base + (i & 3) * 2, 2);
+        r[q] = v;
+    }
+    barrier_wait(cx.wave_bar);
+    return r;
+}
+}  // namespace emu
+
 #define LEDN_LAUNCH(kernel, grid, block, smem, stream, ...) \
     emu::launch((grid), (block), (smem), [=] { kernel(__VA_ARGS__); })

@@ -110,6 +110,31 @@ __device__ __forceinline__ float wave_min(float v) {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// ---- matrix-core (MFMA) fragments and the LDS transposing read ------------------
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));   // 8 bf16 = one 32x32x16 A/B fragment
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));  // one 32x32 f32 accumulator tile
+
+#ifdef LEDN_CPU_EMU
+__device__ __forceinline__ f32x16_t mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    return emu::mfma_32x32x16_bf16(a, b, c);
+}
+__device__ __forceinline__ bf16x4_t lds_read_tr16(const void* p) { return emu::lds_read_tr16(p); }
+#else
+typedef __bf16 hw_bf16x8_t __attribute__((ext_vector_type(8)));
+// v_mfma_f32_32x32x16_bf16: lane l (r=l&31,h=l>>5) holds A[r][8h+j], B[8h+j][r];
+// D: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5)   (cdna_hip_programming.md section 3)
+__device__ __forceinline__ f32x16_t mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hw_bf16x8_t, a),
+                                                   __builtin_bit_cast(hw_bf16x8_t, b), c, 0, 0, 0);
+}
+// ds_read_b64_tr_b16; needs all 64 lanes active and an 8-byte aligned LDS address per lane
+__device__ __forceinline__ bf16x4_t lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) bf16x4_t*)(const_cast<void*>(p)));
+}
+#endif
+
 // ---- host-side helpers ----------------------------------------------------------
 inline int check_launch() {
     hipError_t e = hipGetLastError();

@@ -94,9 +94,10 @@ def conv_out_size(h, k, stride, pad, dil):
 
 def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, in_shift=None,
            in_act=ACT_NONE, out_scale=None, out_shift=None, act=ACT_NONE, slope=None, res=None,
-           res_mode=RES_NONE, stats=None, out_dtype=None, transposed=False, out_hw=None):
+           res_mode=RES_NONE, stats=None, out_dtype=None, transposed=False, out_hw=None, w_bf16=None):
     """Dense/grouped convolution.  x: [N,H,W,Cin]; w: OIHW f32 [Cout_f, Cin_f/groups, KH, KW].
-    transposed=True: x is dz [N,Ho_f,Wo_f,Cout_f]; returns dx [N,*out_hw,Cin_f]."""
+    transposed=True: x is dz [N,Ho_f,Wo_f,Cout_f]; returns dx [N,*out_hw,Cin_f].
+    w_bf16: pack_conv_weights(w, mode=int(transposed)) -- enables the MFMA path for bf16."""
     lib = _lib.get_lib()
     N, H, W, Cin = x.shape
     cof, cigf, KH, KW = w.shape
@@ -119,8 +120,10 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
         raise LednError('conv2d: residual shape/dtype mismatch')
     if xadd is not None and (xadd.shape != x.shape or xadd.dtype != x.dtype):
         raise LednError('conv2d: xadd shape/dtype mismatch')
-    _check(lib, x, w, y, res, xadd, in_scale, in_shift, out_scale, out_shift, slope)
-    d.x, d.xadd, d.w, d.y, d.res = _p(x), _p(xadd), _p(w), _p(y), _p(res)
+    _check(lib, x, w, y, res, xadd, in_scale, in_shift, out_scale, out_shift, slope, w_bf16)
+    if w_bf16 is not None and (w_bf16.dtype != torch.bfloat16 or w_bf16.numel() != w.numel()):
+        raise LednError('conv2d: w_bf16 must be the bfloat16 pack of w')
+    d.x, d.xadd, d.w, d.y, d.res, d.w_bf16 = _p(x), _p(xadd), _p(w), _p(y), _p(res), _p(w_bf16)
     d.in_scale, d.in_shift = _p(_f32(in_scale, Cin)), _p(_f32(in_shift, Cin))
     d.out_scale, d.out_shift = _p(_f32(out_scale, Cout)), _p(_f32(out_shift, Cout))
     d.slope = _p(_f32(slope, Cout))
@@ -136,6 +139,24 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
     sig = f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}'
     _run(lib, 'ledn_conv2d', x, d, work=(sig, _nb(x, xadd, y, res, w), flops))
     return y
+
+
+def mfma_weight_ok(w):
+    """shape gate of the MFMA conv path (csrc/conv_mfma.hip: conv_mfma_supported)."""
+    co, ci, kh, kw = w.shape
+    return co % 32 == 0 and ci % 32 == 0 and kh == kw and kh in (1, 3)
+
+
+def pack_conv_weights(w, mode=0):
+    """bf16 weight pack for the MFMA path: mode 0 forward [tap][co][ci], mode 1 dgrad."""
+    lib = _lib.get_lib()
+    Cout, Cin, KH, KW = w.shape
+    _f32(w)
+    out = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+    _check(lib, w, out)
+    _run(lib, 'ledn_pack_conv_weights', w, _p(w), _p(out), Cout, Cin, KH, KW, mode,
+         work=(f'packw {tuple(w.shape)} m{mode}', _nb(w, out), 0))
+    return out
 
 
 def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None,

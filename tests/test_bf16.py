@@ -1,0 +1,68 @@
+"""bf16 activation storage (MFMA conv engine active): whole network vs the fp32 CPU
+oracle.  Tolerances are bf16-level: activations are rounded to 8 significant bits
+after every layer (accumulation stays fp32)."""
+import os
+
+import pytest
+import torch
+
+from oracle import spec
+from test_blocks import _randomize
+
+_DEV = [torch.device('cpu')]
+
+
+@pytest.fixture(autouse=True)
+def _track_device(request):
+    _DEV[0] = request.getfixturevalue('be').dev if 'be' in request.fixturenames else torch.device('cpu')
+    yield
+
+
+def D(t):
+    return t.to(_DEV[0])
+
+
+def _model(seed=1):
+    import led_net_amd as L
+    torch.manual_seed(304)
+    cfg = L.load_config(os.path.join(os.path.dirname(__file__), 'data', 'lednet_test_config.py'))
+    for c in cfg['model']['decode_head']['loss_decode']:
+        c['min_kept'] = 20000
+    model = L.MODELS.build(cfg['model'])
+    _randomize(model, seed)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.set_act_dtype(torch.bfloat16)
+    return L, cfg, model.to(_DEV[0]), sd
+
+
+def test_predict_bf16_vs_oracle(be):
+    L, cfg, model, sd = _model()
+    model.eval()
+    img = torch.randint(0, 256, (1, 3, 320, 328), dtype=torch.uint8)
+    with torch.no_grad():
+        want, want_mask = spec.predict(spec.preprocess(img), sd)
+        out = model(D(img), mode='predict')
+    logits = torch.stack([o.seg_logits.data for o in out]).cpu()
+    mask = torch.cat([o.pred_sem_seg.data for o in out]).long().cpu()
+    scale = want.abs().max().item()
+    err = (logits - want).abs()
+    assert err.max().item() < 0.08 * scale and err.mean().item() < 0.01 * scale, (err.max().item(), err.mean().item(), scale)
+    margin = (want[:, 0] - want[:, 1]).abs()
+    disagree = ((mask != want_mask) & (margin > 0.1 * scale)).float().mean().item()
+    assert disagree < 1e-3, disagree
+
+
+def test_train_step_bf16_vs_oracle(be):
+    L, cfg, model, sd = _model(3)
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (2, 3, 320, 320), dtype=torch.uint8, generator=g)
+    lab = torch.randint(0, 2, (2, 1, 320, 320), dtype=torch.int64, generator=g)
+    lab[:, :, :6, :] = 255
+    want = spec.loss(spec.preprocess(img), lab, sd, loss_cfg=((0.9, 20000, 1.0), (0.9, 20000, 0.4)))
+    tr = L.Trainer(model, cfg, max_iters=80000)
+    got = tr.train_step(D(img), [L.SegDataSample(gt=D(lab[i])) for i in range(2)])
+    for k in ('decode.loss_context', 'decode.loss_spatial', 'decode.acc_seg'):
+        a, b = float(got[k].reshape(-1)[0]), float(want[k].reshape(-1)[0])
+        assert abs(a - b) <= 0.03 * abs(b) + 1e-3, (k, a, b)
+    got2 = tr.train_step(D(img), [L.SegDataSample(gt=D(lab[i])) for i in range(2)])
+    assert all(torch.isfinite(v).all() for v in got2.values())

@@ -1,0 +1,85 @@
+"""MFMA implicit-GEMM convolution engine (forward, data gradient, weight gradient)
+against torch on bf16-rounded operands, plus agreement with the direct kernels.
+Runs on the emulator (MFMA + ds_read_tr emulated lane-exactly) and on the GPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+torch.manual_seed(2)
+_DEV = [torch.device('cpu')]
+
+
+@pytest.fixture(autouse=True)
+def _track_device(request):
+    _DEV[0] = request.getfixturevalue('be').dev if 'be' in request.fixturenames else torch.device('cpu')
+    yield
+
+
+def D(t):
+    return t.to(_DEV[0])
+
+
+def nhwc(t):
+    return D(t.detach().permute(0, 2, 3, 1).contiguous())
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu().float()
+
+
+def r16(t):
+    return t.bfloat16().float()
+
+
+CASES = [  # cin, cout, k, stride, hw
+    (32, 32, 3, 1, (20, 37)), (32, 32, 3, 2, (21, 70)), (32, 64, 3, 2, (18, 40)), (64, 64, 3, 1, (9, 33)),
+    (64, 128, 3, 2, (16, 34)), (128, 64, 3, 1, (7, 40)), (128, 256, 3, 2, (10, 36)),
+    (128, 384, 1, 1, (8, 24)), (512, 128, 1, 1, (5, 6)), (32, 64, 1, 2, (13, 35)), (256, 64, 1, 1, (6, 33)),
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,hw', CASES)
+def test_mfma_conv_forward(be, cin, cout, k, stride, hw):
+    from led_net_amd import ops
+    x = r16(torch.randn(2, cin, *hw))
+    w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    s_in, b_in = torch.rand(cin) + 0.5, torch.randn(cin) * 0.1
+    s_o, b_o, sl = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1, torch.rand(cout) * 0.3
+    pad = k // 2
+    xin = r16(F.relu(x * s_in.view(1, -1, 1, 1) + b_in.view(1, -1, 1, 1)))
+    z = F.conv2d(xin, r16(w), stride=stride, padding=pad)
+    v = z * s_o.view(1, -1, 1, 1) + b_o.view(1, -1, 1, 1)
+    res = r16(torch.randn_like(v))
+    want = F.prelu(v + res, sl)
+    stats = (D(torch.zeros(cout)), D(torch.zeros(cout)))
+    wp = ops.pack_conv_weights(D(w), 0)
+    got = ops.conv2d(nhwc(x).bfloat16(), D(w), stride=stride, pad=pad, in_scale=D(s_in), in_shift=D(b_in),
+                     in_act=ops.ACT_RELU, out_scale=D(s_o), out_shift=D(b_o), act=ops.ACT_PRELU, slope=D(sl),
+                     res=nhwc(res).bfloat16(), res_mode=ops.RES_ADD, stats=stats, w_bf16=wp)
+    assert got.dtype == torch.bfloat16
+    torch.testing.assert_close(nchw(got), want, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(stats[0].cpu(), v.sum((0, 2, 3)), rtol=1e-2, atol=0.05 * v.shape[2] * v.shape[3] ** 0.5)
+    # the direct (VALU) kernel on the same bf16 operands agrees to bf16 output rounding
+    ref = ops.conv2d(nhwc(x).bfloat16(), D(r16(w)), stride=stride, pad=pad, in_scale=D(s_in), in_shift=D(b_in),
+                     in_act=ops.ACT_RELU, out_scale=D(s_o), out_shift=D(b_o), act=ops.ACT_PRELU, slope=D(sl),
+                     res=nhwc(res).bfloat16(), res_mode=ops.RES_ADD)
+    torch.testing.assert_close(nchw(got), nchw(ref), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,hw', CASES)
+def test_mfma_conv_dgrad_wgrad(be, cin, cout, k, stride, hw):
+    from led_net_amd import ops
+    pad = k // 2
+    x = r16(torch.randn(2, cin, *hw)).requires_grad_(True)
+    w = r16(torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).requires_grad_(True)
+    z = F.conv2d(x, w, stride=stride, padding=pad)
+    dz = r16(torch.randn_like(z))
+    z.backward(dz)
+    wp1 = ops.pack_conv_weights(D(w.detach()), 1)
+    dx = ops.conv2d(nhwc(dz).bfloat16(), D(w.detach()), stride=stride, pad=pad, transposed=True, out_hw=hw,
+                    w_bf16=wp1)
+    torch.testing.assert_close(nchw(dx), x.grad, rtol=2e-2, atol=2e-2 * float(x.grad.abs().max()))
+    dw, db = ops.conv2d_wgrad(nhwc(x).bfloat16(), nhwc(dz).bfloat16(), tuple(w.shape), stride=stride, pad=pad,
+                              bias=True)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-2, atol=1e-2 * float(w.grad.abs().max()))
+    torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
