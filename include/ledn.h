@@ -57,7 +57,7 @@ typedef struct {
     const float* w;
     const void* w_bf16;    /* optional: bf16 weights packed by ledn_pack_conv_weights (mode 0 for
                               forward, mode 1 for transposed); enables the MFMA implicit-GEMM
-                              path when x/y are bf16, groups=1, Cin%32==0, Cout%32==0 */
+                              path when x/y are bf16, Cin%32==0, Cout%16==0, groups=1 (or a grouped 1x1) */
     void* y;
     const void* res;       /* optional [N,Ho,Wo,Cout], dtype_y */
     const float* in_scale; /* optional [Cin] */
@@ -76,11 +76,12 @@ typedef struct {
 } ledn_conv_desc;
 int ledn_conv2d(const ledn_conv_desc* d, void* stream);
 
-/* bf16 weight pack for the MFMA path, from the OIHW f32 master [Cout][Cin][KH][KW]:
+/* bf16 weight pack for the MFMA path, from the OIHW f32 master [Cout][Cin/groups][KH][KW]
+ * (Cin = full input width; a grouped 1x1 is densified: zeros outside its group):
  *   mode 0 (forward):  out[tap][co][ci]        = w[co][ci][tap]
  *   mode 1 (dgrad):    out[KK-1-tap][ci][co]   = w[co][ci][tap]   (flipped taps, roles swapped) */
 int ledn_pack_conv_weights(const float* w, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode,
-                           void* stream);
+                           int groups, void* stream);
 
 /* Weight (and bias) gradient of the same convolution:
  *   dw(co,ci,tap) += sum_{n,ho,wo} pre(x)[n, ho*s-pad+kh*dil, .., ci] * dz[n,ho,wo,co]

@@ -123,7 +123,7 @@ _PROTOS = {
     'ledn_sgd_step': ([vp, i32, i64, C.c_float, C.c_float, C.c_float, C.c_float, vp], i32),
     'ledn_abi_version': ([], i32),
     'ledn_conv2d': ([C.POINTER(ConvDesc), vp], i32),
-    'ledn_pack_conv_weights': ([fp, vp, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_pack_conv_weights': ([fp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_conv2d_wgrad': ([C.POINTER(WgradDesc), vp], i32),
     'ledn_dwconv2d': ([C.POINTER(DwDesc), vp], i32),
     'ledn_sesp_pyramid': ([C.POINTER(PyrDesc), vp], i32),

@@ -59,12 +59,12 @@ def fold_bn(bn, conv_bias=None):
     return scale.contiguous(), shift.contiguous()
 
 
-def packed(block, w, x, mode=0):
+def packed(block, w, x, mode=0, groups=1):
     """bf16 weight pack for the MFMA conv path (None when the layer runs on the direct
     kernel): cached per block in eval mode, rebuilt per call in training."""
-    if x.dtype != torch.bfloat16 or not ops.mfma_weight_ok(w):
+    if x.dtype != torch.bfloat16 or not ops.mfma_weight_ok(w, groups):
         return None
-    return block.cached(('wp', id(w), mode), lambda: ops.pack_conv_weights(w.detach(), mode))
+    return block.cached(('wp', id(w), mode), lambda: ops.pack_conv_weights(w.detach(), mode, groups))
 
 
 def pack_dw(weights):
@@ -204,8 +204,10 @@ class SESP(Block):
         uses_input = (self.stride == 2 and not self.spatial) or (self.stride == 1 and self.nIn == self.nOut)
         assert not (in_relu and uses_input)
         s, b = self.cached('proj', lambda: fold_bn(self.proj_1x1.bn))
-        o1 = ops.conv2d(x, self.proj_1x1.conv.weight, groups=4, in_act=ACT_RELU if in_relu else ACT_NONE,
-                        out_scale=s, out_shift=b, act=ACT_PRELU, slope=self.proj_1x1.act.weight)
+        wpj = self.proj_1x1.conv.weight
+        o1 = ops.conv2d(x, wpj, groups=4, in_act=ACT_RELU if in_relu else ACT_NONE,
+                        out_scale=s, out_shift=b, act=ACT_PRELU, slope=self.proj_1x1.act.weight,
+                        w_bf16=packed(self, wpj, x, 0, 4))
         w1 = self.cached('dw1', lambda: torch.stack(
             [m.conv.weight[:, 0].permute(1, 2, 0) for m in self.spp_dw]).contiguous())
         p = ops.sesp_pyramid(o1, w1, self.dil, self.stride)
@@ -215,12 +217,13 @@ class SESP(Block):
                            out_shift=b, act=ACT_PRELU, slope=self.br_after_cat.act.weight)
         s, b = self.cached('exp', lambda: fold_bn(self.conv_1x1_exp.bn))
         w = self.conv_1x1_exp.conv.weight
+        wp = packed(self, w, cat, 0, 4)
         if self.stride == 2 and not self.spatial:                       # eesp.py:110-111
             return ops.conv2d(cat, w, groups=4, out_scale=s, out_shift=b, res=ops.avgpool3x3s2(x),
-                              res_mode=RES_ADD)
+                              res_mode=RES_ADD, w_bf16=wp)
         res = x if (self.stride == 1 and self.nIn == self.nOut) else None  # eesp.py:114-115
         return ops.conv2d(cat, w, groups=4, out_scale=s, out_shift=b, res=res, res_mode=RES_ADD,
-                          act=ACT_PRELU, slope=self.module_act.weight)
+                          act=ACT_PRELU, slope=self.module_act.weight, w_bf16=wp)
 
 
 class CESPB(nn.Sequential):

@@ -696,68 +696,100 @@ int getb_pool_bwd_impl(const void* dout, void* da, int N, int H, int W, int C, i
 // ===========================================================================
 // MFAF gate backward + combine
 // ===========================================================================
+// One workgroup = a 64-pixel segment of one image row.  The context-map gradients
+// (sum of ds over every pixel that reads a cell) are accumulated in LDS per workgroup and
+// flushed with one global atomic per touched (cell, channel): the 1x1 "global" cell would
+// otherwise receive one same-address atomic per pixel.
+constexpr int MFAF_SEG = 64, MFAF_SLOTS = 18;
 template <typename T, int V>
 __global__ void __launch_bounds__(256) mfaf_gate_bwd_kernel(ledn_mfafbwd_desc d) {
-    const int cv = d.C / V;
-    const long total = (long)d.N * d.H * d.W * cv;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int x = (int)(pix % d.W);
-    const int y = (int)((pix / d.W) % d.H);
-    const int n = (int)(pix / ((long)d.W * d.H));
-    float s[V], t[V];
-    ldv<V>(reinterpret_cast<const T*>(d.xl) + pix * d.C + c, t);
-#pragma unroll
-    for (int v = 0; v < V; ++v) s[v] = t[v] * d.scale[0][c + v] + d.shift[0][c + v];
-    long cell[4];
+    __shared__ float s_ctx[4 * MFAF_SLOTS * 128];
+    const int cvn = d.C / V;
+    const int slots = 256 / cvn;
+    const int pslot = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    const int c = cv * V;
+    const int y = blockIdx.x % d.H, n = blockIdx.x / d.H;
+    const int x0 = blockIdx.y * MFAF_SEG, x1 = min(d.W, x0 + MFAF_SEG);
+    for (int i = threadIdx.x; i < 4 * MFAF_SLOTS * d.C; i += blockDim.x) s_ctx[i] = 0.f;
+    __syncthreads();
+    int sy[4], sx_first[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int S = d.ctx_size[k];
-        int sy = (int)((float)y * ((float)S / (float)d.H));
-        int sx = (int)((float)x * ((float)S / (float)d.W));
-        if (sy > S - 1) sy = S - 1;
-        if (sx > S - 1) sx = S - 1;
-        cell[k] = (((long)n * S + sy) * S + sx) * d.C + c;
-        ldv<V>(d.ctx[k] + cell[k], t);
-#pragma unroll
-        for (int v = 0; v < V; ++v) s[v] += t[v] * d.scale[k + 1][c + v] + d.shift[k + 1][c + v];
+        int t = (int)((float)y * ((float)S / (float)d.H));
+        sy[k] = t > S - 1 ? S - 1 : t;
+        t = (int)((float)x0 * ((float)S / (float)d.W));
+        sx_first[k] = t > S - 1 ? S - 1 : t;
     }
-    float xv[V], rv[V], g[V], dxv[V], drv[V], dsv[V];
-    ldv<V>(reinterpret_cast<const T*>(d.x) + pix * d.C + c, xv);
-    ldv<V>(reinterpret_cast<const T*>(d.r) + pix * d.C + c, rv);
-    ldv<V>(reinterpret_cast<const T*>(d.dout) + pix * d.C + c, g);
+    if (pslot < slots) {
+        for (int x = x0 + pslot; x < x1; x += slots) {
+            const long pix = ((long)n * d.H + y) * d.W + x;
+            float s[V], t[V];
+            ldv<V>(reinterpret_cast<const T*>(d.xl) + pix * d.C + c, t);
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-        const float w = 1.f / (1.f + __expf(-s[v]));
-        float go = g[v];
-        if (d.act == LEDN_ACT_RELU) {
-            const float o = 2.f * xv[v] * w + 2.f * rv[v] * (1.f - w);
-            if (o <= 0.f) go = 0.f;
+            for (int v = 0; v < V; ++v) s[v] = t[v] * d.scale[0][c + v] + d.shift[0][c + v];
+            int slot[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int S = d.ctx_size[k];
+                int sx = (int)((float)x * ((float)S / (float)d.W));
+                if (sx > S - 1) sx = S - 1;
+                slot[k] = sx - sx_first[k];
+                ldv<V>(d.ctx[k] + (((long)n * S + sy[k]) * S + sx) * d.C + c, t);
+#pragma unroll
+                for (int v = 0; v < V; ++v) s[v] += t[v] * d.scale[k + 1][c + v] + d.shift[k + 1][c + v];
+            }
+            float xv[V], rv[V], g[V], dxv[V], drv[V], dsv[V];
+            ldv<V>(reinterpret_cast<const T*>(d.x) + pix * d.C + c, xv);
+            ldv<V>(reinterpret_cast<const T*>(d.r) + pix * d.C + c, rv);
+            ldv<V>(reinterpret_cast<const T*>(d.dout) + pix * d.C + c, g);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float w = 1.f / (1.f + __expf(-s[v]));
+                float go = g[v];
+                if (d.act == LEDN_ACT_RELU) {
+                    const float o = 2.f * xv[v] * w + 2.f * rv[v] * (1.f - w);
+                    if (o <= 0.f) go = 0.f;
+                }
+                dxv[v] = 2.f * w * go;
+                drv[v] = 2.f * (1.f - w) * go;
+                dsv[v] = 2.f * (xv[v] - rv[v]) * go * w * (1.f - w);
+            }
+            stv<V>(reinterpret_cast<T*>(d.dx) + pix * d.C + c, dxv);
+            stv<V>(reinterpret_cast<T*>(d.dr) + pix * d.C + c, drv);
+            stv<V>(reinterpret_cast<T*>(d.ds) + pix * d.C + c, dsv);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int v = 0; v < V; ++v) atomicAdd(&s_ctx[(k * MFAF_SLOTS + slot[k]) * d.C + c + v], dsv[v]);
         }
-        dxv[v] = 2.f * w * go;
-        drv[v] = 2.f * (1.f - w) * go;
-        dsv[v] = 2.f * (xv[v] - rv[v]) * go * w * (1.f - w);
     }
-    stv<V>(reinterpret_cast<T*>(d.dx) + pix * d.C + c, dxv);
-    stv<V>(reinterpret_cast<T*>(d.dr) + pix * d.C + c, drv);
-    stv<V>(reinterpret_cast<T*>(d.ds) + pix * d.C + c, dsv);
-    // context gradients: sum of ds over the pixels of each cell (the value stored to ds
-    // is what the local branch sees; the same un-rounded ds goes to the cells)
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int v = 0; v < V; ++v) atomicAdd(d.dctx[k] + cell[k] + v, dsv[v]);
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+        const int S = d.ctx_size[k];
+        int sx_last = (int)((float)(x1 - 1) * ((float)S / (float)d.W));
+        if (sx_last > S - 1) sx_last = S - 1;
+        const int nslot = sx_last - sx_first[k] + 1;
+        for (int i = threadIdx.x; i < nslot * d.C; i += blockDim.x) {
+            const int sl = i / d.C, ch = i % d.C;
+            const float v = s_ctx[(k * MFAF_SLOTS + sl) * d.C + ch];
+            if (v != 0.f)
+                atomicAdd(d.dctx[k] + (((long)n * S + sy[k]) * S + sx_first[k] + sl) * d.C + ch, v);
+        }
+    }
 }
 
 int mfaf_gate_bwd_impl(const ledn_mfafbwd_desc& d, hipStream_t s) {
     LEDN_REQUIRE(d.x && d.r && d.xl && d.dout && d.dx && d.dr && d.ds);
-    LEDN_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.C % 4 == 0);
-    for (int k = 0; k < 4; ++k) LEDN_REQUIRE(d.ctx[k] && d.dctx[k] && d.ctx_size[k] > 0);
+    LEDN_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.C % 4 == 0 && d.C <= 128);
+    for (int k = 0; k < 4; ++k) {
+        LEDN_REQUIRE(d.ctx[k] && d.dctx[k] && d.ctx_size[k] > 0);
+        // cells touched by one 64-pixel segment must fit the LDS slots
+        const int seg = d.W < MFAF_SEG ? d.W : MFAF_SEG;
+        LEDN_REQUIRE((long)seg * d.ctx_size[k] / d.W + 2 <= MFAF_SLOTS);
+    }
     for (int k = 0; k < 5; ++k) LEDN_REQUIRE(d.scale[k] && d.shift[k]);
-    const long total = (long)d.N * d.H * d.W * (d.C / 4);
-    const dim3 grid((unsigned)cdiv(total, 256));
+    const dim3 grid((unsigned)(d.N * d.H), (unsigned)cdiv(d.W, MFAF_SEG));
     if (d.dtype == LEDN_F32) LEDN_LAUNCH((mfaf_gate_bwd_kernel<float, 4>), grid, dim3(256), 0, s, d);
     else if (d.dtype == LEDN_BF16) LEDN_LAUNCH((mfaf_gate_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, d);
     else return LEDN_EINVAL;

@@ -10,7 +10,7 @@ int conv_mfma(const ledn_conv_desc& d, hipStream_t s);
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d);
 int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s);
 int pack_conv_weights_impl(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode,
-                           hipStream_t s);
+                           int groups, hipStream_t s);
 int wgrad_validate(const ledn_wgrad_desc& d);
 int conv_wgrad_direct(const ledn_wgrad_desc& d, hipStream_t s);
 int dwconv_impl(const ledn_dw_desc& d, hipStream_t s);
@@ -80,8 +80,8 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
 }
 
 int ledn_pack_conv_weights(const float* w, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode,
-                           void* stream) {
-    return pack_conv_weights_impl(w, out_bf16, Cout, Cin, KH, KW, mode, S(stream));
+                           int groups, void* stream) {
+    return pack_conv_weights_impl(w, out_bf16, Cout, Cin, KH, KW, mode, groups, S(stream));
 }
 
 int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream) {

@@ -17,131 +17,165 @@ namespace ledn {
 
 template <typename TX, typename TY, int CO_T, int VEC>
 __global__ void __launch_bounds__(256) conv_direct_kernel(ledn_conv_desc d) {
+    // weights of this workgroup's CO_T output channels, one ci-chunk at a time:
+    // s_w[(tap * cib + ci) * CO_T + j]; every lane reads the same address (LDS broadcast)
+    constexpr int CIB = 32;
+    __shared__ __attribute__((aligned(16))) float s_w[9 * CIB * CO_T];
+    __shared__ float s_stat[4][2 * CO_T];
     const long npix = (long)d.N * d.Ho * d.Wo;
-    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = pix < npix;
     const int cog = d.Cout / d.groups, cig = d.Cin / d.groups;
     const int co0 = blockIdx.y * CO_T;
     const int g = co0 / cog;
     const int ci0 = g * cig;
     const int col0 = co0 - g * cog;  // channel index inside the group
-
-    float acc[CO_T];
+    const int taps = d.KH * d.KW;
+    const bool one_chunk = cig <= CIB;
+    const TX* x = reinterpret_cast<const TX*>(d.x);
+    const TX* xadd = reinterpret_cast<const TX*>(d.xadd);
+    float st1[CO_T], st2[CO_T];
 #pragma unroll
-    for (int j = 0; j < CO_T; ++j) acc[j] = 0.f;
+    for (int j = 0; j < CO_T; ++j) st1[j] = st2[j] = 0.f;
 
-    int wo = 0, ho = 0, n = 0;
-    if (active) {
-        wo = (int)(pix % d.Wo);
-        ho = (int)((pix / d.Wo) % d.Ho);
-        n = (int)(pix / ((long)d.Wo * d.Ho));
-        const TX* x = reinterpret_cast<const TX*>(d.x);
-        const TX* xadd = reinterpret_cast<const TX*>(d.xadd);
-        for (int kh = 0; kh < d.KH; ++kh) {
-            int hi;
-            if (!d.transposed) {
-                hi = ho * d.stride - d.pad + kh * d.dil;
-            } else {
-                const int t = ho + d.pad - kh * d.dil;
-                if (t < 0 || (t % d.stride) != 0) continue;
-                hi = t / d.stride;
+    // grid-stride over 256-pixel batches: a bounded grid keeps the per-channel statistics
+    // atomics to one per workgroup (same-address atomics serialise at ~0.3 us each)
+    for (long base = (long)blockIdx.x * blockDim.x; base < npix; base += (long)gridDim.x * blockDim.x) {
+        const long pix = base + threadIdx.x;
+        const bool active = pix < npix;
+        float acc[CO_T];
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j) acc[j] = 0.f;
+        int wo = 0, ho = 0, n = 0;
+        if (active) {
+            wo = (int)(pix % d.Wo);
+            ho = (int)((pix / d.Wo) % d.Ho);
+            n = (int)(pix / ((long)d.Wo * d.Ho));
+        }
+        for (int cb = 0; cb < cig; cb += CIB) {
+            const int cib = min(CIB, cig - cb);
+            if (!one_chunk || base == (long)blockIdx.x * blockDim.x) {
+                if (!one_chunk) __syncthreads();   // previous chunk's readers are done
+                // forward: W(co_global, ci_local); transposed: W(ci_global_fwd, co_local_fwd)
+                for (int e = threadIdx.x; e < taps * cib * CO_T; e += blockDim.x) {
+                    const int j = e % CO_T, ci = (e / CO_T) % cib, tap = e / (CO_T * cib);
+                    const long wb = d.transposed ? (long)(col0 + j) * d.ws_co + (long)ci0 * d.ws_ci
+                                                 : (long)(co0 + j) * d.ws_co;
+                    s_w[e] = d.w[wb + (long)(cb + ci) * d.ws_ci + (long)tap * d.ws_tap];
+                }
+                __syncthreads();
             }
-            if (hi < 0 || hi >= d.H) continue;
-            for (int kw = 0; kw < d.KW; ++kw) {
-                int wi;
+            if (!active) continue;
+            for (int kh = 0; kh < d.KH; ++kh) {
+                int hi;
                 if (!d.transposed) {
-                    wi = wo * d.stride - d.pad + kw * d.dil;
+                    hi = ho * d.stride - d.pad + kh * d.dil;
                 } else {
-                    const int t = wo + d.pad - kw * d.dil;
+                    const int t = ho + d.pad - kh * d.dil;
                     if (t < 0 || (t % d.stride) != 0) continue;
-                    wi = t / d.stride;
+                    hi = t / d.stride;
                 }
-                if (wi < 0 || wi >= d.W) continue;
-                const long xoff = (((long)n * d.H + hi) * d.W + wi) * d.Cin + ci0;
-                const long wtap = (long)(kh * d.KW + kw) * d.ws_tap;
-                for (int ci = 0; ci < cig; ci += VEC) {
-                    float xv[VEC];
-                    ldv<VEC>(x + xoff + ci, xv);
-                    if (xadd) {
-                        float xa[VEC];
-                        ldv<VEC>(xadd + xoff + ci, xa);
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) xv[v] += xa[v];
+                if (hi < 0 || hi >= d.H) continue;
+                for (int kw = 0; kw < d.KW; ++kw) {
+                    int wi;
+                    if (!d.transposed) {
+                        wi = wo * d.stride - d.pad + kw * d.dil;
+                    } else {
+                        const int t = wo + d.pad - kw * d.dil;
+                        if (t < 0 || (t % d.stride) != 0) continue;
+                        wi = t / d.stride;
                     }
-                    if (d.in_scale) {
+                    if (wi < 0 || wi >= d.W) continue;
+                    const long xoff = (((long)n * d.H + hi) * d.W + wi) * d.Cin + ci0 + cb;
+                    const float* wt = s_w + (kh * d.KW + kw) * cib * CO_T;
+                    for (int ci = 0; ci < cib; ci += VEC) {
+                        float xv[VEC];
+                        ldv<VEC>(x + xoff + ci, xv);
+                        if (xadd) {
+                            float xa[VEC];
+                            ldv<VEC>(xadd + xoff + ci, xa);
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v)
-                            xv[v] = xv[v] * d.in_scale[ci0 + ci + v] + d.in_shift[ci0 + ci + v];
-                    }
-                    if (d.in_act == LEDN_ACT_RELU) {
+                            for (int v = 0; v < VEC; ++v) xv[v] += xa[v];
+                        }
+                        if (d.in_scale) {
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) xv[v] = fmaxf(xv[v], 0.f);
-                    }
+                            for (int v = 0; v < VEC; ++v)
+                                xv[v] = xv[v] * d.in_scale[ci0 + cb + ci + v] + d.in_shift[ci0 + cb + ci + v];
+                        }
+                        if (d.in_act == LEDN_ACT_RELU) {
 #pragma unroll
-                    for (int j = 0; j < CO_T; ++j) {
-                        // forward: W(co_global, ci_local); transposed: W(ci_global_fwd, co_local_fwd)
-                        const float* wp = d.w + wtap +
-                            (d.transposed ? (long)(col0 + j) * d.ws_co + (long)ci0 * d.ws_ci
-                                          : (long)(co0 + j) * d.ws_co);
+                            for (int v = 0; v < VEC; ++v) xv[v] = fmaxf(xv[v], 0.f);
+                        }
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v)
-                            acc[j] = fmaf(xv[v], wp[(long)(ci + v) * d.ws_ci], acc[j]);
+                        for (int v = 0; v < VEC; ++v) {
+                            const float* wr = wt + (ci + v) * CO_T;
+#pragma unroll
+                            for (int j = 0; j < CO_T; ++j) acc[j] = fmaf(xv[v], wr[j], acc[j]);
+                        }
                     }
                 }
             }
         }
-    }
-
-    // ---- epilogue: affine, statistics, residual, activation, store
-    float v[CO_T];
-#pragma unroll
-    for (int j = 0; j < CO_T; ++j) {
-        const int co = co0 + j;
-        const float s = d.out_scale ? d.out_scale[co] : 1.f;
-        const float b = d.out_shift ? d.out_shift[co] : 0.f;
-        v[j] = acc[j] * s + b;
-    }
-    if (d.stat_sum) {
+        if (!active) continue;
+        // ---- epilogue: affine, statistics, residual, activation, store
+        float v[CO_T];
 #pragma unroll
         for (int j = 0; j < CO_T; ++j) {
-            const float t = active ? v[j] : 0.f;
-            const float s1 = wave_sum(t);
-            const float s2 = wave_sum(t * t);
+            const int co = co0 + j;
+            const float s = d.out_scale ? d.out_scale[co] : 1.f;
+            const float b = d.out_shift ? d.out_shift[co] : 0.f;
+            v[j] = acc[j] * s + b;
+            st1[j] += v[j];
+            st2[j] = fmaf(v[j], v[j], st2[j]);
+        }
+        const long yoff = pix * d.Cout + co0;
+        if (d.res_mode != LEDN_RES_NONE) {
+            const TY* r = reinterpret_cast<const TY*>(d.res) + yoff;
+#pragma unroll
+            for (int j = 0; j < CO_T; ++j) {
+                const float rv = ld(r + j);
+                v[j] = d.res_mode == LEDN_RES_ADD ? v[j] + rv : v[j] * rv + rv;
+            }
+        }
+        if (d.act_out != LEDN_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < CO_T; ++j)
+                v[j] = act_apply(d.act_out, v[j], d.slope ? d.slope[co0 + j] : 0.f);
+        }
+        TY* y = reinterpret_cast<TY*>(d.y) + yoff;
+        if constexpr (CO_T % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j < CO_T; j += 4) st4(y + j, v + j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < CO_T; ++j) st(y + j, v[j]);
+        }
+    }
+    if (d.stat_sum) {   // wave reduction -> 4 partials in LDS -> one atomic per channel per workgroup
+#pragma unroll
+        for (int j = 0; j < CO_T; ++j) {
+            const float a1 = wave_sum(st1[j]), a2 = wave_sum(st2[j]);
             if (lane_id() == 0) {
-                atomicAdd(d.stat_sum + co0 + j, s1);
-                atomicAdd(d.stat_sqsum + co0 + j, s2);
+                s_stat[threadIdx.x >> 6][j] = a1;
+                s_stat[threadIdx.x >> 6][CO_T + j] = a2;
             }
         }
-    }
-    if (!active) return;
-    const long yoff = pix * d.Cout + co0;
-    if (d.res_mode != LEDN_RES_NONE) {
-        const TY* r = reinterpret_cast<const TY*>(d.res) + yoff;
-#pragma unroll
-        for (int j = 0; j < CO_T; ++j) {
-            const float rv = ld(r + j);
-            v[j] = d.res_mode == LEDN_RES_ADD ? v[j] + rv : v[j] * rv + rv;
+        __syncthreads();
+        if (threadIdx.x < 2 * CO_T) {
+            const float t = s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x] + s_stat[2][threadIdx.x] +
+                            s_stat[3][threadIdx.x];
+            float* dst = threadIdx.x < CO_T ? d.stat_sum + co0 + threadIdx.x
+                                            : d.stat_sqsum + co0 + threadIdx.x - CO_T;
+            atomicAdd(dst, t);
         }
-    }
-    if (d.act_out != LEDN_ACT_NONE) {
-#pragma unroll
-        for (int j = 0; j < CO_T; ++j)
-            v[j] = act_apply(d.act_out, v[j], d.slope ? d.slope[co0 + j] : 0.f);
-    }
-    TY* y = reinterpret_cast<TY*>(d.y) + yoff;
-    if constexpr (CO_T % 4 == 0) {
-#pragma unroll
-        for (int j = 0; j < CO_T; j += 4) st4(y + j, v + j);
-    } else {
-#pragma unroll
-        for (int j = 0; j < CO_T; ++j) st(y + j, v[j]);
     }
 }
 
 template <typename TX, typename TY, int CO_T>
 static int launch_vec(const ledn_conv_desc& d, hipStream_t s) {
     const long npix = (long)d.N * d.Ho * d.Wo;
-    const dim3 grid((unsigned)cdiv(npix, 256), (unsigned)(d.Cout / CO_T));
+    long gx = cdiv(npix, 256);
+    const long cap = 2048 / (d.Cout / CO_T) > 64 ? 2048 / (d.Cout / CO_T) : 64;   // bounded grid (see kernel)
+    if (gx > cap) gx = cap;
+    const dim3 grid((unsigned)gx, (unsigned)(d.Cout / CO_T));
     const int cig = d.Cin / d.groups;
     if (cig % 4 == 0 && d.ws_ci != 0)
         LEDN_LAUNCH((conv_direct_kernel<TX, TY, CO_T, 4>), grid, dim3(256), 0, s, d);
@@ -172,6 +206,7 @@ int conv_validate(const ledn_conv_desc& d) {
     LEDN_REQUIRE(d.x && d.w && d.y);
     LEDN_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Ho > 0 && d.Wo > 0 && d.Cout > 0);
     LEDN_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.dil > 0 && d.pad >= 0 && d.groups > 0);
+    LEDN_REQUIRE(d.KH * d.KW <= 9);
     LEDN_REQUIRE(d.Cin % d.groups == 0 && d.Cout % d.groups == 0);
     LEDN_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr));
     LEDN_REQUIRE((d.stat_sum == nullptr) == (d.stat_sqsum == nullptr));
@@ -263,10 +298,126 @@ __global__ void __launch_bounds__(256) conv_wgrad_direct_kernel(ledn_wgrad_desc 
     }
 }
 
+// ---------------------------------------------------------------------------
+// weight gradient when one side has <= 4 channels (stem 3->32, heads 32->2, SEAM 1->64,
+// 1x1 classifiers 64->2): thread = (pixel slot, channel of the WIDE side), the narrow
+// side x taps live in registers; lanes of a wave read 64-256 contiguous bytes of the wide
+// tensor, the narrow tensor is a wave-uniform (broadcast) load.  LDS reduction over the
+// pixel slots, then one atomic per dW element per workgroup.
+// ---------------------------------------------------------------------------
+template <typename TX, typename TZ, bool NARROW_CO, int NC, int TAPS>
+__global__ void __launch_bounds__(256) conv_wgrad_narrow_kernel(ledn_wgrad_desc d, int pix_per_block) {
+    __shared__ float s_red[256];
+    const int wide = NARROW_CO ? d.Cin : d.Cout;
+    const int slots = 256 / wide;
+    const int slot = threadIdx.x / wide, wc = threadIdx.x % wide;
+    const bool worker = slot < slots;
+    float acc[TAPS][NC];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[t][c] = 0.f;
+    const TX* x = reinterpret_cast<const TX*>(d.x);
+    const TZ* dz = reinterpret_cast<const TZ*>(d.dz);
+    const int ncn = NARROW_CO ? d.Cout : d.Cin;   // actual narrow channel count (<= NC)
+    if (worker) {
+        const long npix = (long)d.N * d.Ho * d.Wo;
+        const long p0 = (long)blockIdx.x * pix_per_block;
+        const long p1 = min(npix, p0 + (long)pix_per_block);
+        for (long p = p0 + slot; p < p1; p += slots) {
+            const int wo = (int)(p % d.Wo);
+            const int ho = (int)((p / d.Wo) % d.Ho);
+            const int n = (int)(p / ((long)d.Wo * d.Ho));
+            float zv[NC];
+            float zw = 0.f;
+            if (NARROW_CO) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) zv[c] = c < ncn ? ld(dz + p * d.Cout + c) : 0.f;
+            } else {
+                zw = ld(dz + p * d.Cout + wc);
+            }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int kh = t / d.KW, kw = t % d.KW;
+                const int hi = ho * d.stride - d.pad + kh * d.dil, wi = wo * d.stride - d.pad + kw * d.dil;
+                if (hi < 0 || hi >= d.H || wi < 0 || wi >= d.W) continue;
+                const long xoff = (((long)n * d.H + hi) * d.W + wi) * d.Cin;
+                if (NARROW_CO) {
+                    float xv = ld(x + xoff + wc);
+                    if (d.in_scale) xv = xv * d.in_scale[wc] + d.in_shift[wc];
+                    if (d.in_act == LEDN_ACT_RELU) xv = fmaxf(xv, 0.f);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[t][c] = fmaf(xv, zv[c], acc[t][c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        if (c >= ncn) break;
+                        float xv = ld(x + xoff + c);
+                        if (d.in_scale) xv = xv * d.in_scale[c] + d.in_shift[c];
+                        if (d.in_act == LEDN_ACT_RELU) xv = fmaxf(xv, 0.f);
+                        acc[t][c] = fmaf(xv, zw, acc[t][c]);
+                    }
+                }
+            }
+        }
+    }
+    // reduce over the pixel slots, one (tap, narrow channel) at a time
+    for (int t = 0; t < TAPS; ++t)
+        for (int c = 0; c < ncn; ++c) {
+            s_red[threadIdx.x] = worker ? acc[t][c] : 0.f;
+            __syncthreads();
+            if (threadIdx.x < wide) {
+                float v = 0.f;
+                for (int sl = 0; sl < slots; ++sl) v += s_red[sl * wide + threadIdx.x];
+                const int co = NARROW_CO ? c : threadIdx.x, ci = NARROW_CO ? threadIdx.x : c;
+                atomicAdd(d.dw + (long)co * d.ws_co + (long)ci * d.ws_ci + (long)t * d.ws_tap, v);
+            }
+            __syncthreads();
+        }
+}
+
+template <typename TX, typename TZ>
+static int launch_narrow(const ledn_wgrad_desc& d, hipStream_t s) {
+    const long npix = (long)d.N * d.Ho * d.Wo;
+    long ppb = cdiv(npix, 256);   // <= 256 workgroups: one atomic per dW element per workgroup
+    if (ppb < 64) ppb = 64;
+    const dim3 grid((unsigned)cdiv(npix, ppb));
+    const bool nco = d.Cout <= 4;
+    const int taps = d.KH * d.KW;
+#define LEDN_NW(NCO, TP) \
+    LEDN_LAUNCH((conv_wgrad_narrow_kernel<TX, TZ, NCO, 4, TP>), grid, dim3(256), 0, s, d, (int)ppb)
+    if (nco && taps == 9) LEDN_NW(true, 9);
+    else if (nco && taps == 1) LEDN_NW(true, 1);
+    else if (!nco && taps == 9) LEDN_NW(false, 9);
+    else if (!nco && taps == 1) LEDN_NW(false, 1);
+    else return LEDN_EINVAL;
+#undef LEDN_NW
+    return check_launch();
+}
+
+static bool narrow_ok(const ledn_wgrad_desc& d) {
+    if (d.groups != 1 || d.xadd) return false;
+    const int taps = d.KH * d.KW;
+    if (taps != 1 && taps != 9) return false;
+    if (d.Cout <= 4 && d.Cin <= 256 && d.Cin > 4) return true;
+    if (d.Cin <= 4 && d.Cout <= 256 && d.Cout > 4) return true;
+    return false;
+}
+
 int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
                        float* sqsum, hipStream_t s);
 
 int conv_wgrad_direct(const ledn_wgrad_desc& d, hipStream_t s) {
+    if (narrow_ok(d)) {
+        int rc;
+        if (d.dtype_x == LEDN_F32 && d.dtype_dz == LEDN_F32) rc = launch_narrow<float, float>(d, s);
+        else if (d.dtype_x == LEDN_BF16 && d.dtype_dz == LEDN_BF16) rc = launch_narrow<bf16_t, bf16_t>(d, s);
+        else if (d.dtype_x == LEDN_BF16 && d.dtype_dz == LEDN_F32) rc = launch_narrow<bf16_t, float>(d, s);
+        else if (d.dtype_x == LEDN_F32 && d.dtype_dz == LEDN_BF16) rc = launch_narrow<float, bf16_t>(d, s);
+        else return LEDN_EINVAL;
+        if (rc != LEDN_OK || !d.db) return rc;
+        return channel_stats_impl(d.dz, nullptr, (long long)d.N * d.Ho * d.Wo, d.Cout, d.dtype_dz, d.db, nullptr, s);
+    }
     const int cog = d.Cout / d.groups, cig = d.Cin / d.groups;
     const int ci_tiles = (int)cdiv(cig, 64), co_tiles = (int)cdiv(cog, 64);
     const long npix = (long)d.N * d.Ho * d.Wo;

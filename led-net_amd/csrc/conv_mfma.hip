@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaConvArgs a) {
     const int n = b / a.tiles_h;
     const int ho0 = th * TR, wo0 = tw * 32;
     const int co = blockIdx.y * (WN * 32) + wn * 32 + lr;   // this lane's output channel (B column)
+    const bool co_ok = co < a.Cout;                         // Cout % 32 == 16 tail (grouped 1x1 reduce convs)
 
     f32x16_t acc[MT];
 #pragma unroll
@@ -129,7 +130,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaConvArgs a) {
                 const bf16_t* wrow = a.wp + ((long)(kh * K + kw) * a.Cout + co) * a.Cin + c0 + lh * 8;
 #pragma unroll
                 for (int kk = 0; kk < CK / 16; ++kk) {
-                    const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(wrow + kk * 16);
+                    bf16x8_t bf = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (co_ok) bf = *reinterpret_cast<const bf16x8_t*>(wrow + kk * 16);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const int row = wm * MT + m;
@@ -145,6 +147,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaConvArgs a) {
     }
 
     // ---- epilogue: lane holds channel `co` for 16 pixels of each of its MT rows
+    if (!co_ok) return;    // (no wave collective below needs the masked lanes: shfl partner lane^32 has the same co)
     const float sc = a.out_scale ? a.out_scale[co] : 1.f;
     const float sh = a.out_shift ? a.out_shift[co] : 0.f;
     const float sl = a.slope ? a.slope[co] : 0.f;
@@ -184,7 +187,7 @@ static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {
     constexpr int TR = WM * MT;
     a.tiles_h = (int)cdiv(a.Ho, TR);
     a.tiles_w = (int)cdiv(a.Wo, 32);
-    const dim3 grid((unsigned)((long)a.N * a.tiles_h * a.tiles_w), (unsigned)(a.Cout / (WN * 32)));
+    const dim3 grid((unsigned)((long)a.N * a.tiles_h * a.tiles_w), (unsigned)cdiv(a.Cout, WN * 32));
     LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP>), grid, dim3(256), 0, s, a);
     return check_launch();
 }
@@ -199,8 +202,9 @@ static int launch_shape(const MfmaConvArgs& a, hipStream_t s) {
 
 bool conv_mfma_supported(const ledn_conv_desc& d) {
     if (!d.w_bf16 || d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16) return false;
-    if (d.groups != 1 || d.dil != 1 || d.xadd) return false;
-    if (d.Cin % 32 || d.Cout % 32) return false;
+    if (d.dil != 1 || d.xadd) return false;
+    if (d.groups != 1 && !(d.KH == 1 && d.KW == 1)) return false;   // grouped 1x1: densified weight pack
+    if (d.Cin % 32 || d.Cout % 16) return false;
     if (d.KH != d.KW || !((d.KH == 3 && d.pad == 1) || (d.KH == 1 && d.pad == 0))) return false;
     if (d.stride != 1 && d.stride != 2) return false;
     if (d.transposed && d.stride == 2 && d.KH == 1) return false;
@@ -228,14 +232,19 @@ int conv_mfma(const ledn_conv_desc& d, hipStream_t s) {
 // ---------------------------------------------------------------------------
 // weight pack (f32 OIHW -> bf16 [tap][co][ci], or the dgrad variant)
 // ---------------------------------------------------------------------------
-__global__ void pack_weights_kernel(const float* w, bf16_t* out, int Cout, int Cin, int KK, int mode) {
+// w: [Cout][Cin/groups][KK] f32; the pack is DENSE over the full Cin (zeros outside the group)
+__global__ void pack_weights_kernel(const float* w, bf16_t* out, int Cout, int Cin, int KK, int mode,
+                                    int groups) {
     const long total = (long)Cout * Cin * KK;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int tap = (int)(i % KK);
     const int ci = (int)((i / KK) % Cin);
     const int co = (int)(i / ((long)KK * Cin));
-    const float v = w[i];
+    const int cig = Cin / groups, cog = Cout / groups;
+    const int g = co / cog;
+    float v = 0.f;
+    if (ci / cig == g) v = w[((long)co * cig + (ci - g * cig)) * KK + tap];
     long o;
     if (mode == 0) o = ((long)tap * Cout + co) * Cin + ci;
     else o = ((long)(KK - 1 - tap) * Cin + ci) * Cout + co;
@@ -243,11 +252,12 @@ __global__ void pack_weights_kernel(const float* w, bf16_t* out, int Cout, int C
 }
 
 int pack_conv_weights_impl(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode,
-                           hipStream_t s) {
+                           int groups, hipStream_t s) {
     LEDN_REQUIRE(w && out && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && (mode == 0 || mode == 1));
+    LEDN_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0);
     const long total = (long)Cout * Cin * KH * KW;
     LEDN_LAUNCH(pack_weights_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, (bf16_t*)out, Cout,
-                Cin, KH * KW, mode);
+                Cin, KH * KW, mode, groups);
     return check_launch();
 }
 
@@ -262,7 +272,7 @@ struct MfmaWgradArgs {
     const float* in_shift;
     long long ws_co, ws_ci, ws_tap;
     int N, H, W, Cin, Ho, Wo, Cout;
-    int pad, in_act;
+    int pad, in_act, groups;
     int tiles_h, tiles_w, tiles_per_block, ci_tiles;
 };
 
@@ -283,6 +293,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
     const int q = l16 >> 2, pp = l16 & 3;          // tr-read: this lane supplies row q, columns 4pp..4pp+3
     const int ci_tile = blockIdx.y % a.ci_tiles, co_tile = blockIdx.y / a.ci_tiles;
     const int ci0 = ci_tile * 32, co0 = co_tile * 32;
+    const int cig = a.Cin / a.groups, cog = a.Cout / a.groups;
+    if (a.groups > 1) {   // grouped conv: only tile pairs that touch the block diagonal (workgroup-uniform exit)
+        const int g_lo = co0 / cog, g_hi = min(co0 + 31, a.Cout - 1) / cog;
+        if (ci0 + 31 < g_lo * cig || ci0 >= (g_hi + 1) * cig) return;
+    }
 
     f32x16_t acc[KK];
 #pragma unroll
@@ -311,7 +326,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
         for (int p = tid >> 2; p < TR * 32; p += 64) {
             const int pr = p / 32, pc = p % 32, part = tid & 3;
             const int ho = ho0 + pr, wo = wo0 + pc;
-            const bool valid = ho < a.Ho && wo < a.Wo;
+            const bool valid = ho < a.Ho && wo < a.Wo && co0 + part * 8 < a.Cout;
             stage_piece(s_z + (long)p * PIXB + part * 16,
                         a.dz + (((long)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co0 + part * 8, valid, nullptr,
                         nullptr, 0, 0);
@@ -362,14 +377,18 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
         __syncthreads();
     }
     for (int e = tid; e < KK * 1024; e += 256) {
-        const int t = e / 1024, co_l = (e / 32) % 32, ci_l = e % 32;
-        atomicAdd(a.dw + (long)(co0 + co_l) * a.ws_co + (long)(ci0 + ci_l) * a.ws_ci + (long)t * a.ws_tap, red[e]);
+        const int t = e / 1024, co = co0 + (e / 32) % 32, ci = ci0 + e % 32;
+        if (co >= a.Cout) continue;
+        const int g = co / cog;
+        if (ci / cig != g) continue;   // off-diagonal element of a grouped conv
+        atomicAdd(a.dw + (long)co * a.ws_co + (long)(ci - g * cig) * a.ws_ci + (long)t * a.ws_tap, red[e]);
     }
 }
 
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d) {
-    if (d.dtype_x != LEDN_BF16 || d.dtype_dz != LEDN_BF16 || d.groups != 1 || d.dil != 1 || d.xadd) return false;
-    if (d.Cin % 32 || d.Cout % 32) return false;
+    if (d.dtype_x != LEDN_BF16 || d.dtype_dz != LEDN_BF16 || d.dil != 1 || d.xadd) return false;
+    if (d.groups != 1 && !(d.KH == 1 && d.KW == 1)) return false;
+    if (d.Cin % 32 || d.Cout % 16) return false;
     if (d.KH != d.KW || !((d.KH == 3 && d.pad == 1) || (d.KH == 1 && d.pad == 0))) return false;
     return d.stride == 1 || d.stride == 2;
 }
@@ -380,8 +399,9 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s) {
     a.tiles_w = (int)cdiv(a.Wo, 32);
     a.ci_tiles = a.Cin / 32;
     const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
-    const int pairs = a.ci_tiles * (a.Cout / 32);
-    long blocks_x = cdiv(1024, pairs);               // ~1k workgroups in flight in total
+    const int pairs = a.ci_tiles * (int)cdiv(a.Cout, 32);
+    long blocks_x = cdiv(512, pairs);                // bounded grid: one atomic per dW element per workgroup
+    if (blocks_x < 32) blocks_x = 32;
     if (blocks_x > ntiles) blocks_x = ntiles;
     a.tiles_per_block = (int)cdiv(ntiles, blocks_x);
     const dim3 grid((unsigned)cdiv(ntiles, a.tiles_per_block), (unsigned)pairs);
@@ -395,7 +415,7 @@ int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s) {
     a.in_scale = d.in_scale; a.in_shift = d.in_shift;
     a.ws_co = d.ws_co; a.ws_ci = d.ws_ci; a.ws_tap = d.ws_tap;
     a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
-    a.pad = d.pad; a.in_act = d.in_act;
+    a.pad = d.pad; a.in_act = d.in_act; a.groups = d.groups;
     a.tiles_h = a.tiles_w = a.tiles_per_block = a.ci_tiles = 0;
     if (d.KH == 3) return d.stride == 1 ? launch_wgrad<3, 1>(a, s) : launch_wgrad<3, 2>(a, s);
     return d.stride == 1 ? launch_wgrad<1, 1>(a, s) : launch_wgrad<1, 2>(a, s);

@@ -121,7 +121,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
     if xadd is not None and (xadd.shape != x.shape or xadd.dtype != x.dtype):
         raise LednError('conv2d: xadd shape/dtype mismatch')
     _check(lib, x, w, y, res, xadd, in_scale, in_shift, out_scale, out_shift, slope, w_bf16)
-    if w_bf16 is not None and (w_bf16.dtype != torch.bfloat16 or w_bf16.numel() != w.numel()):
+    if w_bf16 is not None and (w_bf16.dtype != torch.bfloat16 or w_bf16.numel() != w.numel() * groups):
         raise LednError('conv2d: w_bf16 must be the bfloat16 pack of w')
     d.x, d.xadd, d.w, d.y, d.res, d.w_bf16 = _p(x), _p(xadd), _p(w), _p(y), _p(res), _p(w_bf16)
     d.in_scale, d.in_shift = _p(_f32(in_scale, Cin)), _p(_f32(in_shift, Cin))
@@ -141,20 +141,24 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
     return y
 
 
-def mfma_weight_ok(w):
+def mfma_weight_ok(w, groups=1):
     """shape gate of the MFMA conv path (csrc/conv_mfma.hip: conv_mfma_supported)."""
-    co, ci, kh, kw = w.shape
-    return co % 32 == 0 and ci % 32 == 0 and kh == kw and kh in (1, 3)
+    co, cig, kh, kw = w.shape
+    if groups != 1 and kh != 1:
+        return False
+    return co % 16 == 0 and (cig * groups) % 32 == 0 and kh == kw and kh in (1, 3)
 
 
-def pack_conv_weights(w, mode=0):
-    """bf16 weight pack for the MFMA path: mode 0 forward [tap][co][ci], mode 1 dgrad."""
+def pack_conv_weights(w, mode=0, groups=1):
+    """bf16 weight pack for the MFMA path: mode 0 forward [tap][co][ci], mode 1 dgrad;
+    dense over the full input width (a grouped 1x1 gets zeros outside its group)."""
     lib = _lib.get_lib()
-    Cout, Cin, KH, KW = w.shape
+    Cout, cig, KH, KW = w.shape
+    Cin = cig * groups
     _f32(w)
-    out = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+    out = torch.empty(Cout * Cin * KH * KW, dtype=torch.bfloat16, device=w.device)
     _check(lib, w, out)
-    _run(lib, 'ledn_pack_conv_weights', w, _p(w), _p(out), Cout, Cin, KH, KW, mode,
+    _run(lib, 'ledn_pack_conv_weights', w, _p(w), _p(out), Cout, Cin, KH, KW, mode, groups,
          work=(f'packw {tuple(w.shape)} m{mode}', _nb(w, out), 0))
     return out
 

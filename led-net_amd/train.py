@@ -42,9 +42,9 @@ class ConvFn(Function):
     def forward(ctx, x, w, b, xadd, stride, pad, groups, stats, out_dtype):
         st = (stats[0], stats[1]) if stats is not None else None
         wp = None
-        if (groups == 1 and xadd is None and x.dtype == torch.bfloat16 and ops.mfma_weight_ok(w)
+        if (xadd is None and x.dtype == torch.bfloat16 and ops.mfma_weight_ok(w, groups)
                 and out_dtype in (None, torch.bfloat16)):
-            wp = ops.pack_conv_weights(w, 0)
+            wp = ops.pack_conv_weights(w, 0, groups)
         z = ops.conv2d(x, w, stride=stride, pad=pad, groups=groups, xadd=xadd, out_shift=b, stats=st,
                        out_dtype=out_dtype, w_bf16=wp)
         ctx.save_for_backward(x, w, xadd)
@@ -59,9 +59,10 @@ class ConvFn(Function):
         dx = None
         if ctx.needs_input_grad[0] or (xadd is not None and ctx.needs_input_grad[3]):
             wp = None
-            if (groups == 1 and dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
-                    and ops.mfma_weight_ok(w) and not (stride == 2 and w.shape[2] == 1)):
-                wp = ops.pack_conv_weights(w, 1)
+            if (dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and w.shape[1] * groups % 32 == 0
+                    and w.shape[0] % 32 == 0 and ops.mfma_weight_ok(w, groups)
+                    and not (stride == 2 and w.shape[2] == 1)):
+                wp = ops.pack_conv_weights(w, 1, groups)
             dx = ops.conv2d(dz, w, stride=stride, pad=pad, groups=groups, transposed=True,
                             out_hw=(x.shape[1], x.shape[2]), out_dtype=x.dtype, w_bf16=wp)
         dw, db = ops.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, pad=pad, groups=groups, xadd=xadd,

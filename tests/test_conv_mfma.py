@@ -83,3 +83,26 @@ def test_mfma_conv_dgrad_wgrad(be, cin, cout, k, stride, hw):
                               bias=True)
     torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-2, atol=1e-2 * float(w.grad.abs().max()))
     torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize('cin,cout,hw', [(64, 16, (9, 40)), (64, 64, (12, 33)), (128, 32, (8, 35)), (256, 256, (5, 34))])
+def test_mfma_grouped_1x1(be, cin, cout, hw):
+    """SESP's grouped (g=4) 1x1 convs on the MFMA path: densified weight pack, Cout = 16 tail."""
+    from led_net_amd import ops
+    g = 4
+    x = r16(torch.randn(2, cin, *hw)).requires_grad_(True)
+    w = r16(torch.randn(cout, cin // g, 1, 1) / (cin // g) ** 0.5).requires_grad_(True)
+    z = F.conv2d(x, w, groups=g)
+    dz = r16(torch.randn_like(z))
+    z.backward(dz)
+    stats = (D(torch.zeros(cout)), D(torch.zeros(cout)))
+    got = ops.conv2d(nhwc(x).bfloat16(), D(w.detach()), groups=g, stats=stats,
+                     w_bf16=ops.pack_conv_weights(D(w.detach()), 0, g))
+    torch.testing.assert_close(nchw(got), z.detach(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(stats[0].cpu(), z.detach().sum((0, 2, 3)), rtol=1e-2, atol=0.5)
+    if cout % 32 == 0:
+        dx = ops.conv2d(nhwc(dz).bfloat16(), D(w.detach()), groups=g, transposed=True, out_hw=hw,
+                        w_bf16=ops.pack_conv_weights(D(w.detach()), 1, g))
+        torch.testing.assert_close(nchw(dx), x.grad, rtol=2e-2, atol=2e-2 * float(x.grad.abs().max()))
+    dw, _ = ops.conv2d_wgrad(nhwc(x).bfloat16(), nhwc(dz).bfloat16(), tuple(w.shape), groups=g)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-2, atol=1e-2 * float(w.grad.abs().max()))
