@@ -83,6 +83,11 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream);
 int ledn_pack_conv_weights(const float* w, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode,
                            int groups, void* stream);
 
+/* im2col of the 3-channel stem (3x3, stride 2, pad 1): p[n,ho,wo,(kh*3+kw)*C + c], bf16,
+ * 32 columns (9*C used, rest zero).  The stem (ddrnet.py:123-130) then runs as a K=32 1x1
+ * GEMM on the MFMA path with the weight reshaped to [Cout][32][1][1]. */
+int ledn_im2col_stem(const void* x, void* p, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+
 /* Weight (and bias) gradient of the same convolution:
  *   dw(co,ci,tap) += sum_{n,ho,wo} pre(x)[n, ho*s-pad+kh*dil, .., ci] * dz[n,ho,wo,co]
  *   db[co]        += sum dz[n,ho,wo,co]
@@ -408,7 +413,8 @@ typedef struct {
     long long n;
 } ledn_sgd_entry;
 int ledn_sgd_step(const ledn_sgd_entry* table_dev, int n_tensors, long long max_n, float lr,
-                  float momentum, float weight_decay, float grad_scale, void* stream);
+                  const float* lr_dev, float momentum, float weight_decay, float grad_scale,
+                  void* stream);   /* lr_dev != NULL: learning rate read from device memory (hipGraph replay) */
 
 #ifdef __cplusplus
 }

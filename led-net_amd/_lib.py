@@ -120,9 +120,10 @@ _PROTOS = {
     'ledn_ohem_work_floats': ([i64], i64),
     'ledn_ohem_ce_fwd': ([fp, vp, i64, i32, C.c_float, i64, C.c_float, i32, fp, fp, vp], i32),
     'ledn_ohem_ce_bwd': ([fp, vp, i64, i32, i32, fp, fp, fp, C.c_float, fp, vp], i32),
-    'ledn_sgd_step': ([vp, i32, i64, C.c_float, C.c_float, C.c_float, C.c_float, vp], i32),
+    'ledn_sgd_step': ([vp, i32, i64, C.c_float, fp, C.c_float, C.c_float, C.c_float, vp], i32),
     'ledn_abi_version': ([], i32),
     'ledn_conv2d': ([C.POINTER(ConvDesc), vp], i32),
+    'ledn_im2col_stem': ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_pack_conv_weights': ([fp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_conv2d_wgrad': ([C.POINTER(WgradDesc), vp], i32),
     'ledn_dwconv2d': ([C.POINTER(DwDesc), vp], i32),

@@ -375,8 +375,9 @@ int ohem_ce_bwd_impl(const float* logits, const long long* target, long long P, 
 // ===========================================================================
 // multi-tensor SGD: grid = (chunks, tensors)
 // ===========================================================================
-__global__ void __launch_bounds__(256) sgd_kernel(const ledn_sgd_entry* table, float lr, float momentum,
-                                                  float wd, float gscale) {
+__global__ void __launch_bounds__(256) sgd_kernel(const ledn_sgd_entry* table, float lr_arg, const float* lr_dev,
+                                                  float momentum, float wd, float gscale) {
+    const float lr = lr_dev ? *lr_dev : lr_arg;   // device-resident lr: a captured graph replays with a new value
     const ledn_sgd_entry e = table[blockIdx.y];
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < e.n; i += stride) {
@@ -389,13 +390,13 @@ __global__ void __launch_bounds__(256) sgd_kernel(const ledn_sgd_entry* table, f
     }
 }
 
-int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_n, float lr, float momentum,
-                  float weight_decay, float grad_scale, hipStream_t s) {
+int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_n, float lr,
+                  const float* lr_dev, float momentum, float weight_decay, float grad_scale, hipStream_t s) {
     LEDN_REQUIRE(table_dev && n_tensors > 0 && max_n > 0);
     long chunks = cdiv(max_n, 256 * 8);
     if (chunks > 64) chunks = 64;
     LEDN_LAUNCH(sgd_kernel, dim3((unsigned)chunks, (unsigned)n_tensors), dim3(256), 0, s, table_dev, lr,
-                momentum, weight_decay, grad_scale);
+                lr_dev, momentum, weight_decay, grad_scale);
     return check_launch();
 }
 

@@ -9,23 +9,43 @@ namespace ledn {
 
 // ===========================================================================
 // BatchNorm (+ residual / gate) + activation backward
+// Thread = (pixel row r, channel vector cv): the per-channel parameters are loaded ONCE
+// into registers, then the thread walks pixels r, r+rows, ... (grid-stride), so the
+// streaming loop issues only the 2-3 wide activation loads per element.
 // ===========================================================================
+template <int V>
+struct BnParams {
+    float sc[V], sh[V], sl[V], mean[V], invstd[V];
+};
+
+template <int V>
+__device__ __forceinline__ BnParams<V> bn_params(const ledn_bnbwd_desc& d, int c) {
+    BnParams<V> p;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        p.sc[i] = d.scale ? d.scale[c + i] : 1.f;
+        p.sh[i] = d.shift ? d.shift[c + i] : 0.f;
+        p.sl[i] = d.slope ? d.slope[c + i] : 0.f;
+        p.mean[i] = d.bn_mode ? d.mean[c + i] : 0.f;
+        p.invstd[i] = d.bn_mode ? d.invstd[c + i] : 0.f;
+    }
+    return p;
+}
+
 template <typename TZ, typename TY, int V>
-__device__ __forceinline__ void bn_g(const ledn_bnbwd_desc& d, long off, int c, float* gv, float* xh,
-                                     float* gres, float* dsl) {
+__device__ __forceinline__ void bn_g(const ledn_bnbwd_desc& d, const BnParams<V>& p, long off, float* gv,
+                                     float* xh, float* gres, float* dsl) {
     float z[V], dy[V], r[V];
     ldv<V>(reinterpret_cast<const TZ*>(d.z) + off, z);
     ldv<V>(reinterpret_cast<const TY*>(d.dy) + off, dy);
     if (d.res_mode != LEDN_RES_NONE) ldv<V>(reinterpret_cast<const TY*>(d.res) + off, r);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        const float sc = d.scale ? d.scale[c + i] : 1.f, sh = d.shift ? d.shift[c + i] : 0.f;
-        const float v = z[i] * sc + sh;
+        const float v = z[i] * p.sc[i] + p.sh[i];
         float t = v;
         if (d.res_mode == LEDN_RES_ADD) t = v + r[i];
         else if (d.res_mode == LEDN_RES_GATE) t = v * r[i] + r[i];
-        const float sl = d.slope ? d.slope[c + i] : 0.f;
-        const float gt = dy[i] * act_grad(d.act, t, sl);
+        const float gt = dy[i] * act_grad(d.act, t, p.sl[i]);
         dsl[i] = (d.act == LEDN_ACT_PRELU && t <= 0.f) ? dy[i] * t : 0.f;
         if (d.res_mode == LEDN_RES_GATE) {
             gv[i] = gt * r[i];
@@ -34,12 +54,12 @@ __device__ __forceinline__ void bn_g(const ledn_bnbwd_desc& d, long off, int c, 
             gv[i] = gt;
             gres[i] = gt;
         }
-        xh[i] = d.bn_mode ? (z[i] - d.mean[c + i]) * d.invstd[c + i] : 0.f;
+        xh[i] = (z[i] - p.mean[i]) * p.invstd[i];
     }
 }
 
 template <typename TZ, typename TY, int V>
-__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(ledn_bnbwd_desc d, int pix_per_block) {
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(ledn_bnbwd_desc d) {
     __shared__ float s_part[3][256 * 4];
     const int cvn = d.C / V;
     const int rows = 256 / cvn;
@@ -48,11 +68,10 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(ledn_bnbwd_desc d, i
 #pragma unroll
     for (int v = 0; v < V; ++v) a[v] = b[v] = e[v] = 0.f;
     if (r < rows) {
-        const long p0 = (long)blockIdx.x * pix_per_block;
-        const long p1 = min((long)d.P, p0 + (long)pix_per_block);
-        for (long p = p0 + r; p < p1; p += rows) {
+        const BnParams<V> prm = bn_params<V>(d, cv * V);
+        for (long p = (long)blockIdx.x * rows + r; p < d.P; p += (long)gridDim.x * rows) {
             float gv[V], xh[V], gres[V], dsl[V];
-            bn_g<TZ, TY, V>(d, p * d.C + cv * V, cv * V, gv, xh, gres, dsl);
+            bn_g<TZ, TY, V>(d, prm, p * d.C + cv * V, gv, xh, gres, dsl);
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 a[v] += gv[v];
@@ -86,22 +105,29 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(ledn_bnbwd_desc d, i
 
 template <typename TZ, typename TY, int V>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(ledn_bnbwd_desc d) {
-    const long total = d.P * (d.C / V);
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = (int)(idx % (d.C / V)) * V;
-    const long off = idx * V;
-    float gv[V], xh[V], gres[V], dsl[V], dz[V];
-    bn_g<TZ, TY, V>(d, off, c, gv, xh, gres, dsl);
+    const int cvn = d.C / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    if (r >= rows) return;
+    const int c = cv * V;
+    const BnParams<V> prm = bn_params<V>(d, c);
     const float invn = (float)(1.0 / d.count);
+    float mg[V], mgx[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        const float sc = d.scale ? d.scale[c + i] : 1.f;
-        dz[i] = d.bn_mode ? sc * (gv[i] - d.sum_g[c + i] * invn - xh[i] * d.sum_gx[c + i] * invn)
-                          : gv[i] * sc;
+        mg[i] = d.bn_mode ? d.sum_g[c + i] * invn : 0.f;
+        mgx[i] = d.bn_mode ? d.sum_gx[c + i] * invn : 0.f;
     }
-    stv<V>(reinterpret_cast<TZ*>(d.dz) + off, dz);
-    if (d.dres) stv<V>(reinterpret_cast<TY*>(d.dres) + off, gres);
+    for (long p = (long)blockIdx.x * rows + r; p < d.P; p += (long)gridDim.x * rows) {
+        const long off = p * d.C + c;
+        float gv[V], xh[V], gres[V], dsl[V], dz[V];
+        bn_g<TZ, TY, V>(d, prm, off, gv, xh, gres, dsl);
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+            dz[i] = d.bn_mode ? prm.sc[i] * (gv[i] - mg[i] - xh[i] * mgx[i]) : gv[i] * prm.sc[i];
+        stv<V>(reinterpret_cast<TZ*>(d.dz) + off, dz);
+        if (d.dres) stv<V>(reinterpret_cast<TY*>(d.dres) + off, gres);
+    }
 }
 
 static int bnbwd_validate(const ledn_bnbwd_desc& d, bool apply) {
@@ -135,21 +161,27 @@ static int bnbwd_validate(const ledn_bnbwd_desc& d, bool apply) {
         } else return LEDN_EINVAL;                                                                       \
     } while (0)
 
+static long bn_rows(const ledn_bnbwd_desc& d) {
+    const int V = d.C % 4 == 0 ? 4 : 1;
+    return 256 / (d.C / V);
+}
+
 int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
     const int rc = bnbwd_validate(d, false);
     if (rc != LEDN_OK) return rc;
-    long ppb = cdiv(d.P, 2048);
-    if (ppb < 256) ppb = 256;
-    const dim3 grid((unsigned)cdiv(d.P, ppb));
-    LEDN_BNB_DISPATCH(bn_bwd_reduce_kernel, d, (int)ppb);
+    long nb = cdiv(d.P, bn_rows(d) * 8);
+    if (nb > 256) nb = 256;     // every workgroup ends in one atomic per channel: keep the grid bounded
+    const dim3 grid((unsigned)nb);
+    LEDN_BNB_DISPATCH(bn_bwd_reduce_kernel, d);
     return check_launch();
 }
 
 int bn_act_bwd_apply_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
     const int rc = bnbwd_validate(d, true);
     if (rc != LEDN_OK) return rc;
-    const long total = d.P * (d.C % 4 == 0 ? d.C / 4 : d.C);
-    const dim3 grid((unsigned)cdiv(total, 256));
+    long nb = cdiv(d.P, bn_rows(d) * 4);
+    if (nb > 4096) nb = 4096;
+    const dim3 grid((unsigned)nb);
     LEDN_BNB_DISPATCH(bn_bwd_apply_kernel, d);
     return check_launch();
 }

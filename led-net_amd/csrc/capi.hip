@@ -9,6 +9,7 @@ bool conv_mfma_supported(const ledn_conv_desc& d);
 int conv_mfma(const ledn_conv_desc& d, hipStream_t s);
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d);
 int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s);
+int im2col_stem_impl(const void* x, void* p, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 int pack_conv_weights_impl(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode,
                            int groups, hipStream_t s);
 int wgrad_validate(const ledn_wgrad_desc& d);
@@ -60,8 +61,8 @@ int ohem_ce_fwd_impl(const float* logits, const long long* target, long long P, 
 int ohem_ce_bwd_impl(const float* logits, const long long* target, long long P, int C, int ignore_label,
                      const float* work, const float* out, const float* dloss, float loss_weight,
                      float* dlogits, hipStream_t s);
-int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_n, float lr, float momentum,
-                  float weight_decay, float grad_scale, hipStream_t s);
+int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_n, float lr,
+                  const float* lr_dev, float momentum, float weight_decay, float grad_scale, hipStream_t s);
 }  // namespace ledn
 
 using namespace ledn;
@@ -77,6 +78,10 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
     if (rc != LEDN_OK) return rc;
     if (conv_mfma_supported(*d)) return conv_mfma(*d, S(stream));
     return conv_direct(*d, S(stream));
+}
+
+int ledn_im2col_stem(const void* x, void* p, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+    return im2col_stem_impl(x, p, N, H, W, C, Ho, Wo, S(stream));
 }
 
 int ledn_pack_conv_weights(const float* w, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode,
@@ -197,9 +202,10 @@ int ledn_ohem_ce_bwd(const float* logits, const long long* target, long long P, 
     return ohem_ce_bwd_impl(logits, target, P, C, ignore_label, work, out, dloss, loss_weight, dlogits,
                             S(stream));
 }
-int ledn_sgd_step(const ledn_sgd_entry* table_dev, int n_tensors, long long max_n, float lr, float momentum,
-                  float weight_decay, float grad_scale, void* stream) {
-    return sgd_step_impl(table_dev, n_tensors, max_n, lr, momentum, weight_decay, grad_scale, S(stream));
+int ledn_sgd_step(const ledn_sgd_entry* table_dev, int n_tensors, long long max_n, float lr,
+                  const float* lr_dev, float momentum, float weight_decay, float grad_scale, void* stream) {
+    return sgd_step_impl(table_dev, n_tensors, max_n, lr, lr_dev, momentum, weight_decay, grad_scale,
+                         S(stream));
 }
 
 }  // extern "C"

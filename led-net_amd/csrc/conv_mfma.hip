@@ -262,6 +262,47 @@ int pack_conv_weights_impl(const float* w, void* out, int Cout, int Cin, int KH,
 }
 
 // ---------------------------------------------------------------------------
+// im2col of the 3-channel stem (3x3, stride 2, pad 1): p[n,ho,wo, (kh*3+kw)*C + c] (27 of 32
+// columns used, the rest zero) so that the stem runs as a K=32 1x1 GEMM on the matrix cores
+// (forward and weight gradient); the input needs no gradient.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) im2col_stem_kernel(const bf16_t* x, bf16_t* p, int N, int H, int W, int C,
+                                                          int Ho, int Wo) {
+    const long total = (long)N * Ho * Wo;
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= total) return;
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long)Wo * Ho));
+    unsigned short e[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) e[i] = 0;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho * 2 - 1 + kh;
+        if (hi < 0 || hi >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wi = wo * 2 - 1 + kw;
+            if (wi < 0 || wi >= W) continue;
+            const bf16_t* src = x + (((long)n * H + hi) * W + wi) * C;
+            for (int c = 0; c < C; ++c) e[(kh * 3 + kw) * C + c] = src[c].v;
+        }
+    }
+    uint4* dst = reinterpret_cast<uint4*>(p + pix * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        dst[q] = make_uint4(e[8 * q] | ((unsigned)e[8 * q + 1] << 16), e[8 * q + 2] | ((unsigned)e[8 * q + 3] << 16),
+                            e[8 * q + 4] | ((unsigned)e[8 * q + 5] << 16), e[8 * q + 6] | ((unsigned)e[8 * q + 7] << 16));
+}
+
+int im2col_stem_impl(const void* x, void* p, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+    LEDN_REQUIRE(x && p && N > 0 && H > 0 && W > 0 && C > 0 && 9 * C <= 32);
+    LEDN_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1);
+    LEDN_LAUNCH(im2col_stem_kernel, dim3((unsigned)cdiv((long)N * Ho * Wo, 256)), dim3(256), 0, s,
+                (const bf16_t*)x, (bf16_t*)p, N, H, W, C, Ho, Wo);
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------
 struct MfmaWgradArgs {
@@ -326,10 +367,19 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
         for (int p = tid >> 2; p < TR * 32; p += 64) {
             const int pr = p / 32, pc = p % 32, part = tid & 3;
             const int ho = ho0 + pr, wo = wo0 + pc;
-            const bool valid = ho < a.Ho && wo < a.Wo && co0 + part * 8 < a.Cout;
-            stage_piece(s_z + (long)p * PIXB + part * 16,
-                        a.dz + (((long)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co0 + part * 8, valid, nullptr,
-                        nullptr, 0, 0);
+            const bf16_t* zsrc = a.dz + (((long)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co0 + part * 8;
+            if (a.Cout % 8 == 0) {
+                const bool valid = ho < a.Ho && wo < a.Wo && co0 + part * 8 < a.Cout;
+                stage_piece(s_z + (long)p * PIXB + part * 16, zsrc, valid, nullptr, nullptr, 0, 0);
+            } else {   // narrow heads (Cout = 1, 2, 4): element-wise staging, zero-filled to 8 channels
+                unsigned short e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    e[j] = (ho < a.Ho && wo < a.Wo && co0 + part * 8 + j < a.Cout) ? zsrc[j].v : (unsigned short)0;
+                *reinterpret_cast<uint4*>(s_z + (long)p * PIXB + part * 16) =
+                    make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16),
+                               e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16));
+            }
         }
         __syncthreads();
         // ---- 2*TR k-steps of 16 pixels (half a row each); wave w takes k-steps w, w+4, ...
@@ -388,7 +438,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d) {
     if (d.dtype_x != LEDN_BF16 || d.dtype_dz != LEDN_BF16 || d.dil != 1 || d.xadd) return false;
     if (d.groups != 1 && !(d.KH == 1 && d.KW == 1)) return false;
-    if (d.Cin % 32 || d.Cout % 16) return false;
+    if (d.Cin % 32 || (d.Cout % 16 && d.Cout > 4)) return false;   // Cout <= 4: narrow heads, scalar dz staging
     if (d.KH != d.KW || !((d.KH == 3 && d.pad == 1) || (d.KH == 1 && d.pad == 0))) return false;
     return d.stride == 1 || d.stride == 2;
 }

@@ -8,8 +8,7 @@ namespace ledn {
 // x: [P][C].  Thread (r, cv): channel vector cv, pixel rows r, r+rows, ...
 template <typename T, int V>
 __global__ void __launch_bounds__(256) channel_stats_kernel(const T* x, const T* xadd, long P, int C,
-                                                            float* sum, float* sqsum,
-                                                            int pix_per_block) {
+                                                            float* sum, float* sqsum) {
     __shared__ float s_part[2][256 * 4];
     const int cvn = C / V;
     const int rows = 256 / cvn;
@@ -19,9 +18,7 @@ __global__ void __launch_bounds__(256) channel_stats_kernel(const T* x, const T*
     for (int v = 0; v < V; ++v) a[v] = b[v] = 0.f;
     const bool worker = r < rows;
     if (worker) {
-        const long p0 = (long)blockIdx.x * pix_per_block;
-        const long p1 = min(P, p0 + (long)pix_per_block);
-        for (long p = p0 + r; p < p1; p += rows) {
+        for (long p = (long)blockIdx.x * rows + r; p < P; p += (long)gridDim.x * rows) {
             float xv[V];
             ldv<V>(x + p * C + cv * V, xv);
             if (xadd) {
@@ -62,17 +59,17 @@ int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int 
     LEDN_REQUIRE(x && sum && P > 0 && C > 0);
     const int V = (C % 4 == 0) ? 4 : 1;
     LEDN_REQUIRE(C / V <= 256);
-    long ppb = cdiv(P, 2048);
-    if (ppb < 256) ppb = 256;
-    const dim3 grid((unsigned)cdiv(P, ppb));
+    long nb = cdiv(P, (256 / (C / V)) * 8);
+    if (nb > 256) nb = 256;     // one atomic per channel per workgroup: bounded grid
+    const dim3 grid((unsigned)nb);
 #define LEDN_CS(T)                                                                              \
     do {                                                                                        \
         if (V == 4)                                                                             \
             LEDN_LAUNCH((channel_stats_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x,       \
-                        (const T*)xadd, (long)P, C, sum, sqsum, (int)ppb);                      \
+                        (const T*)xadd, (long)P, C, sum, sqsum);                      \
         else                                                                                    \
             LEDN_LAUNCH((channel_stats_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x,       \
-                        (const T*)xadd, (long)P, C, sum, sqsum, (int)ppb);                      \
+                        (const T*)xadd, (long)P, C, sum, sqsum);                      \
     } while (0)
     if (dtype == LEDN_F32) LEDN_CS(float);
     else if (dtype == LEDN_BF16) LEDN_CS(bf16_t);
@@ -106,34 +103,42 @@ __global__ void bn_finalize_kernel(const float* sum, const float* sqsum, double 
 
 template <typename TX, typename TY, int V>
 __global__ void __launch_bounds__(256) affine_act_kernel(ledn_affine_desc d) {
-    const long total = d.P * (d.C / V);
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = (int)(idx % (d.C / V)) * V;
-    const long off = idx * V;
-    float v[V];
-    ldv<V>(reinterpret_cast<const TX*>(d.x) + off, v);
-    if (d.xadd) {
-        float a[V];
-        ldv<V>(reinterpret_cast<const TX*>(d.xadd) + off, a);
+    const int cvn = d.C / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    if (r >= rows) return;
+    const int c = cv * V;
+    float sc[V], sh[V], sl[V];
 #pragma unroll
-        for (int i = 0; i < V; ++i) v[i] += a[i];
+    for (int i = 0; i < V; ++i) {
+        sc[i] = d.scale ? d.scale[c + i] : 1.f;
+        sh[i] = d.shift ? d.shift[c + i] : 0.f;
+        sl[i] = d.slope ? d.slope[c + i] : 0.f;
     }
-    if (d.scale) {
+    for (long p = (long)blockIdx.x * rows + r; p < d.P; p += (long)gridDim.x * rows) {
+        const long off = p * d.C + c;
+        float v[V];
+        ldv<V>(reinterpret_cast<const TX*>(d.x) + off, v);
+        if (d.xadd) {
+            float a[V];
+            ldv<V>(reinterpret_cast<const TX*>(d.xadd) + off, a);
 #pragma unroll
-        for (int i = 0; i < V; ++i) v[i] = v[i] * d.scale[c + i] + d.shift[c + i];
-    }
-    if (d.res_mode != LEDN_RES_NONE) {
-        float r[V];
-        ldv<V>(reinterpret_cast<const TY*>(d.res) + off, r);
+            for (int i = 0; i < V; ++i) v[i] += a[i];
+        }
 #pragma unroll
-        for (int i = 0; i < V; ++i) v[i] = d.res_mode == LEDN_RES_ADD ? v[i] + r[i] : v[i] * r[i] + r[i];
-    }
-    if (d.act != LEDN_ACT_NONE) {
+        for (int i = 0; i < V; ++i) v[i] = v[i] * sc[i] + sh[i];
+        if (d.res_mode != LEDN_RES_NONE) {
+            float rr[V];
+            ldv<V>(reinterpret_cast<const TY*>(d.res) + off, rr);
 #pragma unroll
-        for (int i = 0; i < V; ++i) v[i] = act_apply(d.act, v[i], d.slope ? d.slope[c + i] : 0.f);
+            for (int i = 0; i < V; ++i) v[i] = d.res_mode == LEDN_RES_ADD ? v[i] + rr[i] : v[i] * rr[i] + rr[i];
+        }
+        if (d.act != LEDN_ACT_NONE) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) v[i] = act_apply(d.act, v[i], sl[i]);
+        }
+        stv<V>(reinterpret_cast<TY*>(d.y) + off, v);
     }
-    stv<V>(reinterpret_cast<TY*>(d.y) + off, v);
 }
 
 int affine_act_impl(const ledn_affine_desc& d, hipStream_t s) {
@@ -142,8 +147,10 @@ int affine_act_impl(const ledn_affine_desc& d, hipStream_t s) {
     LEDN_REQUIRE(d.res_mode == LEDN_RES_NONE || d.res != nullptr);
     LEDN_REQUIRE(d.act != LEDN_ACT_PRELU || d.slope != nullptr);
     const bool v4 = d.C % 4 == 0;
-    const long total = d.P * (v4 ? d.C / 4 : d.C);
-    const dim3 grid((unsigned)cdiv(total, 256));
+    LEDN_REQUIRE((v4 ? d.C / 4 : d.C) <= 256);
+    long nb = cdiv(d.P, (256 / (v4 ? d.C / 4 : d.C)) * 4);
+    if (nb > 4096) nb = 4096;
+    const dim3 grid((unsigned)nb);
 #define LEDN_AF(TX, TY)                                                                  \
     do {                                                                                 \
         if (v4) LEDN_LAUNCH((affine_act_kernel<TX, TY, 4>), grid, dim3(256), 0, s, d);   \

@@ -141,6 +141,27 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
     return y
 
 
+def im2col_stem(x):
+    """x: [N,H,W,3] bf16 -> [N,Ho,Wo,32] bf16 patches of the 3x3/s2/p1 stem conv."""
+    lib = _lib.get_lib()
+    N, H, W, Cc = x.shape
+    if x.dtype != torch.bfloat16 or 9 * Cc > 32:
+        raise LednError('im2col_stem: bf16 input with <= 3 channels required')
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    p = torch.empty((N, Ho, Wo, 32), dtype=torch.bfloat16, device=x.device)
+    _check(lib, x, p)
+    _run(lib, 'ledn_im2col_stem', x, _p(x), _p(p), N, H, W, Cc, Ho, Wo,
+         work=(f'im2col_stem {N}x{H}x{W}', _nb(x, p), 0))
+    return p
+
+
+def stem_weight_as_1x1(w):
+    """[Cout][3][3][3] OIHW -> [Cout][32][1][1] matching im2col_stem's column order (differentiable)."""
+    co, ci, kh, kw = w.shape
+    w2 = w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+    return torch.nn.functional.pad(w2, (0, 32 - kh * kw * ci)).reshape(co, 32, 1, 1).contiguous()
+
+
 def mfma_weight_ok(w, groups=1):
     """shape gate of the MFMA conv path (csrc/conv_mfma.hip: conv_mfma_supported)."""
     co, cig, kh, kw = w.shape

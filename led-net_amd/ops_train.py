@@ -234,7 +234,7 @@ class SgdTable:
         self.ref = params[0]
         self.keep = (params, grads, moms)
 
-    def step(self, lr, momentum, weight_decay, grad_scale=1.0):
+    def step(self, lr, momentum, weight_decay, grad_scale=1.0, lr_dev=None):
         lib = _lib.get_lib()
-        _run(lib, 'ledn_sgd_step', self.ref, self.table.data_ptr(), self.n, self.max_n, lr, momentum,
-             weight_decay, grad_scale, work=(f'sgd {self.n} tensors', 16 * sum(p.numel() for p in self.keep[0]), 0))
+        _run(lib, 'ledn_sgd_step', self.ref, self.table.data_ptr(), self.n, self.max_n, float(lr), _p(lr_dev),
+             momentum, weight_decay, grad_scale, work=(f'sgd {self.n} tensors', 16 * sum(p.numel() for p in self.keep[0]), 0))

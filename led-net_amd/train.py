@@ -400,7 +400,15 @@ def lednet_forward_train(m, x, pre=None):
     out_size = (math.ceil(H / 8), math.ceil(W / 8))
     s, b, mp = pre if pre is not None else (None, None, None)
     xin = ops.nchw_to_nhwc(x.contiguous(), m.act_dtype, s, b, mp)
-    x1 = conv_module(m.stem['0'], xin)
+    s0 = m.stem['0']
+    if xin.dtype == torch.bfloat16 and 9 * m.in_channels <= 32 and m.channels % 32 == 0:
+        # stem as a K=32 GEMM on the MFMA path: im2col patches (no gradient needed) x reshaped weight
+        st = _stats(m.channels, xin)
+        z = ConvFn.apply(ops.im2col_stem(xin), ops.stem_weight_as_1x1(s0.conv.weight), None, None, 1, 0, 1,
+                         st, None)
+        x1 = BNActFn.apply(z, s0.bn.weight, s0.bn.bias, None, None, st, s0.bn, ACT_RELU, RES_NONE, None)
+    else:
+        x1 = conv_module(s0, xin)
     x2 = conv_module(m.stem['1'], x1)
     y = basic_block(m.stem['2'][1], basic_block(m.stem['2'][0], x2), final_relu=True)
     y = basic_block(m.stem['4'][1], basic_block(m.stem['4'][0], y), final_relu=True)
@@ -514,6 +522,8 @@ class Trainer:
             self.moms.append(self.flat_mom[off:off + k].view_as(p))
             off += k
         self.table = None
+        self._lr_dev = None
+        self._graph = None
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         sync = getattr(model.backbone, 'sync_bn', False) or getattr(model.decode_head, 'sync_bn', False)
         _Env.world = world_size
@@ -569,9 +579,45 @@ class Trainer:
             n = self.flat_grad.numel()
             for off in range(0, n, self.bucket_elems):
                 self.dist.all_reduce(self.flat_grad[off:off + self.bucket_elems])
-        self.table.step(self.lr(), self.momentum, self.wd, 1.0 / self.world)
+        self.table.step(self.lr(), self.momentum, self.wd, 1.0 / self.world, lr_dev=self._lr_dev)
         self.iter += 1
         return losses
+
+    # ------------------------------------------------------------------ #
+    # hipGraph replay of the whole step (forward + loss + backward + SGD): ~800 launches
+    # per step are submitted as ONE graph, the host only refreshes the input buffers and the
+    # device-resident learning rate.  Single-process only (collectives stay eager).
+    def capture(self, inputs, data_samples, warmup=3):
+        assert self.dist is None, 'graph capture is for the single-GPU step'
+        dev = inputs.device
+        self._static_in = inputs.clone()
+        self._static_lab = [ds.gt_sem_seg.data.clone() for ds in data_samples]
+        from .segmentor import SegDataSample
+        self._static_samples = [SegDataSample(gt=t) for t in self._static_lab]
+        self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._lr_dev.fill_(self.lr())
+                self.train_step(self._static_in, self._static_samples)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._lr_dev.fill_(self.lr())
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_out = self.train_step(self._static_in, self._static_samples)
+        return self
+
+    def replay(self, inputs=None, data_samples=None):
+        """one captured step; new inputs are copied into the static buffers first."""
+        if inputs is not None and inputs is not self._static_in:
+            self._static_in.copy_(inputs)
+            for dst, ds in zip(self._static_lab, data_samples):
+                dst.copy_(ds.gt_sem_seg.data)
+        self._lr_dev.fill_(self.lr())
+        self._graph.replay()
+        self.iter += 1
+        return self._static_out
 
 
 def smoke_train_step(model, dev):
