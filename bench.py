@@ -245,6 +245,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(mode, H, W)
         if os.environ.get('LEDN_BENCH_VERBOSE'):
+            fam = {}
+            for (e, sg), v in agg.items():
+                f = fam.setdefault(e, [0.0, 0])
+                f[0] += v['ms']
+                f[1] += v['n']
+            for e, (ms, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+                print(f'{ms / k_steps:9.3f} ms/step  x{n // k_steps:4d}  [family] {e}', file=sys.stderr)
             for (e, sg), v in top[:25]:
                 print(f'{v["ms"] / k_steps:9.3f} ms/step  x{v["n"] // k_steps:3d}  {e} [{sg}]', file=sys.stderr)
         print(json.dumps(out))

@@ -34,6 +34,12 @@ enum { LEDN_RES_NONE = 0, LEDN_RES_ADD = 1, LEDN_RES_GATE = 2 }; /* v+res | v*re
 
 int ledn_abi_version(void);
 
+/* Optional device scratch (f32 words) owned by the caller and used by every later call on ONE
+ * stream: cross-workgroup reductions (BN statistics, weight gradients) write per-workgroup
+ * partials there and finish with a second tiny kernel instead of same-address atomics.
+ * ptr = NULL, nfloats = 0 detaches it (kernels then fall back to atomics). */
+int ledn_set_workspace(void* ptr, long long nfloats);
+
 /* ------------------------------------------------------------------------- *
  * Dense / grouped convolution, forward and data-gradient.
  *   z[n,ho,wo,co] = sum_{kh,kw,ci} pre(x)[n, ho*s-pad+kh*dil, wo*s-pad+kw*dil, ci] * W[co][ci][kh][kw]

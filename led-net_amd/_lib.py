@@ -122,6 +122,7 @@ _PROTOS = {
     'ledn_ohem_ce_bwd': ([fp, vp, i64, i32, i32, fp, fp, fp, C.c_float, fp, vp], i32),
     'ledn_sgd_step': ([vp, i32, i64, C.c_float, fp, C.c_float, C.c_float, C.c_float, vp], i32),
     'ledn_abi_version': ([], i32),
+    'ledn_set_workspace': ([vp, i64], i32),
     'ledn_conv2d': ([C.POINTER(ConvDesc), vp], i32),
     'ledn_im2col_stem': ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_pack_conv_weights': ([fp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
@@ -165,6 +166,14 @@ class Library:
         v = self.cdll.ledn_abi_version()
         if v != 1:
             raise LednError(f'{path}: ABI version {v}, expected 1')
+        self._workspace = None
+
+    def ensure_workspace(self, device, nfloats=32 << 20):
+        """attach a reusable scratch buffer (128 MiB) for two-stage reductions"""
+        if self._workspace is None or self._workspace.device != device:
+            import torch
+            self._workspace = torch.empty(nfloats, dtype=torch.float32, device=device)
+            self.call('ledn_set_workspace', self._workspace.data_ptr(), nfloats)
 
     def call(self, name, *args):
         rc = getattr(self.cdll, name)(*args)

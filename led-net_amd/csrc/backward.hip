@@ -59,7 +59,7 @@ __device__ __forceinline__ void bn_g(const ledn_bnbwd_desc& d, const BnParams<V>
 }
 
 template <typename TZ, typename TY, int V>
-__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(ledn_bnbwd_desc d) {
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(ledn_bnbwd_desc d, float* part) {
     __shared__ float s_part[3][256 * 4];
     const int cvn = d.C / V;
     const int rows = 256 / cvn;
@@ -96,9 +96,14 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(ledn_bnbwd_desc d) {
                 sb += s_part[1][(rr * cvn + cv) * V + v];
                 se += s_part[2][(rr * cvn + cv) * V + v];
             }
-            atomicAdd(d.sum_g + cv * V + v, sa);
-            if (d.sum_gx) atomicAdd(d.sum_gx + cv * V + v, sb);
-            if (d.dslope) atomicAdd(d.dslope + cv * V + v, se);
+            if (part) {
+                float* pp = part + (long)blockIdx.x * 3 * d.C + cv * V + v;
+                pp[0] = sa; pp[d.C] = sb; pp[2 * d.C] = se;
+            } else {
+                atomicAdd(d.sum_g + cv * V + v, sa);
+                if (d.sum_gx) atomicAdd(d.sum_gx + cv * V + v, sb);
+                if (d.dslope) atomicAdd(d.dslope + cv * V + v, se);
+            }
         }
     }
 }
@@ -170,9 +175,13 @@ int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
     const int rc = bnbwd_validate(d, false);
     if (rc != LEDN_OK) return rc;
     long nb = cdiv(d.P, bn_rows(d) * 8);
-    if (nb > 256) nb = 256;     // every workgroup ends in one atomic per channel: keep the grid bounded
+    float* part = nullptr;
+    if (nb > 2048) nb = 2048;
+    if (nb > 64) part = ws_take(nb * 3 * d.C);
+    if (!part && nb > 256) nb = 256;     // atomics fallback: keep the grid bounded
     const dim3 grid((unsigned)nb);
-    LEDN_BNB_DISPATCH(bn_bwd_reduce_kernel, d);
+    LEDN_BNB_DISPATCH(bn_bwd_reduce_kernel, d, part);
+    if (part) return finish_partials(part, (int)nb, d.C, 3, d.sum_g, d.sum_gx, d.dslope, s);
     return check_launch();
 }
 
@@ -292,6 +301,63 @@ __global__ void __launch_bounds__(256) dw_bwd_weight_kernel(ledn_dwbwd_desc d, i
     }
 }
 
+// 3x3 single pass: thread (row r, channel vector cv) keeps all 9 taps x V sums in registers
+// and reads dz once per pixel; LDS reduction over the rows; per-workgroup partial (workspace)
+// or one atomic per element.
+template <typename T, int V>
+__global__ void __launch_bounds__(256) dw_bwd_weight3x3_kernel(ledn_dwbwd_desc d, float* part) {
+    __shared__ float s_part[9 * 256 * 4];
+    const int cvn = d.C / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    const int c = cv * V;
+    float acc[9][V];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[t][v] = 0.f;
+    if (r < rows) {
+        const int dl = d.dil[c / d.group_size];
+        const int pad = d.pad >= 0 ? d.pad : dl;
+        const T* x = reinterpret_cast<const T*>(d.x);
+        const T* dz = reinterpret_cast<const T*>(d.dz);
+        const long npix = (long)d.N * d.Ho * d.Wo;
+        for (long p = (long)blockIdx.x * rows + r; p < npix; p += (long)gridDim.x * rows) {
+            const int wo = (int)(p % d.Wo);
+            const int ho = (int)((p / d.Wo) % d.Ho);
+            const int n = (int)(p / ((long)d.Wo * d.Ho));
+            float g[V];
+            ldv<V>(dz + p * d.C + c, g);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hi = ho * d.stride - pad + kh * dl;
+                if (hi < 0 || hi >= d.H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int wi = wo * d.stride - pad + kw * dl;
+                    if (wi < 0 || wi >= d.W) continue;
+                    float xv[V];
+                    ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.C + c, xv);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[kh * 3 + kw][v] = fmaf(xv[v], g[v], acc[kh * 3 + kw][v]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < V; ++v) s_part[(t * 256 + threadIdx.x) * V + v] = acc[t][v];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * d.C; e += 256) {
+        const int t = e / d.C, ch = e % d.C;
+        float sum = 0.f;
+        for (int rr = 0; rr < rows; ++rr) sum += s_part[(t * 256 + rr * cvn + ch / V) * V + ch % V];
+        if (part) part[(long)blockIdx.x * 9 * d.C + e] = sum;
+        else atomicAdd(d.dw + e, sum);
+    }
+}
+
 static int dwbwd_validate(const ledn_dwbwd_desc& d) {
     LEDN_REQUIRE(d.dz && d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.Ho > 0 && d.Wo > 0);
     LEDN_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.group_size > 0 && d.C <= 4 * d.group_size);
@@ -333,6 +399,19 @@ int dw_bwd_weight_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
     const bool v4 = d.C % 4 == 0 && d.group_size % 4 == 0;
     LEDN_REQUIRE((v4 ? d.C / 4 : d.C) <= 256);
     const long npix = (long)d.N * d.Ho * d.Wo;
+    if (d.KH == 3 && d.KW == 3 && v4 && !d.ext1 && 256 % (d.C / 4) == 0) {
+        const int rows = 256 / (d.C / 4);
+        long nb = cdiv(npix, rows * 8);
+        if (nb > 1024) nb = 1024;
+        float* part = nb > 32 ? ws_take(nb * 9 * d.C) : nullptr;
+        if (!part && nb > 128) nb = 128;
+        const dim3 g3((unsigned)nb);
+        if (d.dtype == LEDN_F32) LEDN_LAUNCH((dw_bwd_weight3x3_kernel<float, 4>), g3, dim3(256), 0, s, d, part);
+        else if (d.dtype == LEDN_BF16) LEDN_LAUNCH((dw_bwd_weight3x3_kernel<bf16_t, 4>), g3, dim3(256), 0, s, d, part);
+        else return LEDN_EINVAL;
+        if (part) return finish_partials(part, (int)nb, 9 * d.C, 1, d.dw, nullptr, nullptr, s);
+        return check_launch();
+    }
     long ppb = cdiv(npix * d.KH * d.KW, 2048);
     if (ppb < 128) ppb = 128;
     const dim3 grid((unsigned)cdiv(npix, ppb), (unsigned)(d.KH * d.KW));
@@ -408,49 +487,60 @@ __global__ void __launch_bounds__(256) pyr_bwd_data_kernel(ledn_pyrbwd_desc d) {
     stv<V>(reinterpret_cast<T*>(d.dx) + pix * d.n + c, acc);
 }
 
-// blockIdx.y = branch*9 + tap
+// single pass: thread (row r, channel vector cv) keeps one branch's 9 taps x V in registers
+// (blockIdx.y = branch), reads gsum once per pixel.
 template <typename T, int V>
-__global__ void __launch_bounds__(256) pyr_bwd_weight_kernel(ledn_pyrbwd_desc d, int pix_per_block) {
-    __shared__ float s_part[256 * 4];
-    const int b = blockIdx.y / 9, tap = blockIdx.y % 9;
-    const int kh = tap / 3, kw = tap % 3;
+__global__ void __launch_bounds__(256) pyr_bwd_weight_kernel(ledn_pyrbwd_desc d, float* part) {
+    __shared__ float s_part[9 * 256 * 4];
+    const int b = blockIdx.y;
     const int dl = d.dil[b];
     const int cvn = d.n / V;
     const int rows = 256 / cvn;
     const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
     const int c = cv * V;
-    float acc[V];
+    float acc[9][V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[t][v] = 0.f;
     if (r < rows) {
         const T* x = reinterpret_cast<const T*>(d.x);
         const T* g = reinterpret_cast<const T*>(d.gsum);
         const long npix = (long)d.N * d.Ho * d.Wo;
-        const long p0 = (long)blockIdx.x * pix_per_block;
-        const long p1 = min(npix, p0 + (long)pix_per_block);
-        for (long p = p0 + r; p < p1; p += rows) {
+        for (long p = (long)blockIdx.x * rows + r; p < npix; p += (long)gridDim.x * rows) {
             const int wo = (int)(p % d.Wo);
             const int ho = (int)((p / d.Wo) % d.Ho);
             const int n = (int)(p / ((long)d.Wo * d.Ho));
-            const int hi = ho * d.stride + (kh - 1) * dl, wi = wo * d.stride + (kw - 1) * dl;
-            if (hi < 0 || hi >= d.H || wi < 0 || wi >= d.W) continue;
-            float xv[V], gv[V];
-            ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.n + c, xv);
+            float gv[V];
             ldv<V>(g + p * 4L * d.n + (long)b * d.n + c, gv);
 #pragma unroll
-            for (int v = 0; v < V; ++v) acc[v] = fmaf(xv[v], gv[v], acc[v]);
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hi = ho * d.stride + (kh - 1) * dl;
+                if (hi < 0 || hi >= d.H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int wi = wo * d.stride + (kw - 1) * dl;
+                    if (wi < 0 || wi >= d.W) continue;
+                    float xv[V];
+                    ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.n + c, xv);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[kh * 3 + kw][v] = fmaf(xv[v], gv[v], acc[kh * 3 + kw][v]);
+                }
+            }
         }
     }
 #pragma unroll
-    for (int v = 0; v < V; ++v) s_part[threadIdx.x * V + v] = acc[v];
-    __syncthreads();
-    if (threadIdx.x < cvn) {
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            float t = 0.f;
-            for (int rr = 0; rr < rows; ++rr) t += s_part[(rr * cvn + cv) * V + v];
-            atomicAdd(d.dw + (long)blockIdx.y * d.n + c + v, t);
-        }
+        for (int v = 0; v < V; ++v) s_part[(t * 256 + threadIdx.x) * V + v] = acc[t][v];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * d.n; e += 256) {
+        const int t = e / d.n, ch = e % d.n;
+        float sum = 0.f;
+        for (int rr = 0; rr < rows; ++rr) sum += s_part[(t * 256 + rr * cvn + ch / V) * V + ch % V];
+        // dw layout [4][3][3][n]; partial layout [blk][4*9*n]
+        if (part) part[(long)blockIdx.x * 36 * d.n + (long)(b * 9 + t) * d.n + ch] = sum;
+        else atomicAdd(d.dw + (long)(b * 9 + t) * d.n + ch, sum);
     }
 }
 
@@ -493,17 +583,22 @@ int pyr_bwd_weight_impl(const ledn_pyrbwd_desc& d, hipStream_t s) {
     const bool v4 = d.n % 4 == 0;
     LEDN_REQUIRE((v4 ? d.n / 4 : d.n) <= 256);
     const long npix = (long)d.N * d.Ho * d.Wo;
-    long ppb = cdiv(npix * 36, 2048);
-    if (ppb < 128) ppb = 128;
-    const dim3 grid((unsigned)cdiv(npix, ppb), 36u);
-#define LEDN_K(T)                                                                                  \
-    do {                                                                                           \
-        if (v4) LEDN_LAUNCH((pyr_bwd_weight_kernel<T, 4>), grid, dim3(256), 0, s, d, (int)ppb);    \
-        else LEDN_LAUNCH((pyr_bwd_weight_kernel<T, 1>), grid, dim3(256), 0, s, d, (int)ppb);       \
+    const int cvn = v4 ? d.n / 4 : d.n;
+    const int rows = 256 / cvn;
+    long nb = cdiv(npix, rows * 8);
+    if (nb > 512) nb = 512;
+    float* part = nb > 32 ? ws_take(nb * 36 * d.n) : nullptr;
+    if (!part && nb > 128) nb = 128;
+    const dim3 grid((unsigned)nb, 4u);
+#define LEDN_K(T)                                                                              \
+    do {                                                                                       \
+        if (v4) LEDN_LAUNCH((pyr_bwd_weight_kernel<T, 4>), grid, dim3(256), 0, s, d, part);    \
+        else LEDN_LAUNCH((pyr_bwd_weight_kernel<T, 1>), grid, dim3(256), 0, s, d, part);       \
     } while (0)
     if (d.dtype == LEDN_F32) LEDN_K(float);
     else LEDN_K(bf16_t);
 #undef LEDN_K
+    if (part) return finish_partials(part, (int)nb, 36 * d.n, 1, d.dw, nullptr, nullptr, s);
     return check_launch();
 }
 

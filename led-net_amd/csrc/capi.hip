@@ -65,12 +65,24 @@ int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_
                   const float* lr_dev, float momentum, float weight_decay, float grad_scale, hipStream_t s);
 }  // namespace ledn
 
+namespace ledn {
+static Workspace g_ws = {nullptr, 0};
+Workspace& workspace() { return g_ws; }
+}  // namespace ledn
+
 using namespace ledn;
 #define S(stream) ((hipStream_t)(stream))
 
 extern "C" {
 
 int ledn_abi_version(void) { return LEDN_ABI_VERSION; }
+
+int ledn_set_workspace(void* ptr, long long nfloats) {
+    if (nfloats < 0 || (ptr == nullptr) != (nfloats == 0)) return LEDN_EINVAL;
+    workspace().ptr = (float*)ptr;
+    workspace().nfloats = (long)nfloats;
+    return LEDN_OK;
+}
 
 int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
     if (!d) return LEDN_EINVAL;

@@ -49,6 +49,7 @@ struct MfmaConvArgs {
     int N, H, W, Cin, Ho, Wo, Cout;
     int pad, in_act, act_out, res_mode;
     int tiles_h, tiles_w;
+    float* part;      // optional workspace for the statistics: [gridDim.x * WM][2][Cout]
 };
 
 // stage one 16-byte (8-channel) piece of a patch pixel into LDS, prologue applied
@@ -175,8 +176,14 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaConvArgs a) {
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         if (lh == 0) {
-            atomicAdd(a.stat_sum + co, s1);
-            atomicAdd(a.stat_sqsum + co, s2);
+            if (a.part) {
+                float* row = a.part + ((long)blockIdx.x * WM + wm) * 2 * a.Cout;
+                row[co] = s1;
+                row[a.Cout + co] = s2;
+            } else {
+                atomicAdd(a.stat_sum + co, s1);
+                atomicAdd(a.stat_sqsum + co, s2);
+            }
         }
     }
 }
@@ -187,8 +194,11 @@ static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {
     constexpr int TR = WM * MT;
     a.tiles_h = (int)cdiv(a.Ho, TR);
     a.tiles_w = (int)cdiv(a.Wo, 32);
-    const dim3 grid((unsigned)((long)a.N * a.tiles_h * a.tiles_w), (unsigned)cdiv(a.Cout, WN * 32));
+    const long nbx = (long)a.N * a.tiles_h * a.tiles_w;
+    const dim3 grid((unsigned)nbx, (unsigned)cdiv(a.Cout, WN * 32));
+    a.part = (a.stat_sum && nbx * WM > 16) ? ws_take(nbx * WM * 2 * a.Cout) : nullptr;
     LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP>), grid, dim3(256), 0, s, a);
+    if (a.part) return finish_partials(a.part, (int)(nbx * WM), a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
     return check_launch();
 }
 
@@ -219,6 +229,7 @@ int conv_mfma(const ledn_conv_desc& d, hipStream_t s) {
     a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.in_act = d.in_act; a.act_out = d.act_out; a.res_mode = d.res_mode;
     a.tiles_h = a.tiles_w = 0;
+    a.part = nullptr;
     if (!d.transposed) {
         a.pad = d.pad;
         if (d.KH == 3) return d.stride == 1 ? launch_shape<3, 1, 1>(a, s) : launch_shape<3, 2, 1>(a, s);
@@ -315,6 +326,7 @@ struct MfmaWgradArgs {
     int N, H, W, Cin, Ho, Wo, Cout;
     int pad, in_act, groups;
     int tiles_h, tiles_w, tiles_per_block, ci_tiles;
+    float* part;      // optional workspace: [gridDim.x][gridDim.y][KK*1024] per-workgroup partial tiles
 };
 
 template <int K, int S>
@@ -426,6 +438,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
         }
         __syncthreads();
     }
+    if (a.part) {
+        float* dst = a.part + ((long)blockIdx.x * gridDim.y + blockIdx.y) * (KK * 1024);
+        for (int e = tid; e < KK * 1024; e += 256) dst[e] = red[e];
+        return;
+    }
     for (int e = tid; e < KK * 1024; e += 256) {
         const int t = e / 1024, co = co0 + (e / 32) % 32, ci = ci0 + e % 32;
         if (co >= a.Cout) continue;
@@ -433,6 +450,28 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
         if (ci / cig != g) continue;   // off-diagonal element of a grouped conv
         atomicAdd(a.dw + (long)co * a.ws_co + (long)(ci - g * cig) * a.ws_ci + (long)t * a.ws_tap, red[e]);
     }
+}
+
+// second stage: dW element = sum over the pixel-range workgroups of its partial tile
+template <int KK>
+__global__ void __launch_bounds__(256) conv_wgrad_finish_kernel(MfmaWgradArgs a, int nbx, int pairs) {
+    const int pair = blockIdx.y;
+    const int ci_tile = pair % a.ci_tiles, co_tile = pair / a.ci_tiles;
+    const int ci0 = ci_tile * 32, co0 = co_tile * 32;
+    const int cig = a.Cin / a.groups, cog = a.Cout / a.groups;
+    if (a.groups > 1) {
+        const int g_lo = co0 / cog, g_hi = min(co0 + 31, a.Cout - 1) / cog;
+        if (ci0 + 31 < g_lo * cig || ci0 >= (g_hi + 1) * cig) return;
+    }
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= KK * 1024) return;
+    const int t = e / 1024, co = co0 + (e / 32) % 32, ci = ci0 + e % 32;
+    if (co >= a.Cout) return;
+    const int g = co / cog;
+    if (ci / cig != g) return;
+    float acc = 0.f;
+    for (int b = 0; b < nbx; ++b) acc += a.part[((long)b * pairs + pair) * (KK * 1024) + e];
+    a.dw[(long)co * a.ws_co + (long)(ci - g * cig) * a.ws_ci + (long)t * a.ws_tap] += acc;
 }
 
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d) {
@@ -450,12 +489,18 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s) {
     a.ci_tiles = a.Cin / 32;
     const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
     const int pairs = a.ci_tiles * (int)cdiv(a.Cout, 32);
-    long blocks_x = cdiv(512, pairs);                // bounded grid: one atomic per dW element per workgroup
-    if (blocks_x < 32) blocks_x = 32;
+    long blocks_x = cdiv(1024, pairs);               // ~1k workgroups; partial tiles go to the workspace
+    if (blocks_x < 64) blocks_x = 64;
+    if (blocks_x > ntiles) blocks_x = ntiles;
     if (blocks_x > ntiles) blocks_x = ntiles;
     a.tiles_per_block = (int)cdiv(ntiles, blocks_x);
-    const dim3 grid((unsigned)cdiv(ntiles, a.tiles_per_block), (unsigned)pairs);
+    const int nbx = (int)cdiv(ntiles, a.tiles_per_block);
+    const dim3 grid((unsigned)nbx, (unsigned)pairs);
+    a.part = nbx > 4 ? ws_take((long)nbx * pairs * K * K * 1024) : nullptr;
     LEDN_LAUNCH((conv_wgrad_mfma_kernel<K, S>), grid, dim3(256), 0, s, a);
+    if (a.part)
+        LEDN_LAUNCH((conv_wgrad_finish_kernel<K * K>), dim3((unsigned)cdiv(K * K * 1024, 256), (unsigned)pairs),
+                    dim3(256), 0, s, a, nbx, pairs);
     return check_launch();
 }
 
@@ -467,6 +512,7 @@ int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s) {
     a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.pad = d.pad; a.in_act = d.in_act; a.groups = d.groups;
     a.tiles_h = a.tiles_w = a.tiles_per_block = a.ci_tiles = 0;
+    a.part = nullptr;
     if (d.KH == 3) return d.stride == 1 ? launch_wgrad<3, 1>(a, s) : launch_wgrad<3, 2>(a, s);
     return d.stride == 1 ? launch_wgrad<1, 1>(a, s) : launch_wgrad<1, 2>(a, s);
 }

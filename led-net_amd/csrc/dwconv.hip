@@ -8,75 +8,113 @@
 
 namespace ledn {
 
-template <typename TX, typename TY, int V>
-__global__ void __launch_bounds__(256) dwconv_kernel(ledn_dw_desc d) {
-    const int cv = d.C / V;
-    const long total = (long)d.N * d.Ho * d.Wo * cv;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = idx < total;
-    float acc[V];
+// Thread = (pixel row r, channel vector cv) walking pixels r, r+rows, ... (grid-stride):
+// filter taps, epilogue parameters and the running statistics of its V channels stay in
+// registers; statistics leave the workgroup once (LDS reduction over the rows, then a
+// per-workgroup partial in the workspace or one atomic per channel).
+template <typename TX, typename TY, int V, int KK>
+__global__ void __launch_bounds__(256) dwconv_kernel(ledn_dw_desc d, float* part) {
+    __shared__ float s_part[2][256 * 4];
+    const int cvn = d.C / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    const int c = cv * V;
+    float st1[V], st2[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) acc[v] = 0.f;
-    int c = 0;
-    long pix = 0;
-    if (active) {
-        c = (int)(idx % cv) * V;
-        pix = idx / cv;
-        const int wo = (int)(pix % d.Wo);
-        const int ho = (int)((pix / d.Wo) % d.Ho);
-        const int n = (int)(pix / ((long)d.Wo * d.Ho));
+    for (int v = 0; v < V; ++v) st1[v] = st2[v] = 0.f;
+    if (r < rows) {
         const int dl = d.dil[c / d.group_size];
         const int padh = d.pad >= 0 ? d.pad : dl * (d.KH - 1) / 2;
         const int padw = d.pad >= 0 ? d.pad : dl * (d.KW - 1) / 2;
         const int Hx = d.H + (d.ext1 ? 1 : 0), Wx = d.W + (d.ext1 ? 1 : 0);
         const TX* x = reinterpret_cast<const TX*>(d.x);
-        for (int kh = 0; kh < d.KH; ++kh) {
-            int hi = ho * d.stride - padh + kh * dl;
-            if (hi < 0 || hi >= Hx) continue;
-            if (hi == d.H) hi = d.H - 2;  // ext1 reflect row
-            for (int kw = 0; kw < d.KW; ++kw) {
-                int wi = wo * d.stride - padw + kw * dl;
-                if (wi < 0 || wi >= Wx) continue;
-                if (wi == d.W) wi = d.W - 2;
-                float xv[V], wv[V];
-                ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.C + c, xv);
-                ldv<V>(d.w + (long)(kh * d.KW + kw) * d.C + c, wv);
+        float wreg[KK > 0 ? KK : 1][V];
+        if (KK > 0) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) acc[v] = fmaf(xv[v], wv[v], acc[v]);
-            }
+            for (int t = 0; t < KK; ++t) ldv<V>(d.w + (long)t * d.C + c, wreg[t]);
         }
+        float sc[V], sh[V], sl[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const float s = d.out_scale ? d.out_scale[c + v] : 1.f;
-            const float b = d.out_shift ? d.out_shift[c + v] : 0.f;
-            acc[v] = acc[v] * s + b;
+            sc[v] = d.out_scale ? d.out_scale[c + v] : 1.f;
+            sh[v] = d.out_shift ? d.out_shift[c + v] : 0.f;
+            sl[v] = d.slope ? d.slope[c + v] : 0.f;
         }
-    }
-    if (d.stat_sum) {
-        // lanes of a wave hold different channels: reduce through LDS per block
-        __shared__ float s_sum[512 * 2];
-        for (int i = threadIdx.x; i < d.C * 2; i += blockDim.x) s_sum[i] = 0.f;
-        __syncthreads();
-        if (active) {
+        const long npix = (long)d.N * d.Ho * d.Wo;
+        for (long pix = (long)blockIdx.x * rows + r; pix < npix; pix += (long)gridDim.x * rows) {
+            const int wo = (int)(pix % d.Wo);
+            const int ho = (int)((pix / d.Wo) % d.Ho);
+            const int n = (int)(pix / ((long)d.Wo * d.Ho));
+            float acc[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < (KK > 0 ? 3 : 1); ++kh) {
+                for (int kh2 = (KK > 0 ? kh : 0); kh2 < (KK > 0 ? kh + 1 : d.KH); ++kh2) {
+                    int hi = ho * d.stride - padh + kh2 * dl;
+                    if (hi < 0 || hi >= Hx) continue;
+                    if (hi == d.H) hi = d.H - 2;  // ext1 reflect row
+#pragma unroll
+                    for (int kw = 0; kw < (KK > 0 ? 3 : 1); ++kw) {
+                        for (int kw2 = (KK > 0 ? kw : 0); kw2 < (KK > 0 ? kw + 1 : d.KW); ++kw2) {
+                            int wi = wo * d.stride - padw + kw2 * dl;
+                            if (wi < 0 || wi >= Wx) continue;
+                            if (wi == d.W) wi = d.W - 2;
+                            float xv[V], wv[V];
+                            ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.C + c, xv);
+                            if (KK > 0) {
+#pragma unroll
+                                for (int v = 0; v < V; ++v) wv[v] = wreg[kh * 3 + kw][v];
+                            } else {
+                                ldv<V>(d.w + (long)(kh2 * d.KW + kw2) * d.C + c, wv);
+                            }
+#pragma unroll
+                            for (int v = 0; v < V; ++v) acc[v] = fmaf(xv[v], wv[v], acc[v]);
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                atomicAdd(&s_sum[c + v], acc[v]);
-                atomicAdd(&s_sum[d.C + c + v], acc[v] * acc[v]);
+                acc[v] = acc[v] * sc[v] + sh[v];
+                st1[v] += acc[v];
+                st2[v] = fmaf(acc[v], acc[v], st2[v]);
+            }
+            if (d.act_out != LEDN_ACT_NONE) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[v] = act_apply(d.act_out, acc[v], sl[v]);
+            }
+            stv<V>(reinterpret_cast<TY*>(d.y) + pix * d.C + c, acc);
+        }
+    }
+    if (!d.stat_sum) return;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        s_part[0][threadIdx.x * V + v] = st1[v];
+        s_part[1][threadIdx.x * V + v] = st2[v];
+    }
+    __syncthreads();
+    if (threadIdx.x < cvn) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float sa = 0.f, sb = 0.f;
+            for (int rr = 0; rr < rows; ++rr) {
+                sa += s_part[0][(rr * cvn + cv) * V + v];
+                sb += s_part[1][(rr * cvn + cv) * V + v];
+            }
+            if (part) {
+                part[(long)blockIdx.x * 2 * d.C + c + v] = sa;
+                part[(long)blockIdx.x * 2 * d.C + d.C + c + v] = sb;
+            } else {
+                atomicAdd(d.stat_sum + c + v, sa);
+                atomicAdd(d.stat_sqsum + c + v, sb);
             }
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < d.C; i += blockDim.x) {
-            atomicAdd(d.stat_sum + i, s_sum[i]);
-            atomicAdd(d.stat_sqsum + i, s_sum[d.C + i]);
-        }
     }
-    if (!active) return;
-    if (d.act_out != LEDN_ACT_NONE) {
-#pragma unroll
-        for (int v = 0; v < V; ++v) acc[v] = act_apply(d.act_out, acc[v], d.slope ? d.slope[c + v] : 0.f);
-    }
-    stv<V>(reinterpret_cast<TY*>(d.y) + pix * d.C + c, acc);
 }
+
+int finish_partials(const float* part, int nblk, int C, int nout, float* o0, float* o1, float* o2,
+                    hipStream_t s);
 
 int dwconv_impl(const ledn_dw_desc& d, hipStream_t s) {
     LEDN_REQUIRE(d.x && d.w && d.y);
@@ -95,12 +133,24 @@ int dwconv_impl(const ledn_dw_desc& d, hipStream_t s) {
         LEDN_REQUIRE(d.Wo == (Wx + 2 * pw - ((d.KW - 1) * d.dil[g] + 1)) / d.stride + 1);
     }
     const bool v4 = d.C % 4 == 0 && d.group_size % 4 == 0;
-    const long total = (long)d.N * d.Ho * d.Wo * (v4 ? d.C / 4 : d.C);
-    const dim3 grid((unsigned)cdiv(total, 256));
-#define LEDN_DW(TX, TY)                                                              \
-    do {                                                                             \
-        if (v4) LEDN_LAUNCH((dwconv_kernel<TX, TY, 4>), grid, dim3(256), 0, s, d);   \
-        else LEDN_LAUNCH((dwconv_kernel<TX, TY, 1>), grid, dim3(256), 0, s, d);      \
+    const int cvn = v4 ? d.C / 4 : d.C;
+    LEDN_REQUIRE(cvn <= 256);
+    const int rows = 256 / cvn;
+    const long npix = (long)d.N * d.Ho * d.Wo;
+    long nb = cdiv(npix, rows * 4);
+    if (nb > 2048) nb = 2048;
+    float* part = nullptr;
+    if (d.stat_sum) {
+        if (nb > 64) part = ws_take(nb * 2 * d.C);
+        if (!part && nb > 256) nb = 256;
+    }
+    const dim3 grid((unsigned)nb);
+    const bool k3 = d.KH == 3 && d.KW == 3;
+#define LEDN_DW(TX, TY)                                                                          \
+    do {                                                                                         \
+        if (v4 && k3) LEDN_LAUNCH((dwconv_kernel<TX, TY, 4, 9>), grid, dim3(256), 0, s, d, part); \
+        else if (v4) LEDN_LAUNCH((dwconv_kernel<TX, TY, 4, 0>), grid, dim3(256), 0, s, d, part);  \
+        else LEDN_LAUNCH((dwconv_kernel<TX, TY, 1, 0>), grid, dim3(256), 0, s, d, part);          \
     } while (0)
     if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_F32) LEDN_DW(float, float);
     else if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_BF16) LEDN_DW(bf16_t, bf16_t);
@@ -108,6 +158,7 @@ int dwconv_impl(const ledn_dw_desc& d, hipStream_t s) {
     else if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_BF16) LEDN_DW(float, bf16_t);
     else return LEDN_EINVAL;
 #undef LEDN_DW
+    if (part) return finish_partials(part, (int)nb, d.C, 2, d.stat_sum, d.stat_sqsum, nullptr, s);
     return check_launch();
 }
 

@@ -142,6 +142,22 @@ inline int check_launch() {
 }
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
+// Caller-provided scratch (ledn_set_workspace): cross-workgroup reductions write per-workgroup
+// partials here and a tiny second kernel sums them -- no same-address atomics (which serialise
+// at ~0.3 us each on gfx950), deterministic.  Single-stream use.
+struct Workspace {
+    float* ptr;
+    long nfloats;
+};
+Workspace& workspace();
+inline float* ws_take(long nfloats) {
+    Workspace& w = workspace();
+    return (w.ptr && nfloats <= w.nfloats) ? w.ptr : nullptr;
+}
+// out_j[c] += sum_b part[b*K + j*C + c], j < nout (K = nout*C)
+int finish_partials(const float* part, int nblk, int C, int nout, float* o0, float* o1, float* o2,
+                    hipStream_t s);
+
 }  // namespace ledn
 
 #define LEDN_REQUIRE(cond) \

@@ -8,7 +8,7 @@ namespace ledn {
 // x: [P][C].  Thread (r, cv): channel vector cv, pixel rows r, r+rows, ...
 template <typename T, int V>
 __global__ void __launch_bounds__(256) channel_stats_kernel(const T* x, const T* xadd, long P, int C,
-                                                            float* sum, float* sqsum) {
+                                                            float* sum, float* sqsum, float* part) {
     __shared__ float s_part[2][256 * 4];
     const int cvn = C / V;
     const int rows = 256 / cvn;
@@ -48,10 +48,38 @@ __global__ void __launch_bounds__(256) channel_stats_kernel(const T* x, const T*
                 sa += s_part[0][(rr * cvn + cv) * V + v];
                 sb += s_part[1][(rr * cvn + cv) * V + v];
             }
-            atomicAdd(sum + cv * V + v, sa);
-            if (sqsum) atomicAdd(sqsum + cv * V + v, sb);
+            if (part) {
+                part[(long)blockIdx.x * 2 * C + cv * V + v] = sa;
+                part[(long)blockIdx.x * 2 * C + C + cv * V + v] = sb;
+            } else {
+                atomicAdd(sum + cv * V + v, sa);
+                if (sqsum) atomicAdd(sqsum + cv * V + v, sb);
+            }
         }
     }
+}
+
+struct FinishOuts {
+    float* o[3];
+};
+__global__ void finish_partials_kernel(const float* part, int nblk, int C, int nout, FinishOuts outs) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= C * nout) return;
+    float* dst = outs.o[k / C];
+    if (!dst) return;
+    float acc = 0.f;
+    const int K = C * nout;
+    for (int b = 0; b < nblk; ++b) acc += part[(long)b * K + k];
+    dst[k % C] += acc;
+}
+
+int finish_partials(const float* part, int nblk, int C, int nout, float* o0, float* o1, float* o2,
+                    hipStream_t s) {
+    FinishOuts outs;
+    outs.o[0] = o0; outs.o[1] = o1; outs.o[2] = o2;
+    LEDN_LAUNCH(finish_partials_kernel, dim3((unsigned)cdiv((long)C * nout, 64)), dim3(64), 0, s, part, nblk, C,
+                nout, outs);
+    return check_launch();
 }
 
 int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
@@ -60,21 +88,25 @@ int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int 
     const int V = (C % 4 == 0) ? 4 : 1;
     LEDN_REQUIRE(C / V <= 256);
     long nb = cdiv(P, (256 / (C / V)) * 8);
-    if (nb > 256) nb = 256;     // one atomic per channel per workgroup: bounded grid
+    float* part = nullptr;
+    if (nb > 2048) nb = 2048;
+    if (nb > 64) part = ws_take(nb * 2 * C);
+    if (!part && nb > 256) nb = 256;     // atomics fallback: one per channel per workgroup, bounded grid
     const dim3 grid((unsigned)nb);
 #define LEDN_CS(T)                                                                              \
     do {                                                                                        \
         if (V == 4)                                                                             \
             LEDN_LAUNCH((channel_stats_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x,       \
-                        (const T*)xadd, (long)P, C, sum, sqsum);                      \
+                        (const T*)xadd, (long)P, C, sum, sqsum, part);                      \
         else                                                                                    \
             LEDN_LAUNCH((channel_stats_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x,       \
-                        (const T*)xadd, (long)P, C, sum, sqsum);                      \
+                        (const T*)xadd, (long)P, C, sum, sqsum, part);                      \
     } while (0)
     if (dtype == LEDN_F32) LEDN_CS(float);
     else if (dtype == LEDN_BF16) LEDN_CS(bf16_t);
     else return LEDN_EINVAL;
 #undef LEDN_CS
+    if (part) return finish_partials(part, (int)nb, C, 2, sum, sqsum, nullptr, s);
     return check_launch();
 }
 

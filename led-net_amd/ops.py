@@ -77,6 +77,7 @@ def _nb(*ts):
 
 
 def _run(lib, name, ref, *args, work=('', 0, 0)):
+    lib.ensure_workspace(ref.device)
     stream = _stream(lib, ref)
     if _TIMING is not None and lib.is_hip:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -250,3 +250,57 @@ def test_sgd_step(be):
     for p, r_ in zip(pd, ref):
         close(p, r_.detach(), 1e-5, 1e-6)
     assert all(float(g.abs().max()) == 0.0 for g in gd)
+
+
+def test_two_stage_reductions_large(be):
+    """sizes large enough that the per-workgroup-partials + finish path (workspace) is taken
+    instead of the atomics fallback: channel statistics, BN backward sums, depthwise statistics
+    and depthwise / pyramid weight gradients."""
+    from led_net_amd import ops, ops_train as T
+    c, n = 64, 16
+    x = torch.randn(2, c, 96, 100)
+    xs = nhwc(x)
+    st = ops.channel_stats(xs)
+    close(st[0], x.sum((0, 2, 3)), 1e-3, 5e-2)
+    close(st[1], (x * x).sum((0, 2, 3)), 1e-3, 5e-1)
+    z = (x * 2 + 0.5).requires_grad_(True)
+    g, b = (torch.rand(c) + 0.5).requires_grad_(True), torch.randn(c, requires_grad=True)
+    y = F.relu(F.batch_norm(z, None, None, g, b, True, 0.1, 1e-5))
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    zs = nhwc(z)
+    scale, shift, mean, invstd = ops.bn_finalize(ops.channel_stats(zs), z.numel() // c, D(g.detach()), D(b.detach()))
+    dz, _, dgamma, dbeta, _ = T.bn_act_bwd(zs, nhwc(dy), scale=scale, shift=shift, mean=mean, invstd=invstd,
+                                           act=ops.ACT_RELU)
+    close(nchw(dz), z.grad, 2e-3, 2e-4)
+    close(dgamma, g.grad, 2e-3, 2e-2)
+    close(dbeta, b.grad, 2e-3, 2e-2)
+    # depthwise 3x3 (4 dilation groups) with statistics, and its weight gradient
+    dil = [2, 3, 4, 5]
+    xd = torch.randn(2, 4 * n, 70, 90, requires_grad=True)
+    ws = [(torch.randn(n, 1, 3, 3) * 0.3).requires_grad_(True) for _ in range(4)]
+    yd = torch.cat([F.conv2d(xd[:, i * n:(i + 1) * n], ws[i], padding=dil[i], dilation=dil[i], groups=n)
+                    for i in range(4)], 1)
+    wp = torch.cat([w[:, 0].permute(1, 2, 0) for w in ws], 2).detach().contiguous()
+    stats = (D(torch.zeros(4 * n)), D(torch.zeros(4 * n)))
+    got = ops.dwconv2d(nhwc(xd), D(wp), dil=dil, group_size=n, stats=stats)
+    close(nchw(got), yd.detach(), 1e-4, 1e-5)
+    close(stats[0], yd.detach().sum((0, 2, 3)), 1e-3, 5e-2)
+    dyd = torch.randn_like(yd)
+    yd.backward(dyd)
+    _, dw = T.dwconv2d_bwd(nhwc(xd), nhwc(dyd), D(wp), dil=dil, group_size=n, need_dx=False)
+    close(dw, torch.cat([w.grad[:, 0].permute(1, 2, 0) for w in ws], 2), 2e-3, 2e-2)
+    # pyramid weight gradient
+    xp = torch.randn(2, n, 70, 90, requires_grad=True)
+    wq = [(torch.randn(n, 1, 3, 3) * 0.3).requires_grad_(True) for _ in range(4)]
+    outs = []
+    for i in range(4):
+        o = F.conv2d(xp, wq[i], padding=i + 1, dilation=i + 1, groups=n)
+        outs.append(o if i == 0 else o + outs[-1])
+    yp = torch.cat(outs, 1)
+    dyp = torch.randn_like(yp)
+    yp.backward(dyp)
+    wpk = torch.stack([w[:, 0].permute(1, 2, 0) for w in wq]).detach().contiguous()
+    dxp, dwp = T.sesp_pyramid_bwd(nhwc(xp), nhwc(dyp), D(wpk), [1, 2, 3, 4], 1)
+    close(nchw(dxp), xp.grad, 2e-3, 2e-4)
+    close(dwp, torch.stack([w.grad[:, 0].permute(1, 2, 0) for w in wq]), 2e-3, 2e-2)
