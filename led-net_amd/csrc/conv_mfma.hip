@@ -469,9 +469,17 @@ __global__ void __launch_bounds__(256) conv_wgrad_finish_kernel(MfmaWgradArgs a,
     if (co >= a.Cout) return;
     const int g = co / cog;
     if (ci / cig != g) return;
+    const int per = (nbx + gridDim.z - 1) / gridDim.z;       // blockIdx.z: split of the partial rows
+    const int b0 = blockIdx.z * per, b1 = min(nbx, b0 + per);
+    const long stride = (long)pairs * (KK * 1024);
+    const float* src = a.part + (long)pair * (KK * 1024) + e;
     float acc = 0.f;
-    for (int b = 0; b < nbx; ++b) acc += a.part[((long)b * pairs + pair) * (KK * 1024) + e];
-    a.dw[(long)co * a.ws_co + (long)(ci - g * cig) * a.ws_ci + (long)t * a.ws_tap] += acc;
+    int b = b0;
+    for (; b + 3 < b1; b += 4)
+        acc += (src[(long)b * stride] + src[(long)(b + 1) * stride]) +
+               (src[(long)(b + 2) * stride] + src[(long)(b + 3) * stride]);
+    for (; b < b1; ++b) acc += src[(long)b * stride];
+    atomicAdd(a.dw + (long)co * a.ws_co + (long)(ci - g * cig) * a.ws_ci + (long)t * a.ws_tap, acc);
 }
 
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d) {
@@ -489,8 +497,8 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s) {
     a.ci_tiles = a.Cin / 32;
     const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
     const int pairs = a.ci_tiles * (int)cdiv(a.Cout, 32);
-    long blocks_x = cdiv(1024, pairs);               // ~1k workgroups; partial tiles go to the workspace
-    if (blocks_x < 64) blocks_x = 64;
+    long blocks_x = cdiv(512, pairs);                // ~512 workgroups; partial tiles go to the workspace
+    if (blocks_x < 32) blocks_x = 32;
     if (blocks_x > ntiles) blocks_x = ntiles;
     if (blocks_x > ntiles) blocks_x = ntiles;
     a.tiles_per_block = (int)cdiv(ntiles, blocks_x);
@@ -498,9 +506,13 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s) {
     const dim3 grid((unsigned)nbx, (unsigned)pairs);
     a.part = nbx > 4 ? ws_take((long)nbx * pairs * K * K * 1024) : nullptr;
     LEDN_LAUNCH((conv_wgrad_mfma_kernel<K, S>), grid, dim3(256), 0, s, a);
-    if (a.part)
-        LEDN_LAUNCH((conv_wgrad_finish_kernel<K * K>), dim3((unsigned)cdiv(K * K * 1024, 256), (unsigned)pairs),
-                    dim3(256), 0, s, a, nbx, pairs);
+    if (a.part) {
+        int split = (int)cdiv(nbx, 16);
+        if (split > 32) split = 32;
+        LEDN_LAUNCH((conv_wgrad_finish_kernel<K * K>),
+                    dim3((unsigned)cdiv(K * K * 1024, 256), (unsigned)pairs, (unsigned)split), dim3(256), 0, s, a,
+                    nbx, pairs);
+    }
     return check_launch();
 }
 

@@ -62,23 +62,47 @@ __global__ void __launch_bounds__(256) channel_stats_kernel(const T* x, const T*
 struct FinishOuts {
     float* o[3];
 };
-__global__ void finish_partials_kernel(const float* part, int nblk, int C, int nout, FinishOuts outs) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= C * nout) return;
-    float* dst = outs.o[k / C];
-    if (!dst) return;
-    float acc = 0.f;
+// second stage of the two-stage reductions: workgroup (k-tile of 16 outputs, row split) sums
+// its share of the partial rows with 16 row-slots per output, LDS-reduces the slots and adds the
+// result with ONE atomic per output (<= 32 splits per address).
+__global__ void __launch_bounds__(256) finish_partials_kernel(const float* part, int nblk, int C, int nout,
+                                                              FinishOuts outs) {
+    __shared__ float s_red[256];
     const int K = C * nout;
-    for (int b = 0; b < nblk; ++b) acc += part[(long)b * K + k];
-    dst[k % C] += acc;
+    const int j = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + j;
+    const int per = (nblk + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+    float acc = 0.f;
+    if (k < K) {
+        int b = b0 + slot;
+        for (; b + 48 < b1; b += 64) {   // 4 independent loads in flight
+            const float v0 = part[(long)b * K + k], v1 = part[(long)(b + 16) * K + k];
+            const float v2 = part[(long)(b + 32) * K + k], v3 = part[(long)(b + 48) * K + k];
+            acc += (v0 + v1) + (v2 + v3);
+        }
+        for (; b < b1; b += 16) acc += part[(long)b * K + k];
+    }
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16 && k < K) {
+        float t = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) t += s_red[sl * 16 + threadIdx.x];
+        float* dst = outs.o[k / C];
+        if (dst) atomicAdd(dst + k % C, t);
+    }
 }
 
 int finish_partials(const float* part, int nblk, int C, int nout, float* o0, float* o1, float* o2,
                     hipStream_t s) {
     FinishOuts outs;
     outs.o[0] = o0; outs.o[1] = o1; outs.o[2] = o2;
-    LEDN_LAUNCH(finish_partials_kernel, dim3((unsigned)cdiv((long)C * nout, 64)), dim3(64), 0, s, part, nblk, C,
-                nout, outs);
+    long split = cdiv(nblk, 16 * 16);      // <= 16 rows per slot per workgroup
+    if (split > 32) split = 32;
+    if (split < 1) split = 1;
+    LEDN_LAUNCH(finish_partials_kernel, dim3((unsigned)cdiv((long)C * nout, 16), (unsigned)split), dim3(256), 0,
+                s, part, nblk, C, nout, outs);
     return check_launch();
 }
 
