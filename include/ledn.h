@@ -89,6 +89,14 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream);
 int ledn_pack_conv_weights(const float* w, void* out_bf16, int Cout, int Cin, int KH, int KW, int mode,
                            int groups, void* stream);
 
+/* The same pack for a whole table of weights in one launch (training: once per step after SGD). */
+typedef struct {
+    const float* w;
+    void* out;
+    int Cout, Cin, KK, mode, groups;
+} ledn_pack_entry;
+int ledn_pack_conv_weights_multi(const ledn_pack_entry* table_dev, int n, long long max_elems, void* stream);
+
 /* im2col of the 3-channel stem (3x3, stride 2, pad 1): p[n,ho,wo,(kh*3+kw)*C + c], bf16,
  * 32 columns (9*C used, rest zero).  The stem (ddrnet.py:123-130) then runs as a K=32 1x1
  * GEMM on the MFMA path with the weight reshaped to [Cout][32][1][1]. */

@@ -100,6 +100,10 @@ class MfafBwdDesc(C.Structure):
                 ('dctx', fp * 4), ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('dtype', i32), ('act', i32)]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [('w', fp), ('out', vp), ('Cout', i32), ('Cin', i32), ('KK', i32), ('mode', i32), ('groups', i32)]
+
+
 class SgdEntry(C.Structure):
     _fields_ = [('p', fp), ('g', fp), ('m', fp), ('n', i64)]
 
@@ -124,6 +128,7 @@ _PROTOS = {
     'ledn_abi_version': ([], i32),
     'ledn_set_workspace': ([vp, i64], i32),
     'ledn_conv2d': ([C.POINTER(ConvDesc), vp], i32),
+    'ledn_pack_conv_weights_multi': ([vp, i32, i64, vp], i32),
     'ledn_im2col_stem': ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_pack_conv_weights': ([fp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_conv2d_wgrad': ([C.POINTER(WgradDesc), vp], i32),

@@ -9,6 +9,7 @@ bool conv_mfma_supported(const ledn_conv_desc& d);
 int conv_mfma(const ledn_conv_desc& d, hipStream_t s);
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d);
 int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s);
+int pack_conv_weights_multi_impl(const ledn_pack_entry* table_dev, int n, long long max_elems, hipStream_t s);
 int im2col_stem_impl(const void* x, void* p, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 int pack_conv_weights_impl(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode,
                            int groups, hipStream_t s);
@@ -90,6 +91,10 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
     if (rc != LEDN_OK) return rc;
     if (conv_mfma_supported(*d)) return conv_mfma(*d, S(stream));
     return conv_direct(*d, S(stream));
+}
+
+int ledn_pack_conv_weights_multi(const ledn_pack_entry* table_dev, int n, long long max_elems, void* stream) {
+    return pack_conv_weights_multi_impl(table_dev, n, max_elems, S(stream));
 }
 
 int ledn_im2col_stem(const void* x, void* p, int N, int H, int W, int C, int Ho, int Wo, void* stream) {

@@ -362,8 +362,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_narrow_kernel(ledn_wgrad_desc 
         }
     }
     // reduce over the pixel slots, one (tap, narrow channel) at a time
+    // (fully unrolled: a runtime index into acc[][] would push it to scratch)
+#pragma unroll
     for (int t = 0; t < TAPS; ++t)
-        for (int c = 0; c < ncn; ++c) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c >= ncn) break;
             s_red[threadIdx.x] = worker ? acc[t][c] : 0.f;
             __syncthreads();
             if (threadIdx.x < wide) {

@@ -119,8 +119,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaConvArgs a) {
             }
             const int c = c0 + part * 8;
             stage_piece(s_patch + (long)p * PIXB + part * 16,
-                        a.x + (((long)n * a.H + hi) * a.W + wi) * a.Cin + c, valid, a.in_scale, a.in_shift,
-                        a.in_act, c);
+                        a.x + (((long)n * a.H + hi) * a.W + wi) * a.Cin + c, valid && c < a.Cin, a.in_scale,
+                        a.in_shift, a.in_act, c);
         }
         __syncthreads();
         // ---- taps x k-steps: one B fragment (global, L1/L2) feeds MT MFMAs
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaConvArgs a) {
 #pragma unroll
                 for (int kk = 0; kk < CK / 16; ++kk) {
                     bf16x8_t bf = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (co_ok) bf = *reinterpret_cast<const bf16x8_t*>(wrow + kk * 16);
+                    if (co_ok && c0 + kk * 16 + lh * 8 < a.Cin) bf = *reinterpret_cast<const bf16x8_t*>(wrow + kk * 16);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const int row = wm * MT + m;
@@ -214,7 +214,7 @@ bool conv_mfma_supported(const ledn_conv_desc& d) {
     if (!d.w_bf16 || d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16) return false;
     if (d.dil != 1 || d.xadd) return false;
     if (d.groups != 1 && !(d.KH == 1 && d.KW == 1)) return false;   // grouped 1x1: densified weight pack
-    if (d.Cin % 32 || d.Cout % 16) return false;
+    if (d.Cin % 16 || (d.Cout % 16 && d.Cout > 8)) return false;   // 16-channel tails are masked
     if (d.KH != d.KW || !((d.KH == 3 && d.pad == 1) || (d.KH == 1 && d.pad == 0))) return false;
     if (d.stride != 1 && d.stride != 2) return false;
     if (d.transposed && d.stride == 2 && d.KH == 1) return false;
@@ -260,6 +260,33 @@ __global__ void pack_weights_kernel(const float* w, bf16_t* out, int Cout, int C
     if (mode == 0) o = ((long)tap * Cout + co) * Cin + ci;
     else o = ((long)(KK - 1 - tap) * Cin + ci) * Cout + co;
     st(out + o, v);
+}
+
+// table-driven variant: every packed weight of the model in ONE launch (grid.y = tensor)
+__global__ void __launch_bounds__(256) pack_weights_multi_kernel(const ledn_pack_entry* table) {
+    const ledn_pack_entry e = table[blockIdx.y];
+    const long total = (long)e.Cout * e.Cin * e.KK;
+    const int cig = e.Cin / e.groups, cog = e.Cout / e.groups;
+    bf16_t* out = reinterpret_cast<bf16_t*>(e.out);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % e.KK);
+        const int ci = (int)((i / e.KK) % e.Cin);
+        const int co = (int)(i / ((long)e.KK * e.Cin));
+        const int g = co / cog;
+        float v = 0.f;
+        if (ci / cig == g) v = e.w[((long)co * cig + (ci - g * cig)) * e.KK + tap];
+        const long o = e.mode == 0 ? ((long)tap * e.Cout + co) * e.Cin + ci
+                                   : ((long)(e.KK - 1 - tap) * e.Cin + ci) * e.Cout + co;
+        st(out + o, v);
+    }
+}
+
+int pack_conv_weights_multi_impl(const ledn_pack_entry* table_dev, int n, long long max_elems, hipStream_t s) {
+    LEDN_REQUIRE(table_dev && n > 0 && max_elems > 0);
+    long chunks = cdiv(max_elems, 256 * 4);
+    if (chunks > 32) chunks = 32;
+    LEDN_LAUNCH(pack_weights_multi_kernel, dim3((unsigned)chunks, (unsigned)n), dim3(256), 0, s, table_dev);
+    return check_launch();
 }
 
 int pack_conv_weights_impl(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode,
@@ -374,7 +401,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
             const bool valid = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
             const int c = ci0 + part * 8;
             stage_piece(s_x + (long)p * PIXB + part * 16, a.x + (((long)n * a.H + hi) * a.W + wi) * a.Cin + c,
-                        valid, a.in_scale, a.in_shift, a.in_act, c);
+                        valid && c < a.Cin, a.in_scale, a.in_shift, a.in_act, c);
         }
         for (int p = tid >> 2; p < TR * 32; p += 64) {
             const int pr = p / 32, pc = p % 32, part = tid & 3;
@@ -445,7 +472,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
     }
     for (int e = tid; e < KK * 1024; e += 256) {
         const int t = e / 1024, co = co0 + (e / 32) % 32, ci = ci0 + e % 32;
-        if (co >= a.Cout) continue;
+        if (co >= a.Cout || ci >= a.Cin) continue;
         const int g = co / cog;
         if (ci / cig != g) continue;   // off-diagonal element of a grouped conv
         atomicAdd(a.dw + (long)co * a.ws_co + (long)(ci - g * cig) * a.ws_ci + (long)t * a.ws_tap, red[e]);
@@ -466,7 +493,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_finish_kernel(MfmaWgradArgs a,
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= KK * 1024) return;
     const int t = e / 1024, co = co0 + (e / 32) % 32, ci = ci0 + e % 32;
-    if (co >= a.Cout) return;
+    if (co >= a.Cout || ci >= a.Cin) return;
     const int g = co / cog;
     if (ci / cig != g) return;
     const int per = (nbx + gridDim.z - 1) / gridDim.z;       // blockIdx.z: split of the partial rows
@@ -485,7 +512,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_finish_kernel(MfmaWgradArgs a,
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d) {
     if (d.dtype_x != LEDN_BF16 || d.dtype_dz != LEDN_BF16 || d.dil != 1 || d.xadd) return false;
     if (d.groups != 1 && !(d.KH == 1 && d.KW == 1)) return false;
-    if (d.Cin % 32 || (d.Cout % 16 && d.Cout > 4)) return false;   // Cout <= 4: narrow heads, scalar dz staging
+    if (d.Cin % 16 || (d.Cout % 16 && d.Cout > 4)) return false;   // Cout <= 4: narrow heads, scalar dz staging
     if (d.KH != d.KW || !((d.KH == 3 && d.pad == 1) || (d.KH == 1 && d.pad == 0))) return false;
     return d.stride == 1 || d.stride == 2;
 }
@@ -494,7 +521,7 @@ template <int K, int S>
 static int launch_wgrad(MfmaWgradArgs a, hipStream_t s) {
     a.tiles_h = (int)cdiv(a.Ho, S == 2 ? 4 : 8);
     a.tiles_w = (int)cdiv(a.Wo, 32);
-    a.ci_tiles = a.Cin / 32;
+    a.ci_tiles = (int)cdiv(a.Cin, 32);
     const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
     const int pairs = a.ci_tiles * (int)cdiv(a.Cout, 32);
     long blocks_x = cdiv(512, pairs);                // ~512 workgroups; partial tiles go to the workspace

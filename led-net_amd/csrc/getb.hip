@@ -42,23 +42,26 @@ __global__ void __launch_bounds__(64) window_attn_kernel(const T* qkv, const flo
     __syncthreads();
     const float scale = rsqrtf((float)D);
     const float* b = biasT + (long)head * T2 * T2 + t;  // biasT[head][key][query]
-    float sc[T2];
+    // two passes over the 64 keys, scores recomputed instead of kept (64 live score
+    // registers spill; 2 x 16 FMAs per key are cheaper than scratch traffic)
     float m = -3.0e38f;
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < T2; ++k) {
         float dot = 0.f;
 #pragma unroll
         for (int j = 0; j < D; ++j) dot = fmaf(q[j], s_k[k * D + j], dot);
-        sc[k] = dot * scale + b[k * T2];
-        m = fmaxf(m, sc[k]);
+        m = fmaxf(m, dot * scale + b[k * T2]);
     }
     float o[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) o[j] = 0.f;
     float l = 0.f;
-#pragma unroll
+#pragma unroll 4
     for (int k = 0; k < T2; ++k) {
-        const float e = __expf(sc[k] - m);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) dot = fmaf(q[j], s_k[k * D + j], dot);
+        const float e = __expf(dot * scale + b[k * T2] - m);
         l += e;
 #pragma unroll
         for (int j = 0; j < D; ++j) o[j] = fmaf(e, s_v[k * D + j], o[j]);

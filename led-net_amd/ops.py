@@ -168,7 +168,7 @@ def mfma_weight_ok(w, groups=1):
     co, cig, kh, kw = w.shape
     if groups != 1 and kh != 1:
         return False
-    return co % 16 == 0 and (cig * groups) % 32 == 0 and kh == kw and kh in (1, 3)
+    return (co % 16 == 0 or co <= 8) and (cig * groups) % 16 == 0 and kh == kw and kh in (1, 3)
 
 
 def pack_conv_weights(w, mode=0, groups=1):

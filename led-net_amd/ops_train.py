@@ -238,3 +238,28 @@ class SgdTable:
         lib = _lib.get_lib()
         _run(lib, 'ledn_sgd_step', self.ref, self.table.data_ptr(), self.n, self.max_n, float(lr), _p(lr_dev),
              momentum, weight_decay, grad_scale, work=(f'sgd {self.n} tensors', 16 * sum(p.numel() for p in self.keep[0]), 0))
+
+
+class PackTable:
+    """Device table for ledn_pack_conv_weights_multi: all bf16 weight packs of the model
+    (forward and data-gradient variants) refreshed by ONE launch per training step."""
+
+    def __init__(self, entries):
+        """entries: list of (w_param [Cout, Cin/g, KH, KW] f32, out bf16 buffer, mode, groups)"""
+        lib = _lib.get_lib()
+        n = len(entries)
+        host = (_lib.PackEntry * n)()
+        self.max_elems = 0
+        for i, (w, out, mode, groups) in enumerate(entries):
+            co, cig, kh, kw = w.shape
+            _check(lib, w, out)
+            host[i].w, host[i].out = w.data_ptr(), out.data_ptr()
+            host[i].Cout, host[i].Cin, host[i].KK, host[i].mode, host[i].groups = co, cig * groups, kh * kw, mode, groups
+            self.max_elems = max(self.max_elems, out.numel())
+        self.table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(entries[0][0].device)
+        self.n, self.ref, self.keep = n, entries[0][0], entries
+
+    def run(self):
+        lib = _lib.get_lib()
+        _run(lib, 'ledn_pack_conv_weights_multi', self.ref, self.table.data_ptr(), self.n, self.max_elems,
+             work=(f'packw_multi {self.n} tensors', 0, 0))

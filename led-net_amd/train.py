@@ -31,6 +31,33 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _Packs:
+    """bf16 weight packs of the MFMA conv path.  First (eager) step: packed per call and
+    recorded; afterwards the Trainer refreshes all of them with one table-driven launch at
+    the start of every step and the conv Functions just pick up their buffer."""
+    entries = {}     # (id(param), mode, groups) -> (param, buffer)
+    table = None
+    frozen = False
+
+    @staticmethod
+    def reset():
+        _Packs.entries, _Packs.table, _Packs.frozen = {}, None, False
+
+
+def get_pack(w, mode, groups):
+    if not isinstance(w, nn.Parameter):
+        return ops.pack_conv_weights(w, mode, groups)      # derived weights (stem im2col form)
+    key = (id(w), mode, groups)
+    if _Packs.frozen:
+        e = _Packs.entries.get(key)
+        if e is not None:
+            return e[1]
+        return ops.pack_conv_weights(w, mode, groups)
+    buf = ops.pack_conv_weights(w.detach(), mode, groups)
+    _Packs.entries[key] = (w, buf)
+    return buf
+
+
 # --------------------------------------------------------------------------- #
 # autograd Functions (forward/backward = C-ABI kernels)
 # --------------------------------------------------------------------------- #
@@ -44,7 +71,7 @@ class ConvFn(Function):
         wp = None
         if (xadd is None and x.dtype == torch.bfloat16 and ops.mfma_weight_ok(w, groups)
                 and out_dtype in (None, torch.bfloat16)):
-            wp = ops.pack_conv_weights(w, 0, groups)
+            wp = get_pack(w, 0, groups)
         z = ops.conv2d(x, w, stride=stride, pad=pad, groups=groups, xadd=xadd, out_shift=b, stats=st,
                        out_dtype=out_dtype, w_bf16=wp)
         ctx.save_for_backward(x, w, xadd)
@@ -59,10 +86,11 @@ class ConvFn(Function):
         dx = None
         if ctx.needs_input_grad[0] or (xadd is not None and ctx.needs_input_grad[3]):
             wp = None
-            if (dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and w.shape[1] * groups % 32 == 0
-                    and w.shape[0] % 32 == 0 and ops.mfma_weight_ok(w, groups)
+            cin_f = w.shape[1] * groups     # dgrad kernel: "Cin" = Cout_f (16-multiple), "Cout" = Cin_f
+            if (dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and w.shape[0] % 16 == 0
+                    and (cin_f % 16 == 0 or cin_f <= 8) and ops.mfma_weight_ok(w, groups)
                     and not (stride == 2 and w.shape[2] == 1)):
-                wp = ops.pack_conv_weights(w, 1, groups)
+                wp = get_pack(w, 1, groups)
             dx = ops.conv2d(dz, w, stride=stride, pad=pad, groups=groups, transposed=True,
                             out_hw=(x.shape[1], x.shape[2]), out_dtype=x.dtype, w_bf16=wp)
         dw, db = ops.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, pad=pad, groups=groups, xadd=xadd,
@@ -555,10 +583,13 @@ class Trainer:
         self.model.train()
         first = self.table is None
         if first:
+            _Packs.reset()
             for p in self.params:
                 p.grad = None
         else:
             self._attach_grads()
+            if _Packs.table is not None:
+                _Packs.table.run()          # all bf16 weight packs in one launch
         losses = self.model(inputs, data_samples, mode='loss')
         total = None
         for k, v in losses.items():
@@ -575,6 +606,9 @@ class Trainer:
                 v.copy_(p.grad)
             self._attach_grads()
             self.table = T.SgdTable(self.live, self.live_views, [self.moms[i] for i in idx])
+            if _Packs.entries:
+                _Packs.table = T.PackTable([(w, buf, k[1], k[2]) for k, (w, buf) in _Packs.entries.items()])
+                _Packs.frozen = True
         if self.dist is not None:
             n = self.flat_grad.numel()
             for off in range(0, n, self.bucket_elems):

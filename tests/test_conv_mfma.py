@@ -106,3 +106,21 @@ def test_mfma_grouped_1x1(be, cin, cout, hw):
         torch.testing.assert_close(nchw(dx), x.grad, rtol=2e-2, atol=2e-2 * float(x.grad.abs().max()))
     dw, _ = ops.conv2d_wgrad(nhwc(x).bfloat16(), nhwc(dz).bfloat16(), tuple(w.shape), groups=g)
     torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-2, atol=1e-2 * float(w.grad.abs().max()))
+
+
+@pytest.mark.parametrize('cin,cout,k,hw', [(16, 64, 1, (9, 40)), (64, 16, 1, (12, 33)), (32, 2, 3, (20, 37)),
+                                           (64, 2, 1, (10, 34)), (64, 1, 3, (9, 33)), (48, 32, 3, (8, 35))])
+def test_mfma_channel_tails(be, cin, cout, k, hw):
+    """Cin = 16 / 48 (half-filled K chunk) and Cout = 1, 2 (segmentation heads, SEAM) on the MFMA path."""
+    from led_net_amd import ops
+    pad = k // 2
+    x = r16(torch.randn(2, cin, *hw)).requires_grad_(True)
+    w = r16(torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).requires_grad_(True)
+    z = F.conv2d(x, w, padding=pad)
+    dz = r16(torch.randn_like(z))
+    z.backward(dz)
+    assert ops.mfma_weight_ok(w)
+    got = ops.conv2d(nhwc(x).bfloat16(), D(w.detach()), pad=pad, w_bf16=ops.pack_conv_weights(D(w.detach()), 0))
+    torch.testing.assert_close(nchw(got), z.detach(), rtol=2e-2, atol=2e-2)
+    dw, _ = ops.conv2d_wgrad(nhwc(x).bfloat16(), nhwc(dz).bfloat16(), tuple(w.shape), pad=pad)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-2, atol=1e-2 * float(w.grad.abs().max()))
