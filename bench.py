@@ -252,7 +252,7 @@ def main():
                 f[1] += v['n']
             for e, (ms, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
                 print(f'{ms / k_steps:9.3f} ms/step  x{n // k_steps:4d}  [family] {e}', file=sys.stderr)
-            for (e, sg), v in top[:25]:
+            for (e, sg), v in top[:int(os.environ.get("LEDN_BENCH_VERBOSE", "25")) if os.environ.get("LEDN_BENCH_VERBOSE", "1").isdigit() and int(os.environ.get("LEDN_BENCH_VERBOSE", "1")) > 1 else 25]:
                 print(f'{v["ms"] / k_steps:9.3f} ms/step  x{v["n"] // k_steps:3d}  {e} [{sg}]', file=sys.stderr)
         print(json.dumps(out))
     if world > 1:

@@ -76,7 +76,7 @@ def _nb(*ts):
     return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
-def _run(lib, name, ref, *args, work=('', 0, 0)):
+def _run(lib, name, ref, *args, work=None):
     lib.ensure_workspace(ref.device)
     stream = _stream(lib, ref)
     if _TIMING is not None and lib.is_hip:
@@ -84,7 +84,7 @@ def _run(lib, name, ref, *args, work=('', 0, 0)):
         e0.record()
         lib.call(name, *args, stream)
         e1.record()
-        _TIMING.append((name, work, e0, e1))
+        _TIMING.append((name, work or ('', 0, 0), e0, e1))
     else:
         lib.call(name, *args, stream)
 
@@ -136,9 +136,9 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
     d.KH, d.KW, d.stride, d.pad, d.dil, d.groups = KH, KW, stride, pad, dil, groups
     d.in_act, d.act_out, d.res_mode = in_act, act, res_mode if res is not None else RES_NONE
     d.dtype_x, d.dtype_y, d.transposed = _dt(x), _dt(y), int(transposed)
-    flops = 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW
-    sig = f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}'
-    _run(lib, 'ledn_conv2d', x, d, work=(sig, _nb(x, xadd, y, res, w), flops))
+    _run(lib, 'ledn_conv2d', x, d, work=_TIMING is not None and (
+        f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}',
+        _nb(x, xadd, y, res, w), 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW))
     return y
 
 
@@ -152,7 +152,7 @@ def im2col_stem(x):
     p = torch.empty((N, Ho, Wo, 32), dtype=torch.bfloat16, device=x.device)
     _check(lib, x, p)
     _run(lib, 'ledn_im2col_stem', x, _p(x), _p(p), N, H, W, Cc, Ho, Wo,
-         work=(f'im2col_stem {N}x{H}x{W}', _nb(x, p), 0))
+         work=_TIMING is not None and (f'im2col_stem {N}x{H}x{W}', _nb(x, p), 0))
     return p
 
 
@@ -181,7 +181,7 @@ def pack_conv_weights(w, mode=0, groups=1):
     out = torch.empty(Cout * Cin * KH * KW, dtype=torch.bfloat16, device=w.device)
     _check(lib, w, out)
     _run(lib, 'ledn_pack_conv_weights', w, _p(w), _p(out), Cout, Cin, KH, KW, mode, groups,
-         work=(f'packw {tuple(w.shape)} m{mode}', _nb(w, out), 0))
+         work=_TIMING is not None and (f'packw {tuple(w.shape)} m{mode}', _nb(w, out), 0))
     return out
 
 
@@ -206,7 +206,7 @@ def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None,
     d.in_act, d.dtype_x, d.dtype_dz = in_act, _dt(x), _dt(dz)
     flops = 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW
     _run(lib, 'ledn_conv2d_wgrad', x, d,
-         work=(f'wgrad{KH}x{KW} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W}', _nb(x, xadd, dz, dw), flops))
+         work=_TIMING is not None and (f'wgrad{KH}x{KW} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W}', _nb(x, xadd, dz, dw), flops))
     return dw, db
 
 
@@ -238,7 +238,7 @@ def dwconv2d(x, w_khwc, *, stride=1, pad=-1, dil=(1, 1, 1, 1), group_size=None, 
         d.dil[i] = dil[i] if i < len(dil) else dil[-1]
     d.group_size, d.act_out, d.ext1 = group_size, act, int(ext1)
     d.dtype_x, d.dtype_y = _dt(x), _dt(y)
-    _run(lib, 'ledn_dwconv2d', x, d, work=(f'dw{KH}x{KW} C{Cc} s{stride} {N}x{H}x{W}', _nb(x, y, w_khwc), 2 * y.numel() * KH * KW))
+    _run(lib, 'ledn_dwconv2d', x, d, work=_TIMING is not None and (f'dw{KH}x{KW} C{Cc} s{stride} {N}x{H}x{W}', _nb(x, y, w_khwc), 2 * y.numel() * KH * KW))
     return y
 
 
@@ -257,7 +257,7 @@ def sesp_pyramid(x, w_b33n, dil, stride):
     for i in range(4):
         d.dil[i] = dil[i]
     d.dtype_x = d.dtype_y = _dt(x)
-    _run(lib, 'ledn_sesp_pyramid', x, d, work=(f'pyr n{n} s{stride} {N}x{H}x{W}', _nb(x, y, w_b33n), 2 * y.numel() * 9))
+    _run(lib, 'ledn_sesp_pyramid', x, d, work=_TIMING is not None and (f'pyr n{n} s{stride} {N}x{H}x{W}', _nb(x, y, w_b33n), 2 * y.numel() * 9))
     return y
 
 
@@ -271,7 +271,7 @@ def channel_stats(x, xadd=None, stats=None):
                  torch.zeros(Cc, dtype=torch.float32, device=x.device))
     _check(lib, x, xadd, stats[0], stats[1])
     _run(lib, 'ledn_channel_stats', x, _p(x), _p(xadd), P, Cc, _dt(x), _p(_f32(stats[0], Cc)),
-         _p(_f32(stats[1], Cc)), work=(f'stats C{Cc} P{P}', _nb(x, xadd), 3 * x.numel()))
+         _p(_f32(stats[1], Cc)), work=_TIMING is not None and (f'stats C{Cc} P{P}', _nb(x, xadd), 3 * x.numel()))
     return stats
 
 
@@ -284,7 +284,7 @@ def bn_finalize(stats, count, gamma, beta, running_mean=None, running_var=None, 
     _check(lib, stats[0], stats[1], gamma, beta, running_mean, running_var)
     _run(lib, 'ledn_bn_finalize', stats[0], _p(stats[0]), _p(stats[1]), float(count), _p(_f32(gamma, Cc)),
          _p(_f32(beta, Cc)), _p(_f32(running_mean, Cc)), _p(_f32(running_var, Cc)), momentum, eps,
-         _p(scale), _p(shift), _p(mean), _p(invstd), Cc, work=(f'bnfin C{Cc}', 0, 0))
+         _p(scale), _p(shift), _p(mean), _p(invstd), Cc, work=_TIMING is not None and (f'bnfin C{Cc}', 0, 0))
     return scale, shift, mean, invstd
 
 
@@ -302,7 +302,7 @@ def affine_act(x, scale=None, shift=None, *, act=ACT_NONE, slope=None, res=None,
     d.P, d.C, d.act = x.numel() // Cc, Cc, act
     d.res_mode = res_mode if res is not None else RES_NONE
     d.dtype_x, d.dtype_y = _dt(x), _dt(y)
-    _run(lib, 'ledn_affine_act', x, d, work=(f'affine C{Cc} P{x.numel() // Cc}', _nb(x, xadd, y, res), 2 * x.numel()))
+    _run(lib, 'ledn_affine_act', x, d, work=_TIMING is not None and (f'affine C{Cc} P{x.numel() // Cc}', _nb(x, xadd, y, res), 2 * x.numel()))
     return y
 
 
@@ -318,7 +318,7 @@ def nchw_to_nhwc(x, out_dtype, scale=None, shift=None, chan_map=None):
         raise LednError('nchw_to_nhwc: chan_map must be int32[C]')
     _check(lib, x, y, scale, shift, chan_map)
     _run(lib, 'ledn_nchw_to_nhwc', x, _p(x), dtx, _p(y), _DT[out_dtype], N, Cc, H, W, _p(_f32(scale, Cc)),
-         _p(_f32(shift, Cc)), _p(chan_map), work=(f'nchw2nhwc {N}x{Cc}x{H}x{W}', _nb(x, y), 2 * x.numel()))
+         _p(_f32(shift, Cc)), _p(chan_map), work=_TIMING is not None and (f'nchw2nhwc {N}x{Cc}x{H}x{W}', _nb(x, y), 2 * x.numel()))
     return y
 
 
@@ -337,7 +337,7 @@ def bilinear(x, size, *, add=None, out_dtype=None, nchw=False, argmax=False):
     d.x, d.add, d.y, d.argmax = _p(x), _p(add), _p(y), _p(am)
     d.N, d.H, d.W, d.C, d.Ho, d.Wo = N, H, W, Cc, Ho, Wo
     d.out_nchw, d.dtype_x, d.dtype_y = int(nchw), _dt(x), _DT[odt]
-    _run(lib, 'ledn_bilinear', x, d, work=(f'bilinear C{Cc} {H}x{W}->{Ho}x{Wo} N{N}', _nb(x, y, add, am), 8 * y.numel()))
+    _run(lib, 'ledn_bilinear', x, d, work=_TIMING is not None and (f'bilinear C{Cc} {H}x{W}->{Ho}x{Wo} N{N}', _nb(x, y, add, am), 8 * y.numel()))
     return (y, am) if argmax else y
 
 
@@ -347,7 +347,7 @@ def adaptive_avgpool(x, S, xadd=None):
     y = torch.empty((N, S, S, Cc), dtype=torch.float32, device=x.device)
     _check(lib, x, xadd, y)
     _run(lib, 'ledn_adaptive_avgpool', x, _p(x), _p(xadd), _p(y), N, H, W, Cc, S, _dt(x),
-         work=(f'apool S{S} C{Cc} {N}x{H}x{W}', _nb(x, xadd, y), x.numel()))
+         work=_TIMING is not None and (f'apool S{S} C{Cc} {N}x{H}x{W}', _nb(x, xadd, y), x.numel()))
     return y
 
 
@@ -358,7 +358,7 @@ def avgpool3x3s2(x):
     y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
     _check(lib, x, y)
     _run(lib, 'ledn_avgpool3x3s2', x, _p(x), _p(y), N, H, W, Cc, Ho, Wo, _dt(x),
-         work=(f'avgpool3s2 C{Cc} {N}x{H}x{W}', _nb(x, y), 9 * y.numel()))
+         work=_TIMING is not None and (f'avgpool3s2 C{Cc} {N}x{H}x{W}', _nb(x, y), 9 * y.numel()))
     return y
 
 
@@ -372,7 +372,7 @@ def window_attn(qkv, biasT, heads, ws=8):
     _check(lib, qkv, biasT, out)
     nwin = N * ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
     _run(lib, 'ledn_window_attn', qkv, _p(qkv), _p(_f32(biasT)), _p(out), N, H, W, Cc, heads, ws, _dt(qkv),
-         work=(f'wattn C{Cc} h{heads} {N}x{H}x{W}', _nb(qkv, out, biasT), 4 * nwin * (ws * ws) ** 2 * Cc))
+         work=_TIMING is not None and (f'wattn C{Cc} h{heads} {N}x{H}x{W}', _nb(qkv, out, biasT), 4 * nwin * (ws * ws) ** 2 * Cc))
     return out
 
 
@@ -384,7 +384,7 @@ def getb_pool(a, local, ws=8):
     out = torch.empty_like(a)
     _check(lib, a, local, out)
     _run(lib, 'ledn_getb_pool', a, _p(a), _p(local), _p(out), N, H, W, Cc, ws, _dt(a),
-         work=(f'getbpool C{Cc} {N}x{H}x{W}', _nb(a, local, out), 17 * a.numel()))
+         work=_TIMING is not None and (f'getbpool C{Cc} {N}x{H}x{W}', _nb(a, local, out), 17 * a.numel()))
     return out
 
 
@@ -410,7 +410,7 @@ def mfaf_gate(x, r, xl, ctx, affines, act=ACT_NONE):
         keep += [s, b]
     _check(lib, *keep)
     d.N, d.H, d.W, d.C, d.dtype, d.act = N, H, W, Cc, _dt(x), act
-    _run(lib, 'ledn_mfaf_gate', x, d, work=(f'mfafgate C{Cc} {N}x{H}x{W}', _nb(x, r, xl, out), 20 * x.numel()))
+    _run(lib, 'ledn_mfaf_gate', x, d, work=_TIMING is not None and (f'mfafgate C{Cc} {N}x{H}x{W}', _nb(x, r, xl, out), 20 * x.numel()))
     return out
 
 
@@ -425,5 +425,5 @@ def seam_edge(seg, percentile=0.8, thr=0.1, final_thr=0.1):
     kth = 0 if percentile is None else max(1, math.ceil(percentile * h * w))
     _check(lib, seg, edge, scratch)
     _run(lib, 'ledn_seam_edge', seg, _p(seg), _p(edge), _p(scratch), N, h, w, kth, thr, final_thr,
-         work=(f'seam {N}x{h}x{w}', _nb(seg, edge), 60 * seg.numel()))
+         work=_TIMING is not None and (f'seam {N}x{h}x{w}', _nb(seg, edge), 60 * seg.numel()))
     return edge

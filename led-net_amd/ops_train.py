@@ -5,6 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from . import ops as _ops
 from .ops import (ACT_NONE, RES_NONE, _DT, LednError, _check, _dt, _f32, _nb, _p, _run,  # noqa: F401
                   conv_out_size)
 
@@ -35,10 +36,10 @@ def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT
     d.res_mode = res_mode if res is not None else RES_NONE
     d.bn_mode, d.dtype_z, d.dtype_y = int(bn), _dt(z), _dt(dy)
     if bn or slope is not None:
-        _run(lib, 'ledn_bn_act_bwd_reduce', z, d, work=(f'bnbwd_reduce C{Cc} P{P}', _nb(z, dy, res), 6 * z.numel()))
+        _run(lib, 'ledn_bn_act_bwd_reduce', z, d, work=_ops._TIMING is not None and (f'bnbwd_reduce C{Cc} P{P}', _nb(z, dy, res), 6 * z.numel()))
         if bn and sync is not None:
             sync(sums)
-    _run(lib, 'ledn_bn_act_bwd_apply', z, d, work=(f'bnbwd_apply C{Cc} P{P}', _nb(z, dy, res, dz, dres), 8 * z.numel()))
+    _run(lib, 'ledn_bn_act_bwd_apply', z, d, work=_ops._TIMING is not None and (f'bnbwd_apply C{Cc} P{P}', _nb(z, dy, res, dz, dres), 8 * z.numel()))
     return dz, dres, (sums[1] if bn else None), (sums[0] if bn else None), dslope
 
 
@@ -68,11 +69,11 @@ def dwconv2d_bwd(x, dz, w_khwc, *, stride=1, pad=-1, dil=(1, 1, 1, 1), group_siz
     if need_dx:
         dx = torch.empty_like(x)
         d.dx = _p(dx)
-        _run(lib, 'ledn_dwconv2d_bwd_data', x, d, work=(f'dwbwd_data{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(dz, dx, add), 2 * dz.numel() * KH * KW))
+        _run(lib, 'ledn_dwconv2d_bwd_data', x, d, work=_ops._TIMING is not None and (f'dwbwd_data{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(dz, dx, add), 2 * dz.numel() * KH * KW))
     if need_dw:
         dw = torch.zeros_like(w_khwc)
         d.dw = _p(dw)
-        _run(lib, 'ledn_dwconv2d_bwd_weight', x, d, work=(f'dwbwd_w{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(x, dz) , 2 * dz.numel() * KH * KW))
+        _run(lib, 'ledn_dwconv2d_bwd_weight', x, d, work=_ops._TIMING is not None and (f'dwbwd_w{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(x, dz) , 2 * dz.numel() * KH * KW))
     return dx, dw
 
 
@@ -92,8 +93,8 @@ def sesp_pyramid_bwd(x, dy, w_b33n, dil, stride):
     for i in range(4):
         d.dil[i] = dil[i]
     d.dtype = _dt(x)
-    _run(lib, 'ledn_sesp_pyramid_bwd_data', x, d, work=(f'pyrbwd_data n{n} {tuple(x.shape)}', _nb(dy, gsum, gsum, dx), 2 * dy.numel() * 9))
-    _run(lib, 'ledn_sesp_pyramid_bwd_weight', x, d, work=(f'pyrbwd_w n{n} {tuple(x.shape)}', _nb(x, gsum), 2 * dy.numel() * 9))
+    _run(lib, 'ledn_sesp_pyramid_bwd_data', x, d, work=_ops._TIMING is not None and (f'pyrbwd_data n{n} {tuple(x.shape)}', _nb(dy, gsum, gsum, dx), 2 * dy.numel() * 9))
+    _run(lib, 'ledn_sesp_pyramid_bwd_weight', x, d, work=_ops._TIMING is not None and (f'pyrbwd_w n{n} {tuple(x.shape)}', _nb(x, gsum), 2 * dy.numel() * 9))
     return dx, dw
 
 
@@ -104,7 +105,7 @@ def bilinear_bwd(dy, in_hw, out_dtype=None):
     dx = torch.empty((N, H, W, Cc), dtype=out_dtype or dy.dtype, device=dy.device)
     _check(lib, dy, dx)
     _run(lib, 'ledn_bilinear_bwd', dy, _p(dy), _p(dx), N, H, W, Cc, Ho, Wo, _dt(dy), _dt(dx),
-         work=(f'bilinear_bwd C{Cc} {Ho}x{Wo}->{H}x{W} N{N}', _nb(dy, dx), 8 * dy.numel()))
+         work=_ops._TIMING is not None and (f'bilinear_bwd C{Cc} {Ho}x{Wo}->{H}x{W} N{N}', _nb(dy, dx), 8 * dy.numel()))
     return dx
 
 
@@ -117,7 +118,7 @@ def avgpool3x3s2_bwd(dy, in_hw, add=None):
         raise LednError('avgpool3x3s2_bwd: add mismatch')
     _check(lib, dy, dx, add)
     _run(lib, 'ledn_avgpool3x3s2_bwd', dy, _p(dy), _p(add), _p(dx), N, H, W, Cc, Ho, Wo, _dt(dy),
-         work=(f'avgpool_bwd C{Cc} {N}x{H}x{W}', _nb(dy, dx, add), 3 * dx.numel()))
+         work=_ops._TIMING is not None and (f'avgpool_bwd C{Cc} {N}x{H}x{W}', _nb(dy, dx, add), 3 * dx.numel()))
     return dx
 
 
@@ -132,7 +133,7 @@ def window_attn_bwd(qkv, biasT, dout, heads, ws=8):
     _check(lib, qkv, biasT, dout)
     nwin = N * ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
     _run(lib, 'ledn_window_attn_bwd', qkv, _p(qkv), _p(_f32(biasT)), _p(dout), _p(dq32), _p(dbias), N, H, W,
-         Cc, heads, ws, _dt(qkv), work=(f'wattn_bwd C{Cc} h{heads} {N}x{H}x{W}', _nb(qkv, dout, dq32), 10 * nwin * (ws * ws) ** 2 * Cc))
+         Cc, heads, ws, _dt(qkv), work=_ops._TIMING is not None and (f'wattn_bwd C{Cc} h{heads} {N}x{H}x{W}', _nb(qkv, dout, dq32), 10 * nwin * (ws * ws) ** 2 * Cc))
     if qkv.dtype != torch.float32:
         from .ops import affine_act
         dq32 = affine_act(dq32, out_dtype=qkv.dtype)
@@ -145,7 +146,7 @@ def getb_pool_bwd(dout, ws=8):
     da = torch.empty_like(dout)
     _check(lib, dout, da)
     _run(lib, 'ledn_getb_pool_bwd', dout, _p(dout), _p(da), N, H, W, Cc, ws, _dt(dout),
-         work=(f'getbpool_bwd C{Cc} {N}x{H}x{W}', _nb(dout, da), 18 * da.numel()))
+         work=_ops._TIMING is not None and (f'getbpool_bwd C{Cc} {N}x{H}x{W}', _nb(dout, da), 18 * da.numel()))
     return da
 
 
@@ -166,7 +167,7 @@ def mfaf_gate_bwd(x, r, xl, ctx, affines, dout, act=ACT_NONE):
         keep += [s, b]
     _check(lib, *keep)
     d.N, d.H, d.W, d.C, d.dtype, d.act = N, H, W, Cc, _dt(x), act
-    _run(lib, 'ledn_mfaf_gate_bwd', x, d, work=(f'mfafgate_bwd C{Cc} {N}x{H}x{W}', _nb(x, r, xl, dout, dx, dr, ds), 30 * x.numel()))
+    _run(lib, 'ledn_mfaf_gate_bwd', x, d, work=_ops._TIMING is not None and (f'mfafgate_bwd C{Cc} {N}x{H}x{W}', _nb(x, r, xl, dout, dx, dr, ds), 30 * x.numel()))
     return dx, dr, ds, dctx
 
 
@@ -179,7 +180,7 @@ def mfaf_bwd_combine(dx, dr, dxl, dpools):
     sizes = (C.c_int * max(n, 1))(*[p.shape[1] for p in dpools])
     _check(lib, dx, dr, dxl, *dpools)
     _run(lib, 'ledn_mfaf_bwd_combine', dx, _p(dx), _p(dr), _p(dxl), ptrs, sizes, n, N, H, W, Cc, _dt(dx),
-         work=(f'mfaf_combine C{Cc} {N}x{H}x{W}', _nb(dx, dr, dxl) * 2, 8 * dx.numel()))
+         work=_ops._TIMING is not None and (f'mfaf_combine C{Cc} {N}x{H}x{W}', _nb(dx, dr, dxl) * 2, 8 * dx.numel()))
     return dx, dr
 
 
@@ -196,7 +197,7 @@ def ohem_ce_fwd(logits, target, thres, min_kept, loss_weight, ignore_label=255):
     out = torch.empty(4, dtype=torch.float32, device=logits.device)
     _check(lib, logits, target, work, out)
     _run(lib, 'ledn_ohem_ce_fwd', logits, _p(logits), _p(target), P, Cc, thres, int(min_kept), loss_weight,
-         ignore_label, _p(work), _p(out), work=(f'ohem_fwd P{P} C{Cc}', _nb(logits, target) + 5 * 8 * P, 30 * P))
+         ignore_label, _p(work), _p(out), work=_ops._TIMING is not None and (f'ohem_fwd P{P} C{Cc}', _nb(logits, target) + 5 * 8 * P, 30 * P))
     return out, work
 
 
@@ -208,7 +209,7 @@ def ohem_ce_bwd(logits, target, work, out, dloss, loss_weight, ignore_label=255)
     dloss = dloss.reshape(1).to(torch.float32).contiguous()
     _check(lib, logits, target, work, out, dloss, dl)
     _run(lib, 'ledn_ohem_ce_bwd', logits, _p(logits), _p(target), P, Cc, ignore_label, _p(work), _p(out),
-         _p(dloss), loss_weight, _p(dl), work=(f'ohem_bwd P{P} C{Cc}', _nb(logits, target, dl) + 4 * P, 20 * P))
+         _p(dloss), loss_weight, _p(dl), work=_ops._TIMING is not None and (f'ohem_bwd P{P} C{Cc}', _nb(logits, target, dl) + 4 * P, 20 * P))
     return dl
 
 
@@ -237,7 +238,7 @@ class SgdTable:
     def step(self, lr, momentum, weight_decay, grad_scale=1.0, lr_dev=None):
         lib = _lib.get_lib()
         _run(lib, 'ledn_sgd_step', self.ref, self.table.data_ptr(), self.n, self.max_n, float(lr), _p(lr_dev),
-             momentum, weight_decay, grad_scale, work=(f'sgd {self.n} tensors', 16 * sum(p.numel() for p in self.keep[0]), 0))
+             momentum, weight_decay, grad_scale, work=_ops._TIMING is not None and (f'sgd {self.n} tensors', 16 * sum(p.numel() for p in self.keep[0]), 0))
 
 
 class PackTable:
@@ -262,4 +263,4 @@ class PackTable:
     def run(self):
         lib = _lib.get_lib()
         _run(lib, 'ledn_pack_conv_weights_multi', self.ref, self.table.data_ptr(), self.n, self.max_elems,
-             work=(f'packw_multi {self.n} tensors', 0, 0))
+             work=_ops._TIMING is not None and (f'packw_multi {self.n} tensors', 0, 0))
