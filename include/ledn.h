@@ -40,6 +40,14 @@ int ledn_abi_version(void);
  * ptr = NULL, nfloats = 0 detaches it (kernels then fall back to atomics). */
 int ledn_set_workspace(void* ptr, long long nfloats);
 
+/* Launch-shape knobs (process-wide; defaults are tuned for a 256-CU MI355X).  value <= 0 restores
+ * the default.  Results never depend on them beyond f32 summation order. */
+enum {
+    LEDN_OPT_CONV_WORKGROUPS = 0,   /* persistent workgroups of the MFMA conv (default 512) */
+    LEDN_OPT_WGRAD_WORKGROUPS = 1   /* pixel-range workgroups of the MFMA weight gradient (default 512) */
+};
+int ledn_set_option(int option, long long value);
+
 /* ------------------------------------------------------------------------- *
  * Dense / grouped convolution, forward and data-gradient.
  *   z[n,ho,wo,co] = sum_{kh,kw,ci} pre(x)[n, ho*s-pad+kh*dil, wo*s-pad+kw*dil, ci] * W[co][ci][kh][kw]

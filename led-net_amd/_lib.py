@@ -127,6 +127,7 @@ _PROTOS = {
     'ledn_sgd_step': ([vp, i32, i64, C.c_float, fp, C.c_float, C.c_float, C.c_float, vp], i32),
     'ledn_abi_version': ([], i32),
     'ledn_set_workspace': ([vp, i64], i32),
+    'ledn_set_option': ([i32, i64], i32),
     'ledn_conv2d': ([C.POINTER(ConvDesc), vp], i32),
     'ledn_pack_conv_weights_multi': ([vp, i32, i64, vp], i32),
     'ledn_im2col_stem': ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
@@ -179,6 +180,10 @@ class Library:
             import torch
             self._workspace = torch.empty(nfloats, dtype=torch.float32, device=device)
             self.call('ledn_set_workspace', self._workspace.data_ptr(), nfloats)
+
+    def set_option(self, option, value):
+        """launch-shape knob (include/ledn.h LEDN_OPT_*); value <= 0 restores the default"""
+        self.call('ledn_set_option', option, value)
 
     def call(self, name, *args):
         rc = getattr(self.cdll, name)(*args)

@@ -69,6 +69,8 @@ int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_
 namespace ledn {
 static Workspace g_ws = {nullptr, 0};
 Workspace& workspace() { return g_ws; }
+static Options g_opt = {512, 512};
+Options& options() { return g_opt; }
 }  // namespace ledn
 
 using namespace ledn;
@@ -83,6 +85,15 @@ int ledn_set_workspace(void* ptr, long long nfloats) {
     workspace().ptr = (float*)ptr;
     workspace().nfloats = (long)nfloats;
     return LEDN_OK;
+}
+
+int ledn_set_option(int option, long long value) {
+    if (value > (1 << 20)) return LEDN_EINVAL;
+    switch (option) {
+        case LEDN_OPT_CONV_WORKGROUPS: options().conv_workgroups = value > 0 ? (int)value : 512; return LEDN_OK;
+        case LEDN_OPT_WGRAD_WORKGROUPS: options().wgrad_workgroups = value > 0 ? (int)value : 512; return LEDN_OK;
+        default: return LEDN_EINVAL;
+    }
 }
 
 int ledn_conv2d(const ledn_conv_desc* d, void* stream) {

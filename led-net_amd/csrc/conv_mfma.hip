@@ -3,30 +3,36 @@
 // bf16 activations / bf16 packed weights / f32 accumulation, v_mfma_f32_32x32x16_bf16.
 //
 // Forward + data-gradient kernel (conv_mfma_kernel)
-//   GEMM view: M = output pixels, N = Cout, K = taps x Cin.
-//   Workgroup = 4 wavefronts = an output patch of TR rows x 32 columns (one MFMA M-tile
-//   = 32 consecutive pixels of a row) x WN*32 output channels.  Wave (wm, wn) owns MT
-//   rows and one 32-channel N-tile: MT accumulator tiles (16 f32 VGPRs each).
-//   The NHWC input patch (with halo) of one 32-channel K-chunk is staged ONCE per chunk
-//   in LDS as [patch pixel][32 ch + 8 pad] bf16: the 80-byte pixel stride makes the
-//   A-fragment read (16 B of 8 consecutive channels per lane, lanes = 32 pixels of a
-//   row) hit 16 distinct 16-B slots per 16-lane group -> conflict-free ds_read_b128.
-//   Every tap re-reads the same LDS patch (im2col never materialised); the B fragment
-//   (8 consecutive ci of one cout) is a 16-B global load from the [tap][co][ci] bf16
-//   weight pack (L1/L2 resident) reused for the wave's MT tiles.
-//   BatchNorm/activation of the producer can be applied while staging (prologue),
-//   BN-affine / residual / activation / per-channel statistics in the epilogue.
-//   Data gradient = the same kernel: stride-1 convs use the flipped/transposed weight
-//   pack; stride-2 convs read dz as a zero-upsampled patch (UP = 2).
+//   GEMM view: M = Cout, N = output pixels, K = taps x Cin  (A = weights, B = pixels, so that an
+//   accumulator lane owns one pixel and 4 x 4 consecutive channels of the NHWC output).
+//   Workgroup = 4 wavefronts = an output patch of TR rows x 32 columns x WN*32 output channels;
+//   wave (wm, wn) owns MT rows and one 32-channel tile: MT accumulator tiles (16 f32 VGPRs each).
+//   Workgroups are PERSISTENT (about two per CU): each walks a contiguous range of tiles and the
+//   flattened (tile, 32-channel K-chunk) sequence is software-pipelined -- the 16-byte global loads
+//   of step i+1 are issued right after the LDS commit of step i and fly during its MFMA phase and
+//   epilogue.  vmcnt retires in order, so nothing inside a step may wait on vector memory: the
+//   weight fragments of the K-chunk live in LDS too, and the epilogue flavour is a template
+//   parameter (no runtime-switched parameter loads between the stores).
+//   The NHWC input patch (with halo) of one K-chunk is staged in LDS as [patch pixel][32 ch + 8 pad]
+//   bf16: the 80-byte pixel stride makes the fragment read (16 B of 8 consecutive channels per
+//   lane, lanes = 32 pixels of a row) conflict-free.  Every tap re-reads the same patch (im2col is
+//   never materialised).  The producer's BatchNorm/ReLU can be applied while staging (prologue);
+//   BN-affine / residual / activation / per-channel statistics in the epilogue; the bf16 output
+//   tile goes through a per-wave LDS transposition so that global stores are 16 B per lane and
+//   cover whole 64-byte channel rows.
+//   Data gradient = the same kernel: stride-1 convs use the flipped/transposed weight pack;
+//   stride-2 convs read dz as a zero-upsampled patch (UP = 2).
+//   The hot loop is kept small on purpose (~30 KB of code): the first unrolled version was 90 KB and
+//   ran instruction-cache bound.
 //
 // Weight-gradient kernel (conv_wgrad_mfma_kernel)
 //   GEMM view: M = Cout tile (32), N = Cin tile (32), K = output pixels.
-//   dz and the x patch are staged pixel-major exactly as above; the K-contiguous
-//   fragments (8 consecutive pixels of one channel) come out of the SAME layout through
-//   ds_read_b64_tr_b16 (hardware transpose read), so tap shifts are whole-pixel address
-//   offsets (always aligned).  Each wave accumulates 9 taps x [32 x 32] in registers over
-//   its share of the pixels; partial tiles are reduced across the 4 waves through LDS and
-//   added to dW with one f32 atomic per element per workgroup.
+//   dz and the x patch are staged pixel-major exactly as above (one tile ahead, through
+//   registers); the K-contiguous fragments (8 consecutive pixels of one channel) come out of the
+//   SAME layout through ds_read_b64_tr_b16 (hardware transpose read), so tap shifts are whole-pixel
+//   address offsets.  3x3: the nine taps are split over the four waves (3 accumulator tiles per wave,
+//   no cross-wave reduction); 1x1: the waves split the pixels and reduce through LDS.  Per-workgroup
+//   partial tiles go to the workspace and a second kernel sums them (no same-address atomics).
 #include "ledn_rt.h"
 
 namespace ledn {
@@ -48,171 +54,436 @@ struct MfmaConvArgs {
     float* stat_sqsum;
     int N, H, W, Cin, Ho, Wo, Cout;
     int pad, in_act, act_out, res_mode;
-    int tiles_h, tiles_w;
+    int tiles_h, tiles_w, tiles_per_block;
     float* part;      // optional workspace for the statistics: [gridDim.x * WM][2][Cout]
 };
 
-// stage one 16-byte (8-channel) piece of a patch pixel into LDS, prologue applied
-__device__ __forceinline__ void stage_piece(unsigned char* dst, const bf16_t* src, bool valid,
-                                            const float* in_scale, const float* in_shift, int in_act,
-                                            int c) {
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (valid) {
-        v = *reinterpret_cast<const uint4*>(src);
-        if (in_scale || in_act) {
-            unsigned w[4] = {v.x, v.y, v.z, v.w};
+// producer BatchNorm / ReLU applied to one 16-byte (8-channel) piece while it is staged
+__device__ __forceinline__ uint4 prologue_piece(uint4 v, const float* in_scale, const float* in_shift, int in_act,
+                                                int c) {
+    if (in_scale || in_act) {
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
-                if (in_scale) {
-                    lo = lo * in_scale[c + 2 * i] + in_shift[c + 2 * i];
-                    hi = hi * in_scale[c + 2 * i + 1] + in_shift[c + 2 * i + 1];
-                }
-                if (in_act == LEDN_ACT_RELU) {
-                    lo = fmaxf(lo, 0.f);
-                    hi = fmaxf(hi, 0.f);
-                }
-                w[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+        for (int i = 0; i < 4; ++i) {
+            float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+            if (in_scale) {
+                lo = lo * in_scale[c + 2 * i] + in_shift[c + 2 * i];
+                hi = hi * in_scale[c + 2 * i + 1] + in_shift[c + 2 * i + 1];
             }
-            v = make_uint4(w[0], w[1], w[2], w[3]);
+            if (in_act == LEDN_ACT_RELU) {
+                lo = fmaxf(lo, 0.f);
+                hi = fmaxf(hi, 0.f);
+            }
+            w[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
         }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    *reinterpret_cast<uint4*>(dst) = v;
+    return v;
 }
 
-template <int WM, int WN, int MT, int K, int S, int UP>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(MfmaConvArgs a) {
+// The patch of one 32-channel K-chunk, fetched in two phases so that every global load of a
+// thread is in flight before the first one is consumed (and, across K-chunks / tiles, while the
+// matrix cores work on the previous chunk): fetch() issues NL unconditional 16-byte loads
+// (addresses of out-of-image pieces are clamped to the tensor base), commit() zeroes the invalid
+// pieces, applies the prologue and writes the [pixel][32 ch + 8 pad] LDS layout.
+template <int PR, int PC, int S, int UP>
+struct PatchStage {
+    static constexpr int NPIX = PR * PC;
+    static constexpr int NL = (NPIX * 4 + 255) / 256;
+    uint4 v[NL];
+    unsigned ok;   // bit j: piece j holds image data
+
+    __device__ __forceinline__ void fetch(const bf16_t* x, int n, int H, int W, int C, int h0, int w0, int c0,
+                                          int tid) {
+        tid = opaque(tid);   // recompute the piece coordinates per call instead of keeping 3 x NL registers
+        ok = 0u;
+        const int part = tid & 3;
+        const int c = c0 + part * 8;
+        const bf16_t* img = x + (long)n * H * W * C;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int p = (tid >> 2) + j * 64;
+            const int pr = p / PC, pc = p % PC;
+            const int uh = h0 + pr, uw = w0 + pc;
+            bool valid;
+            int hi, wi;
+            if (UP == 1) {
+                hi = uh; wi = uw;
+                valid = uh >= 0 && uh < H && uw >= 0 && uw < W;
+            } else {
+                hi = uh / UP; wi = uw / UP;
+                valid = uh >= 0 && uw >= 0 && (uh % UP) == 0 && (uw % UP) == 0 && hi < H && wi < W;
+            }
+            valid = valid && p < NPIX && c < C;
+            // 32-bit element offset inside image n (the host checks H*W*C < 2^31): scalar base + vector offset
+            const unsigned off = valid ? (unsigned)((hi * W + wi) * C + c) : 0u;
+            v[j] = *reinterpret_cast<const uint4*>(img + off);
+            ok |= valid ? (1u << j) : 0u;
+        }
+    }
+
+    // raw pieces -> LDS; when the producer's BatchNorm / ReLU is folded into this conv (prologue) the
+    // thread then transforms its own valid pieces in place (rolled loop: keeps the hot loop's code
+    // small; zero padding stays zero, i.e. padding is applied AFTER the prologue)
+    __device__ __forceinline__ void commit(unsigned char* s_patch, const float* in_scale, const float* in_shift,
+                                           int in_act, int c0, int tid) const {
+        const int part = tid & 3;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int p = (tid >> 2) + j * 64;
+            if (p >= NPIX) continue;
+            const bool valid = ok & (1u << j);
+            uint4 q = v[j];
+            q.x = valid ? q.x : 0u; q.y = valid ? q.y : 0u; q.z = valid ? q.z : 0u; q.w = valid ? q.w : 0u;
+            *reinterpret_cast<uint4*>(s_patch + (long)p * PIXB + part * 16) = q;
+        }
+        if (in_scale || in_act) {
+#pragma unroll 1
+            for (int j = 0; j < NL; ++j) {
+                const int p = (tid >> 2) + j * 64;
+                if (p >= NPIX || !((ok >> j) & 1u)) continue;
+                uint4* slot = reinterpret_cast<uint4*>(s_patch + (long)p * PIXB + part * 16);
+                *slot = prologue_piece(*slot, in_scale, in_shift, in_act, c0 + part * 8);
+            }
+        }
+    }
+};
+
+// dz tile of a narrow head (Cout = 1..4, pixel stride not 16-byte aligned): the first 4 channels
+// of each pixel are fetched element-wise by the pixel's first thread, the rest of the 32-channel
+// LDS row is zero.
+template <int NPIX>
+struct NarrowStage {
+    static constexpr int NL = (NPIX * 4 + 255) / 256;
+    unsigned short e[NL][4];
+
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[j][k] = 0;
+    }
+    __device__ __forceinline__ void fetch(const bf16_t* dz, int n, int Ho, int Wo, int C, int h0, int w0, int tid) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int p = (tid >> 2) + j * 64;
+            const int ho = h0 + p / 32, wo = w0 + p % 32;
+            const bool valid = (tid & 3) == 0 && p < NPIX && ho < Ho && wo < Wo;
+            const bf16_t* src = valid ? dz + (((long)n * Ho + ho) * Wo + wo) * C : dz;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned short u = src[k < C ? k : 0].v;
+                e[j][k] = (valid && k < C) ? u : (unsigned short)0;
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(unsigned char* s_z, int tid) const {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int p = (tid >> 2) + j * 64;
+            if (p >= NPIX) continue;
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if ((tid & 3) == 0) {
+                q.x = e[j][0] | ((unsigned)e[j][1] << 16);
+                q.y = e[j][2] | ((unsigned)e[j][3] << 16);
+            }
+            *reinterpret_cast<uint4*>(s_z + (long)p * PIXB + (tid & 3) * 16) = q;
+        }
+    }
+};
+
+// sum over the 32 lanes that share lane>>5 of 16 per-lane values: every lane ends up with the total
+// of value index ((l>>4)&1)*8 + ((l>>3)&1)*4 + ((l>>2)&1)*2 + ((l>>1)&1).  16 shuffles instead of 80
+// (each of the first four steps halves the number of live values).
+__device__ __forceinline__ float reduce16_over32(const float* v, int lane) {
+    float r8[8], r4[4], r2[2];
+    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float keep = b4 ? v[8 + j] : v[j], send = b4 ? v[j] : v[8 + j];
+        r8[j] = keep + __shfl_xor(send, 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = b3 ? r8[4 + j] : r8[j], send = b3 ? r8[j] : r8[4 + j];
+        r4[j] = keep + __shfl_xor(send, 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = b2 ? r4[2 + j] : r4[j], send = b2 ? r4[j] : r4[2 + j];
+        r2[j] = keep + __shfl_xor(send, 4);
+    }
+    const float keep = b1 ? r2[1] : r2[0], send = b1 ? r2[0] : r2[1];
+    float r = keep + __shfl_xor(send, 2);
+    r += __shfl_xor(r, 1);
+    return r;
+}
+
+// epilogue flavours (compile-time: the runtime-switched version cost a vmcnt(0) drain per store group)
+constexpr int EPI_RAW = 0;        // y = bf16(z)                                  (data gradients)
+constexpr int EPI_RAW_STATS = 1;  // y = bf16(z) + per-channel sum / sum of squares (training forward)
+constexpr int EPI_FULL = 2;       // scale/shift, residual, activation, optional statistics (inference)
+
+// Persistent workgroups: each owns a contiguous range of output tiles and walks the flattened
+// (tile, K-chunk) sequence.  The global loads of step i+1 are issued right after the LDS commit of
+// step i and fly during its MFMA phase and epilogue.  Because vmcnt retires in order, nothing in
+// the MFMA phase or the RAW epilogues waits on vector memory: the weight fragments of the current
+// K-chunk sit in LDS ([tap][cout][32 ci + 8 pad], zero-filled tails; loaded once when Cin <= 32).
+template <int WM, int WN, int MT, int K, int S, int UP, int EPI>
+__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     constexpr int TR = WM * MT;
     constexpr int PR = (TR - 1) * S + K, PC = 31 * S + K;
+    constexpr int KK = K * K;
+    constexpr int NCO = WN * 32;                            // output channels per workgroup
+    constexpr int WROWS = KK * NCO;                         // weight rows of one K-chunk
+    constexpr int NLW = (WROWS * 4 + 255) / 256;
+    static_assert(PR * PC * PIXB >= 4 * 32 * PIXB, "store-transposition buffers alias the patch");
     __shared__ __attribute__((aligned(16))) unsigned char s_patch[PR * PC * PIXB];
+    __shared__ __attribute__((aligned(16))) unsigned char s_w[WROWS * PIXB];
+    __shared__ float s_par[3 * NCO];                        // EPI_FULL: out_scale, out_shift, slope
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int lr = lane & 31, lh = lane >> 5;
-    int b = blockIdx.x;
-    const int tw = b % a.tiles_w; b /= a.tiles_w;
-    const int th = b % a.tiles_h;
-    const int n = b / a.tiles_h;
-    const int ho0 = th * TR, wo0 = tw * 32;
-    const int co = blockIdx.y * (WN * 32) + wn * 32 + lr;   // this lane's output channel (B column)
-    const bool co_ok = co < a.Cout;                         // Cout % 32 == 16 tail (grouped 1x1 reduce convs)
+    const int cbw = blockIdx.y * NCO;                       // first output channel of the workgroup
+    const int cb0 = cbw + wn * 32;                          // ... of this wave's N-tile
+    const bool vec = (a.Cout & 7) == 0;                     // 16-byte NHWC stores through LDS
+    unsigned char* s_ow = s_patch + wid * (32 * PIXB);      // per-wave store transposition (after the MFMA phase)
+
+    const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
+    const long tb = (long)blockIdx.x * a.tiles_per_block;
+    const long te = min(ntiles, tb + a.tiles_per_block);
+    if (tb >= te) return;                                   // workgroup-uniform
+    const bool one_chunk = a.Cin <= CK;
+
+    // weights of K-chunk c0 -> LDS (16-byte pieces; rows beyond Cout / channels beyond Cin are zero)
+#define LEDN_CONV_WEIGHTS(c0_)                                                                        \
+    do {                                                                                              \
+        uint4 wv_[NLW];                                                                               \
+        _Pragma("unroll") for (int j = 0; j < NLW; ++j) {                                             \
+            const int e_ = tid + j * 256, row_ = e_ >> 2, part_ = e_ & 3;                             \
+            const int co_ = cbw + row_ % NCO, ci_ = (c0_) + part_ * 8;                                \
+            const bool ok_ = row_ < WROWS && co_ < a.Cout && ci_ < a.Cin;                             \
+            const long off_ = ok_ ? ((long)(row_ / NCO) * a.Cout + co_) * a.Cin + ci_ : 0;            \
+            wv_[j] = *reinterpret_cast<const uint4*>(a.wp + off_);                                    \
+            if (!ok_) wv_[j] = make_uint4(0u, 0u, 0u, 0u);                                            \
+        }                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < NLW; ++j) {                                             \
+            const int e_ = tid + j * 256;                                                             \
+            if (e_ < WROWS * 4) *reinterpret_cast<uint4*>(s_w + (e_ >> 2) * PIXB + (e_ & 3) * 16) = wv_[j]; \
+        }                                                                                             \
+    } while (0)
+    if (one_chunk) LEDN_CONV_WEIGHTS(0);
+    if (EPI == EPI_FULL) {
+        for (int i = tid; i < NCO; i += 256) {
+            const int c = cbw + i;
+            s_par[i] = (a.out_scale && c < a.Cout) ? a.out_scale[c] : 1.f;
+            s_par[NCO + i] = (a.out_shift && c < a.Cout) ? a.out_shift[c] : 0.f;
+            s_par[2 * NCO + i] = (a.act_out == LEDN_ACT_PRELU && c < a.Cout) ? a.slope[c]
+                                 : (a.act_out == LEDN_ACT_NONE ? 1.f : 0.f);
+        }
+    }
 
     f32x16_t acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+    constexpr int NST = EPI == EPI_RAW ? 1 : 16;            // per-lane running channel statistics
+    float st1[NST], st2[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
 
-    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
-        // ---- stage the input patch of this K-chunk (4 threads x 16 B per pixel)
-        for (int p = tid >> 2; p < PR * PC; p += 64) {
-            const int pr = p / PC, pc = p % PC;
-            const int part = tid & 3;
-            const int uh = ho0 * S - a.pad + pr, uw = wo0 * S - a.pad + pc;
-            bool valid;
-            int hi, wi;
-            if (UP == 1) {
-                hi = uh; wi = uw;
-                valid = uh >= 0 && uh < a.H && uw >= 0 && uw < a.W;
-            } else {
-                hi = uh / UP; wi = uw / UP;
-                valid = uh >= 0 && uw >= 0 && (uh % UP) == 0 && (uw % UP) == 0 && hi < a.H && wi < a.W;
-            }
-            const int c = c0 + part * 8;
-            stage_piece(s_patch + (long)p * PIXB + part * 16,
-                        a.x + (((long)n * a.H + hi) * a.W + wi) * a.Cin + c, valid && c < a.Cin, a.in_scale,
-                        a.in_shift, a.in_act, c);
-        }
+    PatchStage<PR, PC, S, UP> stage;
+#define LEDN_CONV_FETCH(tile_, c0_)                                                                   \
+    do {                                                                                              \
+        long b_ = (tile_);                                                                            \
+        const int tw_ = (int)(b_ % a.tiles_w); b_ /= a.tiles_w;                                       \
+        const int th_ = (int)(b_ % a.tiles_h);                                                        \
+        stage.fetch(a.x, (int)(b_ / a.tiles_h), a.H, a.W, a.Cin, th_ * TR * S - a.pad,                \
+                    tw_ * 32 * S - a.pad, (c0_), tid);                                                \
+    } while (0)
+    long tile = tb;
+    int c0 = 0;
+    LEDN_CONV_FETCH(tile, 0);
+    while (tile < te) {
+        stage.commit(s_patch, a.in_scale, a.in_shift, a.in_act, c0, tid);
+        if (!one_chunk) LEDN_CONV_WEIGHTS(c0);
         __syncthreads();
-        // ---- taps x k-steps: one B fragment (global, L1/L2) feeds MT MFMAs
+        long ntile = tile;
+        int nc0 = c0 + CK;
+        if (nc0 >= a.Cin) { nc0 = 0; ntile = tile + 1; }
+        if (ntile < te) LEDN_CONV_FETCH(ntile, nc0);
+        // ---- taps x k-steps, all operands from LDS.  A = weights (M = cout), B = pixels (N = 32
+        // pixels of a row): the accumulator lane owns ONE pixel and 4 x 4 consecutive channels.
 #pragma unroll
-        for (int kh = 0; kh < K; ++kh) {
+        for (int t = 0; t < KK; ++t) {
+            const int kh = t / K, kw = t % K;
 #pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                const bf16_t* wrow = a.wp + ((long)(kh * K + kw) * a.Cout + co) * a.Cin + c0 + lh * 8;
+            for (int kk = 0; kk < CK / 16; ++kk) {
+                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(s_w + (t * NCO + wn * 32 + lr) * PIXB +
+                                                                       (kk * 16 + lh * 8) * 2);
 #pragma unroll
-                for (int kk = 0; kk < CK / 16; ++kk) {
-                    bf16x8_t bf = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (co_ok && c0 + kk * 16 + lh * 8 < a.Cin) bf = *reinterpret_cast<const bf16x8_t*>(wrow + kk * 16);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const int row = wm * MT + m;
-                        const unsigned char* ap = s_patch + (long)((row * S + kh) * PC + lr * S + kw) * PIXB +
-                                                  (kk * 16 + lh * 8) * 2;
-                        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ap);
-                        acc[m] = mfma_32x32x16_bf16(af, bf, acc[m]);
-                    }
+                for (int m = 0; m < MT; ++m) {
+                    const int row = wm * MT + m;
+                    const unsigned char* xp = s_patch + (long)((row * S + kh) * PC + lr * S + kw) * PIXB +
+                                              (kk * 16 + lh * 8) * 2;
+                    const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xp);
+                    acc[m] = mfma_32x32x16_bf16(wf, xf, acc[m]);
                 }
             }
         }
-        __syncthreads();
-    }
+        __syncthreads();     // patch and chunk weights may be overwritten from here on
 
-    // ---- epilogue: lane holds channel `co` for 16 pixels of each of its MT rows
-    if (!co_ok) return;    // (no wave collective below needs the masked lanes: shfl partner lane^32 has the same co)
-    const float sc = a.out_scale ? a.out_scale[co] : 1.f;
-    const float sh = a.out_shift ? a.out_shift[co] : 0.f;
-    const float sl = a.slope ? a.slope[co] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+        if (nc0 == 0) {
+            // ---- epilogue of `tile`: lane = pixel (ho, wo0 + lr); register i = channel
+            // cb0 + (i&3) + 8*(i>>2) + 4*lh
+            long b = tile;
+            const int tw = (int)(b % a.tiles_w); b /= a.tiles_w;
+            const int th = (int)(b % a.tiles_h);
+            const int n = (int)(b / a.tiles_h);
+            const int ho0 = th * TR + wm * MT, wo0 = tw * 32;
+            const int wo = wo0 + lr;
+            const float hi = a.act_out == LEDN_ACT_RELU6 ? 6.f : 3.0e38f;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int ho = ho0 + wm * MT + m;
+            for (int m = 0; m < MT; ++m) {
+                const int ho = ho0 + m;
+                const bool pix_ok = ho < a.Ho && wo < a.Wo;
+                const long pix = (((long)n * a.Ho + ho) * a.Wo + wo) * a.Cout;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int wo = wo0 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-            if (ho >= a.Ho || wo >= a.Wo) continue;
-            float v = acc[m][i] * sc + sh;
-            s1 += v;
-            s2 = fmaf(v, v, s2);
-            const long off = (((long)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co;
-            if (a.res_mode != LEDN_RES_NONE) {
-                const float r = ld(a.res + off);
-                v = a.res_mode == LEDN_RES_ADD ? v + r : v * r + r;
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = wn * 32 + 8 * q + 4 * lh;         // channel inside the workgroup's slice
+                    const int c4 = cbw + cl;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[m][4 * q + j];
+                        acc[m][4 * q + j] = 0.f;
+                    }
+                    if (EPI == EPI_FULL) {
+                        float sc[4], sh[4];
+                        ld4(s_par + cl, sc);
+                        ld4(s_par + NCO + cl, sh);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[j] + sh[j];
+                    }
+                    if (EPI != EPI_RAW) {   // statistics of the BatchNorm input (pre-residual, pre-activation)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float vm = pix_ok ? v[j] : 0.f;
+                            st1[4 * q + j] += vm;
+                            st2[4 * q + j] = fmaf(vm, vm, st2[4 * q + j]);
+                        }
+                    }
+                    if (EPI == EPI_FULL) {
+                        float ng[4];
+                        ld4(s_par + 2 * NCO + cl, ng);
+                        if (a.res_mode != LEDN_RES_NONE) {
+                            float r[4] = {0.f, 0.f, 0.f, 0.f};
+                            if (vec) {
+                                if (pix_ok && c4 < a.Cout) ld4(a.res + pix + c4, r);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (pix_ok && c4 + j < a.Cout) r[j] = ld(a.res + pix + c4 + j);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = a.res_mode == LEDN_RES_ADD ? v[j] + r[j] : v[j] * r[j] + r[j];
+                        }
+                        // activation as min(max(v,0) + neg * min(v,0), hi): none (1, inf), relu (0, inf),
+                        // relu6 (0, 6), prelu (slope[c], inf)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], 0.f) + ng[j] * fminf(v[j], 0.f), hi);
+                    }
+                    if (vec) {
+                        st4(reinterpret_cast<bf16_t*>(s_ow + lr * PIXB) + 8 * q + 4 * lh, v);
+                    } else if (q == 0) {   // narrow heads (Cout < 8): channels 4*lh + j, scalar stores
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (pix_ok && c4 + j < a.Cout) st(a.y + pix + c4 + j, v[j]);
+                    }
+                }
+                if (vec) {
+                    // bf16 tile through the per-wave LDS buffer: every global store is 16 B per lane,
+                    // 4 lanes per pixel (whole 64-byte channel rows)
+                    wave_sync();
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int px = (lane >> 2) + 16 * h, piece = lane & 3;
+                        const uint4 o = *reinterpret_cast<const uint4*>(s_ow + px * PIXB + piece * 16);
+                        if (ho < a.Ho && wo0 + px < a.Wo && cb0 + piece * 8 < a.Cout)
+                            *reinterpret_cast<uint4*>(a.y + (((long)n * a.Ho + ho) * a.Wo + wo0 + px) * a.Cout + cb0 +
+                                                      piece * 8) = o;
+                    }
+                    wave_sync();
+                }
             }
-            v = act_apply(a.act_out, v, sl);
-            st(a.y + off, v);
+            if (vec) __syncthreads();   // the transposition buffers alias the patch of the next step
         }
+        tile = ntile;
+        c0 = nc0;
     }
-    if (a.stat_sum) {
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (lh == 0) {
+#undef LEDN_CONV_FETCH
+#undef LEDN_CONV_WEIGHTS
+
+    if (EPI != EPI_RAW && a.stat_sum) {   // workgroup-uniform; every lane takes part in the exchange
+        const float t1 = reduce16_over32(st1, lane), t2 = reduce16_over32(st2, lane);
+        const int idx = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        const int c = cb0 + (idx & 3) + 8 * (idx >> 2) + 4 * lh;
+        if ((lane & 1) == 0 && c < a.Cout) {
             if (a.part) {
                 float* row = a.part + ((long)blockIdx.x * WM + wm) * 2 * a.Cout;
-                row[co] = s1;
-                row[a.Cout + co] = s2;
+                row[c] = t1;
+                row[a.Cout + c] = t2;
             } else {
-                atomicAdd(a.stat_sum + co, s1);
-                atomicAdd(a.stat_sqsum + co, s2);
+                atomicAdd(a.stat_sum + c, t1);
+                atomicAdd(a.stat_sqsum + c, t2);
             }
         }
     }
 }
 
-template <int WM, int WN, int MT, int K, int S, int UP>
-static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {
-    MfmaConvArgs a = a0;
+template <int WM, int WN, int MT, int K, int S, int UP, int EPI>
+static int launch_epi(MfmaConvArgs a, hipStream_t s) {
     constexpr int TR = WM * MT;
     a.tiles_h = (int)cdiv(a.Ho, TR);
     a.tiles_w = (int)cdiv(a.Wo, 32);
-    const long nbx = (long)a.N * a.tiles_h * a.tiles_w;
-    const dim3 grid((unsigned)nbx, (unsigned)cdiv(a.Cout, WN * 32));
-    a.part = (a.stat_sum && nbx * WM > 16) ? ws_take(nbx * WM * 2 * a.Cout) : nullptr;
-    LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP>), grid, dim3(256), 0, s, a);
+    const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
+    const long gy = cdiv(a.Cout, WN * 32);
+    long nbx = cdiv(options().conv_workgroups, gy);  // default ~2 resident workgroups per CU
+    if (nbx > ntiles) nbx = ntiles;
+    a.tiles_per_block = (int)cdiv(ntiles, nbx);
+    nbx = cdiv(ntiles, a.tiles_per_block);
+    const dim3 grid((unsigned)nbx, (unsigned)gy);
+    a.part = (EPI != EPI_RAW && a.stat_sum && nbx * WM > 16) ? ws_take(nbx * WM * 2 * a.Cout) : nullptr;
+    LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI>), grid, dim3(256), 0, s, a);
     if (a.part) return finish_partials(a.part, (int)(nbx * WM), a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
     return check_launch();
 }
 
+template <int WM, int WN, int MT, int K, int S, int UP>
+static int launch_cfg(const MfmaConvArgs& a, hipStream_t s) {
+    const bool raw = !a.out_scale && !a.out_shift && a.act_out == LEDN_ACT_NONE && a.res_mode == LEDN_RES_NONE;
+    if (!raw) return launch_epi<WM, WN, MT, K, S, UP, EPI_FULL>(a, s);
+    if (a.stat_sum) return launch_epi<WM, WN, MT, K, S, UP, EPI_RAW_STATS>(a, s);
+    return launch_epi<WM, WN, MT, K, S, UP, EPI_RAW>(a, s);
+}
+
 template <int K, int S, int UP>
 static int launch_shape(const MfmaConvArgs& a, hipStream_t s) {
-    constexpr int MTS = S == 2 ? 1 : 4;   // stride 2 needs a (2*TR+1) x 65 pixel patch: keep TR = 4
-    if (a.Cout % 128 == 0) return launch_cfg<1, 4, 4, K, S, UP>(a, s);
-    if (a.Cout % 64 == 0) return launch_cfg<2, 2, S == 2 ? 2 : 4, K, S, UP>(a, s);
-    return launch_cfg<4, 1, MTS, K, S, UP>(a, s);
+    // stride 2 stages a (2*TR+1) x 65 pixel patch: TR = 4.  The LDS weight slice (taps x 32/64 cout)
+    // and the patch leave room for two workgroups per CU.
+    if constexpr (S == 2) {
+        return launch_cfg<4, 1, 1, K, S, UP>(a, s);
+    } else {
+        if (a.Cout % 64 == 0) return launch_cfg<2, 2, 4, K, S, UP>(a, s);
+        return launch_cfg<4, 1, 4, K, S, UP>(a, s);
+    }
 }
 
 bool conv_mfma_supported(const ledn_conv_desc& d) {
     if (!d.w_bf16 || d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16) return false;
     if (d.dil != 1 || d.xadd) return false;
+    if (d.act_out == LEDN_ACT_SIGMOID || (d.in_act != LEDN_ACT_NONE && d.in_act != LEDN_ACT_RELU)) return false;
     if (d.groups != 1 && !(d.KH == 1 && d.KW == 1)) return false;   // grouped 1x1: densified weight pack
     if (d.Cin % 16 || (d.Cout % 16 && d.Cout > 8)) return false;   // 16-channel tails are masked
     if (d.KH != d.KW || !((d.KH == 3 && d.pad == 1) || (d.KH == 1 && d.pad == 0))) return false;
@@ -228,7 +499,7 @@ int conv_mfma(const ledn_conv_desc& d, hipStream_t s) {
     a.slope = d.slope; a.stat_sum = d.stat_sum; a.stat_sqsum = d.stat_sqsum;
     a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.in_act = d.in_act; a.act_out = d.act_out; a.res_mode = d.res_mode;
-    a.tiles_h = a.tiles_w = 0;
+    a.tiles_h = a.tiles_w = a.tiles_per_block = 0;
     a.part = nullptr;
     if (!d.transposed) {
         a.pad = d.pad;
@@ -362,7 +633,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
     constexpr int PR = (TR - 1) * S + K, PC = 31 * S + K;
     constexpr int XB = PR * PC * PIXB, ZB = TR * 32 * PIXB;
     constexpr int KK = K * K;
-    constexpr int RED = KK * 32 * 32 * 4;          // bytes of one wave's partial tiles
+    constexpr int RED = 32 * 32 * 4;               // K = 1: cross-wave reduction of the single tile
     constexpr int LDSB = (XB + ZB) > RED ? (XB + ZB) : RED;
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDSB];
     unsigned char* s_x = s_mem;
@@ -379,51 +650,52 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
         if (ci0 + 31 < g_lo * cig || ci0 >= (g_hi + 1) * cig) return;
     }
 
-    f32x16_t acc[KK];
+    // K = 3: the nine taps are split over the four waves (wave w owns taps w, w+4, w+8): three
+    // accumulator tiles per wave instead of nine (3 workgroups per CU instead of 1) and no cross-wave
+    // reduction.  K = 1: the waves split the pixels and reduce through LDS.
+    constexpr bool TAPSPLIT = K == 3;
+    constexpr int NT = TAPSPLIT ? 3 : 1;
+    f32x16_t acc[NT];
 #pragma unroll
-    for (int t = 0; t < KK; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    int tapoff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = TAPSPLIT ? wid + 4 * t : 0;
+        tapoff[t] = ((tap / K) * PC + tap % K) * PIXB;
+    }
 
     const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
     const long t0 = (long)blockIdx.x * a.tiles_per_block;
     const long t1 = min(ntiles, t0 + a.tiles_per_block);
+    const bool narrow = (a.Cout & 7) != 0;   // heads with Cout = 1, 2, 4: element-wise dz staging
+    PatchStage<PR, PC, S, 1> sx;
+    PatchStage<TR, 32, 1, 1> sz;
+    NarrowStage<TR * 32> szn;
+    szn.clear();
+    // every tile's loads are issued one tile ahead: they fly while the matrix cores work
+#define LEDN_WGRAD_FETCH(tile_)                                                                          \
+    do {                                                                                                 \
+        long b_ = (tile_);                                                                               \
+        const int tw_ = (int)(b_ % a.tiles_w); b_ /= a.tiles_w;                                          \
+        const int th_ = (int)(b_ % a.tiles_h);                                                           \
+        const int n_ = (int)(b_ / a.tiles_h);                                                            \
+        sx.fetch(a.x, n_, a.H, a.W, a.Cin, th_ * TR * S - a.pad, tw_ * 32 * S - a.pad, ci0, tid);        \
+        if (!narrow) sz.fetch(a.dz, n_, a.Ho, a.Wo, a.Cout, th_ * TR, tw_ * 32, co0, tid);               \
+        else szn.fetch(a.dz, n_, a.Ho, a.Wo, a.Cout, th_ * TR, tw_ * 32, tid);                           \
+    } while (0)
+    if (t0 < t1) LEDN_WGRAD_FETCH(t0);
     for (long tile = t0; tile < t1; ++tile) {
-        long b = tile;
-        const int tw = (int)(b % a.tiles_w); b /= a.tiles_w;
-        const int th = (int)(b % a.tiles_h);
-        const int n = (int)(b / a.tiles_h);
-        const int ho0 = th * TR, wo0 = tw * 32;
-        // ---- stage x patch (32 input channels) and dz tile (32 output channels); zeros outside
-        for (int p = tid >> 2; p < PR * PC; p += 64) {
-            const int pr = p / PC, pc = p % PC, part = tid & 3;
-            const int hi = ho0 * S - a.pad + pr, wi = wo0 * S - a.pad + pc;
-            const bool valid = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-            const int c = ci0 + part * 8;
-            stage_piece(s_x + (long)p * PIXB + part * 16, a.x + (((long)n * a.H + hi) * a.W + wi) * a.Cin + c,
-                        valid && c < a.Cin, a.in_scale, a.in_shift, a.in_act, c);
-        }
-        for (int p = tid >> 2; p < TR * 32; p += 64) {
-            const int pr = p / 32, pc = p % 32, part = tid & 3;
-            const int ho = ho0 + pr, wo = wo0 + pc;
-            const bf16_t* zsrc = a.dz + (((long)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co0 + part * 8;
-            if (a.Cout % 8 == 0) {
-                const bool valid = ho < a.Ho && wo < a.Wo && co0 + part * 8 < a.Cout;
-                stage_piece(s_z + (long)p * PIXB + part * 16, zsrc, valid, nullptr, nullptr, 0, 0);
-            } else {   // narrow heads (Cout = 1, 2, 4): element-wise staging, zero-filled to 8 channels
-                unsigned short e[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    e[j] = (ho < a.Ho && wo < a.Wo && co0 + part * 8 + j < a.Cout) ? zsrc[j].v : (unsigned short)0;
-                *reinterpret_cast<uint4*>(s_z + (long)p * PIXB + part * 16) =
-                    make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16),
-                               e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16));
-            }
-        }
+        sx.commit(s_x, a.in_scale, a.in_shift, a.in_act, ci0, tid);
+        if (!narrow) sz.commit(s_z, nullptr, nullptr, 0, co0, tid);
+        else szn.commit(s_z, tid);
         __syncthreads();
-        // ---- 2*TR k-steps of 16 pixels (half a row each); wave w takes k-steps w, w+4, ...
-#pragma unroll 1
-        for (int ks = wid; ks < TR * 2; ks += 4) {
+        if (tile + 1 < t1) LEDN_WGRAD_FETCH(tile + 1);
+        // ---- 2*TR k-steps of 16 pixels (half a row each)
+#pragma unroll 2
+        for (int ks = TAPSPLIT ? 0 : wid; ks < TR * 2; ks += TAPSPLIT ? 1 : 4) {
             const int row = ks >> 1, cb = (ks & 1) * 16;       // pixels (row, cb + 0..15)
             // A = dz^T: lane needs 8 pixels cb+8*lh+0..7 of channel colblk*16+l16
             const unsigned char* zp = s_z + (long)(row * 32 + cb + lh * 8 + q) * PIXB + (colblk * 16 + pp * 4) * 2;
@@ -432,36 +704,57 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
             bf16x8_t af;
             af[0] = a_lo[0]; af[1] = a_lo[1]; af[2] = a_lo[2]; af[3] = a_lo[3];
             af[4] = a_hi[0]; af[5] = a_hi[1]; af[6] = a_hi[2]; af[7] = a_hi[3];
+            const unsigned char* xp0 = s_x + (long)(row * S * PC + (cb + lh * 8 + q) * S) * PIXB + (colblk * 16 + pp * 4) * 2;
 #pragma unroll
-            for (int kh = 0; kh < K; ++kh) {
-#pragma unroll
-                for (int kw = 0; kw < K; ++kw) {
-                    const unsigned char* xp = s_x + (long)((row * S + kh) * PC + (cb + lh * 8 + q) * S + kw) * PIXB +
-                                              (colblk * 16 + pp * 4) * 2;
-                    const bf16x4_t b_lo = lds_read_tr16(xp);
-                    const bf16x4_t b_hi = lds_read_tr16(xp + 4 * S * PIXB);
-                    bf16x8_t bfv;
-                    bfv[0] = b_lo[0]; bfv[1] = b_lo[1]; bfv[2] = b_lo[2]; bfv[3] = b_lo[3];
-                    bfv[4] = b_hi[0]; bfv[5] = b_hi[1]; bfv[6] = b_hi[2]; bfv[7] = b_hi[3];
-                    acc[kh * K + kw] = mfma_32x32x16_bf16(af, bfv, acc[kh * K + kw]);
-                }
+            for (int t = 0; t < NT; ++t) {
+                if (TAPSPLIT && wid + 4 * t >= KK) continue;   // wave-uniform
+                const unsigned char* xp = xp0 + tapoff[t];
+                const bf16x4_t b_lo = lds_read_tr16(xp);
+                const bf16x4_t b_hi = lds_read_tr16(xp + 4 * S * PIXB);
+                bf16x8_t bfv;
+                bfv[0] = b_lo[0]; bfv[1] = b_lo[1]; bfv[2] = b_lo[2]; bfv[3] = b_lo[3];
+                bfv[4] = b_hi[0]; bfv[5] = b_hi[1]; bfv[6] = b_hi[2]; bfv[7] = b_hi[3];
+                acc[t] = mfma_32x32x16_bf16(af, bfv, acc[t]);
             }
         }
         __syncthreads();
     }
+#undef LEDN_WGRAD_FETCH
 
-    // ---- reduce the 4 waves' partial tiles through LDS, then one atomic per element
+    // accumulator register i of lane l = dW[co0 + (i&3) + 8*(i>>2) + 4*(l>>5)][ci0 + (l&31)]
+    if (TAPSPLIT) {   // every wave owns whole taps: straight to the workspace / dW
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int tap = wid + 4 * t;
+            if (tap >= KK) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co_l = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), ci_l = lane & 31;
+                if (a.part) {
+                    a.part[((long)blockIdx.x * gridDim.y + blockIdx.y) * (KK * 1024) + (tap * 32 + co_l) * 32 + ci_l] =
+                        acc[t][i];
+                } else {
+                    const int co = co0 + co_l, ci = ci0 + ci_l;
+                    if (co >= a.Cout || ci >= a.Cin) continue;
+                    const int g = co / cog;
+                    if (ci / cig != g) continue;
+                    atomicAdd(a.dw + (long)co * a.ws_co + (long)(ci - g * cig) * a.ws_ci + (long)tap * a.ws_tap,
+                              acc[t][i]);
+                }
+            }
+        }
+        return;
+    }
+    // ---- K = 1: reduce the 4 waves' partial tiles through LDS, then one atomic per element
     float* red = reinterpret_cast<float*>(s_mem);
     for (int w = 0; w < 4; ++w) {
         if (wid == w) {
 #pragma unroll
-            for (int t = 0; t < KK; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int co_l = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), ci_l = lane & 31;
-                    float* r = red + (t * 32 + co_l) * 32 + ci_l;
-                    *r = (w == 0 ? 0.f : *r) + acc[t][i];
-                }
+            for (int i = 0; i < 16; ++i) {
+                const int co_l = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), ci_l = lane & 31;
+                float* r = red + co_l * 32 + ci_l;
+                *r = (w == 0 ? 0.f : *r) + acc[0][i];
+            }
         }
         __syncthreads();
     }
@@ -524,7 +817,7 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s) {
     a.ci_tiles = (int)cdiv(a.Cin, 32);
     const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
     const int pairs = a.ci_tiles * (int)cdiv(a.Cout, 32);
-    long blocks_x = cdiv(512, pairs);                // ~512 workgroups; partial tiles go to the workspace
+    long blocks_x = cdiv(options().wgrad_workgroups, pairs);   // partial tiles go to the workspace
     if (blocks_x < 32) blocks_x = 32;
     if (blocks_x > ntiles) blocks_x = ntiles;
     if (blocks_x > ntiles) blocks_x = ntiles;

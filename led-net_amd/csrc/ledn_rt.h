@@ -24,12 +24,19 @@ struct bf16_t {
 };
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+#ifdef LEDN_CPU_EMU
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {  // round-to-nearest-even, NaN stays NaN
     unsigned u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x0040u);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+#else
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even, quiet NaN)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+#endif
 
 __device__ __forceinline__ float ld(const float* p) { return *p; }
 __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(p->v); }
@@ -120,7 +127,25 @@ __device__ __forceinline__ f32x16_t mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f
     return emu::mfma_32x32x16_bf16(a, b, c);
 }
 __device__ __forceinline__ bf16x4_t lds_read_tr16(const void* p) { return emu::lds_read_tr16(p); }
+__device__ __forceinline__ void sched_fence() {}
+__device__ __forceinline__ int opaque(int x) { return x; }
+__device__ __forceinline__ void wave_sync() { emu::barrier_wait(LEDN_EMU_CUR->wave_bar); }
 #else
+// value the optimiser must treat as freshly computed: keeps loop-invariant address arithmetic from
+// being hoisted out of a persistent loop into (spilled) registers
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// orders one wave's LDS accesses across its lanes (the DS unit executes a wave's instructions in
+// order; this keeps the compiler from reordering them).  Every lane of the wave must call.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// keeps the instruction scheduler from hoisting later loads above this point (bounds live registers)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 typedef __bf16 hw_bf16x8_t __attribute__((ext_vector_type(8)));
 // v_mfma_f32_32x32x16_bf16: lane l (r=l&31,h=l>>5) holds A[r][8h+j], B[8h+j][r];
 // D: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5)   (cdna_hip_programming.md section 3)
@@ -154,6 +179,12 @@ inline float* ws_take(long nfloats) {
     Workspace& w = workspace();
     return (w.ptr && nfloats <= w.nfloats) ? w.ptr : nullptr;
 }
+// launch-shape knobs (ledn_set_option)
+struct Options {
+    int conv_workgroups;
+    int wgrad_workgroups;
+};
+Options& options();
 // out_j[c] += sum_b part[b*K + j*C + c], j < nout (K = nout*C)
 int finish_partials(const float* part, int nblk, int C, int nout, float* o0, float* o1, float* o2,
                     hipStream_t s);

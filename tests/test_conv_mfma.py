@@ -85,6 +85,28 @@ def test_mfma_conv_dgrad_wgrad(be, cin, cout, k, stride, hw):
     torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
 
 
+@pytest.fixture
+def few_workgroups(be):
+    """3 persistent conv workgroups / 2 wgrad workgroups: every workgroup walks several tiles and
+    K-chunks (the software-pipelined loop), as at the 1024x1024 sizes."""
+    from led_net_amd import _lib
+    lib = _lib.get_lib()
+    lib.set_option(0, 3)
+    lib.set_option(1, 2)
+    yield
+    lib.set_option(0, 0)
+    lib.set_option(1, 0)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,hw', [(32, 32, 3, 1, (37, 70)), (64, 64, 3, 1, (35, 40)),
+                                                  (32, 64, 3, 2, (40, 67)), (128, 256, 1, 1, (20, 66)),
+                                                  (64, 32, 1, 2, (33, 130)), (32, 2, 3, 1, (36, 40))])
+def test_mfma_persistent_multi_tile(be, few_workgroups, cin, cout, k, stride, hw):
+    test_mfma_conv_forward(be, cin, cout, k, stride, hw)
+    if not (k == 1 and stride == 2):
+        test_mfma_conv_dgrad_wgrad(be, cin, cout, k, stride, hw)
+
+
 @pytest.mark.parametrize('cin,cout,hw', [(64, 16, (9, 40)), (64, 64, (12, 33)), (128, 32, (8, 35)), (256, 256, (5, 34))])
 def test_mfma_grouped_1x1(be, cin, cout, hw):
     """SESP's grouped (g=4) 1x1 convs on the MFMA path: densified weight pack, Cout = 16 tail."""
@@ -124,3 +146,28 @@ def test_mfma_channel_tails(be, cin, cout, k, hw):
     torch.testing.assert_close(nchw(got), z.detach(), rtol=2e-2, atol=2e-2)
     dw, _ = ops.conv2d_wgrad(nhwc(x).bfloat16(), nhwc(dz).bfloat16(), tuple(w.shape), pad=pad)
     torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-2, atol=1e-2 * float(w.grad.abs().max()))
+
+
+@pytest.mark.parametrize('cin,cout,k', [(64, 2, 1), (32, 6, 3), (32, 32, 3), (64, 16, 1)])
+@pytest.mark.parametrize('epi', ['bias', 'scale', 'relu6', 'gate'])
+def test_mfma_epilogue_variants(be, cin, cout, k, epi):
+    """bias-only (cls_seg), scale-only, ReLU6 and gated-residual epilogues incl. narrow heads (Cout = 2, 6)."""
+    from led_net_amd import ops
+    pad = k // 2
+    x = r16(torch.randn(2, cin, 11, 37))
+    w = r16(torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5)
+    z = F.conv2d(x, w, padding=pad)
+    sc, sh = torch.rand(cout) + 0.5, torch.randn(cout)
+    kw = {}
+    if epi == 'bias':
+        want, kw = z + sh.view(1, -1, 1, 1), dict(out_shift=D(sh))
+    elif epi == 'scale':
+        want, kw = z * sc.view(1, -1, 1, 1), dict(out_scale=D(sc))
+    elif epi == 'relu6':
+        want = F.relu6(z * 8 + sh.view(1, -1, 1, 1))
+        kw = dict(out_scale=D(torch.full((cout,), 8.0)), out_shift=D(sh), act=ops.ACT_RELU6)
+    else:
+        res = r16(torch.randn_like(z))
+        want, kw = z * res + res, dict(res=nhwc(res).bfloat16(), res_mode=ops.RES_GATE)
+    got = ops.conv2d(nhwc(x).bfloat16(), D(w), pad=pad, w_bf16=ops.pack_conv_weights(D(w), 0), **kw)
+    torch.testing.assert_close(nchw(got), want, rtol=2e-2, atol=3e-2)

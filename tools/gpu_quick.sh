@@ -7,3 +7,4 @@ for MODE in train infer; do
   LEDN_BENCH_VERBOSE=400 timeout 900 python bench.py --mode $MODE --steps 4 --warmup 2 --dtype bf16 --no-cpu-baseline > $OUT/bench_$MODE.json 2> $OUT/bench_$MODE.err
   echo "bench $MODE rc=$?"; cat $OUT/bench_$MODE.json; grep -v amdgpu.ids $OUT/bench_$MODE.err | head -${3:-30}
 done
+timeout 600 python bench.py --mode train --steps 4 --warmup 2 --dtype bf16 --no-cpu-baseline --no-graph > $OUT/bench_train_eager.json 2> /dev/null; echo "eager:"; cat $OUT/bench_train_eager.json
