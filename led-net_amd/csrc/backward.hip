@@ -202,7 +202,7 @@ template <typename T, int V>
 __global__ void __launch_bounds__(256) dw_bwd_data_kernel(ledn_dwbwd_desc d) {
     const int cv = d.C / V;
     const long total = (long)d.N * d.H * d.W * cv;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long idx = (long)xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % cv) * V;
     const long pix = idx / cv;
@@ -216,6 +216,30 @@ __global__ void __launch_bounds__(256) dw_bwd_data_kernel(ledn_dwbwd_desc d) {
     float acc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    if (d.KH == 3 && d.KW == 3 && !d.ext1) {
+        // nine unconditional tap loads (+ weights) in flight, then the FMAs
+        float g[9][V], wv[9][V];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int th = y + padh - (t / 3) * dl, tw = x + padw - (t % 3) * dl;
+            const int ho = th / d.stride, wo = tw / d.stride;
+            const bool valid = th >= 0 && tw >= 0 && th % d.stride == 0 && tw % d.stride == 0 && ho < d.Ho && wo < d.Wo;
+            ldv_if<V>(dz, (((long)n * d.Ho + ho) * d.Wo + wo) * d.C + c, valid, g[t]);
+            ldv<V>(d.w + (long)t * d.C + c, wv[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fmaf(g[t][v], wv[t][v], acc[v]);
+        if (d.add) {
+            float a[V];
+            ldv<V>(reinterpret_cast<const T*>(d.add) + pix * d.C + c, a);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] += a[v];
+        }
+        stv<V>(reinterpret_cast<T*>(d.dx) + pix * d.C + c, acc);
+        return;
+    }
     // virtual source positions: (y,x) itself plus the reflected row H / column W it feeds
     const int ny = (d.ext1 && y == d.H - 2) ? 2 : 1, nx = (d.ext1 && x == d.W - 2) ? 2 : 1;
     for (int iy = 0; iy < ny; ++iy) {
@@ -322,26 +346,24 @@ __global__ void __launch_bounds__(256) dw_bwd_weight3x3_kernel(ledn_dwbwd_desc d
         const T* x = reinterpret_cast<const T*>(d.x);
         const T* dz = reinterpret_cast<const T*>(d.dz);
         const long npix = (long)d.N * d.Ho * d.Wo;
-        for (long p = (long)blockIdx.x * rows + r; p < npix; p += (long)gridDim.x * rows) {
+        const long ppb = cdiv(cdiv(npix, (long)gridDim.x), (long)rows) * rows;   // contiguous, XCD-aware range
+        const long p0 = (long)xcd_block(blockIdx.x, gridDim.x) * ppb, p1 = min(npix, p0 + ppb);
+        for (long p = p0 + r; p < p1; p += rows) {
             const int wo = (int)(p % d.Wo);
             const int ho = (int)((p / d.Wo) % d.Ho);
             const int n = (int)(p / ((long)d.Wo * d.Ho));
-            float g[V];
+            float g[V], xv[9][V];
             ldv<V>(dz + p * d.C + c, g);
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int hi = ho * d.stride - pad + kh * dl;
-                if (hi < 0 || hi >= d.H) continue;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int wi = wo * d.stride - pad + kw * dl;
-                    if (wi < 0 || wi >= d.W) continue;
-                    float xv[V];
-                    ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.C + c, xv);
-#pragma unroll
-                    for (int v = 0; v < V; ++v) acc[kh * 3 + kw][v] = fmaf(xv[v], g[v], acc[kh * 3 + kw][v]);
-                }
+            for (int t = 0; t < 9; ++t) {   // nine unconditional tap loads in flight
+                const int hi = ho * d.stride - pad + (t / 3) * dl, wi = wo * d.stride - pad + (t % 3) * dl;
+                ldv_if<V>(x, (((long)n * d.H + hi) * d.W + wi) * d.C + c, hi >= 0 && hi < d.H && wi >= 0 && wi < d.W,
+                          xv[t]);
             }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[t][v] = fmaf(xv[t][v], g[v], acc[t][v]);
         }
     }
 #pragma unroll
@@ -373,10 +395,16 @@ static int dwbwd_validate(const ledn_dwbwd_desc& d) {
     return LEDN_OK;
 }
 
+int dw3x3_bwd_data_bf16(const ledn_dwbwd_desc& b, hipStream_t s);   // dwconv.hip; -1 = shape not covered
+
 int dw_bwd_data_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
     int rc = dwbwd_validate(d);
     if (rc != LEDN_OK) return rc;
     LEDN_REQUIRE(d.w && d.dx);
+    if (d.Ho == d.H && d.Wo == d.W) {
+        rc = dw3x3_bwd_data_bf16(d, s);
+        if (rc >= 0) return rc;
+    }
     const bool v4 = d.C % 4 == 0 && d.group_size % 4 == 0;
     const long total = (long)d.N * d.H * d.W * (v4 ? d.C / 4 : d.C);
     const dim3 grid((unsigned)cdiv(total, 256));
@@ -392,10 +420,16 @@ int dw_bwd_data_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
     return check_launch();
 }
 
+int dw3x3_bwd_weight_bf16(const ledn_dwbwd_desc& d, hipStream_t s);   // stencil_bf16.hip; -1 = shape not covered
+int pyr_bwd_data_bf16(const ledn_pyrbwd_desc& d, hipStream_t s);
+int pyr_bwd_weight_bf16(const ledn_pyrbwd_desc& d, hipStream_t s);
+
 int dw_bwd_weight_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
     int rc = dwbwd_validate(d);
     if (rc != LEDN_OK) return rc;
     LEDN_REQUIRE(d.x && d.dw);
+    rc = dw3x3_bwd_weight_bf16(d, s);
+    if (rc >= 0) return rc;
     const bool v4 = d.C % 4 == 0 && d.group_size % 4 == 0;
     LEDN_REQUIRE((v4 ? d.C / 4 : d.C) <= 256);
     const long npix = (long)d.N * d.Ho * d.Wo;
@@ -453,7 +487,7 @@ template <typename T, int V>
 __global__ void __launch_bounds__(256) pyr_bwd_data_kernel(ledn_pyrbwd_desc d) {
     const int cv = d.n / V;
     const long total = (long)d.N * d.H * d.W * cv;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long idx = (long)xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % cv) * V;
     const long pix = idx / cv;
@@ -466,23 +500,19 @@ __global__ void __launch_bounds__(256) pyr_bwd_data_kernel(ledn_pyrbwd_desc d) {
     for (int v = 0; v < V; ++v) acc[v] = 0.f;
     for (int b = 0; b < 4; ++b) {
         const int dl = d.dil[b];
-        for (int kh = 0; kh < 3; ++kh) {
-            const int th = y - (kh - 1) * dl;
-            if (th < 0 || th % d.stride) continue;
-            const int ho = th / d.stride;
-            if (ho >= d.Ho) continue;
-            for (int kw = 0; kw < 3; ++kw) {
-                const int tw = x - (kw - 1) * dl;
-                if (tw < 0 || tw % d.stride) continue;
-                const int wo = tw / d.stride;
-                if (wo >= d.Wo) continue;
-                float gv[V], wv[V];
-                ldv<V>(g + (((long)n * d.Ho + ho) * d.Wo + wo) * 4L * d.n + (long)b * d.n + c, gv);
-                ldv<V>(d.w + (long)((b * 3 + kh) * 3 + kw) * d.n + c, wv);
+        float gv[9][V], wv[9][V];
 #pragma unroll
-                for (int v = 0; v < V; ++v) acc[v] = fmaf(gv[v], wv[v], acc[v]);
-            }
+        for (int t = 0; t < 9; ++t) {   // nine unconditional tap loads (+ weights) in flight
+            const int th = y - (t / 3 - 1) * dl, tw = x - (t % 3 - 1) * dl;
+            const int ho = th / d.stride, wo = tw / d.stride;
+            const bool valid = th >= 0 && tw >= 0 && th % d.stride == 0 && tw % d.stride == 0 && ho < d.Ho && wo < d.Wo;
+            ldv_if<V>(g, (((long)n * d.Ho + ho) * d.Wo + wo) * 4L * d.n + (long)b * d.n + c, valid, gv[t]);
+            ldv<V>(d.w + (long)(b * 9 + t) * d.n + c, wv[t]);
         }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fmaf(gv[t][v], wv[t][v], acc[v]);
     }
     stv<V>(reinterpret_cast<T*>(d.dx) + pix * d.n + c, acc);
 }
@@ -507,26 +537,24 @@ __global__ void __launch_bounds__(256) pyr_bwd_weight_kernel(ledn_pyrbwd_desc d,
         const T* x = reinterpret_cast<const T*>(d.x);
         const T* g = reinterpret_cast<const T*>(d.gsum);
         const long npix = (long)d.N * d.Ho * d.Wo;
-        for (long p = (long)blockIdx.x * rows + r; p < npix; p += (long)gridDim.x * rows) {
+        const long ppb = cdiv(cdiv(npix, (long)gridDim.x), (long)rows) * rows;   // contiguous, XCD-aware range
+        const long p0 = (long)xcd_block(blockIdx.x, gridDim.x) * ppb, p1 = min(npix, p0 + ppb);
+        for (long p = p0 + r; p < p1; p += rows) {
             const int wo = (int)(p % d.Wo);
             const int ho = (int)((p / d.Wo) % d.Ho);
             const int n = (int)(p / ((long)d.Wo * d.Ho));
-            float gv[V];
+            float gv[V], xv[9][V];
             ldv<V>(g + p * 4L * d.n + (long)b * d.n + c, gv);
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int hi = ho * d.stride + (kh - 1) * dl;
-                if (hi < 0 || hi >= d.H) continue;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int wi = wo * d.stride + (kw - 1) * dl;
-                    if (wi < 0 || wi >= d.W) continue;
-                    float xv[V];
-                    ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.n + c, xv);
-#pragma unroll
-                    for (int v = 0; v < V; ++v) acc[kh * 3 + kw][v] = fmaf(xv[v], gv[v], acc[kh * 3 + kw][v]);
-                }
+            for (int t = 0; t < 9; ++t) {   // nine unconditional tap loads in flight
+                const int hi = ho * d.stride + (t / 3 - 1) * dl, wi = wo * d.stride + (t % 3 - 1) * dl;
+                ldv_if<V>(x, (((long)n * d.H + hi) * d.W + wi) * d.n + c, hi >= 0 && hi < d.H && wi >= 0 && wi < d.W,
+                          xv[t]);
             }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[t][v] = fmaf(xv[t][v], gv[v], acc[t][v]);
         }
     }
 #pragma unroll
@@ -559,6 +587,12 @@ int pyr_bwd_data_impl(const ledn_pyrbwd_desc& d, hipStream_t s) {
     const bool v4 = d.n % 4 == 0;
     const int cvn = v4 ? d.n / 4 : d.n;
     const long npo = (long)d.N * d.Ho * d.Wo;
+    if (d.dtype == LEDN_BF16 && v4 && d.stride == 1) {   // suffix sums, then the vectorised gather
+        LEDN_LAUNCH((pyr_suffix_kernel<bf16_t, 4>), dim3((unsigned)cdiv(npo * cvn, 256)), dim3(256), 0, s,
+                    (const bf16_t*)d.dy, (bf16_t*)d.gsum, npo, d.n);
+        rc = pyr_bwd_data_bf16(d, s);
+        if (rc >= 0) return rc;
+    }
     const dim3 g1((unsigned)cdiv(npo * cvn, 256)), g2((unsigned)cdiv((long)d.N * d.H * d.W * cvn, 256));
 #define LEDN_K(T)                                                                                          \
     do {                                                                                                   \
@@ -580,6 +614,8 @@ int pyr_bwd_weight_impl(const ledn_pyrbwd_desc& d, hipStream_t s) {
     int rc = pyrbwd_validate(d);
     if (rc != LEDN_OK) return rc;
     LEDN_REQUIRE(d.x && d.dw);
+    rc = pyr_bwd_weight_bf16(d, s);
+    if (rc >= 0) return rc;
     const bool v4 = d.n % 4 == 0;
     LEDN_REQUIRE((v4 ? d.n / 4 : d.n) <= 256);
     const long npix = (long)d.N * d.Ho * d.Wo;

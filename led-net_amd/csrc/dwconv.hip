@@ -5,6 +5,7 @@
 // (16 B f32 / 8 B bf16 per lane, lanes run along channels then pixels, so a
 // wave reads whole NHWC rows).  Filter taps are read through L1 (wave-coherent).
 #include "ledn_rt.h"
+#include "stencil.h"
 
 namespace ledn {
 
@@ -40,37 +41,46 @@ __global__ void __launch_bounds__(256) dwconv_kernel(ledn_dw_desc d, float* part
             sh[v] = d.out_shift ? d.out_shift[c + v] : 0.f;
             sl[v] = d.slope ? d.slope[c + v] : 0.f;
         }
+        // contiguous pixel range per workgroup, XCD-aware: the rows above / below come from the same L2
         const long npix = (long)d.N * d.Ho * d.Wo;
-        for (long pix = (long)blockIdx.x * rows + r; pix < npix; pix += (long)gridDim.x * rows) {
+        const long ppb = cdiv(cdiv(npix, (long)gridDim.x), (long)rows) * rows;
+        const long p0 = (long)xcd_block(blockIdx.x, gridDim.x) * ppb, p1 = min(npix, p0 + ppb);
+        for (long pix = p0 + r; pix < p1; pix += rows) {
             const int wo = (int)(pix % d.Wo);
             const int ho = (int)((pix / d.Wo) % d.Ho);
             const int n = (int)(pix / ((long)d.Wo * d.Ho));
             float acc[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) acc[v] = 0.f;
+            if (KK > 0) {
+                // 3x3: nine unconditional tap loads in flight, then the FMAs
+                float xv[9][V];
 #pragma unroll
-            for (int kh = 0; kh < (KK > 0 ? 3 : 1); ++kh) {
-                for (int kh2 = (KK > 0 ? kh : 0); kh2 < (KK > 0 ? kh + 1 : d.KH); ++kh2) {
+                for (int t = 0; t < 9; ++t) {
+                    int hi = ho * d.stride - padh + (t / 3) * dl, wi = wo * d.stride - padw + (t % 3) * dl;
+                    const bool valid = hi >= 0 && hi < Hx && wi >= 0 && wi < Wx;
+                    if (hi == d.H) hi = d.H - 2;  // ext1 reflect row / column
+                    if (wi == d.W) wi = d.W - 2;
+                    ldv_if<V>(x, (((long)n * d.H + hi) * d.W + wi) * d.C + c, valid, xv[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[v] = fmaf(xv[t][v], wreg[t][v], acc[v]);
+            } else {
+                for (int kh2 = 0; kh2 < d.KH; ++kh2) {
                     int hi = ho * d.stride - padh + kh2 * dl;
                     if (hi < 0 || hi >= Hx) continue;
                     if (hi == d.H) hi = d.H - 2;  // ext1 reflect row
+                    for (int kw2 = 0; kw2 < d.KW; ++kw2) {
+                        int wi = wo * d.stride - padw + kw2 * dl;
+                        if (wi < 0 || wi >= Wx) continue;
+                        if (wi == d.W) wi = d.W - 2;
+                        float xv[V], wv[V];
+                        ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.C + c, xv);
+                        ldv<V>(d.w + (long)(kh2 * d.KW + kw2) * d.C + c, wv);
 #pragma unroll
-                    for (int kw = 0; kw < (KK > 0 ? 3 : 1); ++kw) {
-                        for (int kw2 = (KK > 0 ? kw : 0); kw2 < (KK > 0 ? kw + 1 : d.KW); ++kw2) {
-                            int wi = wo * d.stride - padw + kw2 * dl;
-                            if (wi < 0 || wi >= Wx) continue;
-                            if (wi == d.W) wi = d.W - 2;
-                            float xv[V], wv[V];
-                            ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.C + c, xv);
-                            if (KK > 0) {
-#pragma unroll
-                                for (int v = 0; v < V; ++v) wv[v] = wreg[kh * 3 + kw][v];
-                            } else {
-                                ldv<V>(d.w + (long)(kh2 * d.KW + kw2) * d.C + c, wv);
-                            }
-#pragma unroll
-                            for (int v = 0; v < V; ++v) acc[v] = fmaf(xv[v], wv[v], acc[v]);
-                        }
+                        for (int v = 0; v < V; ++v) acc[v] = fmaf(xv[v], wv[v], acc[v]);
                     }
                 }
             }
@@ -113,6 +123,137 @@ __global__ void __launch_bounds__(256) dwconv_kernel(ledn_dw_desc d, float* part
     }
 }
 
+// bf16 3x3 depthwise conv, stride 1, zero padding = dilation (SESP second stage): the vectorised
+// form of stencil.h.  Thread = 8 channels x pixel row r; a workgroup walks one contiguous pixel
+// range (XCD-aware numbering); the nine 16-byte tap loads of a pixel are in flight together.
+// FLIP = 1 computes the data gradient (taps mirrored, optional `add` input, no epilogue).
+template <int FLIP>
+__global__ void __launch_bounds__(256) dw3x3_bf16_kernel(ledn_dw_desc d, const bf16_t* add, float* part) {
+    constexpr int V = 8;
+    __shared__ float s_part[2][256 * V];
+    const int cvn = d.C / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    const int c = cv * V;
+    f32x2_t st1[4], st2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st1[i] = st2[i] = f32x2_t{0.f, 0.f};
+    if (r < rows) {
+        const int dl = d.dil[c / d.group_size];
+        const bf16_t* x = reinterpret_cast<const bf16_t*>(d.x);
+        bf16_t* y = reinterpret_cast<bf16_t*>(d.y);
+        f32x2_t w[9][4];
+        int toff[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            f32x8_load(d.w + (long)(FLIP ? 8 - t : t) * d.C + c, w[t]);
+            toff[t] = ((t / 3 - 1) * dl * d.W + (t % 3 - 1) * dl) * d.C;
+        }
+        f32x2_t sc[4], sh[4], ng[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc[i] = f32x2_t{1.f, 1.f};
+            sh[i] = f32x2_t{0.f, 0.f};
+            ng[i] = d.act_out == LEDN_ACT_NONE ? f32x2_t{1.f, 1.f} : f32x2_t{0.f, 0.f};
+        }
+        if (!FLIP) {
+            if (d.out_scale) f32x8_load(d.out_scale + c, sc);
+            if (d.out_shift) f32x8_load(d.out_shift + c, sh);
+            if (d.act_out == LEDN_ACT_PRELU) f32x8_load(d.slope + c, ng);
+        }
+        const float hi = (!FLIP && d.act_out == LEDN_ACT_RELU6) ? 6.f : 3.0e38f;
+        const bool has_act = !FLIP && d.act_out != LEDN_ACT_NONE;
+        const long npix = (long)d.N * d.H * d.W;
+        const long ppb = cdiv(cdiv(npix, (long)gridDim.x), (long)rows) * rows;
+        const long p0 = (long)xcd_block(blockIdx.x, gridDim.x) * ppb, p1 = min(npix, p0 + ppb);
+        PixCursor cur;
+        cur.init(p0 + r, d.H, d.W);
+        unsigned base = (unsigned)((p0 + r) * d.C + c);
+        for (long p = p0 + r; p < p1; p += rows, base += (unsigned)(rows * d.C), cur.advance(rows, d.H, d.W)) {
+            const unsigned mask = tap_mask(cur.y, cur.x, dl, d.H, d.W);
+            uint4 raw[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) raw[t] = ld_tap(x, base + (unsigned)toff[t], base, (mask >> t) & 1u);
+            f32x2_t acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = f32x2_t{0.f, 0.f};
+            if (FLIP && add) bf16x8_unpack(*reinterpret_cast<const uint4*>(add + base), acc);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                f32x2_t xv[4];
+                bf16x8_unpack(raw[t], xv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = pk_fma(xv[i], w[t][i], acc[i]);
+            }
+            if (!FLIP) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i] = pk_fma(acc[i], sc[i], sh[i]);
+                    st1[i] += acc[i];
+                    st2[i] = pk_fma(acc[i], acc[i], st2[i]);
+                }
+                if (has_act) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i].x = fminf(fmaxf(acc[i].x, 0.f) + ng[i].x * fminf(acc[i].x, 0.f), hi);
+                        acc[i].y = fminf(fmaxf(acc[i].y, 0.f) + ng[i].y * fminf(acc[i].y, 0.f), hi);
+                    }
+                }
+            }
+            *reinterpret_cast<uint4*>(y + base) = bf16x8_pack(acc);
+        }
+    }
+    if (FLIP || !d.stat_sum) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s_part[0][threadIdx.x * V + 2 * i] = st1[i].x;
+        s_part[0][threadIdx.x * V + 2 * i + 1] = st1[i].y;
+        s_part[1][threadIdx.x * V + 2 * i] = st2[i].x;
+        s_part[1][threadIdx.x * V + 2 * i + 1] = st2[i].y;
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < d.C; ch += 256) {
+        float sa = 0.f, sb = 0.f;
+        for (int rr = 0; rr < rows; ++rr) {
+            sa += s_part[0][(rr * cvn + ch / V) * V + ch % V];
+            sb += s_part[1][(rr * cvn + ch / V) * V + ch % V];
+        }
+        if (part) {
+            part[(long)blockIdx.x * 2 * d.C + ch] = sa;
+            part[(long)blockIdx.x * 2 * d.C + d.C + ch] = sb;
+        } else {
+            atomicAdd(d.stat_sum + ch, sa);
+            atomicAdd(d.stat_sqsum + ch, sb);
+        }
+    }
+}
+
+// shape gate of the vectorised 3x3 kernels (forward and data gradient)
+static bool dw3x3_bf16_ok(int C, int group_size, int KH, int KW, int stride, int pad, int ext1, const int* dil,
+                          long numel) {
+    if (KH != 3 || KW != 3 || stride != 1 || ext1 || C % 8 || group_size % 8 || 256 % (C / 8) || C / 8 > 256) return false;
+    if (numel >= (1L << 31)) return false;
+    for (int g = 0; g * group_size < C; ++g)
+        if (pad >= 0 && pad != dil[g]) return false;
+    return true;
+}
+
+int dw3x3_bwd_data_bf16(const ledn_dwbwd_desc& b, hipStream_t s) {   // used by backward.hip
+    if (b.dtype != LEDN_BF16 || !dw3x3_bf16_ok(b.C, b.group_size, b.KH, b.KW, b.stride, b.pad, b.ext1, b.dil,
+                                               (long)b.N * b.H * b.W * b.C))
+        return -1;
+    ledn_dw_desc d = {};
+    d.x = b.dz; d.w = b.w; d.y = b.dx;
+    d.N = b.N; d.H = b.H; d.W = b.W; d.C = b.C; d.Ho = b.H; d.Wo = b.W;
+    d.KH = d.KW = 3; d.stride = 1; d.pad = b.pad; d.group_size = b.group_size;
+    for (int i = 0; i < 4; ++i) d.dil[i] = b.dil[i];
+    const int rows = 256 / (d.C / 8);
+    long nb = cdiv((long)d.N * d.H * d.W, rows * 4);
+    if (nb > 2048) nb = 2048;
+    LEDN_LAUNCH((dw3x3_bf16_kernel<1>), dim3((unsigned)nb), dim3(256), 0, s, d, (const bf16_t*)b.add, (float*)nullptr);
+    return check_launch();
+}
+
 int finish_partials(const float* part, int nblk, int C, int nout, float* o0, float* o1, float* o2,
                     hipStream_t s);
 
@@ -131,6 +272,21 @@ int dwconv_impl(const ledn_dw_desc& d, hipStream_t s) {
         const int pw = d.pad >= 0 ? d.pad : d.dil[g] * (d.KW - 1) / 2;
         LEDN_REQUIRE(d.Ho == (Hx + 2 * ph - ((d.KH - 1) * d.dil[g] + 1)) / d.stride + 1);
         LEDN_REQUIRE(d.Wo == (Wx + 2 * pw - ((d.KW - 1) * d.dil[g] + 1)) / d.stride + 1);
+    }
+    if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_BF16 && d.act_out != LEDN_ACT_SIGMOID && d.Ho == d.H &&
+        d.Wo == d.W &&
+        dw3x3_bf16_ok(d.C, d.group_size, d.KH, d.KW, d.stride, d.pad, d.ext1, d.dil, (long)d.N * d.H * d.W * d.C)) {
+        const int rows8 = 256 / (d.C / 8);
+        long nb8 = cdiv((long)d.N * d.H * d.W, rows8 * 4);
+        if (nb8 > 2048) nb8 = 2048;
+        float* part8 = nullptr;
+        if (d.stat_sum) {
+            if (nb8 > 64) part8 = ws_take(nb8 * 2 * d.C);
+            if (!part8 && nb8 > 256) nb8 = 256;
+        }
+        LEDN_LAUNCH((dw3x3_bf16_kernel<0>), dim3((unsigned)nb8), dim3(256), 0, s, d, (const bf16_t*)nullptr, part8);
+        if (part8) return finish_partials(part8, (int)nb8, d.C, 2, d.stat_sum, d.stat_sqsum, nullptr, s);
+        return check_launch();
     }
     const bool v4 = d.C % 4 == 0 && d.group_size % 4 == 0;
     const int cvn = v4 ? d.C / 4 : d.C;
@@ -167,7 +323,7 @@ template <typename TX, typename TY, int V>
 __global__ void __launch_bounds__(256) sesp_pyramid_kernel(ledn_pyr_desc d) {
     const int cv = d.n / V;
     const long total = (long)d.N * d.Ho * d.Wo * cv;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long idx = (long)xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % cv) * V;
     const long pix = idx / cv;
@@ -181,28 +337,33 @@ __global__ void __launch_bounds__(256) sesp_pyramid_kernel(ledn_pyr_desc d) {
     for (int v = 0; v < V; ++v) run[v] = 0.f;
     for (int b = 0; b < 4; ++b) {
         const int dl = d.dil[b];
-        for (int kh = 0; kh < 3; ++kh) {
-            const int hi = ho * d.stride + (kh - 1) * dl;
-            if (hi < 0 || hi >= d.H) continue;
-            for (int kw = 0; kw < 3; ++kw) {
-                const int wi = wo * d.stride + (kw - 1) * dl;
-                if (wi < 0 || wi >= d.W) continue;
-                float xv[V], wv[V];
-                ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.n + c, xv);
-                ldv<V>(d.w + (long)((b * 3 + kh) * 3 + kw) * d.n + c, wv);
+        float xv[9][V], wv[9][V];
 #pragma unroll
-                for (int v = 0; v < V; ++v) run[v] = fmaf(xv[v], wv[v], run[v]);
-            }
+        for (int t = 0; t < 9; ++t) {   // nine unconditional tap loads (+ their weights) in flight
+            const int hi = ho * d.stride + (t / 3 - 1) * dl, wi = wo * d.stride + (t % 3 - 1) * dl;
+            const bool valid = hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+            ldv_if<V>(x, (((long)n * d.H + hi) * d.W + wi) * d.n + c, valid, xv[t]);
+            ldv<V>(d.w + (long)(b * 9 + t) * d.n + c, wv[t]);
         }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int v = 0; v < V; ++v) run[v] = fmaf(xv[t][v], wv[t][v], run[v]);
         stv<V>(y + (long)b * d.n, run);
     }
 }
+
+int pyr_fwd_bf16(const ledn_pyr_desc& d, hipStream_t s);   // stencil_bf16.hip; -1 = shape not covered
 
 int sesp_pyramid_impl(const ledn_pyr_desc& d, hipStream_t s) {
     LEDN_REQUIRE(d.x && d.w && d.y);
     LEDN_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.n > 0 && (d.stride == 1 || d.stride == 2));
     LEDN_REQUIRE(d.Ho == (d.H - 1) / d.stride + 1 && d.Wo == (d.W - 1) / d.stride + 1);
     for (int b = 0; b < 4; ++b) LEDN_REQUIRE(d.dil[b] > 0);
+    {
+        const int rc = pyr_fwd_bf16(d, s);
+        if (rc >= 0) return rc;
+    }
     const bool v4 = d.n % 4 == 0;
     const long total = (long)d.N * d.Ho * d.Wo * (v4 ? d.n / 4 : d.n);
     const dim3 grid((unsigned)cdiv(total, 256));

@@ -77,6 +77,15 @@ template <int V, typename T> __device__ __forceinline__ void stv(T* p, const flo
     }
 }
 
+// stencil tap: an UNCONDITIONAL load (out-of-image taps read the tensor base and are zeroed) --
+// no branch around the load, so all taps of a stencil are in flight together
+template <int V, typename T>
+__device__ __forceinline__ void ldv_if(const T* base, long off, bool valid, float* o) {
+    ldv<V>(base + (valid ? off : 0L), o);
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = valid ? o[i] : 0.f;
+}
+
 // ---- activations --------------------------------------------------------------
 __device__ __forceinline__ float act_apply(int act, float v, float slope) {
     switch (act) {
@@ -116,6 +125,26 @@ __device__ __forceinline__ float wave_min(float v) {
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// dynamically sized LDS (the launch's shared-memory argument), 16-byte aligned
+#ifdef LEDN_CPU_EMU
+#define LEDN_DYN_SHARED(T, name) T* name = reinterpret_cast<T*>(LEDN_DYN_SMEM)
+#else
+#define LEDN_DYN_SHARED(T, name)                                                  \
+    extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_[];   \
+    T* name = reinterpret_cast<T*>(name##_raw_)
+#endif
+
+// ---- XCD-aware block numbering ----------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  xcd_block() renumbers
+// them so that the workgroups resident on one XCD own ONE contiguous eighth of the logical block
+// range: neighbouring tiles / pixel rows then find their halo lines in the same L2 instead of
+// every XCD pulling them over the fabric again.
+__device__ __forceinline__ unsigned xcd_block(unsigned bid, unsigned nblocks) {
+    if (nblocks < 16u) return bid;
+    const unsigned x = bid & 7u, q = nblocks >> 3, rem = nblocks & 7u;
+    return x * q + (x < rem ? x : rem) + (bid >> 3);
+}
 
 // ---- matrix-core (MFMA) fragments and the LDS transposing read ------------------
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));   // 8 bf16 = one 32x32x16 A/B fragment
@@ -165,7 +194,7 @@ inline int check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? LEDN_OK : LEDN_ELAUNCH;
 }
-inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+__host__ __device__ inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
 // Caller-provided scratch (ledn_set_workspace): cross-workgroup reductions write per-workgroup
 // partials here and a tiny second kernel sums them -- no same-address atomics (which serialise

@@ -1,0 +1,297 @@
+// stencil_bf16.hip -- vectorised bf16 kernels (see stencil.h) for the depthwise weight gradient
+// and the SESP pyramid forward / data gradient / weight gradient.  Each returns -1 when the shape
+// is outside its gate so that the caller (dwconv.hip / backward.hip) falls back to the generic kernel.
+#include "stencil.h"
+
+namespace ledn {
+
+static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// sums `acc` (9 taps x 8 channels) over the pixel rows of one wave (lanes r*cvn + cv, cvn a power
+// of two), then over the 4 waves through LDS; thread e < nine*C then owns element e of [9][C]
+__device__ __forceinline__ void reduce_taps(f32x2_t (&acc)[9][4], int cvn, float* s_red /* [4][9*C] */, int C,
+                                            int c) {
+    for (int m = 32; m >= cvn; m >>= 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[t][i].x += __shfl_xor(acc[t][i].x, m);
+                acc[t][i].y += __shfl_xor(acc[t][i].y, m);
+            }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane < cvn) {   // cvn <= 64: the first cvn lanes of the wave hold its sums (cvn == 64: one row per wave)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s_red[(wid * 9 + t) * C + c + 2 * i] = acc[t][i].x;
+                s_red[(wid * 9 + t) * C + c + 2 * i + 1] = acc[t][i].y;
+            }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// depthwise 3x3 weight gradient: dw[t][c] = sum_pix x[pix @ tap t] * dz[pix]   (stride 1, pad = dil)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dw3x3_bwd_weight_bf16_kernel(ledn_dwbwd_desc d, float* part) {
+    constexpr int V = 8;
+    LEDN_DYN_SHARED(float, s_red);   // [4][9*C]
+    const int cvn = d.C / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    const int c = cv * V;
+    f32x2_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x2_t{0.f, 0.f};
+    {
+        const int dl = d.dil[c / d.group_size];
+        const bf16_t* x = reinterpret_cast<const bf16_t*>(d.x);
+        const bf16_t* dz = reinterpret_cast<const bf16_t*>(d.dz);
+        int toff[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) toff[t] = ((t / 3 - 1) * dl * d.W + (t % 3 - 1) * dl) * d.C;
+        const long npix = (long)d.N * d.H * d.W;
+        const long ppb = cdiv(cdiv(npix, (long)gridDim.x), (long)rows) * rows;
+        const long p0 = (long)xcd_block(blockIdx.x, gridDim.x) * ppb, p1 = min(npix, p0 + ppb);
+        PixCursor cur;
+        cur.init(p0 + r, d.H, d.W);
+        unsigned base = (unsigned)((p0 + r) * d.C + c);
+        for (long p = p0 + r; p < p1; p += rows, base += (unsigned)(rows * d.C), cur.advance(rows, d.H, d.W)) {
+            const unsigned mask = tap_mask(cur.y, cur.x, dl, d.H, d.W);
+            uint4 raw[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) raw[t] = ld_tap(x, base + (unsigned)toff[t], base, (mask >> t) & 1u);
+            f32x2_t g[4];
+            bf16x8_unpack(*reinterpret_cast<const uint4*>(dz + base), g);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                f32x2_t xv[4];
+                bf16x8_unpack(raw[t], xv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][i] = pk_fma(xv[i], g[i], acc[t][i]);
+            }
+        }
+    }
+    reduce_taps(acc, cvn, s_red, d.C, c);
+    for (int e = threadIdx.x; e < 9 * d.C; e += 256) {
+        const float sum = (s_red[e] + s_red[9 * d.C + e]) + (s_red[18 * d.C + e] + s_red[27 * d.C + e]);
+        if (part) part[(long)blockIdx.x * 9 * d.C + e] = sum;
+        else atomicAdd(d.dw + e, sum);
+    }
+}
+
+int dw3x3_bwd_weight_bf16(const ledn_dwbwd_desc& d, hipStream_t s) {
+    const int cvn = d.C / 8;
+    if (d.dtype != LEDN_BF16 || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.ext1 || d.C % 8 || d.group_size % 8 ||
+        !pow2(cvn) || cvn > 64 || d.Ho != d.H || d.Wo != d.W || (long)d.N * d.H * d.W * d.C >= (1L << 31))
+        return -1;
+    for (int g = 0; g * d.group_size < d.C; ++g)
+        if (d.pad >= 0 && d.pad != d.dil[g]) return -1;
+    const int rows = 256 / cvn;
+    long nb = cdiv((long)d.N * d.H * d.W, rows * 8);
+    if (nb > 1024) nb = 1024;
+    float* part = nb > 32 ? ws_take(nb * 9 * d.C) : nullptr;
+    if (!part && nb > 128) nb = 128;
+    LEDN_LAUNCH(dw3x3_bwd_weight_bf16_kernel, dim3((unsigned)nb), dim3(256), (size_t)(36 * d.C) * sizeof(float), s, d,
+                part);
+    if (part) return finish_partials(part, (int)nb, 9 * d.C, 1, d.dw, nullptr, nullptr, s);
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// SESP pyramid.  Weights [4][9][n] f32 sit in LDS (one copy per workgroup).
+//   forward      : y[po][b*n + c] = sum_{b' <= b} dw3x3_{dil[b'], stride}(x)[po][c]
+//   data gradient: dx[p][c] = sum_b sum_t g_b[p - tap_b(t)][c] * w[b][t][c]        (stride 1)
+//   weight grad. : dw[b][t][c] = sum_po x[po*stride @ tap_b(t)][c] * g_b[po][c]
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void pyr_stage_weights(const float* w, float* s_w, int n) {
+    for (int i = threadIdx.x; i < 36 * n; i += 256) s_w[i] = w[i];
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) pyr_fwd_bf16_kernel(ledn_pyr_desc d) {
+    constexpr int V = 8;
+    LEDN_DYN_SHARED(float, s_w);   // [36][n]
+    pyr_stage_weights(d.w, s_w, d.n);
+    const int cvn = d.n / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    const int c = cv * V;
+    const bf16_t* x = reinterpret_cast<const bf16_t*>(d.x);
+    bf16_t* y = reinterpret_cast<bf16_t*>(d.y);
+    const long npo = (long)d.N * d.Ho * d.Wo;
+    const long ppb = cdiv(cdiv(npo, (long)gridDim.x), (long)rows) * rows;
+    const long p0 = (long)xcd_block(blockIdx.x, gridDim.x) * ppb, p1 = min(npo, p0 + ppb);
+    PixCursor cur;
+    cur.init(p0 + r, d.Ho, d.Wo);
+    for (long p = p0 + r; p < p1; p += rows, cur.advance(rows, d.Ho, d.Wo)) {
+        const int yi = cur.y * d.stride, xi = cur.x * d.stride;
+        const unsigned base = (unsigned)((((long)cur.n * d.H + yi) * d.W + xi) * d.n + c);
+        f32x2_t run[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) run[i] = f32x2_t{0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int dl = d.dil[b];
+            const unsigned mask = tap_mask(yi, xi, dl, d.H, d.W);
+            const int co = opaque(dl * d.n), ro = co * d.W;   // recomputed per pixel: 36 hoisted offsets cost a wave/SIMD
+            uint4 raw[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                raw[t] = ld_tap(x, base + (unsigned)((t / 3 - 1) * ro + (t % 3 - 1) * co), base, (mask >> t) & 1u);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                f32x2_t xv[4], wv[4];
+                bf16x8_unpack(raw[t], xv);
+                f32x8_load(s_w + (b * 9 + t) * d.n + c, wv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) run[i] = pk_fma(xv[i], wv[i], run[i]);
+            }
+            *reinterpret_cast<uint4*>(y + p * (4L * d.n) + (long)b * d.n + c) = bf16x8_pack(run);
+            sched_fence();   // one branch's nine taps in flight at a time (36 would cost the occupancy)
+        }
+    }
+}
+
+int pyr_fwd_bf16(const ledn_pyr_desc& d, hipStream_t s) {
+    const int cvn = d.n / 8;
+    if (d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16 || d.n % 8 || 256 % cvn || cvn > 256 ||
+        (long)d.N * d.H * d.W * d.n * 4 >= (1L << 31))
+        return -1;
+    const int rows = 256 / cvn;
+    long nb = cdiv((long)d.N * d.Ho * d.Wo, rows * 2);
+    if (nb > 2048) nb = 2048;
+    LEDN_LAUNCH(pyr_fwd_bf16_kernel, dim3((unsigned)nb), dim3(256), (size_t)(36 * d.n) * sizeof(float), s, d);
+    return check_launch();
+}
+
+// gsum holds the suffix sums g_b = sum_{b' >= b} dy_b' (pyr_suffix_kernel)
+__global__ void __launch_bounds__(256) pyr_bwd_data_bf16_kernel(ledn_pyrbwd_desc d) {
+    constexpr int V = 8;
+    LEDN_DYN_SHARED(float, s_w);   // [36][n]
+    pyr_stage_weights(d.w, s_w, d.n);
+    const int cvn = d.n / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    const int c = cv * V;
+    const bf16_t* g = reinterpret_cast<const bf16_t*>(d.gsum);
+    bf16_t* dx = reinterpret_cast<bf16_t*>(d.dx);
+    const long npix = (long)d.N * d.H * d.W;
+    const long ppb = cdiv(cdiv(npix, (long)gridDim.x), (long)rows) * rows;
+    const long p0 = (long)xcd_block(blockIdx.x, gridDim.x) * ppb, p1 = min(npix, p0 + ppb);
+    PixCursor cur;
+    cur.init(p0 + r, d.H, d.W);
+    const int n4 = 4 * d.n;
+    for (long p = p0 + r; p < p1; p += rows, cur.advance(rows, d.H, d.W)) {
+        const unsigned base = (unsigned)(p * n4 + c);
+        f32x2_t acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x2_t{0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int dl = d.dil[b];
+            const unsigned mask = tap_mask(cur.y, cur.x, dl, d.H, d.W);
+            const int co = opaque(dl * n4), ro = co * d.W;
+            uint4 raw[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)   // source pixel of tap t is p - tap offset: mirrored index 8 - t
+                raw[t] = ld_tap(g, base + (unsigned)(b * d.n) + (unsigned)((t / 3 - 1) * ro + (t % 3 - 1) * co), base,
+                                (mask >> t) & 1u);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                f32x2_t gv[4], wv[4];
+                bf16x8_unpack(raw[t], gv);
+                f32x8_load(s_w + (b * 9 + (8 - t)) * d.n + c, wv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = pk_fma(gv[i], wv[i], acc[i]);
+            }
+            sched_fence();
+        }
+        *reinterpret_cast<uint4*>(dx + p * d.n + c) = bf16x8_pack(acc);
+    }
+}
+
+int pyr_bwd_data_bf16(const ledn_pyrbwd_desc& d, hipStream_t s) {   // gsum already holds the suffix sums
+    const int cvn = d.n / 8;
+    if (d.dtype != LEDN_BF16 || d.stride != 1 || d.n % 8 || 256 % cvn || cvn > 256 ||
+        (long)d.N * d.H * d.W * d.n * 4 >= (1L << 31))
+        return -1;
+    const int rows = 256 / cvn;
+    long nb = cdiv((long)d.N * d.H * d.W, rows * 2);
+    if (nb > 2048) nb = 2048;
+    LEDN_LAUNCH(pyr_bwd_data_bf16_kernel, dim3((unsigned)nb), dim3(256), (size_t)(36 * d.n) * sizeof(float), s, d);
+    return check_launch();
+}
+
+__global__ void __launch_bounds__(256) pyr_bwd_weight_bf16_kernel(ledn_pyrbwd_desc d, float* part) {
+    constexpr int V = 8;
+    LEDN_DYN_SHARED(float, s_red);   // [4][9*n]
+    const int b = blockIdx.y;
+    const int dl = d.dil[b];
+    const int cvn = d.n / V;
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    const int c = cv * V;
+    f32x2_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x2_t{0.f, 0.f};
+    {
+        const bf16_t* x = reinterpret_cast<const bf16_t*>(d.x);
+        const bf16_t* g = reinterpret_cast<const bf16_t*>(d.gsum);
+        const long npo = (long)d.N * d.Ho * d.Wo;
+        const long ppb = cdiv(cdiv(npo, (long)gridDim.x), (long)rows) * rows;
+        const long p0 = (long)xcd_block(blockIdx.x, gridDim.x) * ppb, p1 = min(npo, p0 + ppb);
+        PixCursor cur;
+        cur.init(p0 + r, d.Ho, d.Wo);
+        for (long p = p0 + r; p < p1; p += rows, cur.advance(rows, d.Ho, d.Wo)) {
+            const int yi = cur.y * d.stride, xi = cur.x * d.stride;
+            const unsigned base = (unsigned)((((long)cur.n * d.H + yi) * d.W + xi) * d.n + c);
+            const unsigned mask = tap_mask(yi, xi, dl, d.H, d.W);
+            uint4 raw[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                raw[t] = ld_tap(x, base + (unsigned)(((t / 3 - 1) * dl * d.W + (t % 3 - 1) * dl) * d.n), base,
+                                (mask >> t) & 1u);
+            f32x2_t gv[4];
+            bf16x8_unpack(*reinterpret_cast<const uint4*>(g + p * (4L * d.n) + (long)b * d.n + c), gv);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                f32x2_t xv[4];
+                bf16x8_unpack(raw[t], xv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][i] = pk_fma(xv[i], gv[i], acc[t][i]);
+            }
+        }
+    }
+    reduce_taps(acc, cvn, s_red, d.n, c);
+    for (int e = threadIdx.x; e < 9 * d.n; e += 256) {
+        const float sum = (s_red[e] + s_red[9 * d.n + e]) + (s_red[18 * d.n + e] + s_red[27 * d.n + e]);
+        // dw layout [4][3][3][n]; partial layout [blk][4*9*n]
+        if (part) part[(long)blockIdx.x * 36 * d.n + (long)b * 9 * d.n + e] = sum;
+        else atomicAdd(d.dw + (long)b * 9 * d.n + e, sum);
+    }
+}
+
+int pyr_bwd_weight_bf16(const ledn_pyrbwd_desc& d, hipStream_t s) {
+    const int cvn = d.n / 8;
+    if (d.dtype != LEDN_BF16 || d.n % 8 || !pow2(cvn) || cvn > 64 || (long)d.N * d.H * d.W * d.n * 4 >= (1L << 31))
+        return -1;
+    const int rows = 256 / cvn;
+    long nb = cdiv((long)d.N * d.Ho * d.Wo, rows * 8);
+    if (nb > 512) nb = 512;
+    float* part = nb > 32 ? ws_take(nb * 36 * d.n) : nullptr;
+    if (!part && nb > 128) nb = 128;
+    LEDN_LAUNCH(pyr_bwd_weight_bf16_kernel, dim3((unsigned)nb, 4u), dim3(256), (size_t)(36 * d.n) * sizeof(float), s, d,
+                part);
+    if (part) return finish_partials(part, (int)nb, 36 * d.n, 1, d.dw, nullptr, nullptr, s);
+    return check_launch();
+}
+
+}  // namespace ledn
