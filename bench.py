@@ -54,25 +54,60 @@ def build_model(dev, dtype, train):
     return model, cfg
 
 
+def pmc_traffic(kernel, mode, dtype):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command
+    (tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections of
+    MI355X_MICROARCH.md applied), committed as profiles/pmc_traffic_<mode>_<dtype>.json; None when
+    no such collection exists."""
+    path = os.path.join(ROOT, 'profiles', f'pmc_traffic_{mode}_{dtype}.json')
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)['kernels'].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None
+    return None if rec is None else rec['hbm_bytes_per_launch']
+
+
+def host_cores():
+    """Threads the CPU leg may use: the cgroup CPU share / affinity of this process, never
+    os.cpu_count() (the GPU box reports 256 logical CPUs for a 16-CPU share; 256 torch threads on
+    16 CPUs ran the oracle 50x slower).  LEDN_CPU_THREADS overrides."""
+    if os.environ.get('LEDN_CPU_THREADS'):
+        return max(1, int(os.environ['LEDN_CPU_THREADS']))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            pr = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // pr))
+        except (OSError, ValueError):
+            pass
+    return min(n, 16)    # one GPU's share of the box's host cores
+
+
 def cpu_baseline(mode, h, w, budget_s=20.0):
-    """Time the CPU oracle on a bounded sample (bs=1 images, a few iterations)."""
+    """Time the CPU oracle on a bounded sample (batch 1-2 of the bench image size, a few iterations)."""
     from oracle import spec
     import led_net_amd as L
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(304)
     cfg = L.load_config(os.path.join(ROOT, 'tests', 'data', 'lednet_test_config.py'))
     model = L.MODELS.build(cfg['model'])
     sd = {k: v.clone() for k, v in model.state_dict().items()}
-    bs = 2 if mode == 'train' else 1
-    img, lab = synthetic_batch(bs, h, w, 'cpu')
-    x = spec.preprocess(img)
+    bs = 2 if mode == 'train' else 1   # train-mode BN over the global-pool branch needs > 1 value per channel
     if mode == 'train':
         for k, v in sd.items():
             if v.is_floating_point() and 'running_' not in k:
                 v.requires_grad_(True)
 
-        def step():
+    def step(x, lab):
+        if mode == 'train':
             out = spec.loss(x, lab, sd)
             (out['decode.loss_context'] + out['decode.loss_spatial']).backward()
             with torch.no_grad():
@@ -80,19 +115,23 @@ def cpu_baseline(mode, h, w, budget_s=20.0):
                     if v.grad is not None:
                         v -= 0.01 * v.grad
                         v.grad = None
-    else:
-        def step():
+        else:
             with torch.no_grad():
                 spec.predict(x, sd)
-    step()  # warm-up
+    img, lab = synthetic_batch(bs, 512, 512, 'cpu')
+    step(spec.preprocess(img), lab)          # warm-up (thread pool, allocator) on a small image
+    img, lab = synthetic_batch(bs, h, w, 'cpu')
+    x = spec.preprocess(img)
+    print(f'[bench] cpu_baseline: oracle {mode} at {bs}x{h}x{w} on {cores} threads ...', file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     n = 0
     while True:
-        step()
+        step(x, lab)
         n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 20:
+        dt = time.perf_counter() - t0
+        print(f'[bench] cpu_baseline: {n} iterations, {dt:.1f} s', file=sys.stderr, flush=True)
+        if dt > budget_s or n >= 20:
             break
-    dt = time.perf_counter() - t0
     return {'value': round(bs * n / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} iterations of oracle.spec.{"loss+backward+SGD" if mode == "train" else "predict"} '
                       f'at batch {bs}, {h}x{w}, fp32, torch CPU ops, {cores} threads'}
@@ -199,27 +238,38 @@ def main():
         dt = t.item()
 
     if rank == 0:
-        # ---- dominant kernel (by summed HIP-event time over the timed region)
-        agg = {}
+        # ---- dominant kernel FUNCTION (as rocprofv3 --stats groups them, template instances merged)
+        # by summed HIP-event time; its roofline = the larger of its two time floors
+        # (algorithmic bytes / HBM peak, algorithmic flops / dense MFMA peak)
+        agg, fam = {}, {}
         for r in launches:
             k = (r['entry'], r['sig'])
-            a = agg.setdefault(k, dict(ms=0.0, n=0, bytes=r['bytes'], flops=r['flops']))
+            a = agg.setdefault(k, dict(ms=0.0, n=0, bytes=r['bytes'], flops=r['flops'], kernel=r['kernel']))
             a['ms'] += r['ms']
             a['n'] += 1
+            f = fam.setdefault(r['kernel'], dict(ms=0.0, n=0, bytes=0, flops=0))
+            f['ms'] += r['ms']
+            f['n'] += 1
+            f['bytes'] += r['bytes']
+            f['flops'] += r['flops']
         top = sorted(agg.items(), key=lambda kv: -kv[1]['ms'])
-        (entry, sig), a = top[0]
-        avg_ms = a['ms'] / a['n']
-        if entry in ('ledn_conv2d', 'ledn_conv2d_wgrad', 'ledn_window_attn'):
-            peak = MFMA_PEAK_TFLOPS[args.dtype]
-            ach = a['flops'] / (avg_ms * 1e-3) / 1e12
-            roof = dict(bound='mfma', achieved=round(ach, 3), peak=peak, unit='TFLOP/s',
-                        frac=round(ach / peak, 5), traffic=None)
+        kname, f = max(fam.items(), key=lambda kv: kv[1]['ms'])
+        avg_ms = f['ms'] / f['n']
+        gbs = f['bytes'] / (f['ms'] * 1e-3) / 1e9
+        tfl = f['flops'] / (f['ms'] * 1e-3) / 1e12
+        peak_t = MFMA_PEAK_TFLOPS[args.dtype]
+        mfma_bound = f['flops'] / (peak_t * 1e12) > f['bytes'] / (HBM_PEAK_GBS * 1e9)
+        if mfma_bound:
+            roof = dict(bound='mfma', achieved=round(tfl, 3), peak=peak_t, unit='TFLOP/s', frac=round(tfl / peak_t, 5))
         else:
-            ach = a['bytes'] / (avg_ms * 1e-3) / 1e9
-            roof = dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=None)
-        roof.update(kernel=f'{entry} [{sig}]', avg_us=round(avg_ms * 1e3, 2), launches_per_step=a['n'] // k_steps,
-                    share_of_gpu_time=round(a['ms'] / max(1e-9, sum(v['ms'] for v in agg.values())), 4))
+            roof = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=round(gbs / HBM_PEAK_GBS, 5))
+        roof['traffic'] = pmc_traffic(kname, mode, args.dtype)
+        roof.update(kernel=kname, avg_us=round(avg_ms * 1e3, 2), launches_per_step=f['n'] // k_steps,
+                    alg_bytes_per_launch=f['bytes'] // f['n'], alg_flops_per_launch=f['flops'] // f['n'],
+                    alg_gbs=round(gbs, 1), alg_tflops=round(tfl, 3), mfma_frac=round(tfl / peak_t, 5),
+                    arithmetic_intensity=round(f['flops'] / max(1, f['bytes']), 1),
+                    share_of_gpu_time=round(f['ms'] / max(1e-9, sum(v['ms'] for v in fam.values())), 4))
         total_flops = sum(v['flops'] * v['n'] for k, v in agg.items() if k[0] in ('ledn_conv2d', 'ledn_conv2d_wgrad', 'ledn_window_attn'))
         total_bytes = sum(v['bytes'] * v['n'] for v in agg.values())
         gpu_ms = sum(v['ms'] for v in agg.values())
@@ -245,15 +295,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(mode, H, W)
         if os.environ.get('LEDN_BENCH_VERBOSE'):
-            fam = {}
-            for (e, sg), v in agg.items():
-                f = fam.setdefault(e, [0.0, 0])
-                f[0] += v['ms']
-                f[1] += v['n']
-            for e, (ms, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
-                print(f'{ms / k_steps:9.3f} ms/step  x{n // k_steps:4d}  [family] {e}', file=sys.stderr)
+            for e, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms']):
+                print(f"{v['ms'] / k_steps:9.3f} ms/step  x{v['n'] // k_steps:4d}  {v['bytes'] / max(1e-9, v['ms']) / 1e6:8.1f} GB/s "
+                      f"{v['flops'] / max(1e-9, v['ms']) / 1e9:8.2f} TF/s  [kernel] {e}", file=sys.stderr)
             for (e, sg), v in top[:int(os.environ.get("LEDN_BENCH_VERBOSE", "25")) if os.environ.get("LEDN_BENCH_VERBOSE", "1").isdigit() and int(os.environ.get("LEDN_BENCH_VERBOSE", "1")) > 1 else 25]:
-                print(f'{v["ms"] / k_steps:9.3f} ms/step  x{v["n"] // k_steps:3d}  {e} [{sg}]', file=sys.stderr)
+                print(f'{v["ms"] / k_steps:9.3f} ms/step  x{v["n"] // k_steps:3d}  {v["bytes"] * v["n"] / max(1e-9, v["ms"]) / 1e6:8.1f} GB/s '
+                      f'{v["flops"] * v["n"] / max(1e-9, v["ms"]) / 1e9:8.2f} TF/s  {e} [{sg}]', file=sys.stderr)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -89,6 +89,9 @@ typedef struct {
     int transposed;
 } ledn_conv_desc;
 int ledn_conv2d(const ledn_conv_desc* d, void* stream);
+/* Pure query, no launch: 1 if ledn_conv2d would run this descriptor on conv_mfma_kernel (matrix
+ * cores), 0 if on conv_direct_kernel (VALU).  bench.py names the kernel in its roofline with it. */
+int ledn_conv2d_uses_mfma(const ledn_conv_desc* d);
 
 /* bf16 weight pack for the MFMA path, from the OIHW f32 master [Cout][Cin/groups][KH][KW]
  * (Cin = full input width; a grouped 1x1 is densified: zeros outside its group):
@@ -129,6 +132,7 @@ typedef struct {
     int dtype_x, dtype_dz;
 } ledn_wgrad_desc;
 int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream);
+int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d);   /* same query for the weight gradient */
 
 /* ------------------------------------------------------------------------- *
  * Depthwise convolution (KxK, per-channel-group dilation, pad = dil*(K-1)/2

@@ -104,6 +104,9 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
     return conv_direct(*d, S(stream));
 }
 
+int ledn_conv2d_uses_mfma(const ledn_conv_desc* d) { return d && conv_mfma_supported(*d) ? 1 : 0; }
+int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d) { return d && wgrad_mfma_supported(*d) ? 1 : 0; }
+
 int ledn_pack_conv_weights_multi(const ledn_pack_entry* table_dev, int n, long long max_elems, void* stream) {
     return pack_conv_weights_multi_impl(table_dev, n, max_elems, S(stream));
 }

@@ -66,10 +66,11 @@ def start_timing():
 
 
 def stop_timing():
-    """-> list of dicts {entry, sig, bytes, flops, ms}; call after a device sync."""
+    """-> list of dicts {entry, sig, bytes, flops, kernel, ms}; call after a device sync."""
     global _TIMING
     rec, _TIMING = _TIMING or [], None
-    return [dict(entry=n, sig=w[0], bytes=w[1], flops=w[2], ms=e0.elapsed_time(e1)) for n, w, e0, e1 in rec]
+    return [dict(entry=n, sig=w[0], bytes=w[1], flops=w[2], kernel=w[3] if len(w) > 3 else n[5:] + '_kernel',
+                 ms=e0.elapsed_time(e1)) for n, w, e0, e1 in rec]
 
 
 def _nb(*ts):
@@ -138,7 +139,8 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
     d.dtype_x, d.dtype_y, d.transposed = _dt(x), _dt(y), int(transposed)
     _run(lib, 'ledn_conv2d', x, d, work=_TIMING is not None and (
         f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}',
-        _nb(x, xadd, y, res, w), 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW))
+        _nb(x, xadd, y, res, w), 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW,
+        'conv_mfma_kernel' if lib.cdll.ledn_conv2d_uses_mfma(d) else 'conv_direct_kernel'))
     return y
 
 
@@ -206,7 +208,8 @@ def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None,
     d.in_act, d.dtype_x, d.dtype_dz = in_act, _dt(x), _dt(dz)
     flops = 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW
     _run(lib, 'ledn_conv2d_wgrad', x, d,
-         work=_TIMING is not None and (f'wgrad{KH}x{KW} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W}', _nb(x, xadd, dz, dw), flops))
+         work=_TIMING is not None and (f'wgrad{KH}x{KW} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W}', _nb(x, xadd, dz, dw), flops,
+                                       'conv_wgrad_mfma_kernel' if lib.cdll.ledn_conv2d_wgrad_uses_mfma(d) else 'conv_wgrad_direct'))
     return dw, db
 
 
