@@ -11,25 +11,38 @@ from .ops import (ACT_NONE, RES_NONE, _DT, LednError, _check, _dt, _f32, _nb, _p
 
 
 def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
-               res=None, res_mode=RES_NONE, count=None, want_dres=False, sync=None):
+               res=None, res_mode=RES_NONE, count=None, want_dres=False, sync=None, sinks=None):
     """Backward of y = act(res_mode(z*scale+shift, res)).
     BN mode (mean/invstd given): returns (dz, dres, dgamma, dbeta, dslope).
     Plain mode: returns (dz, dres, None, None, dslope).
-    sync: optional callable all-reducing the [2,C] (sum_g, sum_gx) buffer (SyncBN)."""
+    sync: optional callable all-reducing the [2,C] (sum_g, sum_gx) buffer (SyncBN).
+    sinks: optional (dgamma, dbeta, dslope) ZEROED f32 [C] buffers (any may be None) the kernels
+    reduce straight into (the trainer's gradient views); the matching return value is then None."""
     lib = _lib.get_lib()
     Cc = z.shape[-1]
     P = z.numel() // Cc
     bn = mean is not None
     d = _lib.BnBwdDesc()
-    sums = torch.zeros((2, Cc), dtype=torch.float32, device=z.device)
-    dslope = torch.zeros(Cc, dtype=torch.float32, device=z.device) if slope is not None else None
+    sk_g, sk_b, sk_s = sinks if sinks is not None else (None, None, None)
+    if bn and sync is None and sk_g is not None and sk_b is not None:
+        sum_g, sum_gx, sunk = sk_b, sk_g, True
+        _f32(sum_g, Cc), _f32(sum_gx, Cc)
+    else:
+        sums = _ops.zeros_f32((2, Cc), z.device)
+        sum_g, sum_gx, sunk = sums[0], sums[1], False
+    dslope, slope_sunk = None, False
+    if slope is not None:
+        if sk_s is not None:
+            dslope, slope_sunk = _f32(sk_s, Cc), True
+        else:
+            dslope = _ops.zeros_f32(Cc, z.device)
     dz = torch.empty_like(z)
     dres = torch.empty_like(dy) if (want_dres and res_mode != RES_NONE) else None
-    _check(lib, z, dy, res, scale, shift, slope, mean, invstd)
+    _check(lib, z, dy, res, scale, shift, slope, mean, invstd, sum_g, sum_gx, dslope)
     d.z, d.res, d.dy = _p(z), _p(res), _p(dy)
     d.scale, d.shift, d.slope = _p(_f32(scale, Cc)), _p(_f32(shift, Cc)), _p(_f32(slope, Cc))
     d.mean, d.invstd = _p(_f32(mean, Cc)), _p(_f32(invstd, Cc))
-    d.sum_g, d.sum_gx = sums[0].data_ptr(), sums[1].data_ptr()
+    d.sum_g, d.sum_gx = sum_g.data_ptr(), sum_gx.data_ptr()
     d.dslope, d.dz, d.dres = _p(dslope), _p(dz), _p(dres)
     d.count = float(count if count is not None else P)
     d.P, d.C, d.act = P, Cc, act
@@ -40,7 +53,8 @@ def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT
         if bn and sync is not None:
             sync(sums)
     _run(lib, 'ledn_bn_act_bwd_apply', z, d, work=_ops._TIMING is not None and (f'bnbwd_apply C{Cc} P{P}', _nb(z, dy, res, dz, dres), 8 * z.numel()))
-    return dz, dres, (sums[1] if bn else None), (sums[0] if bn else None), dslope
+    return (dz, dres, (sum_gx if bn and not sunk else None), (sum_g if bn and not sunk else None),
+            None if slope_sunk else dslope)
 
 
 def _dw_desc(x_shape, dz, w_khwc, stride, pad, dil, group_size, ext1, dtype):
@@ -71,7 +85,7 @@ def dwconv2d_bwd(x, dz, w_khwc, *, stride=1, pad=-1, dil=(1, 1, 1, 1), group_siz
         d.dx = _p(dx)
         _run(lib, 'ledn_dwconv2d_bwd_data', x, d, work=_ops._TIMING is not None and (f'dwbwd_data{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(dz, dx, add), 2 * dz.numel() * KH * KW))
     if need_dw:
-        dw = torch.zeros_like(w_khwc)
+        dw = _ops.zeros_f32(tuple(w_khwc.shape), x.device)
         d.dw = _p(dw)
         _run(lib, 'ledn_dwconv2d_bwd_weight', x, d, work=_ops._TIMING is not None and (f'dwbwd_w{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(x, dz) , 2 * dz.numel() * KH * KW))
     return dx, dw
@@ -86,7 +100,7 @@ def sesp_pyramid_bwd(x, dy, w_b33n, dil, stride):
     d = _lib.PyrBwdDesc()
     gsum = torch.empty_like(dy)
     dx = torch.empty_like(x)
-    dw = torch.zeros_like(w_b33n)
+    dw = _ops.zeros_f32(tuple(w_b33n.shape), x.device)
     _check(lib, x, dy, w_b33n)
     d.x, d.dy, d.w, d.gsum, d.dx, d.dw = _p(x), _p(dy), _p(_f32(w_b33n)), _p(gsum), _p(dx), _p(dw)
     d.N, d.H, d.W, d.n, d.Ho, d.Wo, d.stride = N, H, W, n, dy.shape[1], dy.shape[2], stride
@@ -129,7 +143,7 @@ def window_attn_bwd(qkv, biasT, dout, heads, ws=8):
     Cc = C3 // 3
     padded = (H % ws != 0) or (W % ws != 0)
     dq32 = (torch.zeros if padded else torch.empty)((N, H, W, C3), dtype=torch.float32, device=qkv.device)
-    dbias = torch.zeros_like(biasT)
+    dbias = _ops.zeros_f32(tuple(biasT.shape), qkv.device)
     _check(lib, qkv, biasT, dout)
     nwin = N * ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
     _run(lib, 'ledn_window_attn_bwd', qkv, _p(qkv), _p(_f32(biasT)), _p(dout), _p(dq32), _p(dbias), N, H, W,
@@ -156,7 +170,7 @@ def mfaf_gate_bwd(x, r, xl, ctx, affines, dout, act=ACT_NONE):
     N, H, W, Cc = x.shape
     d = _lib.MfafBwdDesc()
     dx, dr, ds = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-    dctx = [torch.zeros_like(c) for c in ctx]
+    dctx = [_ops.zeros_f32(tuple(c.shape), c.device) if c.dtype == torch.float32 else torch.zeros_like(c) for c in ctx]
     keep = [x, r, xl, dout]
     d.x, d.r, d.xl, d.dout, d.dx, d.dr, d.ds = _p(x), _p(r), _p(xl), _p(dout), _p(dx), _p(dr), _p(ds)
     for k, c in enumerate(ctx):

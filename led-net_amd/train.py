@@ -44,6 +44,18 @@ class _Packs:
         _Packs.entries, _Packs.table, _Packs.frozen = {}, None, False
 
 
+class _Sinks:
+    """Gradient sinks: from its second step on the Trainer maps every live parameter to its view of
+    the flat gradient buffer (zeroed by the SGD kernel); the backward kernels of conv / BatchNorm /
+    PReLU then reduce straight into those views and hand autograd None, instead of returning a fresh
+    tensor that AccumulateGrad adds in (one fill + one add kernel per parameter per step)."""
+    map = {}
+
+    @staticmethod
+    def get(p):
+        return _Sinks.map.get(id(p)) if isinstance(p, nn.Parameter) else None
+
+
 def get_pack(w, mode, groups):
     if not isinstance(w, nn.Parameter):
         return ops.pack_conv_weights(w, mode, groups)      # derived weights (stem im2col form)
@@ -76,6 +88,7 @@ class ConvFn(Function):
                        out_dtype=out_dtype, w_bf16=wp)
         ctx.save_for_backward(x, w, xadd)
         ctx.cfg = (stride, pad, groups, b is not None)
+        ctx.sinks = (_Sinks.get(w), _Sinks.get(b))
         return z
 
     @staticmethod
@@ -93,9 +106,11 @@ class ConvFn(Function):
                 wp = get_pack(w, 1, groups)
             dx = ops.conv2d(dz, w, stride=stride, pad=pad, groups=groups, transposed=True,
                             out_hw=(x.shape[1], x.shape[2]), out_dtype=x.dtype, w_bf16=wp)
+        sw, sb = ctx.sinks
         dw, db = ops.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, pad=pad, groups=groups, xadd=xadd,
-                                  bias=has_b)
-        return (dx if ctx.needs_input_grad[0] else None, dw, db,
+                                  bias=has_b, dw_out=sw, db_out=sb)
+        return (dx if ctx.needs_input_grad[0] else None, None if sw is not None else dw,
+                None if sb is not None else db,
                 dx if (xadd is not None and ctx.needs_input_grad[3]) else None, None, None, None, None, None)
 
 
@@ -108,7 +123,7 @@ class BNActFn(Function):
         Cc = z.shape[-1]
         count = z.numel() // Cc
         if stats is None:
-            stats = torch.zeros((2, Cc), dtype=torch.float32, device=z.device)
+            stats = ops.zeros_f32((2, Cc), z.device)
             ops.channel_stats(z, stats=(stats[0], stats[1]))
         if _Env.sync_bn is not None:
             _Env.sync_bn(stats)
@@ -119,6 +134,7 @@ class BNActFn(Function):
                            out_dtype=out_dtype)
         ctx.save_for_backward(z, res, scale, shift, mean, invstd, slope)
         ctx.cfg = (act, res_mode, count)
+        ctx.sinks = (_Sinks.get(gamma), _Sinks.get(beta), _Sinks.get(slope))
         return y
 
     @staticmethod
@@ -128,7 +144,7 @@ class BNActFn(Function):
         dz, dres, dgamma, dbeta, dslope = T.bn_act_bwd(
             z, _c(dy), scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, slope=slope, res=res,
             res_mode=res_mode, count=count, want_dres=res is not None and ctx.needs_input_grad[4],
-            sync=_Env.sync_bn)
+            sync=_Env.sync_bn, sinks=ctx.sinks)
         return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None
 
 
@@ -265,7 +281,7 @@ class MfafTailFn(Function):
         for k, raw in enumerate(raws):
             Cc = raw.shape[-1]
             count = raw.numel() // Cc
-            stats = torch.zeros((2, Cc), dtype=torch.float32, device=raw.device)
+            stats = ops.zeros_f32((2, Cc), raw.device)
             ops.channel_stats(raw, stats=(stats[0], stats[1]))
             if _Env.sync_bn is not None:
                 _Env.sync_bn(stats)
@@ -280,6 +296,7 @@ class MfafTailFn(Function):
         out = ops.mfaf_gate(x, r, xl, [c1, c2, c3, xg], affs, act=act)
         ctx.save_for_backward(x, r, xl, c1, c2, c3, xg, *saved)
         ctx.act, ctx.counts = act, counts
+        ctx.sinks = [(_Sinks.get(gb[2 * k]), _Sinks.get(gb[2 * k + 1]), None) for k in range(5)]
         return out
 
     @staticmethod
@@ -294,7 +311,7 @@ class MfafTailFn(Function):
         for k in range(5):
             dz, _, dgamma, dbeta, _ = T.bn_act_bwd(raws[k], gys[k], scale=sv[4 * k], shift=sv[4 * k + 1],
                                                     mean=sv[4 * k + 2], invstd=sv[4 * k + 3],
-                                                    count=ctx.counts[k], sync=_Env.sync_bn)
+                                                    count=ctx.counts[k], sync=_Env.sync_bn, sinks=ctx.sinks[k])
             draws.append(dz)
             dgb += [dgamma, dbeta]
         return (dx, dr, *draws, None, None, *dgb)
@@ -321,7 +338,7 @@ class OhemFn(Function):
 # train-mode forward of the blocks (mirrors blocks.py; BatchNorm on batch statistics)
 # --------------------------------------------------------------------------- #
 def _stats(c, ref):
-    return torch.zeros((2, c), dtype=torch.float32, device=ref.device)
+    return ops.zeros_f32((2, c), ref.device)
 
 
 def relu(x):
@@ -527,7 +544,7 @@ class Trainer:
     large RCCL all-reduces over contiguous slices instead of one per tensor."""
 
     def __init__(self, model, cfg=None, world_size=1, lr=None, momentum=None, weight_decay=None,
-                 max_iters=None, power=0.9, eta_min=0.0, bucket_mb=2.0):
+                 max_iters=None, power=0.9, eta_min=0.0, bucket_mb=2.0, direct_grads=True):
         opt = dict((cfg or {}).get('optimizer', {}))
         self.model = model
         self.base_lr = lr if lr is not None else opt.get('lr', 0.01)
@@ -550,6 +567,9 @@ class Trainer:
             self.moms.append(self.flat_mom[off:off + k].view_as(p))
             off += k
         self.table = None
+        self.direct_grads = direct_grads     # backward kernels reduce into the flat gradient buffer
+        self._sink_map = {}
+        self._arena = ops.ZeroArena(dev)
         self._lr_dev = None
         self._graph = None
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
@@ -582,6 +602,31 @@ class Trainer:
         (device scalars; no host synchronisation)."""
         self.model.train()
         first = self.table is None
+        self._arena.reset()                  # one fill for every small zeroed scratch of the step
+        ops.set_zero_arena(self._arena)
+        _Sinks.map = self._sink_map
+        try:
+            return self._train_step(inputs, data_samples, first)
+        finally:
+            ops.set_zero_arena(None)
+            _Sinks.map = {}
+
+    def forward_backward(self, inputs, data_samples):
+        """forward + loss + backward only (gradients left in ``flat_grad``; no exchange, no SGD):
+        the first half of train_step, for tests and gradient inspection.  Needs one completed
+        train_step (the flat gradient views are attached there)."""
+        assert self.table is not None, 'run one train_step first'
+        self.model.train()
+        self._arena.reset()
+        ops.set_zero_arena(self._arena)
+        _Sinks.map = self._sink_map
+        try:
+            return self._forward_backward(inputs, data_samples, False)
+        finally:
+            ops.set_zero_arena(None)
+            _Sinks.map = {}
+
+    def _forward_backward(self, inputs, data_samples, first):
         if first:
             _Packs.reset()
             for p in self.params:
@@ -606,9 +651,15 @@ class Trainer:
                 v.copy_(p.grad)
             self._attach_grads()
             self.table = T.SgdTable(self.live, self.live_views, [self.moms[i] for i in idx])
+            if self.direct_grads:
+                self._sink_map = {id(p): v for p, v in zip(self.live, self.live_views)}
             if _Packs.entries:
                 _Packs.table = T.PackTable([(w, buf, k[1], k[2]) for k, (w, buf) in _Packs.entries.items()])
                 _Packs.frozen = True
+        return losses
+
+    def _train_step(self, inputs, data_samples, first):
+        losses = self._forward_backward(inputs, data_samples, first)
         if self.dist is not None:
             n = self.flat_grad.numel()
             for off in range(0, n, self.bucket_elems):

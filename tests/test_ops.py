@@ -83,6 +83,33 @@ def test_conv2d_dgrad_wgrad(be, cin, cout, k, stride, groups, hw):
     close(db, dz.sum((0, 2, 3)), 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize('n,cin,cout,k,stride,groups,hw', [
+    (4, 64, 16, 1, 1, 1, (16, 16)), (16, 16, 64, 1, 1, 1, (4, 4)), (3, 1, 64, 3, 1, 1, (40, 40)),
+    (2, 64, 2, 1, 1, 1, (48, 40)), (2, 3, 32, 3, 2, 1, (33, 31)), (2, 20, 12, 3, 1, 2, (17, 9)),
+    (1, 72, 80, 1, 1, 1, (37, 3))])
+def test_conv2d_wgrad_vector_paths(be, n, cin, cout, k, stride, groups, hw):
+    """conv_wgrad_direct_kernel (LDS-staged pixel chunks, workspace partial tiles summed by
+    finish_partials) and conv_wgrad_narrow_kernel at pixel counts that take the multi-workgroup
+    paths, with the producer's BatchNorm+ReLU folded in (in_scale/in_shift/in_act) and
+    accumulation into a caller-provided gradient buffer (dw_out)."""
+    from led_net_amd import ops
+    x = torch.randn(n, cin, *hw)
+    w = (torch.randn(cout, cin // groups, k, k) * 0.2).requires_grad_(True)
+    s_in, b_in = torch.rand(cin) + 0.5, torch.randn(cin) * 0.1
+    pad = k // 2
+    z = F.conv2d(F.relu(x * s_in.view(1, -1, 1, 1) + b_in.view(1, -1, 1, 1)), w, stride=stride, padding=pad,
+                 groups=groups)
+    dz = torch.randn_like(z)
+    z.backward(dz)
+    base = torch.randn_like(w.detach())
+    sink = D(base.clone())
+    dw, db = ops.conv2d_wgrad(nhwc(x), nhwc(dz), tuple(w.shape), stride=stride, pad=pad, groups=groups,
+                              in_scale=D(s_in), in_shift=D(b_in), in_act=ops.ACT_RELU, bias=True, dw_out=sink)
+    assert dw is sink
+    close(dw.cpu() - base, w.grad, 1e-4, 1e-4 * (n * hw[0] * hw[1]) ** 0.5)
+    close(db, dz.sum((0, 2, 3)), 1e-4, 1e-4 * (n * hw[0] * hw[1]) ** 0.5)
+
+
 def test_conv2d_bf16(be):
     from led_net_amd import ops
     x = torch.randn(1, 32, 8, 8)

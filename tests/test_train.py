@@ -210,3 +210,57 @@ def test_whole_train_step_vs_oracle(be):
     for k, v in sd.items():
         if 'running_' in k:
             close(new[k], v, 2e-3, 2e-4, k)
+
+
+def test_direct_gradient_sinks_match_autograd_accumulation(be):
+    """From the second step on conv / BatchNorm / PReLU backward kernels reduce straight into the
+    Trainer's flat gradient buffer (train._Sinks) and small zeroed scratch comes from one arena
+    fill.  At ONE model state, forward+backward through the sinks must give the gradients that the
+    autograd-accumulated path gives; the run-to-run noise floor of the latter (f32 atomics order ->
+    ReLU kinks, SEAM percentile) is measured with a second reference pass and bounds the check."""
+    import led_net_amd as L
+    torch.manual_seed(304)
+    cfg = L.load_config(os.path.join(os.path.dirname(__file__), 'data', 'lednet_test_config.py'))
+    cfg['model']['decode_head']['loss_decode'][0]['min_kept'] = 5000
+    cfg['model']['decode_head']['loss_decode'][1]['min_kept'] = 5000
+    model = L.MODELS.build(cfg['model'])
+    _randomize(model, 5)
+    model.to(_DEV[0])
+    g = torch.Generator().manual_seed(12)
+    img = torch.randint(0, 256, (2, 3, 320, 320), dtype=torch.uint8, generator=g)
+    lab = torch.randint(0, 2, (2, 1, 320, 320), dtype=torch.int64, generator=g)
+    lab[:, :, :4, :] = 255
+    samples = [L.SegDataSample(gt=D(lab[i])) for i in range(2)]
+    tr = L.Trainer(model, cfg, max_iters=100)
+    tr.train_step(D(img), samples)                        # attaches the flat gradient views / sinks
+    assert tr._sink_map and float(tr.flat_grad.abs().max()) == 0.0   # SGD re-zeroed the buffer
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    sinks = tr._sink_map
+
+    def grads(use_sinks):
+        model.load_state_dict(state)                      # running statistics move in every forward
+        tr.flat_grad.zero_()
+        tr._sink_map = sinks if use_sinks else {}
+        out = tr.forward_backward(D(img), samples)
+        return tr.flat_grad.detach().cpu().clone(), {k: float(v.reshape(-1)[0]) for k, v in out.items()}
+    g_ref, o_ref = grads(False)
+    g_ref2, _ = grads(False)
+    g_snk, o_snk = grads(True)
+    tr._sink_map = sinks
+    for k in o_ref:
+        assert abs(o_snk[k] - o_ref[k]) <= 1e-4 * abs(o_ref[k]) + 1e-5, (k, o_snk[k], o_ref[k])
+    rel, floor, off = [], [], 0
+    for p_ in tr.params:
+        n = p_.numel()
+        if any(p_ is q for q in tr.live):
+            a, b, c = g_snk[off:off + n], g_ref[off:off + n], g_ref2[off:off + n]
+            den = b.norm().item() + 1e-12
+            rel.append((a - b).norm().item() / den)
+            floor.append((c - b).norm().item() / den)
+        off += n
+    rel_s, floor_s = sorted(rel), sorted(floor)
+    med, worst = rel_s[len(rel_s) // 2], rel_s[-1]
+    fmed, fworst = floor_s[len(floor_s) // 2], floor_s[-1]
+    print(f'sinks vs autograd: median rel-L2 {med:.2e} worst {worst:.2e}; noise floor {fmed:.2e} / {fworst:.2e}')
+    # a missed or doubled accumulation is rel ~ 1 on that parameter
+    assert med <= max(1e-4, 5 * fmed) and worst <= max(1e-3, 5 * fworst), (med, worst, fmed, fworst)
