@@ -863,7 +863,7 @@ int getb_pool_bwd_impl(const void* dout, void* da, int N, int H, int W, int C, i
 // (sum of ds over every pixel that reads a cell) are accumulated in LDS per workgroup and
 // flushed with one global atomic per touched (cell, channel): the 1x1 "global" cell would
 // otherwise receive one same-address atomic per pixel.
-constexpr int MFAF_SEG = 64, MFAF_SLOTS = 18;
+constexpr int MFAF_SEG = 128, MFAF_SLOTS = 18;
 template <typename T, int V>
 __global__ void __launch_bounds__(256) mfaf_gate_bwd_kernel(ledn_mfafbwd_desc d) {
     __shared__ float s_ctx[4 * MFAF_SLOTS * 128];
@@ -885,22 +885,51 @@ __global__ void __launch_bounds__(256) mfaf_gate_bwd_kernel(ledn_mfafbwd_desc d)
         sx_first[k] = t > S - 1 ? S - 1 : t;
     }
     if (pslot < slots) {
-        for (int x = x0 + pslot; x < x1; x += slots) {
+        // every thread owns a CONTIGUOUS run of pixels: the context cell of each level changes
+        // rarely along the run, so its gate contribution is loaded once per cell and its ds sum is
+        // kept in registers and flushed to LDS once per cell (the first version issued 16 LDS
+        // atomics per pixel, most of them on the same address across the 16 pixel slots)
+        const int run = (x1 - x0 + slots - 1) / slots;
+        const int xa = x0 + pslot * run, xb = min(x1, xa + run);
+        int cur[4] = {-1, -1, -1, -1};
+        float cs[4][V], acc[4][V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int v = 0; v < V; ++v) cs[k][v] = acc[k][v] = 0.f;
+        float sc0[V], sh0[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            sc0[v] = d.scale[0][c + v];
+            sh0[v] = d.shift[0][c + v];
+        }
+        for (int x = xa; x < xb; ++x) {
             const long pix = ((long)n * d.H + y) * d.W + x;
             float s[V], t[V];
             ldv<V>(reinterpret_cast<const T*>(d.xl) + pix * d.C + c, t);
 #pragma unroll
-            for (int v = 0; v < V; ++v) s[v] = t[v] * d.scale[0][c + v] + d.shift[0][c + v];
-            int slot[4];
+            for (int v = 0; v < V; ++v) s[v] = t[v] * sc0[v] + sh0[v];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int S = d.ctx_size[k];
                 int sx = (int)((float)x * ((float)S / (float)d.W));
                 if (sx > S - 1) sx = S - 1;
-                slot[k] = sx - sx_first[k];
-                ldv<V>(d.ctx[k] + (((long)n * S + sy[k]) * S + sx) * d.C + c, t);
+                const int slot = sx - sx_first[k];
+                if (slot != cur[k]) {
+                    if (cur[k] >= 0) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) s[v] += t[v] * d.scale[k + 1][c + v] + d.shift[k + 1][c + v];
+                        for (int v = 0; v < V; ++v) {
+                            atomicAdd(&s_ctx[(k * MFAF_SLOTS + cur[k]) * d.C + c + v], acc[k][v]);
+                            acc[k][v] = 0.f;
+                        }
+                    }
+                    cur[k] = slot;
+                    ldv<V>(d.ctx[k] + (((long)n * S + sy[k]) * S + sx) * d.C + c, t);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) cs[k][v] = t[v] * d.scale[k + 1][c + v] + d.shift[k + 1][c + v];
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v) s[v] += cs[k][v];
             }
             float xv[V], rv[V], g[V], dxv[V], drv[V], dsv[V];
             ldv<V>(reinterpret_cast<const T*>(d.x) + pix * d.C + c, xv);
@@ -924,8 +953,14 @@ __global__ void __launch_bounds__(256) mfaf_gate_bwd_kernel(ledn_mfafbwd_desc d)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int v = 0; v < V; ++v) atomicAdd(&s_ctx[(k * MFAF_SLOTS + slot[k]) * d.C + c + v], dsv[v]);
+                for (int v = 0; v < V; ++v) acc[k][v] += dsv[v];
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (cur[k] >= 0) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) atomicAdd(&s_ctx[(k * MFAF_SLOTS + cur[k]) * d.C + c + v], acc[k][v]);
+            }
     }
     __syncthreads();
     for (int k = 0; k < 4; ++k) {
@@ -947,7 +982,7 @@ int mfaf_gate_bwd_impl(const ledn_mfafbwd_desc& d, hipStream_t s) {
     LEDN_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.C % 4 == 0 && d.C <= 128);
     for (int k = 0; k < 4; ++k) {
         LEDN_REQUIRE(d.ctx[k] && d.dctx[k] && d.ctx_size[k] > 0);
-        // cells touched by one 64-pixel segment must fit the LDS slots
+        // cells touched by one MFAF_SEG-pixel segment must fit the LDS slots
         const int seg = d.W < MFAF_SEG ? d.W : MFAF_SEG;
         LEDN_REQUIRE((long)seg * d.ctx_size[k] / d.W + 2 <= MFAF_SLOTS);
     }

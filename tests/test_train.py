@@ -244,11 +244,12 @@ def test_direct_gradient_sinks_match_autograd_accumulation(be):
         out = tr.forward_backward(D(img), samples)
         return tr.flat_grad.detach().cpu().clone(), {k: float(v.reshape(-1)[0]) for k, v in out.items()}
     g_ref, o_ref = grads(False)
-    g_ref2, _ = grads(False)
+    g_ref2, o_ref2 = grads(False)
     g_snk, o_snk = grads(True)
     tr._sink_map = sinks
     for k in o_ref:
-        assert abs(o_snk[k] - o_ref[k]) <= 1e-4 * abs(o_ref[k]) + 1e-5, (k, o_snk[k], o_ref[k])
+        tol = max(1e-4 * abs(o_ref[k]) + 1e-5, 5 * abs(o_ref2[k] - o_ref[k]))    # forward is the same code in all three
+        assert abs(o_snk[k] - o_ref[k]) <= tol, (k, o_snk[k], o_ref[k], o_ref2[k])
     rel, floor, off = [], [], 0
     for p_ in tr.params:
         n = p_.numel()
