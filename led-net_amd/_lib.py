@@ -174,14 +174,21 @@ class Library:
         v = self.cdll.ledn_abi_version()
         if v != 1:
             raise LednError(f'{path}: ABI version {v}, expected 1')
-        self._workspace = None
+        self._workspaces = {}
+        self._bound = None
 
-    def ensure_workspace(self, device, nfloats=32 << 20):
-        """attach a reusable scratch buffer (128 MiB) for two-stage reductions"""
-        if self._workspace is None or self._workspace.device != device:
-            import torch
-            self._workspace = torch.empty(nfloats, dtype=torch.float32, device=device)
-            self.call('ledn_set_workspace', self._workspace.data_ptr(), nfloats)
+    def ensure_workspace(self, device, slot=0, nfloats=32 << 20):
+        """bind the reusable scratch buffer (128 MiB) of two-stage reductions.  The scratch is
+        reused launch after launch in stream order, so every HIP stream that runs ledn kernels
+        concurrently (ops.Fork) has its own buffer: slot 0 = the main stream."""
+        key = (device, slot)
+        if self._bound != key:
+            ws = self._workspaces.get(key)
+            if ws is None:
+                import torch
+                ws = self._workspaces[key] = torch.empty(nfloats, dtype=torch.float32, device=device)
+            self.call('ledn_set_workspace', ws.data_ptr(), ws.numel())
+            self._bound = key
 
     def set_option(self, option, value):
         """launch-shape knob (include/ledn.h LEDN_OPT_*); value <= 0 restores the default"""

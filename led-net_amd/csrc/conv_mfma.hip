@@ -55,6 +55,7 @@ struct MfmaConvArgs {
     int N, H, W, Cin, Ho, Wo, Cout;
     int pad, in_act, act_out, res_mode;
     int tiles_h, tiles_w, tiles_per_block;
+    int y_f32;        // narrow heads (Cout < 8) only: y is float (the logits of LEDHead stay f32)
     float* part;      // optional workspace for the statistics: [gridDim.x * WM][2][Cout]
 };
 
@@ -399,7 +400,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                     } else if (q == 0) {   // narrow heads (Cout < 8): channels 4*lh + j, scalar stores
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (pix_ok && c4 + j < a.Cout) st(a.y + pix + c4 + j, v[j]);
+                            if (pix_ok && c4 + j < a.Cout) {
+                                if (a.y_f32) reinterpret_cast<float*>(a.y)[pix + c4 + j] = v[j];
+                                else st(a.y + pix + c4 + j, v[j]);
+                            }
                     }
                 }
                 if (vec) {
@@ -481,7 +485,9 @@ static int launch_shape(const MfmaConvArgs& a, hipStream_t s) {
 }
 
 bool conv_mfma_supported(const ledn_conv_desc& d) {
-    if (!d.w_bf16 || d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16) return false;
+    if (!d.w_bf16 || d.dtype_x != LEDN_BF16) return false;
+    // f32 output: narrow heads only (scalar-store epilogue), no residual (it would be f32 too)
+    if (d.dtype_y != LEDN_BF16 && !(d.dtype_y == LEDN_F32 && d.Cout < 8 && !d.res)) return false;
     if (d.dil != 1 || d.xadd) return false;
     if (d.act_out == LEDN_ACT_SIGMOID || (d.in_act != LEDN_ACT_NONE && d.in_act != LEDN_ACT_RELU)) return false;
     if (d.groups != 1 && !(d.KH == 1 && d.KW == 1)) return false;   // grouped 1x1: densified weight pack
@@ -500,6 +506,7 @@ int conv_mfma(const ledn_conv_desc& d, hipStream_t s) {
     a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.in_act = d.in_act; a.act_out = d.act_out; a.res_mode = d.res_mode;
     a.tiles_h = a.tiles_w = a.tiles_per_block = 0;
+    a.y_f32 = d.dtype_y == LEDN_F32;
     a.part = nullptr;
     if (!d.transposed) {
         a.pad = d.pad;

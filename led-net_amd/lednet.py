@@ -107,24 +107,34 @@ class LEDNet(Block):
         x2 = self.stem['1'](x1)                                                # C  @1/4
         y = self.stem['2'][1](self.stem['2'][0](x2), final_relu=True)
         y = self.stem['4'][1](self.stem['4'][0](y), final_relu=True)           # 2C @1/8
-        edge = self.seam.edge(y)
+        # The context branch (1/16 .. 1/64 resolution: small launch-bound kernels) and the SEAM edge map
+        # run on auxiliary streams between the bilateral fusion points (ops.Fork).
+        with ops.Fork(y, 2) as fe:
+            edge = self.seam.edge(y)
         # stage 3
+        with ops.Fork(y, 1) as f3:
+            x_c = self.getb1(self.layer3(y))                                   # 4C @1/16
+            comp = ops.bilinear(self.compression_1(x_c, in_act=ACT_RELU), out_size)
         x_s = self.layer3_(y)
-        x_c = self.getb1(self.layer3(y))                                       # 4C @1/16
-        comp = self.compression_1(x_c, in_act=ACT_RELU)
+        f3.join(x_c, comp)
         x_c_r = self.down_1(x_s, in_act=ACT_RELU, res=x_c, res_mode=RES_ADD, act_override=ACT_RELU)
-        x_s_r = self.aff1(x_s, ops.bilinear(comp, out_size), out_relu=True)     # relu(x_s) for stage 4
+        x_s_r = self.aff1(x_s, comp, out_relu=True)                             # relu(x_s) for stage 4
         # stage 4
-        x_c = self.layer4(x_c_r)                                               # 8C @1/32
+        with ops.Fork(x_c_r, 1) as f4:
+            x_c = self.layer4(x_c_r)                                           # 8C @1/32
+            comp = ops.bilinear(self.compression_2(x_c, in_act=ACT_RELU), out_size)
         x_s = self.layer4_(x_s_r)
-        comp = self.compression_2(x_c, in_act=ACT_RELU)
         d = self.down_2[0](x_s, in_act=ACT_RELU)
+        f4.join(x_c, comp)
         x_c_r = self.down_2[1](d, res=x_c, res_mode=RES_ADD, act_override=ACT_RELU)
-        x_s = self.aff2(x_s, ops.bilinear(comp, out_size))
+        x_s = self.aff2(x_s, comp)
+        fe.join(edge)
         x_s = self.seam.gate(edge, x_s)
         # stage 5
+        with ops.Fork(x_c_r, 1) as f5:
+            x_c = self.layer5(x_c_r)                                           # 16C @1/64
+            x_c = self.getb2(self.spp(x_c))
         x_s = self.layer5_(x_s, in_relu=True)                                  # 4C @1/8
-        x_c = self.layer5(x_c_r)                                               # 16C @1/64
-        x_c = self.getb2(self.spp(x_c))
+        f5.join(x_c)
         c5 = ops.bilinear(x_c, out_size, add=x_s)
         return tuple(to_nchw_view(t) for t in (c5, x1, x2))

@@ -121,8 +121,70 @@ def _nb(*ts):
     return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
+# ---- auxiliary HIP streams: LED-Net's two branches (and the SEAM edge map) are independent between
+# the bilateral fusion points; the context branch is a chain of small launch/latency-bound kernels
+# that leaves most CUs idle, so it runs concurrently with the HBM-bound spatial branch.  Inside a
+# hipGraph capture the fork/join pairs become parallel branches of the graph; autograd replays every
+# backward kernel on the stream of its forward, so the backward overlaps the same way.
+_AUX = {}            # (device, slot) -> torch.cuda.Stream
+MULTI_STREAM = True
+
+
+def _aux_stream(device, slot):
+    st = _AUX.get((device, slot))
+    if st is None:
+        st = _AUX[(device, slot)] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _slot(ref):
+    """workspace slot of the current stream of ref's device (0 = any stream that is not auxiliary)"""
+    if _AUX:
+        sid = torch.cuda.current_stream(ref.device).cuda_stream
+        for (dev, slot), st in _AUX.items():
+            if dev == ref.device and st.cuda_stream == sid:
+                return slot
+    return 0
+
+
+class Fork:
+    """``with Fork(ref, slot, *inputs) as f: ...`` runs the enclosed ops on auxiliary stream `slot`
+    (after everything already queued on the current stream); ``f.join(*outputs)`` makes the
+    current stream wait for it.  A no-op for host tensors (emulator) and when MULTI_STREAM is off."""
+
+    def __init__(self, ref, slot=1, *inputs):
+        self.on = bool(ref.is_cuda and MULTI_STREAM)
+        if self.on:
+            self.main = torch.cuda.current_stream(ref.device)
+            self.side = _aux_stream(ref.device, slot)
+            self.inputs = (ref,) + inputs
+            self.joined = False
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.main)
+            for t in self.inputs:            # caching allocator: these blocks are also in use on `side`
+                t.record_stream(self.side)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *outputs):
+        if self.on and not self.joined:
+            self.main.wait_stream(self.side)
+            for t in outputs:
+                if t is not None:
+                    t.record_stream(self.main)
+            self.joined = True
+
+
 def _run(lib, name, ref, *args, work=None):
-    lib.ensure_workspace(ref.device)
+    lib.ensure_workspace(ref.device, _slot(ref) if lib.is_hip else 0)
     stream = _stream(lib, ref)
     if _TIMING is not None and lib.is_hip:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

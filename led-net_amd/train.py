@@ -457,28 +457,38 @@ def lednet_forward_train(m, x, pre=None):
     x2 = conv_module(m.stem['1'], x1)
     y = basic_block(m.stem['2'][1], basic_block(m.stem['2'][0], x2), final_relu=True)
     y = basic_block(m.stem['4'][1], basic_block(m.stem['4'][0], y), final_relu=True)
-    with torch.no_grad():   # the binarised edge map is piecewise constant: no gradient (ddrnet_speed.py:290-338)
+    # context branch and SEAM edge map on auxiliary streams between the fusion points (ops.Fork);
+    # autograd runs each backward kernel on the stream of its forward
+    with ops.Fork(y, 2) as fe, torch.no_grad():
+        # the binarised edge map is piecewise constant: no gradient (ddrnet_speed.py:290-338)
         seg = conv_module(m.seam.conv_1, y.detach(), out_dtype=torch.float32)
         edge = ops.seam_edge(seg, m.seam.percentile, m.seam.fixed_threshold, 0.1)
     # stage 3
+    with ops.Fork(y, 1) as f3:
+        x_c = getb(m.getb1, cespb(m.layer3, y))
+        comp = BilinearFn.apply(conv_module(m.compression_1, relu(x_c)), None, out_size, None)
     x_s = cespb(m.layer3_, y)
-    x_c = getb(m.getb1, cespb(m.layer3, y))
-    comp = conv_module(m.compression_1, relu(x_c))
+    f3.join(x_c, comp)
     x_c = conv_module(m.down_1, relu(x_s), res=x_c, res_mode=RES_ADD)
-    x_s = mfaf(m.aff1, x_s, BilinearFn.apply(comp, None, out_size, None))
+    x_s = mfaf(m.aff1, x_s, comp)
     c3 = x_s
     # stage 4
-    x_c = cespb(m.layer4, relu(x_c))
+    with ops.Fork(x_c, 1) as f4:
+        x_c = cespb(m.layer4, relu(x_c))
+        comp = BilinearFn.apply(conv_module(m.compression_2, relu(x_c)), None, out_size, None)
     x_s = cespb(m.layer4_, relu(x_s))
-    comp = conv_module(m.compression_2, relu(x_c))
     d = conv_module(m.down_2[0], relu(x_s))
+    f4.join(x_c, comp)
     x_c = conv_module(m.down_2[1], d, res=x_c, res_mode=RES_ADD)
-    x_s = mfaf(m.aff2, x_s, BilinearFn.apply(comp, None, out_size, None))
+    x_s = mfaf(m.aff2, x_s, comp)
+    fe.join(edge)
     x_s = conv_module(m.seam.conv_2, edge, res=x_s, res_mode=RES_GATE, out_dtype=x_s.dtype)
     # stage 5
+    with ops.Fork(x_c, 1) as f5:
+        x_c = cespb(m.layer5, relu(x_c))
+        x_c = getb(m.getb2, conv_module(m.spp, x_c))
     x_s = sesp(m.layer5_, relu(x_s))
-    x_c = cespb(m.layer5, relu(x_c))
-    x_c = getb(m.getb2, conv_module(m.spp, x_c))
+    f5.join(x_c)
     c5 = BilinearFn.apply(x_c, x_s, out_size, None)
     return tuple(to_nchw_view(t) for t in (c3, c5, x1, x2))
 

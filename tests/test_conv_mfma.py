@@ -171,3 +171,23 @@ def test_mfma_epilogue_variants(be, cin, cout, k, epi):
         want, kw = z * res + res, dict(res=nhwc(res).bfloat16(), res_mode=ops.RES_GATE)
     got = ops.conv2d(nhwc(x).bfloat16(), D(w), pad=pad, w_bf16=ops.pack_conv_weights(D(w), 0), **kw)
     torch.testing.assert_close(nchw(got), want, rtol=2e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize('cin,cout,k', [(32, 2, 3), (64, 2, 1), (32, 6, 3)])
+def test_mfma_narrow_head_f32_output(be, cin, cout, k):
+    """LEDHead's head_x1/head_x2 (BN-ReLU-conv3x3(32->2)-BN-ReLU, led_head.py:84-99) keep f32
+    logits: the MFMA kernel's narrow-head epilogue stores float directly (prologue + epilogue)."""
+    from led_net_amd import ops
+    pad = k // 2
+    x = r16(torch.randn(2, cin, 13, 45))
+    w = r16(torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5)
+    s_in, b_in = torch.rand(cin) + 0.5, torch.randn(cin) * 0.1
+    sc, sh = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2
+    xin = r16(F.relu(x * s_in.view(1, -1, 1, 1) + b_in.view(1, -1, 1, 1)))
+    want = F.relu(F.conv2d(xin, w, padding=pad) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    d = ops._lib.ConvDesc()
+    got = ops.conv2d(nhwc(x).bfloat16(), D(w), pad=pad, in_scale=D(s_in), in_shift=D(b_in), in_act=ops.ACT_RELU,
+                     out_scale=D(sc), out_shift=D(sh), act=ops.ACT_RELU, out_dtype=torch.float32,
+                     w_bf16=ops.pack_conv_weights(D(w), 0))
+    assert got.dtype == torch.float32
+    torch.testing.assert_close(nchw(got), want, rtol=1e-3, atol=2e-3)   # f32 store: no output rounding
