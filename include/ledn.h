@@ -161,6 +161,23 @@ typedef struct {
 } ledn_dw_desc;
 int ledn_dwconv2d(const ledn_dw_desc* d, void* stream);
 
+/* Layout bridge between PyTorch's depthwise filters [n_k][1][KH][KW] (the state_dict layout of
+ * CDilated.conv.weight, nn_layers/espnet_utils.py:120-142, and SeparableConvBN's depthwise,
+ * UNetFormer_GETB.py:59-65) and the channel-last filter banks the depthwise kernels read:
+ *   stacked = 0:  packed[tap][c0_k + c]      (filters concatenated along channels, ledn_dwconv2d)
+ *   stacked = 1:  packed[k][tap][c]          (one bank per branch, ledn_sesp_pyramid; all n_k equal)
+ * ledn_dw_pack fills `packed` from w[k]; ledn_dw_unpack_grad ADDS the gradient of `packed` to
+ * dw[k] in PyTorch's layout (the trainer's gradient buffer).  One launch each instead of a
+ * select/permute/stack chain per filter. */
+typedef struct {
+    const float* w[8];
+    float* dw[8];
+    int n[8];
+    int nsrc, taps, stacked;
+} ledn_dwpack_desc;
+int ledn_dw_pack(const ledn_dwpack_desc* d, float* packed, void* stream);
+int ledn_dw_unpack_grad(const ledn_dwpack_desc* d, const float* dpacked, void* stream);
+
 /* SESP split/transform stage 1 with hierarchical feature fusion:
  *   y[..., b*n + c] = sum_{b' <= b} dw3x3_{dil[b'], stride}(x)[..., c]     b = 0..3
  * x [N,H,W,n], w [4][3][3][n], y [N,Ho,Wo,4n].

@@ -50,6 +50,10 @@ class DwDesc(C.Structure):
                 ('dtype_x', i32), ('dtype_y', i32)]
 
 
+class DwPackDesc(C.Structure):
+    _fields_ = [('w', fp * 8), ('dw', fp * 8), ('n', i32 * 8), ('nsrc', i32), ('taps', i32), ('stacked', i32)]
+
+
 class PyrDesc(C.Structure):
     _fields_ = [('x', vp), ('w', fp), ('y', vp),
                 ('N', i32), ('H', i32), ('W', i32), ('n', i32), ('Ho', i32), ('Wo', i32), ('stride', i32),
@@ -136,6 +140,8 @@ _PROTOS = {
     'ledn_pack_conv_weights': ([fp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_conv2d_wgrad': ([C.POINTER(WgradDesc), vp], i32),
     'ledn_dwconv2d': ([C.POINTER(DwDesc), vp], i32),
+    'ledn_dw_pack': ([C.POINTER(DwPackDesc), fp, vp], i32),
+    'ledn_dw_unpack_grad': ([C.POINTER(DwPackDesc), fp, vp], i32),
     'ledn_sesp_pyramid': ([C.POINTER(PyrDesc), vp], i32),
     'ledn_channel_stats': ([vp, vp, i64, i32, i32, fp, fp, vp], i32),
     'ledn_bn_finalize': ([fp, fp, C.c_double, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, fp, fp, i32, vp], i32),

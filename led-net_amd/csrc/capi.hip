@@ -16,6 +16,8 @@ int pack_conv_weights_impl(const float* w, void* out, int Cout, int Cin, int KH,
 int wgrad_validate(const ledn_wgrad_desc& d);
 int conv_wgrad_direct(const ledn_wgrad_desc& d, hipStream_t s);
 int dwconv_impl(const ledn_dw_desc& d, hipStream_t s);
+int dw_pack_impl(const ledn_dwpack_desc& d, float* packed, hipStream_t s);
+int dw_unpack_grad_impl(const ledn_dwpack_desc& d, const float* dpacked, hipStream_t s);
 int sesp_pyramid_impl(const ledn_pyr_desc& d, hipStream_t s);
 int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
                        float* sqsum, hipStream_t s);
@@ -134,6 +136,12 @@ int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream) {
 }
 
 int ledn_dwconv2d(const ledn_dw_desc* d, void* stream) { return d ? dwconv_impl(*d, S(stream)) : LEDN_EINVAL; }
+int ledn_dw_pack(const ledn_dwpack_desc* d, float* packed, void* stream) {
+    return d ? dw_pack_impl(*d, packed, S(stream)) : LEDN_EINVAL;
+}
+int ledn_dw_unpack_grad(const ledn_dwpack_desc* d, const float* dpacked, void* stream) {
+    return d ? dw_unpack_grad_impl(*d, dpacked, S(stream)) : LEDN_EINVAL;
+}
 int ledn_sesp_pyramid(const ledn_pyr_desc* d, void* stream) {
     return d ? sesp_pyramid_impl(*d, S(stream)) : LEDN_EINVAL;
 }

@@ -379,4 +379,43 @@ int sesp_pyramid_impl(const ledn_pyr_desc& d, hipStream_t s) {
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------
+// depthwise filter layout bridge (see include/ledn.h: ledn_dwpack_desc)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dw_repack_kernel(ledn_dwpack_desc d, float* packed, const float* dpacked,
+                                                        int ctot) {
+    const int k = blockIdx.y;
+    const int n = d.n[k];
+    int c0 = 0;
+    if (!d.stacked)
+        for (int j = 0; j < k; ++j) c0 += d.n[j];
+    const int total = n * d.taps;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i / d.taps, t = i % d.taps;      // i = PyTorch's linear index [c][0][tap]
+        const long pi = d.stacked ? ((long)k * d.taps + t) * n + c : (long)t * ctot + c0 + c;
+        if (dpacked) d.dw[k][i] += dpacked[pi];
+        else packed[pi] = d.w[k][i];
+    }
+}
+
+static int dw_repack(const ledn_dwpack_desc& d, float* packed, const float* dpacked, hipStream_t s) {
+    LEDN_REQUIRE(d.nsrc > 0 && d.nsrc <= 8 && d.taps > 0 && (packed != nullptr) != (dpacked != nullptr));
+    int ctot = 0, nmax = 0;
+    for (int k = 0; k < d.nsrc; ++k) {
+        LEDN_REQUIRE(d.n[k] > 0 && (dpacked ? d.dw[k] != nullptr : d.w[k] != nullptr));
+        LEDN_REQUIRE(!d.stacked || d.n[k] == d.n[0]);
+        ctot += d.n[k];
+        if (d.n[k] > nmax) nmax = d.n[k];
+    }
+    long bx = cdiv((long)nmax * d.taps, 256);
+    if (bx > 64) bx = 64;
+    LEDN_LAUNCH(dw_repack_kernel, dim3((unsigned)bx, (unsigned)d.nsrc), dim3(256), 0, s, d, packed, dpacked, ctot);
+    return check_launch();
+}
+
+int dw_pack_impl(const ledn_dwpack_desc& d, float* packed, hipStream_t s) { return dw_repack(d, packed, nullptr, s); }
+int dw_unpack_grad_impl(const ledn_dwpack_desc& d, const float* dpacked, hipStream_t s) {
+    return dw_repack(d, nullptr, dpacked, s);
+}
+
 }  // namespace ledn

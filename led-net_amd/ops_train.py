@@ -91,6 +91,50 @@ def dwconv2d_bwd(x, dz, w_khwc, *, stride=1, pad=-1, dil=(1, 1, 1, 1), group_siz
     return dx, dw
 
 
+def _dwpack_desc(lib, weights, stacked, sinks=None):
+    d = _lib.DwPackDesc()
+    if not 0 < len(weights) <= 8:
+        raise LednError('dw pack: 1..8 filters')
+    KH, KW = weights[0].shape[2:]
+    for k, w in enumerate(weights):
+        if w.dim() != 4 or w.shape[1] != 1 or tuple(w.shape[2:]) != (KH, KW) or w.dtype != torch.float32:
+            raise LednError('dw pack: depthwise filters [n,1,KH,KW] f32 of one kernel size expected')
+        if stacked and w.shape[0] != weights[0].shape[0]:
+            raise LednError('dw pack: stacked banks need equal channel counts')
+        _check(lib, w)
+        d.w[k], d.n[k] = w.data_ptr(), w.shape[0]
+        if sinks is not None:
+            g = sinks[k]
+            if g.shape != w.shape or g.dtype != torch.float32:
+                raise LednError('dw pack: gradient sink shape/dtype mismatch')
+            _check(lib, g)
+            d.dw[k] = g.data_ptr()
+    d.nsrc, d.taps, d.stacked = len(weights), KH * KW, int(stacked)
+    return d, KH, KW
+
+
+def dw_pack(weights, stacked):
+    """[n_k,1,KH,KW] depthwise filters -> [KH,KW,sum n] (stacked=False) or [K,KH,KW,n] (stacked=True)."""
+    lib = _lib.get_lib()
+    d, KH, KW = _dwpack_desc(lib, weights, stacked)
+    n0 = weights[0].shape[0]
+    shape = (len(weights), KH, KW, n0) if stacked else (KH, KW, sum(w.shape[0] for w in weights))
+    out = torch.empty(shape, dtype=torch.float32, device=weights[0].device)
+    _run(lib, 'ledn_dw_pack', out, d, _p(out), work=_ops._TIMING is not None and (f'dwpack {shape}', 8 * out.numel(), 0))
+    return out
+
+
+def dw_unpack_grad(weights, sinks, dpacked, stacked):
+    """sinks[k] ([n_k,1,KH,KW] f32) += the gradient of the packed bank, in PyTorch's layout."""
+    lib = _lib.get_lib()
+    d, KH, KW = _dwpack_desc(lib, weights, stacked, sinks)
+    if dpacked.dtype != torch.float32 or dpacked.numel() != sum(w.numel() for w in weights):
+        raise LednError('dw_unpack_grad: packed gradient size/dtype mismatch')
+    _check(lib, dpacked)
+    _run(lib, 'ledn_dw_unpack_grad', dpacked, d, _p(dpacked),
+         work=_ops._TIMING is not None and (f'dwunpack {tuple(dpacked.shape)}', 12 * dpacked.numel(), 0))
+
+
 def sesp_pyramid_bwd(x, dy, w_b33n, dil, stride):
     """-> (dx [N,H,W,n], dw [4,3,3,n])."""
     lib = _lib.get_lib()

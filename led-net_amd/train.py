@@ -187,6 +187,34 @@ class DwFn(Function):
         return dx, dw, None, None, None, None, None, None
 
 
+class DwPackFn(Function):
+    """Depthwise filters in PyTorch's [n,1,KH,KW] layout -> the channel-last bank the depthwise
+    kernels read (one launch); backward adds the bank's gradient straight into the trainer's
+    gradient views (one launch) or, without sinks, hands autograd per-filter views of it."""
+
+    @staticmethod
+    def forward(ctx, stacked, *weights):
+        ctx.stacked = stacked
+        ctx.save_for_backward(*weights)
+        ctx.sinks = [_Sinks.get(w) for w in weights]
+        return T.dw_pack([w.detach() for w in weights], stacked)
+
+    @staticmethod
+    def backward(ctx, dpacked):
+        weights = ctx.saved_tensors
+        dpacked = _c(dpacked)
+        if all(s is not None for s in ctx.sinks):
+            T.dw_unpack_grad(weights, ctx.sinks, dpacked, ctx.stacked)
+            return (None,) + (None,) * len(weights)
+        grads, c0 = [], 0
+        for k, w in enumerate(weights):
+            n = w.shape[0]
+            g = dpacked[k] if ctx.stacked else dpacked[:, :, c0:c0 + n]
+            grads.append(g.permute(2, 0, 1).unsqueeze(1))
+            c0 += n
+        return (None, *grads)
+
+
 class PyrFn(Function):
     @staticmethod
     def forward(ctx, x, w, dil, stride):
@@ -384,9 +412,9 @@ def basic_block(m, x, final_relu=False):
 
 def sesp(m, x):
     o1 = conv_bn_act(x, m.proj_1x1.conv, m.proj_1x1.bn, ACT_PRELU, slope=m.proj_1x1.act.weight)
-    w1 = torch.stack([d.conv.weight[:, 0].permute(1, 2, 0) for d in m.spp_dw]).contiguous()
+    w1 = DwPackFn.apply(True, *[d.conv.weight for d in m.spp_dw])
     p = PyrFn.apply(o1, w1, m.dil, m.stride)
-    w2 = torch.cat([d.conv.weight[:, 0].permute(1, 2, 0) for d in m.spp_dw_v2], dim=2).contiguous()
+    w2 = DwPackFn.apply(False, *[d.conv.weight for d in m.spp_dw_v2])
     st = _stats(m.nOut, x)
     z = DwFn.apply(p, w2, 1, -1, [d + 1 for d in m.dil], m.n, False, st)
     cat = bn_act(z, m.br_after_cat.bn, ACT_PRELU, slope=m.br_after_cat.act.weight, stats=st)
@@ -407,7 +435,7 @@ def getb(m, x):
     qkv = ConvFn.apply(n1, a.qkv[0].weight, None, None, 1, 0, 1, None, None)
     att = WindowAttnFn.apply(qkv, a.bias_t(), m.heads, m.ws)
     mix = GetbPoolFn.apply(att, n1, m.ws)
-    wdw = a.proj[0].weight[:, 0].permute(1, 2, 0).contiguous()
+    wdw = DwPackFn.apply(False, a.proj[0].weight)
     st = _stats(m.dim, x)
     z = DwFn.apply(mix, wdw, 1, (m.ws - 1) // 2, [1, 1, 1, 1], m.dim, True, st)
     pj = bn_act(z, a.proj[1], stats=st)
