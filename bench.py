@@ -149,6 +149,8 @@ def main():
     ap.add_argument('--width', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--trace-only', action='store_true',
+                    help='stop after the timed region (for rocprofv3 timeline traces: no instrumented eager pass, no JSON)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -218,6 +220,10 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    if args.trace_only:
+        if rank == 0:
+            print(f'[bench] trace-only: {bs * world * args.steps / dt:.1f} images/s', file=sys.stderr)
+        return
     if graphed:
         # per-kernel HIP-event timing needs individual launches: instrumented eager pass of
         # the same step right after the timed (graph-replay) region

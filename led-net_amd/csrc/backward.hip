@@ -60,7 +60,7 @@ __device__ __forceinline__ void bn_g(const ledn_bnbwd_desc& d, const BnParams<V>
 
 template <typename TZ, typename TY, int V>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(ledn_bnbwd_desc d, float* part) {
-    __shared__ float s_part[3][256 * 4];
+    __shared__ float s_part[3][256 * (V > 4 ? V : 4)];
     const int cvn = d.C / V;
     const int rows = 256 / cvn;
     const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
@@ -151,7 +151,9 @@ static int bnbwd_validate(const ledn_bnbwd_desc& d, bool apply) {
 #define LEDN_BNB_DISPATCH(KERNEL, ...)                                                                   \
     do {                                                                                                 \
         const bool v4 = d.C % 4 == 0;                                                                    \
-        if (d.dtype_z == LEDN_F32 && d.dtype_y == LEDN_F32) {                                            \
+        if (d.dtype_z == LEDN_BF16 && d.dtype_y == LEDN_BF16 && d.C % 8 == 0) {   /* 16 B per lane */    \
+            LEDN_LAUNCH((KERNEL<bf16_t, bf16_t, 8>), grid, dim3(256), 0, s, __VA_ARGS__);                \
+        } else if (d.dtype_z == LEDN_F32 && d.dtype_y == LEDN_F32) {                                     \
             if (v4) LEDN_LAUNCH((KERNEL<float, float, 4>), grid, dim3(256), 0, s, __VA_ARGS__);          \
             else LEDN_LAUNCH((KERNEL<float, float, 1>), grid, dim3(256), 0, s, __VA_ARGS__);             \
         } else if (d.dtype_z == LEDN_BF16 && d.dtype_y == LEDN_BF16) {                                   \
@@ -167,7 +169,7 @@ static int bnbwd_validate(const ledn_bnbwd_desc& d, bool apply) {
     } while (0)
 
 static long bn_rows(const ledn_bnbwd_desc& d) {
-    const int V = d.C % 4 == 0 ? 4 : 1;
+    const int V = (d.dtype_z == LEDN_BF16 && d.dtype_y == LEDN_BF16 && d.C % 8 == 0) ? 8 : (d.C % 4 == 0 ? 4 : 1);
     return 256 / (d.C / V);
 }
 

@@ -62,15 +62,56 @@ __device__ __forceinline__ void st4(bf16_t* p, const float* v) {
     o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
     *reinterpret_cast<uint2*>(p) = o;
 }
+// 8-element access: 16 B per lane for bf16 (the width the HBM-bound elementwise kernels want)
+__device__ __forceinline__ void ld8(const float* p, float* o) {
+    ld4(p, o);
+    ld4(p + 4, o + 4);
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float* o) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ void st8(float* p, const float* v) {
+    st4(p, v);
+    st4(p + 4, v + 4);
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float* v) {
+    uint4 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+    o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = o;
+}
+// 2-element access (2-channel logits: one 8-byte / 4-byte access per pixel)
+__device__ __forceinline__ void ld2(const float* p, float* o) {
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    o[0] = v.x; o[1] = v.y;
+}
+__device__ __forceinline__ void ld2(const bf16_t* p, float* o) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(p);
+    o[0] = __uint_as_float(v << 16); o[1] = __uint_as_float(v & 0xffff0000u);
+}
+__device__ __forceinline__ void st2(float* p, const float* v) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+__device__ __forceinline__ void st2(bf16_t* p, const float* v) {
+    *reinterpret_cast<unsigned*>(p) = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+}
 template <int V, typename T> __device__ __forceinline__ void ldv(const T* p, float* o) {
-    if constexpr (V == 4) ld4(p, o);
+    if constexpr (V == 8) ld8(p, o);
+    else if constexpr (V == 2) ld2(p, o);
+    else if constexpr (V == 4) ld4(p, o);
     else {
 #pragma unroll
         for (int i = 0; i < V; ++i) o[i] = ld(p + i);
     }
 }
 template <int V, typename T> __device__ __forceinline__ void stv(T* p, const float* v) {
-    if constexpr (V == 4) st4(p, v);
+    if constexpr (V == 8) st8(p, v);
+    else if constexpr (V == 2) st2(p, v);
+    else if constexpr (V == 4) st4(p, v);
     else {
 #pragma unroll
         for (int i = 0; i < V; ++i) st(p + i, v[i]);

@@ -9,7 +9,7 @@ namespace ledn {
 template <typename T, int V>
 __global__ void __launch_bounds__(256) channel_stats_kernel(const T* x, const T* xadd, long P, int C,
                                                             float* sum, float* sqsum, float* part) {
-    __shared__ float s_part[2][256 * 4];
+    __shared__ float s_part[2][256 * (V > 4 ? V : 4)];
     const int cvn = C / V;
     const int rows = 256 / cvn;
     const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
@@ -109,7 +109,7 @@ int finish_partials(const float* part, int nblk, int C, int nout, float* o0, flo
 int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
                        float* sqsum, hipStream_t s) {
     LEDN_REQUIRE(x && sum && P > 0 && C > 0);
-    const int V = (C % 4 == 0) ? 4 : 1;
+    const int V = (dtype == LEDN_BF16 && C % 8 == 0) ? 8 : ((C % 4 == 0) ? 4 : 1);   // bf16: 16 B per lane
     LEDN_REQUIRE(C / V <= 256);
     long nb = cdiv(P, (256 / (C / V)) * 8);
     float* part = nullptr;
@@ -119,7 +119,10 @@ int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int 
     const dim3 grid((unsigned)nb);
 #define LEDN_CS(T)                                                                              \
     do {                                                                                        \
-        if (V == 4)                                                                             \
+        if (V == 8)                                                                             \
+            LEDN_LAUNCH((channel_stats_kernel<T, 8>), grid, dim3(256), 0, s, (const T*)x,       \
+                        (const T*)xadd, (long)P, C, sum, sqsum, part);                      \
+        else if (V == 4)                                                                        \
             LEDN_LAUNCH((channel_stats_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x,       \
                         (const T*)xadd, (long)P, C, sum, sqsum, part);                      \
         else                                                                                    \
@@ -203,8 +206,10 @@ int affine_act_impl(const ledn_affine_desc& d, hipStream_t s) {
     LEDN_REQUIRE(d.res_mode == LEDN_RES_NONE || d.res != nullptr);
     LEDN_REQUIRE(d.act != LEDN_ACT_PRELU || d.slope != nullptr);
     const bool v4 = d.C % 4 == 0;
-    LEDN_REQUIRE((v4 ? d.C / 4 : d.C) <= 256);
-    long nb = cdiv(d.P, (256 / (v4 ? d.C / 4 : d.C)) * 4);
+    const bool v8 = d.C % 8 == 0 && d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_BF16;   // 16 B per lane
+    const int cvn = v8 ? d.C / 8 : (v4 ? d.C / 4 : d.C);
+    LEDN_REQUIRE(cvn <= 256);
+    long nb = cdiv(d.P, (256 / cvn) * 4);
     if (nb > 4096) nb = 4096;
     const dim3 grid((unsigned)nb);
 #define LEDN_AF(TX, TY)                                                                  \
@@ -212,7 +217,8 @@ int affine_act_impl(const ledn_affine_desc& d, hipStream_t s) {
         if (v4) LEDN_LAUNCH((affine_act_kernel<TX, TY, 4>), grid, dim3(256), 0, s, d);   \
         else LEDN_LAUNCH((affine_act_kernel<TX, TY, 1>), grid, dim3(256), 0, s, d);      \
     } while (0)
-    if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_F32) LEDN_AF(float, float);
+    if (v8) LEDN_LAUNCH((affine_act_kernel<bf16_t, bf16_t, 8>), grid, dim3(256), 0, s, d);
+    else if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_F32) LEDN_AF(float, float);
     else if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_BF16) LEDN_AF(bf16_t, bf16_t);
     else if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_F32) LEDN_AF(bf16_t, float);
     else if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_BF16) LEDN_AF(float, bf16_t);

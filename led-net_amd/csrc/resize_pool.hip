@@ -113,12 +113,13 @@ int bilinear_impl(const ledn_resize_desc& d, hipStream_t s) {
         return check_launch();
     }
     LEDN_REQUIRE(d.argmax == nullptr);
-    const bool v4 = d.C % 4 == 0;
-    const long total = (long)d.N * d.Ho * d.Wo * (v4 ? d.C / 4 : d.C);
+    const bool v4 = d.C % 4 == 0, v2 = d.C % 2 == 0;    // v2: the 2-class logit pyramid (one access per pixel)
+    const long total = (long)d.N * d.Ho * d.Wo * (v4 ? d.C / 4 : (v2 ? d.C / 2 : d.C));
     const dim3 grid((unsigned)cdiv(total, 256));
 #define LEDN_BL(TX, TY)                                                                    \
     do {                                                                                   \
         if (v4) LEDN_LAUNCH((bilinear_nhwc_kernel<TX, TY, 4>), grid, dim3(256), 0, s, d);  \
+        else if (v2) LEDN_LAUNCH((bilinear_nhwc_kernel<TX, TY, 2>), grid, dim3(256), 0, s, d);  \
         else LEDN_LAUNCH((bilinear_nhwc_kernel<TX, TY, 1>), grid, dim3(256), 0, s, d);     \
     } while (0)
     if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_F32) LEDN_BL(float, float);

@@ -110,6 +110,32 @@ def test_conv2d_wgrad_vector_paths(be, n, cin, cout, k, stride, groups, hw):
     close(db, dz.sum((0, 2, 3)), 1e-4, 1e-4 * (n * hw[0] * hw[1]) ** 0.5)
 
 
+@pytest.mark.parametrize('cin,cout,k,transposed,dt', [
+    (32, 2, 3, True, torch.bfloat16), (32, 2, 3, True, torch.float32), (64, 1, 3, True, torch.float32),
+    (64, 2, 1, True, torch.bfloat16), (3, 32, 3, False, torch.float32), (2, 64, 1, False, torch.bfloat16)])
+def test_conv2d_narrow_input_kernel(be, cin, cout, k, transposed, dt):
+    """conv_narrowin_kernel: <= 4 channels in, wide out, stride 1, plain epilogue -- the data
+    gradient of LEDHead's 32->2 heads (transposed: dz [.,2] -> dx [.,32]) and plain narrow convs."""
+    from led_net_amd import ops
+    pad = k // 2
+    w = torch.randn(cout, cin, k, k) * 0.2
+    if transposed:
+        dz = torch.randn(2, cout, 19, 23)
+        if dt == torch.bfloat16:
+            dz = dz.bfloat16().float()
+        want = torch.nn.grad.conv2d_input((2, cin, 19, 23), w, dz, padding=pad)
+        got = ops.conv2d(nhwc(dz).to(dt), D(w), pad=pad, transposed=True, out_hw=(19, 23))
+    else:
+        x = torch.randn(2, cin, 19, 23)
+        if dt == torch.bfloat16:
+            x = x.bfloat16().float()
+        want = F.conv2d(x, w, padding=pad)
+        got = ops.conv2d(nhwc(x).to(dt), D(w), pad=pad)
+    assert got.dtype == dt
+    tol = 2e-2 if dt == torch.bfloat16 else 1e-4
+    close(nchw(got.float()), want, tol, tol)
+
+
 def test_conv2d_bf16(be):
     from led_net_amd import ops
     x = torch.randn(1, 32, 8, 8)

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Timeline analysis of a rocprofv3 --kernel-trace CSV of bench.py (graph replay): for the last
+timed steps, wall time per step, time with 0 / 1 / >=2 kernels in flight, and the kernels that
+own the most EXCLUSIVE time (nothing else running): what to optimise once streams overlap.
+usage: python tools/trace_timeline.py <kernel_trace.csv> [launches_per_step]"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def base(k):
+    k = re.sub(r'^void\s+', '', k)
+    depth, out = 0, []
+    for ch in k:
+        if ch in '<(':
+            depth += 1
+        elif ch in '>)':
+            depth -= 1
+        elif depth == 0:
+            out.append(ch)
+    return ''.join(out).strip().split('::')[-1]
+
+
+rows = []
+with open(sys.argv[1], newline='') as fh:
+    for r in csv.DictReader(fh):
+        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), base(r['Kernel_Name'])))
+rows.sort()
+# steps are delimited by the single sgd_step_kernel launch of each step
+ends = [i for i, r in enumerate(rows) if r[2] == 'sgd_kernel']
+assert len(ends) >= 4, 'run bench.py --trace-only --mode train (steps are delimited by sgd_kernel)'
+lo, hi = ends[-4] + 1, ends[-1] + 1          # the last three steps (graph replays of the timed region)
+seg = rows[lo:hi]
+nsteps = 3
+t0, t1 = seg[0][0], max(r[1] for r in seg)
+ev = []
+for s, e, k in seg:
+    ev.append((s, 1, k))
+    ev.append((e, -1, k))
+ev.sort()
+active = defaultdict(int)
+n = 0
+last = t0
+idle = one = multi = 0
+excl = defaultdict(float)
+gap_after = defaultdict(float)
+prev_end_kernel = None
+for t, d, k in ev:
+    dt = t - last
+    if n == 0:
+        idle += dt
+        if prev_end_kernel:
+            gap_after[prev_end_kernel] += dt
+    elif n == 1:
+        one += dt
+        excl[[kk for kk, c in active.items() if c > 0][0]] += dt
+    else:
+        multi += dt
+    last = t
+    n += d
+    active[k] += d
+    if d < 0:
+        prev_end_kernel = k
+wall = (t1 - t0) / nsteps / 1e6
+print(f'steps analysed: {nsteps}, kernels/step: {len(seg) / nsteps:.0f}, wall {wall:.3f} ms/step')
+print(f'idle {idle / nsteps / 1e6:.3f} ms  one-kernel {one / nsteps / 1e6:.3f} ms  overlapped {multi / nsteps / 1e6:.3f} ms')
+tot = defaultdict(float)
+cnt = defaultdict(int)
+for s, e, k in seg:
+    tot[k] += e - s
+    cnt[k] += 1
+print('--- exclusive time (ms/step), total duration, launches/step')
+for k, v in sorted(excl.items(), key=lambda kv: -kv[1])[:28]:
+    print(f'{v / nsteps / 1e6:8.3f}  {tot[k] / nsteps / 1e6:8.3f}  x{cnt[k] / nsteps:6.1f}  {k}')
+print('--- idle gaps following a kernel (ms/step)')
+for k, v in sorted(gap_after.items(), key=lambda kv: -kv[1])[:10]:
+    print(f'{v / nsteps / 1e6:8.3f}  x{cnt[k] / nsteps:6.1f}  {k}')
