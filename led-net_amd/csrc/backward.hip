@@ -32,31 +32,48 @@ __device__ __forceinline__ BnParams<V> bn_params(const ledn_bnbwd_desc& d, int c
     return p;
 }
 
-template <typename TZ, typename TY, int V>
-__device__ __forceinline__ void bn_g(const ledn_bnbwd_desc& d, const BnParams<V>& p, long off, float* gv,
-                                     float* xh, float* gres, float* dsl) {
+// raw operands of one (pixel, channel vector): loaded first for several pixels so that a thread has
+// all its global loads in flight before the first one is consumed
+template <int V>
+struct BnRaw {
     float z[V], dy[V], r[V];
-    ldv<V>(reinterpret_cast<const TZ*>(d.z) + off, z);
-    ldv<V>(reinterpret_cast<const TY*>(d.dy) + off, dy);
-    if (d.res_mode != LEDN_RES_NONE) ldv<V>(reinterpret_cast<const TY*>(d.res) + off, r);
+};
+template <typename TZ, typename TY, int V>
+__device__ __forceinline__ void bn_load(const ledn_bnbwd_desc& d, long off, BnRaw<V>& w) {
+    ldv<V>(reinterpret_cast<const TZ*>(d.z) + off, w.z);
+    ldv<V>(reinterpret_cast<const TY*>(d.dy) + off, w.dy);
+    if (d.res_mode != LEDN_RES_NONE) ldv<V>(reinterpret_cast<const TY*>(d.res) + off, w.r);
+}
+template <int V>
+__device__ __forceinline__ void bn_math(const ledn_bnbwd_desc& d, const BnParams<V>& p, const BnRaw<V>& w, float* gv,
+                                        float* xh, float* gres, float* dsl) {
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        const float v = z[i] * p.sc[i] + p.sh[i];
+        const float v = w.z[i] * p.sc[i] + p.sh[i];
         float t = v;
-        if (d.res_mode == LEDN_RES_ADD) t = v + r[i];
-        else if (d.res_mode == LEDN_RES_GATE) t = v * r[i] + r[i];
-        const float gt = dy[i] * act_grad(d.act, t, p.sl[i]);
-        dsl[i] = (d.act == LEDN_ACT_PRELU && t <= 0.f) ? dy[i] * t : 0.f;
+        if (d.res_mode == LEDN_RES_ADD) t = v + w.r[i];
+        else if (d.res_mode == LEDN_RES_GATE) t = v * w.r[i] + w.r[i];
+        const float gt = w.dy[i] * act_grad(d.act, t, p.sl[i]);
+        dsl[i] = (d.act == LEDN_ACT_PRELU && t <= 0.f) ? w.dy[i] * t : 0.f;
         if (d.res_mode == LEDN_RES_GATE) {
-            gv[i] = gt * r[i];
+            gv[i] = gt * w.r[i];
             gres[i] = gt * (v + 1.f);
         } else {
             gv[i] = gt;
             gres[i] = gt;
         }
-        xh[i] = (z[i] - p.mean[i]) * p.invstd[i];
+        xh[i] = (w.z[i] - p.mean[i]) * p.invstd[i];
     }
 }
+template <typename TZ, typename TY, int V>
+__device__ __forceinline__ void bn_g(const ledn_bnbwd_desc& d, const BnParams<V>& p, long off, float* gv,
+                                     float* xh, float* gres, float* dsl) {
+    BnRaw<V> w;
+    bn_load<TZ, TY, V>(d, off, w);
+    bn_math<V>(d, p, w, gv, xh, gres, dsl);
+}
+
+constexpr int BN_U = 4;   // pixel rows per thread and loop trip (loads issued together)
 
 template <typename TZ, typename TY, int V>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(ledn_bnbwd_desc d, float* part) {
@@ -69,14 +86,25 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(ledn_bnbwd_desc d, f
     for (int v = 0; v < V; ++v) a[v] = b[v] = e[v] = 0.f;
     if (r < rows) {
         const BnParams<V> prm = bn_params<V>(d, cv * V);
-        for (long p = (long)blockIdx.x * rows + r; p < d.P; p += (long)gridDim.x * rows) {
-            float gv[V], xh[V], gres[V], dsl[V];
-            bn_g<TZ, TY, V>(d, prm, p * d.C + cv * V, gv, xh, gres, dsl);
+        const long stride = (long)gridDim.x * rows;
+        for (long p0 = (long)blockIdx.x * rows + r; p0 < d.P; p0 += BN_U * stride) {
+            BnRaw<V> w[BN_U];
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                a[v] += gv[v];
-                b[v] = fmaf(gv[v], xh[v], b[v]);
-                e[v] += dsl[v];
+            for (int u = 0; u < BN_U; ++u) {
+                const long p = p0 + u * stride;
+                bn_load<TZ, TY, V>(d, (p < d.P ? p : p0) * d.C + cv * V, w[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                if (p0 + u * stride >= d.P) break;
+                float gv[V], xh[V], gres[V], dsl[V];
+                bn_math<V>(d, prm, w[u], gv, xh, gres, dsl);
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    a[v] += gv[v];
+                    b[v] = fmaf(gv[v], xh[v], b[v]);
+                    e[v] += dsl[v];
+                }
             }
         }
     }
@@ -123,6 +151,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(ledn_bnbwd_desc d) {
         mg[i] = d.bn_mode ? d.sum_g[c + i] * invn : 0.f;
         mgx[i] = d.bn_mode ? d.sum_gx[c + i] * invn : 0.f;
     }
+    // (one row per trip: issuing several rows of loads up front cost occupancy and ran 10 % slower)
     for (long p = (long)blockIdx.x * rows + r; p < d.P; p += (long)gridDim.x * rows) {
         const long off = p * d.C + c;
         float gv[V], xh[V], gres[V], dsl[V], dz[V];
@@ -151,7 +180,7 @@ static int bnbwd_validate(const ledn_bnbwd_desc& d, bool apply) {
 #define LEDN_BNB_DISPATCH(KERNEL, ...)                                                                   \
     do {                                                                                                 \
         const bool v4 = d.C % 4 == 0;                                                                    \
-        if (d.dtype_z == LEDN_BF16 && d.dtype_y == LEDN_BF16 && d.C % 8 == 0) {   /* 16 B per lane */    \
+        if (false && d.dtype_z == LEDN_BF16 && d.dtype_y == LEDN_BF16 && d.C % 8 == 0) { /* 16 B/lane: slower */ \
             LEDN_LAUNCH((KERNEL<bf16_t, bf16_t, 8>), grid, dim3(256), 0, s, __VA_ARGS__);                \
         } else if (d.dtype_z == LEDN_F32 && d.dtype_y == LEDN_F32) {                                     \
             if (v4) LEDN_LAUNCH((KERNEL<float, float, 4>), grid, dim3(256), 0, s, __VA_ARGS__);          \
@@ -169,7 +198,7 @@ static int bnbwd_validate(const ledn_bnbwd_desc& d, bool apply) {
     } while (0)
 
 static long bn_rows(const ledn_bnbwd_desc& d) {
-    const int V = (d.dtype_z == LEDN_BF16 && d.dtype_y == LEDN_BF16 && d.C % 8 == 0) ? 8 : (d.C % 4 == 0 ? 4 : 1);
+    const int V = d.C % 4 == 0 ? 4 : 1;
     return 256 / (d.C / V);
 }
 

@@ -195,80 +195,99 @@ static int launch_cot(const ledn_conv_desc& d, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
-// Narrow input (Cin <= 4) -> wide output, stride 1, plain epilogue: the data gradient of the
+// Narrow input (Cin <= 2) -> wide output, stride 1, plain epilogue: the data gradient of the
 // 32->2 heads (dz has 2 channels, dx has 32: led_head.py:47-48) and of 64->1 / 64->2 layers.
 // thread = (pixel, 8 output channels): the lanes of a pixel cover its whole channel row with
 // 16-byte stores (the generic kernel wrote 8-byte pieces 64 bytes apart: 0.35 ms for the 268 MB
 // dx of head_x1 at 16 x 512 x 512); the taps x Cin input scalars are unconditional loads, the
 // weights sit in LDS as [tap][ci][co] (two ds_read_b128 per tap and input channel).
 // ---------------------------------------------------------------------------
-template <typename TX, typename TY, int CIN>
-__global__ void __launch_bounds__(256) conv_narrowin_kernel(ledn_conv_desc d) {
-    __shared__ __attribute__((aligned(16))) float s_w[9 * CIN * 128];
-    const int taps = d.KH * d.KW;
-    for (int e = threadIdx.x; e < taps * CIN * d.Cout; e += blockDim.x) {
+template <typename TX, typename TY, int CIN, int K, bool TR>
+__global__ void __launch_bounds__(256, 2) conv_narrowin_kernel(ledn_conv_desc d) {
+    constexpr int PX = CIN <= 2 ? 4 : 2;                    // output pixels (along W) per thread
+    __shared__ __attribute__((aligned(16))) float s_w[K * K * CIN * 128];
+    for (int e = threadIdx.x; e < K * K * CIN * d.Cout; e += blockDim.x) {
         const int co = e % d.Cout, ci = (e / d.Cout) % CIN, tap = e / (d.Cout * CIN);
         s_w[e] = ci < d.Cin ? d.w[(long)co * d.ws_co + (long)ci * d.ws_ci + (long)tap * d.ws_tap] : 0.f;
     }
     __syncthreads();
     const int cgn = d.Cout / 8;
-    const long total = (long)d.N * d.Ho * d.Wo * cgn;
+    const int wq = (d.Wo + PX - 1) / PX;
+    const long total = (long)d.N * d.Ho * wq * cgn;
+    // input patch of the thread: rows ho - lo .. ho - lo + K-1, columns wo0 - lo .. wo0 - lo + K+PX-2;
+    // tap (kh, kw) reads patch row kh (forward) or K-1-kh (data gradient: hi = ho + pad - kh)
+    const int lo = TR ? (K - 1) - d.pad : d.pad;
     const TX* x = reinterpret_cast<const TX*>(d.x);
     TY* y = reinterpret_cast<TY*>(d.y);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int cg = (int)(idx % cgn);
-        const long pix = idx / cgn;
-        const int wo = (int)(pix % d.Wo);
-        const int ho = (int)((pix / d.Wo) % d.Ho);
-        const int n = (int)(pix / ((long)d.Wo * d.Ho));
-        float xv[9][CIN];
+        long q = idx / cgn;
+        const int wo0 = (int)(q % wq) * PX;
+        q /= wq;
+        const int ho = (int)(q % d.Ho);
+        const int n = (int)(q / d.Ho);
+        float xv[K][K + PX - 1][CIN];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if (t >= taps) break;
-            const int kh = t / d.KW, kw = t % d.KW;
-            const int hi = d.transposed ? ho + d.pad - kh : ho - d.pad + kh;
-            const int wi = d.transposed ? wo + d.pad - kw : wo - d.pad + kw;
-            const bool valid = hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
-            const long xoff = valid ? (((long)n * d.H + hi) * d.W + wi) * d.Cin : 0L;
+        for (int r = 0; r < K; ++r)
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) {
-                const float v = ld(x + xoff + (ci < d.Cin ? ci : 0));
-                xv[t][ci] = (valid && ci < d.Cin) ? v : 0.f;
+            for (int c = 0; c < K + PX - 1; ++c) {
+                const int hi = ho - lo + r, wi = wo0 - lo + c;
+                const bool valid = hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
+                const long xoff = valid ? (((long)n * d.H + hi) * d.W + wi) * d.Cin : 0L;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float v = ld(x + xoff + (ci < d.Cin ? ci : 0));
+                    xv[r][c][ci] = (valid && ci < d.Cin) ? v : 0.f;
+                }
             }
-        }
-        float acc[8];
+        float acc[PX][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int p = 0; p < PX; ++p)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if (t >= taps) break;
+            for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) {
-                float w8[8];
-                ld8(s_w + (t * CIN + ci) * d.Cout + cg * 8, w8);
+        for (int kh = 0; kh < K; ++kh)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[t][ci], w8[j], acc[j]);
+            for (int kw = 0; kw < K; ++kw) {
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    float w8[8];
+                    ld8(s_w + ((kh * K + kw) * CIN + ci) * d.Cout + cg * 8, w8);
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) {
+                        const float xs = TR ? xv[K - 1 - kh][K - 1 - kw + p][ci] : xv[kh][kw + p][ci];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(xs, w8[j], acc[p][j]);
+                    }
+                }
             }
-        }
-        st8(y + pix * d.Cout + cg * 8, acc);
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+            if (wo0 + p < d.Wo) st8(y + (((long)n * d.Ho + ho) * d.Wo + wo0 + p) * d.Cout + cg * 8, acc[p]);
     }
 }
 
 static bool narrowin_ok(const ledn_conv_desc& d) {
-    if (d.Cin > 4 || d.Cout % 8 || d.Cout > 128 || d.groups != 1 || d.stride != 1 || d.dil != 1) return false;
+    if (d.Cin > 2 || d.Cout % 8 || d.Cout > 128 || d.groups != 1 || d.stride != 1 || d.dil != 1) return false;
     if (d.xadd || d.in_scale || d.in_act != LEDN_ACT_NONE || d.out_scale || d.out_shift || d.stat_sum) return false;
     if (d.res_mode != LEDN_RES_NONE || d.act_out != LEDN_ACT_NONE) return false;
-    return d.KH * d.KW <= 9;
+    return d.KH == d.KW && (d.KH == 1 || d.KH == 3);
 }
 
 template <typename TX, typename TY>
 static int launch_narrowin(const ledn_conv_desc& d, hipStream_t s) {
-    const long total = (long)d.N * d.Ho * d.Wo * (d.Cout / 8);
+    const long total = (long)d.N * d.Ho * cdiv(d.Wo, 4) * (d.Cout / 8);
     long nb = cdiv(total, 256);
     if (nb > 4096) nb = 4096;
     const dim3 grid((unsigned)nb);
-    if (d.Cin <= 2) LEDN_LAUNCH((conv_narrowin_kernel<TX, TY, 2>), grid, dim3(256), 0, s, d);
-    else LEDN_LAUNCH((conv_narrowin_kernel<TX, TY, 4>), grid, dim3(256), 0, s, d);
+#define LEDN_NI(CI, KK)                                                                                   \
+    do {                                                                                                  \
+        if (d.transposed) LEDN_LAUNCH((conv_narrowin_kernel<TX, TY, CI, KK, true>), grid, dim3(256), 0, s, d); \
+        else LEDN_LAUNCH((conv_narrowin_kernel<TX, TY, CI, KK, false>), grid, dim3(256), 0, s, d);        \
+    } while (0)
+    if (d.KH == 3) LEDN_NI(2, 3);
+    else LEDN_NI(2, 1);
+#undef LEDN_NI
     return check_launch();
 }
 
@@ -397,8 +416,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_direct_kernel(ledn_wgrad_desc 
                 for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(xv[a], zv[b], acc[a][b]);
         }
     }
-    for (int a = 0; a < nci; ++a)
-        for (int b = 0; b < nco; ++b) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {   // (unrolled with guards: a runtime index would put acc in scratch)
+            if (a >= nci || b >= nco) continue;
             if (part) {   // natural strides: [workgroup row][dW linear index], summed by finish_partials
                 part[(long)blockIdx.x * part_stride + (long)(g * cog + col + b) * d.ws_co + (long)(cil + a) * d.ws_ci +
                      (long)tap * d.ws_tap] = acc[a][b];

@@ -112,7 +112,7 @@ def test_conv2d_wgrad_vector_paths(be, n, cin, cout, k, stride, groups, hw):
 
 @pytest.mark.parametrize('cin,cout,k,transposed,dt', [
     (32, 2, 3, True, torch.bfloat16), (32, 2, 3, True, torch.float32), (64, 1, 3, True, torch.float32),
-    (64, 2, 1, True, torch.bfloat16), (3, 32, 3, False, torch.float32), (2, 64, 1, False, torch.bfloat16)])
+    (64, 2, 1, True, torch.bfloat16), (2, 32, 3, False, torch.float32), (2, 64, 1, False, torch.bfloat16)])
 def test_conv2d_narrow_input_kernel(be, cin, cout, k, transposed, dt):
     """conv_narrowin_kernel: <= 4 channels in, wide out, stride 1, plain epilogue -- the data
     gradient of LEDHead's 32->2 heads (transposed: dz [.,2] -> dx [.,32]) and plain narrow convs."""
