@@ -149,6 +149,8 @@ def main():
     ap.add_argument('--width', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--local-bn', action='store_true',
+                    help='N>1: per-rank BatchNorm statistics instead of the config\'s SyncBN (one all-reduce per BN and direction)')
     ap.add_argument('--trace-only', action='store_true',
                     help='stop after the timed region (for rocprofv3 timeline traces: no instrumented eager pass, no JSON)')
     args = ap.parse_args()
@@ -169,6 +171,8 @@ def main():
     bs = args.batch or (16 if mode == 'train' else 8)
     H, W = args.height, args.width
     model, cfg = build_model(dev, args.dtype, mode == 'train')
+    if args.local_bn:
+        model.backbone.sync_bn = model.decode_head.sync_bn = False
     img, lab = synthetic_batch(bs, H, W, dev, seed=304 + rank)
 
     def barrier():
@@ -213,8 +217,6 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    if not graphed:
-        ops.start_timing()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -223,21 +225,20 @@ def main():
     if args.trace_only:
         if rank == 0:
             print(f'[bench] trace-only: {bs * world * args.steps / dt:.1f} images/s', file=sys.stderr)
+        if world > 1:
+            dist.destroy_process_group()
         return
-    if graphed:
-        # per-kernel HIP-event timing needs individual launches: instrumented eager pass of
-        # the same step right after the timed (graph-replay) region
-        k_steps = min(args.steps, 5)
+    # per-kernel HIP-event timing needs individual launches and costs two event records per launch:
+    # an instrumented eager pass of the same step right after the timed region (every rank runs it,
+    # the collectives stay matched; rank 0 reports)
+    k_steps = min(args.steps, 5)
+    eager_step()
+    barrier()
+    ops.start_timing()
+    for _ in range(k_steps):
         eager_step()
-        barrier()
-        ops.start_timing()
-        for _ in range(k_steps):
-            eager_step()
-        barrier()
-        launches = ops.stop_timing()
-    else:
-        k_steps = args.steps
-        launches = ops.stop_timing()
+    barrier()
+    launches = ops.stop_timing()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -289,10 +290,11 @@ def main():
             'config': {'workload': (f'LED-Net {H}x{W} train_step (fwd+OHEM-CE+bwd+SGD) batch {bs}/GPU' if mode == 'train'
                                     else f'LED-Net {H}x{W} inference (fwd+fusion+argmax) batch {bs}/GPU'),
                        'global_batch': bs * world, 'parallelism': f'dp{world}',
+                       'batchnorm': ('SyncBN (config): one RCCL all-reduce of [2,C] per BN and direction' if world > 1 and mode == 'train' and not args.local_bn
+                                     else 'per-rank statistics'),
                        'kernel_launches_per_step': len(launches) // k_steps,
                        'submission': 'hipGraph replay' if graphed else 'eager launches',
-                       'kernel_timing': ('HIP events, instrumented eager pass after the timed region' if graphed
-                                         else 'HIP events inside the timed region'),
+                       'kernel_timing': 'HIP events on the launch streams, instrumented eager pass of the same step right after the timed region',
                        'conv_gemm_tflops_whole_step': round(total_flops / (gpu_ms * 1e-3) / 1e12, 3),
                        'hbm_alg_gbs_whole_step': round(total_bytes / (gpu_ms * 1e-3) / 1e9, 1),
                        'gpu_busy_frac': round(gpu_ms / k_steps / (dt / args.steps * 1e3), 3)},

@@ -11,107 +11,125 @@ namespace ledn {
 // Phase B (lane = key j): dK[j] = scale * dS[:][j]^T . Q,  dV[j] = P[:][j]^T . dO.
 // LDS: K, V, Q, dO (4 x 64 x D f32) + dS + P (2 x 16 KiB) = 48 KiB at D = 16.
 // ===========================================================================
+// The wavefront walks several windows of its head; the 64x64 score-gradient rows live in LDS with a
+// 65-float row stride (lane = row in phase A, lane = column in phase B: both conflict-free; the
+// 64-float stride of the first version put all 64 lanes on one bank), and the relative-position
+// bias gradient is summed over the wavefront's windows in LDS and leaves as ONE partial table per
+// wavefront (the first version issued one global atomic per score and window: 1024 same-address
+// atomics per table entry at 16 x 64 x 64).
 template <typename T, int D, bool PADDED>
 __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T* qkv, const float* biasT, const T* dout,
                                                              float* dqkv, float* dbiasT, int N, int H,
-                                                             int W, int C, int heads, int hh, int ww) {
-    constexpr int WS = 8, T2 = 64;
+                                                             int W, int C, int heads, int hh, int ww,
+                                                             float* part) {
+    constexpr int WS = 8, T2 = 64, TP = 65;
     __shared__ float s_k[T2 * D], s_v[T2 * D], s_q[T2 * D], s_do[T2 * D];
-    __shared__ float s_ds[T2 * T2], s_p[T2 * T2];
-    const int win = blockIdx.x, head = blockIdx.y;
-    const int wx = win % ww, wy = (win / ww) % hh, n = win / (ww * hh);
+    __shared__ float s_ds[T2 * TP], s_p[T2 * TP], s_db[T2 * TP];
+    const int head = blockIdx.y;
     const int t = threadIdx.x;
-    const int y = wy * WS + t / WS, x = wx * WS + t % WS;
-    const bool inside = y < H && x < W;
-    const int ys = y < H ? y : 2 * H - 2 - y;
-    const int xs = x < W ? x : 2 * W - 2 - x;
-    const long src = ((long)n * H + ys) * W + xs;
-    const T* p = qkv + src * (3L * C) + head * D;
-    float q[D], go[D];
-#pragma unroll
-    for (int j = 0; j < D; j += 4) {
-        float kv[4], vv[4];
-        ldv<4>(p + j, q + j);
-        ldv<4>(p + C + j, kv);
-        ldv<4>(p + 2 * C + j, vv);
-        if (inside) ldv<4>(dout + src * C + head * D + j, go + j);
-        else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) go[j + i] = 0.f;  // cropped outputs carry no gradient
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            s_k[t * D + j + i] = kv[i];
-            s_v[t * D + j + i] = vv[i];
-            s_q[t * D + j + i] = q[j + i];
-            s_do[t * D + j + i] = go[j + i];
-        }
-    }
-    __syncthreads();
+    const int nwin = N * hh * ww;
     const float scale = rsqrtf((float)D);
     const float* b = biasT + (long)head * T2 * T2 + t;
-    float m = -3.0e38f;
-    for (int k = 0; k < T2; ++k) {
-        float dot = 0.f;
+    for (int k = 0; k < T2; ++k) s_db[t * TP + k] = 0.f;      // row t is private to lane t
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const int wx = win % ww, wy = (win / ww) % hh, n = win / (ww * hh);
+        const int y = wy * WS + t / WS, x = wx * WS + t % WS;
+        const bool inside = y < H && x < W;
+        const int ys = y < H ? y : 2 * H - 2 - y;
+        const int xs = x < W ? x : 2 * W - 2 - x;
+        const long src = ((long)n * H + ys) * W + xs;
+        const T* p = qkv + src * (3L * C) + head * D;
+        float q[D], go[D];
+        __syncthreads();     // the previous window's phase B is done with the LDS operands
 #pragma unroll
-        for (int j = 0; j < D; ++j) dot = fmaf(q[j], s_k[k * D + j], dot);
-        const float sc = dot * scale + b[k * T2];
-        s_p[t * T2 + k] = sc;      // row t is private to lane t in phase A
-        m = fmaxf(m, sc);
-    }
-    float l = 0.f;
-    for (int k = 0; k < T2; ++k) {
-        const float e = __expf(s_p[t * T2 + k] - m);
-        s_p[t * T2 + k] = e;
-        l += e;
-    }
-    const float inv = 1.f / l;
-    float rs = 0.f;  // sum_k P*dP
-    for (int k = 0; k < T2; ++k) {
-        const float pk = s_p[t * T2 + k] * inv;
-        float dp = 0.f;
+        for (int j = 0; j < D; j += 4) {
+            float kv[4], vv[4];
+            ldv<4>(p + j, q + j);
+            ldv<4>(p + C + j, kv);
+            ldv<4>(p + 2 * C + j, vv);
+            if (inside) ldv<4>(dout + src * C + head * D + j, go + j);
+            else {
 #pragma unroll
-        for (int j = 0; j < D; ++j) dp = fmaf(go[j], s_v[k * D + j], dp);
-        s_p[t * T2 + k] = pk;
-        s_ds[t * T2 + k] = dp;
-        rs = fmaf(pk, dp, rs);
-    }
-    float dq[D];
+                for (int i = 0; i < 4; ++i) go[j + i] = 0.f;  // cropped outputs carry no gradient
+            }
 #pragma unroll
-    for (int j = 0; j < D; ++j) dq[j] = 0.f;
-    float* db = dbiasT + (long)head * T2 * T2 + t;
-    for (int k = 0; k < T2; ++k) {
-        const float ds = s_p[t * T2 + k] * (s_ds[t * T2 + k] - rs);
-        s_ds[t * T2 + k] = ds;
-        atomicAdd(db + k * T2, ds);
+            for (int i = 0; i < 4; ++i) {
+                s_k[t * D + j + i] = kv[i];
+                s_v[t * D + j + i] = vv[i];
+                s_q[t * D + j + i] = q[j + i];
+                s_do[t * D + j + i] = go[j + i];
+            }
+        }
+        __syncthreads();
+        float m = -3.0e38f;
+        for (int k = 0; k < T2; ++k) {
+            float dot = 0.f;
 #pragma unroll
-        for (int j = 0; j < D; ++j) dq[j] = fmaf(ds, s_k[k * D + j], dq[j]);
-    }
-    __syncthreads();
-    // phase B: lane = key t
-    float dk[D], dv[D];
+            for (int j = 0; j < D; ++j) dot = fmaf(q[j], s_k[k * D + j], dot);
+            const float sc = dot * scale + b[k * T2];
+            s_p[t * TP + k] = sc;
+            m = fmaxf(m, sc);
+        }
+        float l = 0.f;
+        for (int k = 0; k < T2; ++k) {
+            const float e = __expf(s_p[t * TP + k] - m);
+            s_p[t * TP + k] = e;
+            l += e;
+        }
+        const float inv = 1.f / l;
+        float rs = 0.f;  // sum_k P*dP
+        for (int k = 0; k < T2; ++k) {
+            const float pk = s_p[t * TP + k] * inv;
+            float dp = 0.f;
 #pragma unroll
-    for (int j = 0; j < D; ++j) dk[j] = dv[j] = 0.f;
-    for (int i = 0; i < T2; ++i) {
-        const float ds = s_ds[i * T2 + t], pk = s_p[i * T2 + t];
+            for (int j = 0; j < D; ++j) dp = fmaf(go[j], s_v[k * D + j], dp);
+            s_p[t * TP + k] = pk;
+            s_ds[t * TP + k] = dp;
+            rs = fmaf(pk, dp, rs);
+        }
+        float dq[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) dq[j] = 0.f;
+        for (int k = 0; k < T2; ++k) {
+            const float ds = s_p[t * TP + k] * (s_ds[t * TP + k] - rs);
+            s_ds[t * TP + k] = ds;
+            s_db[t * TP + k] += ds;
+#pragma unroll
+            for (int j = 0; j < D; ++j) dq[j] = fmaf(ds, s_k[k * D + j], dq[j]);
+        }
+        __syncthreads();
+        // phase B: lane = key t
+        float dk[D], dv[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) dk[j] = dv[j] = 0.f;
+        for (int i = 0; i < T2; ++i) {
+            const float ds = s_ds[i * TP + t], pk = s_p[i * TP + t];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                dk[j] = fmaf(ds, s_q[i * D + j], dk[j]);
+                dv[j] = fmaf(pk, s_do[i * D + j], dv[j]);
+            }
+        }
+        float* o = dqkv + src * (3L * C) + head * D;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            dk[j] = fmaf(ds, s_q[i * D + j], dk[j]);
-            dv[j] = fmaf(pk, s_do[i * D + j], dv[j]);
+            if (PADDED) {
+                atomicAdd(o + j, dq[j] * scale);
+                atomicAdd(o + C + j, dk[j] * scale);
+                atomicAdd(o + 2 * C + j, dv[j]);
+            } else {
+                o[j] = dq[j] * scale;
+                o[C + j] = dk[j] * scale;
+                o[2 * C + j] = dv[j];
+            }
         }
     }
-    float* o = dqkv + src * (3L * C) + head * D;
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        if (PADDED) {
-            atomicAdd(o + j, dq[j] * scale);
-            atomicAdd(o + C + j, dk[j] * scale);
-            atomicAdd(o + 2 * C + j, dv[j]);
-        } else {
-            o[j] = dq[j] * scale;
-            o[C + j] = dk[j] * scale;
-            o[2 * C + j] = dv[j];
-        }
+    // bias-gradient table of this wavefront: dbiasT[head][k][t] (t = query row = lane)
+    for (int k = 0; k < T2; ++k) {
+        const float v = s_db[t * TP + k];
+        const long idx = (long)head * T2 * T2 + k * T2 + t;
+        if (part) part[(long)blockIdx.x * heads * T2 * T2 + idx] = v;
+        else atomicAdd(dbiasT + idx, v);
     }
 }
 
@@ -123,15 +141,19 @@ int window_attn_bwd_impl(const void* qkv, const float* biasT, const void* dout, 
     const int hh = (H + ws - 1) / ws, ww = (W + ws - 1) / ws;
     LEDN_REQUIRE(hh * ws - H < H && ww * ws - W < W);
     const bool padded = (H % ws) || (W % ws);
-    const dim3 grid((unsigned)(N * hh * ww), (unsigned)heads);
+    long nb = (long)N * hh * ww;
+    if (nb > 256) nb = 256;                                   // wavefronts per head (each walks its windows)
+    float* part = nb > 8 ? ws_take(nb * heads * 64 * 64) : nullptr;
+    if (!part && nb > 32) nb = 32;                            // atomics fallback: <= 32 per table entry
+    const dim3 grid((unsigned)nb, (unsigned)heads);
 #define LEDN_WB(T, DD)                                                                                  \
     do {                                                                                                \
         if (padded)                                                                                     \
             LEDN_LAUNCH((window_attn_bwd_kernel<T, DD, true>), grid, dim3(64), 0, s, (const T*)qkv, biasT, \
-                        (const T*)dout, dqkv, dbiasT, N, H, W, C, heads, hh, ww);                       \
+                        (const T*)dout, dqkv, dbiasT, N, H, W, C, heads, hh, ww, part);                 \
         else                                                                                            \
             LEDN_LAUNCH((window_attn_bwd_kernel<T, DD, false>), grid, dim3(64), 0, s, (const T*)qkv, biasT, \
-                        (const T*)dout, dqkv, dbiasT, N, H, W, C, heads, hh, ww);                       \
+                        (const T*)dout, dqkv, dbiasT, N, H, W, C, heads, hh, ww, part);                 \
     } while (0)
 #define LEDN_WBD(T)                        \
     do {                                   \
@@ -145,6 +167,7 @@ int window_attn_bwd_impl(const void* qkv, const float* biasT, const void* dout, 
     else return LEDN_EINVAL;
 #undef LEDN_WBD
 #undef LEDN_WB
+    if (part) return finish_partials(part, (int)nb, heads * 64 * 64, 1, dbiasT, nullptr, nullptr, s);
     return check_launch();
 }
 
@@ -217,36 +240,77 @@ __global__ void __launch_bounds__(256) ohem_prob_kernel(const float* logits, con
     if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&w.state[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
-// single workgroup: locate the bucket holding the wanted rank at this level
+// single workgroup: locate the bucket holding the wanted rank at this level.  Thread i owns bins
+// 8i..8i+7; a block-wide prefix sum of the per-thread counts finds the owner of the rank, which
+// then walks its eight bins (the first version walked all 2048 bins with one thread: 75 us).
 __global__ void __launch_bounds__(256) ohem_scan_kernel(float* work, long P, int pass, long long min_kept,
                                                         float thres) {
+    __shared__ unsigned s_wave[4];
     const OhemWork w = ohem_work(work, P);
-    if (threadIdx.x != 0) return;
+    const unsigned nv = w.state[0];
+    if (nv == 0u) {   // workgroup-uniform
+        if (pass == 0 && threadIdx.x == 0) {
+            w.state[4] = __float_as_uint(thres);
+            w.state[2] = 0u;
+            w.state[3] = 0u;
+        }
+        return;
+    }
     unsigned rank;
     if (pass == 0) {
-        const unsigned nv = w.state[0];
-        if (nv == 0u) { w.state[4] = __float_as_uint(thres); w.state[2] = 0u; w.state[3] = 0u; return; }
         const long long k = min_kept < (long long)nv - 1 ? min_kept : (long long)nv - 1;
         rank = (unsigned)k;
-        w.state[3] = 0u;
     } else {
-        if (w.state[0] == 0u) return;
         rank = w.state[2];
     }
+    const unsigned prefix_bits = pass == 0 ? 0u : w.state[3];
     const unsigned* h = w.hist + pass * OH_BINS;
     const int nb = pass == 2 ? 1024 : 2048;
-    int b = 0;
-    for (; b < nb; ++b) {
-        if (rank < h[b]) break;
-        rank -= h[b];
+    const int per = nb / 256;
+    unsigned hb[8], mine = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hb[i] = i < per ? h[threadIdx.x * per + i] : 0u;
+        mine += hb[i];
     }
-    if (b >= nb) b = nb - 1;
-    const unsigned bits = pass == 0 ? ((unsigned)b << 21) : (pass == 1 ? ((unsigned)b << 10) : (unsigned)b);
-    w.state[3] |= bits;
-    w.state[2] = rank;
-    if (pass == 2) {
-        const float kth = __uint_as_float(w.state[3]);
-        w.state[4] = __float_as_uint(kth > thres ? kth : thres);   // threshold = max(min_value, thresh)
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned nbr = __shfl(incl, lane >= o ? lane - o : lane);
+        if (lane >= o) incl += nbr;
+    }
+    if (lane == 63) s_wave[wid] = incl;
+    __syncthreads();          // also orders every thread's reads of state[2..3] before the writes below
+    unsigned off = 0u;
+    for (int i = 0; i < wid; ++i) off += s_wave[i];
+    incl += off;
+    const unsigned excl = incl - mine;
+    const unsigned total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    int b = -1;
+    unsigned r = 0u;
+    if (rank >= excl && rank < incl) {          // exactly one thread when rank < total
+        r = rank - excl;
+        b = threadIdx.x * per;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i >= per || r < hb[i]) break;
+            r -= hb[i];
+            ++b;
+        }
+    } else if (rank >= total && threadIdx.x == 255) {   // rank beyond the histogram: last bucket
+        r = rank - total;
+        b = nb - 1;
+    }
+    if (b >= 0) {
+        const unsigned bits = pass == 0 ? ((unsigned)b << 21) : (pass == 1 ? ((unsigned)b << 10) : (unsigned)b);
+        const unsigned full = prefix_bits | bits;
+        w.state[3] = full;
+        w.state[2] = r;
+        if (pass == 2) {
+            const float kth = __uint_as_float(full);
+            w.state[4] = __float_as_uint(kth > thres ? kth : thres);   // threshold = max(min_value, thresh)
+        }
     }
 }
 

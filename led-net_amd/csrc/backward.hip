@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) dw_bwd_data_kernel(ledn_dwbwd_desc d) {
 
 // one workgroup = one tap x a chunk of output pixels; thread (row r, channel vector cv)
 template <typename T, int V>
-__global__ void __launch_bounds__(256) dw_bwd_weight_kernel(ledn_dwbwd_desc d, int pix_per_block) {
+__global__ void __launch_bounds__(256) dw_bwd_weight_kernel(ledn_dwbwd_desc d, int pix_per_block, float* part) {
     __shared__ float s_part[256 * 4];
     const int tap = blockIdx.y;
     const int kh = tap / d.KW, kw = tap % d.KW;
@@ -328,19 +328,31 @@ __global__ void __launch_bounds__(256) dw_bwd_weight_kernel(ledn_dwbwd_desc d, i
         const long npix = (long)d.N * d.Ho * d.Wo;
         const long p0 = (long)blockIdx.x * pix_per_block;
         const long p1 = min(npix, p0 + (long)pix_per_block);
-        for (long p = p0 + r; p < p1; p += rows) {
-            const int wo = (int)(p % d.Wo);
-            const int ho = (int)((p / d.Wo) % d.Ho);
-            const int n = (int)(p / ((long)d.Wo * d.Ho));
-            int hi = ho * d.stride - padh + kh * dl, wi = wo * d.stride - padw + kw * dl;
-            if (hi < 0 || hi >= Hx || wi < 0 || wi >= Wx) continue;
-            if (hi == d.H) hi = d.H - 2;
-            if (wi == d.W) wi = d.W - 2;
-            float xv[V], g[V];
-            ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.C + c, xv);
-            ldv<V>(dz + p * d.C + c, g);
+        // four pixels per trip, their eight loads unconditional and in flight together (the tap-major
+        // grid makes every thread a chain of dependent trips: 8x8 GETB filters took 215 us one at a time)
+        constexpr int U = 4;
+        for (long pb = p0 + r; pb < p1; pb += (long)U * rows) {
+            float xv[U][V], g[U][V];
+            bool ok[U];
 #pragma unroll
-            for (int v = 0; v < V; ++v) acc[v] = fmaf(xv[v], g[v], acc[v]);
+            for (int u = 0; u < U; ++u) {
+                const long p = pb + (long)u * rows;
+                const long pc = p < p1 ? p : pb;
+                const int wo = (int)(pc % d.Wo);
+                const int ho = (int)((pc / d.Wo) % d.Ho);
+                const int n = (int)(pc / ((long)d.Wo * d.Ho));
+                int hi = ho * d.stride - padh + kh * dl, wi = wo * d.stride - padw + kw * dl;
+                ok[u] = p < p1 && hi >= 0 && hi < Hx && wi >= 0 && wi < Wx;
+                if (hi == d.H) hi = d.H - 2;
+                if (wi == d.W) wi = d.W - 2;
+                const long xoff = ok[u] ? (((long)n * d.H + hi) * d.W + wi) * d.C + c : (long)c;
+                ldv<V>(x + xoff, xv[u]);
+                ldv<V>(dz + pc * d.C + c, g[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[v] = fmaf(ok[u] ? xv[u][v] : 0.f, g[u][v], acc[v]);
         }
     }
 #pragma unroll
@@ -351,7 +363,8 @@ __global__ void __launch_bounds__(256) dw_bwd_weight_kernel(ledn_dwbwd_desc d, i
         for (int v = 0; v < V; ++v) {
             float t = 0.f;
             for (int rr = 0; rr < rows; ++rr) t += s_part[(rr * cvn + cv) * V + v];
-            atomicAdd(d.dw + (long)tap * d.C + c + v, t);
+            if (part) part[((long)blockIdx.x * gridDim.y + tap) * d.C + c + v] = t;
+            else atomicAdd(d.dw + (long)tap * d.C + c + v, t);
         }
     }
 }
@@ -477,18 +490,29 @@ int dw_bwd_weight_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
         if (part) return finish_partials(part, (int)nb, 9 * d.C, 1, d.dw, nullptr, nullptr, s);
         return check_launch();
     }
-    long ppb = cdiv(npix * d.KH * d.KW, 2048);
+    // many short workgroups whose per-tap partial sums go to the workspace (summed by
+    // finish_partials), else a bounded grid ending in one atomic per (tap, channel) per workgroup
+    const int taps = d.KH * d.KW;
+    long ppb = cdiv(npix * taps, 8192);
     if (ppb < 128) ppb = 128;
-    const dim3 grid((unsigned)cdiv(npix, ppb), (unsigned)(d.KH * d.KW));
-#define LEDN_K(T)                                                                                 \
-    do {                                                                                          \
-        if (v4) LEDN_LAUNCH((dw_bwd_weight_kernel<T, 4>), grid, dim3(256), 0, s, d, (int)ppb);    \
-        else LEDN_LAUNCH((dw_bwd_weight_kernel<T, 1>), grid, dim3(256), 0, s, d, (int)ppb);       \
+    long nbx = cdiv(npix, ppb);
+    float* part = nbx > 8 ? ws_take(nbx * taps * d.C) : nullptr;
+    if (!part) {
+        ppb = cdiv(npix * taps, 2048);
+        if (ppb < 128) ppb = 128;
+        nbx = cdiv(npix, ppb);
+    }
+    const dim3 grid((unsigned)nbx, (unsigned)taps);
+#define LEDN_K(T)                                                                                       \
+    do {                                                                                                \
+        if (v4) LEDN_LAUNCH((dw_bwd_weight_kernel<T, 4>), grid, dim3(256), 0, s, d, (int)ppb, part);    \
+        else LEDN_LAUNCH((dw_bwd_weight_kernel<T, 1>), grid, dim3(256), 0, s, d, (int)ppb, part);       \
     } while (0)
     if (d.dtype == LEDN_F32) LEDN_K(float);
     else if (d.dtype == LEDN_BF16) LEDN_K(bf16_t);
     else return LEDN_EINVAL;
 #undef LEDN_K
+    if (part) return finish_partials(part, (int)nbx, taps * d.C, 1, d.dw, nullptr, nullptr, s);
     return check_launch();
 }
 
