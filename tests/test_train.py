@@ -32,7 +32,7 @@ def nchw(t):
     return t.detach().permute(0, 3, 1, 2).contiguous().cpu()
 
 
-def close(a, b, rt=1e-3, at=1e-4, what=''):
+def close(a, b, rt=1e-3, at=1e-4, what='', rel_bound=1e-2):
     """Elementwise tolerance, OR (for gradients) a relative-L2 bound of 1%: a ReLU /
     ReLU6 / PReLU kink whose pre-activation is ~1e-7 can flip between two fp32
     summation orders, which moves a handful of gradient elements by O(1) while a
@@ -42,7 +42,7 @@ def close(a, b, rt=1e-3, at=1e-4, what=''):
     if torch.allclose(a, b, rtol=rt, atol=at):
         return
     rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
-    assert rel < 1e-2, f'{what}: rel-L2 {rel:.3e}, max abs diff {(a - b).abs().max().item():.3e}'
+    assert rel < rel_bound, f'{what}: rel-L2 {rel:.3e}, max abs diff {(a - b).abs().max().item():.3e}'
 
 
 def train_names(prefix):
@@ -64,7 +64,13 @@ def _check_block(fx, m, fn, n_in=1):
         got = params[k].grad
         assert got is not None, k
         scale = max(1.0, float(g.abs().max()))
-        close(got, g, 3e-3, 1e-3 * scale, f'{fx.name} grad {k}')   # atol: grads that are analytically 0 (bias before BN) are fp32 noise ~1e-4
+        # MFAF's global_att branch normalises the 1x1 global pool over the BATCH: two values per channel
+        # in these fixtures, so x_hat = +-1 and the gradient divides by |a - b|.  The f32 summation order
+        # of the pool (atomics) moves it by 2e-3..1.3e-2 rel-L2 from run to run on the GPU
+        # (tools/diag_mfaf_golden.py; every other gradient of the block sits at 1e-6): bound 5e-2 there,
+        # a wrong chain rule is ~1.
+        rb = 5e-2 if k.startswith('global_att.') else 1e-2
+        close(got, g, 3e-3, 1e-3 * scale, f'{fx.name} grad {k}', rel_bound=rb)   # atol: grads that are analytically 0 (bias before BN) are fp32 noise ~1e-4
     sd = m.state_dict()
     for k, v in fx.outs.items():
         if k.startswith('post/'):
