@@ -149,6 +149,9 @@ def main():
     ap.add_argument('--width', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--collectives', default=None, choices=['auto', 'rccl', 'torch'],
+                    help='N>1: rccl = ncclAllReduce on the launch stream (graph-capturable), torch = torch.distributed (eager); '
+                         'with --gpus 1, rccl runs the one-rank self-test of that path (SyncBN + gradient all-reduce in the graph)')
     ap.add_argument('--local-bn', action='store_true',
                     help='N>1: per-rank BatchNorm statistics instead of the config\'s SyncBN (one all-reduce per BN and direction)')
     ap.add_argument('--trace-only', action='store_true',
@@ -182,14 +185,14 @@ def main():
 
     graphed = False
     if mode == 'train':
-        trainer = L.Trainer(model, cfg, world_size=world)
+        trainer = L.Trainer(model, cfg, world_size=world, collectives=args.collectives)
         samples = [L.SegDataSample(gt=lab[i]) for i in range(bs)]
 
         def eager_step():
             return trainer.train_step(img, samples)
         step = eager_step
-        if world == 1 and not args.no_graph:
-            try:        # whole step (fwd + loss + bwd + SGD) as one hipGraph
+        if (world == 1 or trainer.comm is not None) and not args.no_graph:
+            try:        # whole step (fwd + loss + bwd [+ in-stream RCCL all-reduces] + SGD) as one hipGraph
                 trainer.capture(img, samples)
                 step, graphed = (lambda: trainer.replay()), True
             except Exception as e:   # noqa: BLE001 -- report and fall back to eager launches
@@ -290,8 +293,10 @@ def main():
             'config': {'workload': (f'LED-Net {H}x{W} train_step (fwd+OHEM-CE+bwd+SGD) batch {bs}/GPU' if mode == 'train'
                                     else f'LED-Net {H}x{W} inference (fwd+fusion+argmax) batch {bs}/GPU'),
                        'global_batch': bs * world, 'parallelism': f'dp{world}',
-                       'batchnorm': ('SyncBN (config): one RCCL all-reduce of [2,C] per BN and direction' if world > 1 and mode == 'train' and not args.local_bn
+                       'batchnorm': ('SyncBN (config): one RCCL all-reduce of [2,C] per BN and direction' if mode == 'train' and not args.local_bn and trainer._all_reduce is not None
                                      else 'per-rank statistics'),
+                       'collectives': (None if mode != 'train' or trainer._all_reduce is None else
+                                       ('ncclAllReduce on the launch stream (in the graph)' if trainer.comm is not None else 'torch.distributed (eager)')),
                        'kernel_launches_per_step': len(launches) // k_steps,
                        'submission': 'hipGraph replay' if graphed else 'eager launches',
                        'kernel_timing': 'HIP events on the launch streams, instrumented eager pass of the same step right after the timed region',

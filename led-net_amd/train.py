@@ -582,7 +582,7 @@ class Trainer:
     large RCCL all-reduces over contiguous slices instead of one per tensor."""
 
     def __init__(self, model, cfg=None, world_size=1, lr=None, momentum=None, weight_decay=None,
-                 max_iters=None, power=0.9, eta_min=0.0, bucket_mb=2.0, direct_grads=True):
+                 max_iters=None, power=0.9, eta_min=0.0, bucket_mb=2.0, direct_grads=True, collectives=None):
         opt = dict((cfg or {}).get('optimizer', {}))
         self.model = model
         self.base_lr = lr if lr is not None else opt.get('lr', 0.01)
@@ -613,6 +613,13 @@ class Trainer:
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         sync = getattr(model.backbone, 'sync_bn', False) or getattr(model.decode_head, 'sync_bn', False)
         _Env.world = world_size
+        # collectives: 'rccl' = ncclAllReduce on the launch stream (rccl.Comm: capturable in the step's
+        # hipGraph), 'torch' = torch.distributed (eager only), default 'auto' = rccl on the GPU when it
+        # initialises, else torch.  'rccl' with world_size 1 is the single-GPU self-test of that path.
+        import os
+        mode = collectives or os.environ.get('LEDN_COLLECTIVES', 'auto')
+        self.comm = None
+        self.dist = None
         if world_size > 1:
             import torch.distributed as dist
             self.dist = dist
@@ -621,10 +628,23 @@ class Trainer:
             for b in model.buffers():
                 if b.is_floating_point():
                     dist.broadcast(b.data, 0)
-            _Env.sync_bn = (lambda t: dist.all_reduce(t)) if sync else None
+        if mode in ('auto', 'rccl') and dev.type == 'cuda' and (world_size > 1 or mode == 'rccl'):
+            try:
+                from . import rccl
+                self.comm = rccl.Comm(self.dist.get_rank() if self.dist is not None else 0, world_size, dev)
+            except Exception as e:   # noqa: BLE001 -- 'auto': fall back to torch.distributed
+                if mode == 'rccl':
+                    raise
+                import sys
+                print(f'[led_net_amd] direct RCCL unavailable ({e!r}); collectives through torch.distributed',
+                      file=sys.stderr)
+        if self.comm is not None:
+            self._all_reduce = self.comm.all_reduce_
+        elif self.dist is not None:
+            self._all_reduce = lambda t: self.dist.all_reduce(t)
         else:
-            self.dist = None
-            _Env.sync_bn = None
+            self._all_reduce = None
+        _Env.sync_bn = self._all_reduce if (sync and self._all_reduce is not None) else None
 
     def lr(self):
         """mmengine PolyLR (by iteration): (base-eta_min)*(1-it/max)^power + eta_min."""
@@ -643,9 +663,13 @@ class Trainer:
         self._arena.reset()                  # one fill for every small zeroed scratch of the step
         ops.set_zero_arena(self._arena)
         _Sinks.map = self._sink_map
+        multi = ops.MULTI_STREAM
+        if self._all_reduce is not None:
+            ops.MULTI_STREAM = False         # collectives of all ranks stay ordered on ONE stream
         try:
             return self._train_step(inputs, data_samples, first)
         finally:
+            ops.MULTI_STREAM = multi
             ops.set_zero_arena(None)
             _Sinks.map = {}
 
@@ -698,10 +722,10 @@ class Trainer:
 
     def _train_step(self, inputs, data_samples, first):
         losses = self._forward_backward(inputs, data_samples, first)
-        if self.dist is not None:
+        if self._all_reduce is not None:
             n = self.flat_grad.numel()
             for off in range(0, n, self.bucket_elems):
-                self.dist.all_reduce(self.flat_grad[off:off + self.bucket_elems])
+                self._all_reduce(self.flat_grad[off:off + self.bucket_elems])
         self.table.step(self.lr(), self.momentum, self.wd, 1.0 / self.world, lr_dev=self._lr_dev)
         self.iter += 1
         return losses
@@ -709,9 +733,10 @@ class Trainer:
     # ------------------------------------------------------------------ #
     # hipGraph replay of the whole step (forward + loss + backward + SGD): ~800 launches
     # per step are submitted as ONE graph, the host only refreshes the input buffers and the
-    # device-resident learning rate.  Single-process only (collectives stay eager).
+    # device-resident learning rate.  With N > 1 ranks the collectives must be stream operations
+    # (rccl.Comm): torch.distributed's cannot be captured.
     def capture(self, inputs, data_samples, warmup=3):
-        assert self.dist is None, 'graph capture is for the single-GPU step'
+        assert self.dist is None or self.comm is not None, 'graph capture with N > 1 needs the direct RCCL communicator'
         dev = inputs.device
         self._static_in = inputs.clone()
         self._static_lab = [ds.gt_sem_seg.data.clone() for ds in data_samples]

@@ -60,3 +60,43 @@ def test_ddp_world2_gloo(tmp_path):
     rm = r0['sd']['backbone.stem.0.bn.running_mean']
     assert rm.abs().max() > 0 and torch.equal(rm, r1['sd']['backbone.stem.0.bn.running_mean'])
     assert x.shape[0] == 4
+
+
+@pytest.mark.gpu
+def test_rccl_in_graph_single_rank():
+    """The N > 1 step keeps its collectives inside the hipGraph by issuing ncclAllReduce on the launch
+    stream (led_net_amd/rccl.py).  One GPU can check everything but the wire: a one-rank communicator,
+    SyncBN statistics and the flat gradient all-reduced through it (identity), the whole step captured
+    and replayed -- same parameters as the plain single-GPU trainer after three steps."""
+    import copy
+    sys.path.insert(0, ROOT)
+    import led_net_amd as L
+    assert torch.cuda.is_available()
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    cfg = L.load_config(os.path.join(ROOT, 'tests', 'data', 'lednet_test_config.py'))
+    for c in cfg['model']['decode_head']['loss_decode']:
+        c['min_kept'] = 5000
+    base = L.MODELS.build(cfg['model'])
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (2, 3, 320, 320), dtype=torch.uint8, generator=g).to(dev)
+    lab = torch.randint(0, 2, (2, 1, 320, 320), dtype=torch.int64, generator=g).to(dev)
+    samples = [L.SegDataSample(gt=lab[i]) for i in range(2)]
+    res = []
+    for mode in (None, 'rccl'):
+        model = copy.deepcopy(base).to(dev)
+        tr = L.Trainer(model, cfg, max_iters=100, collectives=mode)
+        assert (tr.comm is not None) == (mode == 'rccl')
+        tr.capture(img, samples, warmup=2)          # 2 eager steps, then the captured one is replayed once
+        out = tr.replay()
+        torch.cuda.synchronize()
+        res.append(({k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()},
+                    {k: float(v.reshape(-1)[0]) for k, v in out.items()}))
+        if tr.comm is not None:
+            tr.comm.close()
+    (sd0, o0), (sd1, o1) = res
+    for k in o0:      # third step's loss: GPU summation-order noise only (see test_train's sink test)
+        assert abs(o1[k] - o0[k]) <= 2e-2 * abs(o0[k]) + 1e-3, (k, o0[k], o1[k])
+    worst = max(float((sd1[k] - v).norm() / (v.norm() + 1e-6)) for k, v in sd0.items()
+                if v.is_floating_point() and v.numel() > 16)
+    assert worst < 5e-2, worst
