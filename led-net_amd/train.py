@@ -728,7 +728,10 @@ class Trainer:
                 self._all_reduce(self.flat_grad[off:off + self.bucket_elems])
         self.table.step(self.lr(), self.momentum, self.wd, 1.0 / self.world, lr_dev=self._lr_dev)
         self.iter += 1
-        return losses
+        # detached: a caller holding the returned losses would otherwise keep the step's autograd graph
+        # (and its AccumulateGrad nodes, bound to this step's stream) alive into a later hipGraph capture,
+        # where they run on the wrong stream and break the capture
+        return {k: v.detach() for k, v in losses.items()}
 
     # ------------------------------------------------------------------ #
     # hipGraph replay of the whole step (forward + loss + backward + SGD): ~800 launches
