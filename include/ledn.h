@@ -112,6 +112,12 @@ int ledn_pack_conv_weights_multi(const ledn_pack_entry* table_dev, int n, long l
  * 32 columns (9*C used, rest zero).  The stem (ddrnet.py:123-130) then runs as a K=32 1x1
  * GEMM on the MFMA path with the weight reshaped to [Cout][32][1][1]. */
 int ledn_im2col_stem(const void* x, void* p, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+/* The same patches straight from the planar input batch (NCHW uint8 / f32 / bf16) with the
+ * SegDataPreProcessor normalisation and channel map (data_preprocessor.py:98-151) applied on the
+ * way: p[.., (kh*3+kw)*C + c] = bf16(x[n, map[c], hi, wi] * scale[c] + shift[c]).  Fuses
+ * ledn_nchw_to_nhwc + ledn_im2col_stem (the NHWC copy of the input is never written). */
+int ledn_im2col_stem_planar(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
+                            const float* scale, const float* shift, const int* map, void* stream);
 
 /* Weight (and bias) gradient of the same convolution:
  *   dw(co,ci,tap) += sum_{n,ho,wo} pre(x)[n, ho*s-pad+kh*dil, .., ci] * dz[n,ho,wo,co]

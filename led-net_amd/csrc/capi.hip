@@ -16,6 +16,8 @@ int pack_conv_weights_impl(const float* w, void* out, int Cout, int Cin, int KH,
 int wgrad_validate(const ledn_wgrad_desc& d);
 int conv_wgrad_direct(const ledn_wgrad_desc& d, hipStream_t s);
 int dwconv_impl(const ledn_dw_desc& d, hipStream_t s);
+int im2col_stem_planar_impl(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
+                            const float* scale, const float* shift, const int* map, hipStream_t s);
 int dw_pack_impl(const ledn_dwpack_desc& d, float* packed, hipStream_t s);
 int dw_unpack_grad_impl(const ledn_dwpack_desc& d, const float* dpacked, hipStream_t s);
 int sesp_pyramid_impl(const ledn_pyr_desc& d, hipStream_t s);
@@ -113,6 +115,10 @@ int ledn_pack_conv_weights_multi(const ledn_pack_entry* table_dev, int n, long l
     return pack_conv_weights_multi_impl(table_dev, n, max_elems, S(stream));
 }
 
+int ledn_im2col_stem_planar(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
+                            const float* scale, const float* shift, const int* map, void* stream) {
+    return im2col_stem_planar_impl(x, dtype_x, p, N, H, W, C, Ho, Wo, scale, shift, map, S(stream));
+}
 int ledn_im2col_stem(const void* x, void* p, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
     return im2col_stem_impl(x, p, N, H, W, C, Ho, Wo, S(stream));
 }

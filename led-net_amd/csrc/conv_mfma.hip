@@ -610,6 +610,61 @@ __global__ void __launch_bounds__(256) im2col_stem_kernel(const bf16_t* x, bf16_
                             e[8 * q + 4] | ((unsigned)e[8 * q + 5] << 16), e[8 * q + 6] | ((unsigned)e[8 * q + 7] << 16));
 }
 
+// planar source: thread = (output pixel, quarter of the 32 columns): the four lanes of a pixel store its
+// whole 64-byte row (16 B each); along a wave the planar reads run along W (stride 2 pixels)
+__device__ __forceinline__ float ldp(const unsigned char* p) { return (float)*p; }
+__device__ __forceinline__ float ldp(const float* p) { return *p; }
+__device__ __forceinline__ float ldp(const bf16_t* p) { return bf16_to_f32(p->v); }
+
+template <typename TX>
+__global__ void __launch_bounds__(256) im2col_stem_planar_kernel(const TX* x, bf16_t* p, int N, int H, int W, int C,
+                                                                 int Ho, int Wo, const float* scale,
+                                                                 const float* shift, const int* map) {
+    const long total = (long)N * Ho * Wo * 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int q = (int)(idx & 3);
+    const long pix = idx >> 2;
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long)Wo * Ho));
+    const long plane = (long)H * W;
+    unsigned short e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int col = q * 8 + i;
+        const int tap = col / C, c = col - tap * C;       // col = (kh*3+kw)*C + c
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
+        const bool valid = col < 9 * C && hi >= 0 && hi < H && wi >= 0 && wi < W;
+        const int cc = valid ? c : 0;
+        const int cs = map ? map[cc] : cc;
+        float v = ldp(x + ((long)n * C + cs) * plane + (valid ? (long)hi * W + wi : 0L));
+        if (scale) v = v * scale[cc] + shift[cc];
+        e[i] = valid ? f32_to_bf16(v) : (unsigned short)0;
+    }
+    *reinterpret_cast<uint4*>(p + pix * 32 + q * 8) =
+        make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
+                   e[6] | ((unsigned)e[7] << 16));
+}
+
+int im2col_stem_planar_impl(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
+                            const float* scale, const float* shift, const int* map, hipStream_t s) {
+    LEDN_REQUIRE(x && p && N > 0 && H > 0 && W > 0 && C > 0 && 9 * C <= 32);
+    LEDN_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1);
+    LEDN_REQUIRE((scale == nullptr) == (shift == nullptr));
+    const dim3 grid((unsigned)cdiv((long)N * Ho * Wo * 4, 256));
+#define LEDN_IP(TX)                                                                                         \
+    LEDN_LAUNCH((im2col_stem_planar_kernel<TX>), grid, dim3(256), 0, s, (const TX*)x, (bf16_t*)p, N, H, W, C, Ho, \
+                Wo, scale, shift, map)
+    if (dtype_x == LEDN_U8) LEDN_IP(unsigned char);
+    else if (dtype_x == LEDN_F32) LEDN_IP(float);
+    else if (dtype_x == LEDN_BF16) LEDN_IP(bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_IP
+    return check_launch();
+}
+
 int im2col_stem_impl(const void* x, void* p, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
     LEDN_REQUIRE(x && p && N > 0 && H > 0 && W > 0 && C > 0 && 9 * C <= 32);
     LEDN_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1);

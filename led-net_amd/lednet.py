@@ -80,17 +80,19 @@ class LEDNet(Block):
     def init_weights(self):
         kaiming_init(self)
 
-    def _stem0(self, xin):
+    def _stem0(self, xin, patches=None):
         """first stem conv (3x3 s2, 3 -> C).  bf16: im2col to 32 columns + K=32 GEMM on the
         MFMA path (the 3-channel direct conv is VALU-bound); f32: direct kernel."""
         m = self.stem['0']
-        if xin.dtype != torch.bfloat16 or 9 * self.in_channels > 32 or self.channels % 32:
+        if patches is None and (xin.dtype != torch.bfloat16 or 9 * self.in_channels > 32 or self.channels % 32):
             return m(xin)
         from .blocks import fold_bn
         w_eff = self.cached('stem_w', lambda: ops.stem_weight_as_1x1(m.conv.weight.detach()))
         wp = self.cached('stem_wp', lambda: ops.pack_conv_weights(w_eff, 0))
         s, b = self.cached('stem_fold', lambda: fold_bn(m.bn))
-        return ops.conv2d(ops.im2col_stem(xin), w_eff, out_scale=s, out_shift=b, act=ACT_RELU, w_bf16=wp)
+        if patches is None:
+            patches = ops.im2col_stem(xin)
+        return ops.conv2d(patches, w_eff, out_scale=s, out_shift=b, act=ACT_RELU, w_bf16=wp)
 
     # ------------------------------------------------------------------ #
     def forward(self, x, pre=None):
@@ -102,8 +104,11 @@ class LEDNet(Block):
         N, _, H, W = x.shape
         out_size = (math.ceil(H / 8), math.ceil(W / 8))                      # ddrnet.py:185
         s, b, m = pre if pre is not None else (None, None, None)
-        xin = ops.nchw_to_nhwc(x.contiguous(), self.act_dtype, s, b, m)
-        x1 = self._stem0(xin)                                                  # C  @1/2
+        if self.act_dtype == torch.bfloat16 and 9 * self.in_channels <= 32 and self.channels % 32 == 0:
+            # planar batch -> im2col patches in one kernel (normalisation folded in), then a K=32 GEMM
+            x1 = self._stem0(None, ops.im2col_stem_planar(x.contiguous(), s, b, m))
+        else:
+            x1 = self._stem0(ops.nchw_to_nhwc(x.contiguous(), self.act_dtype, s, b, m))    # C  @1/2
         x2 = self.stem['1'](x1)                                                # C  @1/4
         y = self.stem['2'][1](self.stem['2'][0](x2), final_relu=True)
         y = self.stem['4'][1](self.stem['4'][0](y), final_relu=True)           # 2C @1/8

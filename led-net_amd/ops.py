@@ -264,6 +264,25 @@ def im2col_stem(x):
     return p
 
 
+def im2col_stem_planar(x, scale=None, shift=None, chan_map=None):
+    """x: [N,C,H,W] uint8/float32/bfloat16 planar batch -> [N,Ho,Wo,32] bf16 patches of the 3x3/s2/p1 stem
+    conv with y = x[map[c]]*scale[c]+shift[c] applied (= im2col_stem(nchw_to_nhwc(x, bf16, ...)))."""
+    lib = _lib.get_lib()
+    N, Cc, H, W = x.shape
+    dtx = {torch.float32: F32, torch.bfloat16: BF16, torch.uint8: _lib.U8}.get(x.dtype)
+    if dtx is None or 9 * Cc > 32:
+        raise LednError('im2col_stem_planar: uint8/f32/bf16 input with <= 3 channels required')
+    if chan_map is not None and (chan_map.dtype != torch.int32 or chan_map.numel() != Cc):
+        raise LednError('im2col_stem_planar: chan_map must be int32[C]')
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    p = torch.empty((N, Ho, Wo, 32), dtype=torch.bfloat16, device=x.device)
+    _check(lib, x, p, scale, shift, chan_map)
+    _run(lib, 'ledn_im2col_stem_planar', x, _p(x), dtx, _p(p), N, H, W, Cc, Ho, Wo, _p(_f32(scale, Cc)),
+         _p(_f32(shift, Cc)), _p(chan_map),
+         work=_TIMING is not None and (f'im2col_stem_planar {N}x{H}x{W}', _nb(x, p), 0, 'im2col_stem_planar_kernel'))
+    return p
+
+
 def stem_weight_as_1x1(w):
     """[Cout][3][3][3] OIHW -> [Cout][32][1][1] matching im2col_stem's column order (differentiable)."""
     co, ci, kh, kw = w.shape

@@ -472,16 +472,16 @@ def lednet_forward_train(m, x, pre=None):
     H, W = x.shape[2:]
     out_size = (math.ceil(H / 8), math.ceil(W / 8))
     s, b, mp = pre if pre is not None else (None, None, None)
-    xin = ops.nchw_to_nhwc(x.contiguous(), m.act_dtype, s, b, mp)
     s0 = m.stem['0']
-    if xin.dtype == torch.bfloat16 and 9 * m.in_channels <= 32 and m.channels % 32 == 0:
-        # stem as a K=32 GEMM on the MFMA path: im2col patches (no gradient needed) x reshaped weight
-        st = _stats(m.channels, xin)
-        z = ConvFn.apply(ops.im2col_stem(xin), ops.stem_weight_as_1x1(s0.conv.weight), None, None, 1, 0, 1,
-                         st, None)
+    if m.act_dtype == torch.bfloat16 and 9 * m.in_channels <= 32 and m.channels % 32 == 0:
+        # stem as a K=32 GEMM on the MFMA path: im2col patches straight from the planar batch
+        # (normalisation folded in; the input needs no gradient) x reshaped weight
+        st = _stats(m.channels, x)
+        z = ConvFn.apply(ops.im2col_stem_planar(x.contiguous(), s, b, mp), ops.stem_weight_as_1x1(s0.conv.weight),
+                         None, None, 1, 0, 1, st, None)
         x1 = BNActFn.apply(z, s0.bn.weight, s0.bn.bias, None, None, st, s0.bn, ACT_RELU, RES_NONE, None)
     else:
-        x1 = conv_module(s0, xin)
+        x1 = conv_module(s0, ops.nchw_to_nhwc(x.contiguous(), m.act_dtype, s, b, mp))
     x2 = conv_module(m.stem['1'], x1)
     y = basic_block(m.stem['2'][1], basic_block(m.stem['2'][0], x2), final_relu=True)
     y = basic_block(m.stem['4'][1], basic_block(m.stem['4'][0], y), final_relu=True)

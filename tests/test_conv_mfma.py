@@ -191,3 +191,19 @@ def test_mfma_narrow_head_f32_output(be, cin, cout, k):
                      w_bf16=ops.pack_conv_weights(D(w), 0))
     assert got.dtype == torch.float32
     torch.testing.assert_close(nchw(got), want, rtol=1e-3, atol=2e-3)   # f32 store: no output rounding
+
+
+@pytest.mark.parametrize('dt,hw', [(torch.uint8, (37, 50)), (torch.float32, (16, 21))])
+def test_im2col_stem_planar_equals_two_step(be, dt, hw):
+    """ledn_im2col_stem_planar (planar batch -> normalised bf16 patches in one kernel) is bit-identical
+    to ledn_nchw_to_nhwc followed by ledn_im2col_stem (SegDataPreProcessor: BGR->RGB map, mean/std)."""
+    from led_net_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randint(0, 256, (2, 3, *hw), generator=g).to(dt)
+    mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
+    s, b = D(1.0 / std), D(-mean / std)
+    mp = D(torch.tensor([2, 1, 0], dtype=torch.int32))
+    want = ops.im2col_stem(ops.nchw_to_nhwc(D(x), torch.bfloat16, s, b, mp))
+    got = ops.im2col_stem_planar(D(x), s, b, mp)
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    assert torch.equal(got.cpu().view(torch.int16), want.cpu().view(torch.int16))
