@@ -87,6 +87,7 @@ typedef struct {
     int in_act, act_out, res_mode;
     int dtype_x, dtype_y;
     int transposed;
+    const float* in_slope; /* [Cin] when in_act == PRELU (pre(x) = prelu(x*in_scale+in_shift, in_slope)) */
 } ledn_conv_desc;
 int ledn_conv2d(const ledn_conv_desc* d, void* stream);
 /* Pure query, no launch: 1 if ledn_conv2d would run this descriptor on conv_mfma_kernel (matrix
@@ -136,6 +137,7 @@ typedef struct {
     int KH, KW, stride, pad, dil, groups;
     int in_act;
     int dtype_x, dtype_dz;
+    const float* in_slope; /* [Cin] when in_act == PRELU */
 } ledn_wgrad_desc;
 int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream);
 int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d);   /* same query for the weight gradient */

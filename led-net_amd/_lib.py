@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ('N', i32), ('H', i32), ('W', i32), ('Cin', i32), ('Ho', i32), ('Wo', i32), ('Cout', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('groups', i32),
                 ('in_act', i32), ('act_out', i32), ('res_mode', i32),
-                ('dtype_x', i32), ('dtype_y', i32), ('transposed', i32)]
+                ('dtype_x', i32), ('dtype_y', i32), ('transposed', i32), ('in_slope', fp)]
 
 
 class WgradDesc(C.Structure):
@@ -38,7 +38,7 @@ class WgradDesc(C.Structure):
                 ('ws_co', i64), ('ws_ci', i64), ('ws_tap', i64),
                 ('N', i32), ('H', i32), ('W', i32), ('Cin', i32), ('Ho', i32), ('Wo', i32), ('Cout', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('dil', i32), ('groups', i32),
-                ('in_act', i32), ('dtype_x', i32), ('dtype_dz', i32)]
+                ('in_act', i32), ('dtype_x', i32), ('dtype_dz', i32), ('in_slope', fp)]
 
 
 class DwDesc(C.Structure):

@@ -103,6 +103,10 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(ledn_conv_desc d) {
                         if (d.in_act == LEDN_ACT_RELU) {
 #pragma unroll
                             for (int v = 0; v < VEC; ++v) xv[v] = fmaxf(xv[v], 0.f);
+                        } else if (d.in_act == LEDN_ACT_PRELU) {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v)
+                                xv[v] = xv[v] > 0.f ? xv[v] : xv[v] * d.in_slope[ci0 + cb + ci + v];
                         }
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
@@ -316,7 +320,7 @@ int conv_validate(const ledn_conv_desc& d) {
     LEDN_REQUIRE((d.stat_sum == nullptr) == (d.stat_sqsum == nullptr));
     LEDN_REQUIRE(d.res_mode == LEDN_RES_NONE || d.res != nullptr);
     LEDN_REQUIRE(d.act_out != LEDN_ACT_PRELU || d.slope != nullptr);
-    LEDN_REQUIRE(d.in_act == LEDN_ACT_NONE || d.in_act == LEDN_ACT_RELU);
+    LEDN_REQUIRE(d.in_act == LEDN_ACT_NONE || d.in_act == LEDN_ACT_RELU || (d.in_act == LEDN_ACT_PRELU && d.in_slope));
     const int kh_ext = (d.KH - 1) * d.dil + 1, kw_ext = (d.KW - 1) * d.dil + 1;
     if (!d.transposed) {
         LEDN_REQUIRE(d.Ho == (d.H + 2 * d.pad - kh_ext) / d.stride + 1);
@@ -397,6 +401,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_direct_kernel(ledn_wgrad_desc 
                         if (xadd) xv += ld(xadd + xoff);
                         if (d.in_scale) xv = xv * d.in_scale[g * cig + ci] + d.in_shift[g * cig + ci];
                         if (d.in_act == LEDN_ACT_RELU) xv = fmaxf(xv, 0.f);
+                        else if (d.in_act == LEDN_ACT_PRELU) xv = xv > 0.f ? xv : xv * d.in_slope[g * cig + ci];
                     }
                     if (co < cog) zv = ld(dz + p * d.Cout + g * cog + co);
                 }
@@ -481,6 +486,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_narrow_kernel(ledn_wgrad_desc 
                     float xv = ld(x + xoff + wc);
                     if (d.in_scale) xv = xv * d.in_scale[wc] + d.in_shift[wc];
                     if (d.in_act == LEDN_ACT_RELU) xv = fmaxf(xv, 0.f);
+                    else if (d.in_act == LEDN_ACT_PRELU) xv = xv > 0.f ? xv : xv * d.in_slope[wc];
 #pragma unroll
                     for (int c = 0; c < NC; ++c) acc[t][c] = fmaf(xv, zv[c], acc[t][c]);
                 } else {
@@ -490,6 +496,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_narrow_kernel(ledn_wgrad_desc 
                         float xv = ld(x + xoff + c);
                         if (d.in_scale) xv = xv * d.in_scale[c] + d.in_shift[c];
                         if (d.in_act == LEDN_ACT_RELU) xv = fmaxf(xv, 0.f);
+                        else if (d.in_act == LEDN_ACT_PRELU) xv = xv > 0.f ? xv : xv * d.in_slope[c];
                         acc[t][c] = fmaf(xv, zw, acc[t][c]);
                     }
                 }
@@ -604,6 +611,7 @@ int wgrad_validate(const ledn_wgrad_desc& d) {
     LEDN_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.dil > 0 && d.pad >= 0 && d.groups > 0);
     LEDN_REQUIRE(d.Cin % d.groups == 0 && d.Cout % d.groups == 0);
     LEDN_REQUIRE((d.in_scale == nullptr) == (d.in_shift == nullptr));
+    LEDN_REQUIRE(d.in_act == LEDN_ACT_NONE || d.in_act == LEDN_ACT_RELU || (d.in_act == LEDN_ACT_PRELU && d.in_slope));
     LEDN_REQUIRE(d.Ho == (d.H + 2 * d.pad - ((d.KH - 1) * d.dil + 1)) / d.stride + 1);
     LEDN_REQUIRE(d.Wo == (d.W + 2 * d.pad - ((d.KW - 1) * d.dil + 1)) / d.stride + 1);
     return LEDN_OK;

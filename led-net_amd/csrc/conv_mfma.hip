@@ -47,6 +47,7 @@ struct MfmaConvArgs {
     const bf16_t* res;
     const float* in_scale;
     const float* in_shift;
+    const float* in_slope;
     const float* out_scale;
     const float* out_shift;
     const float* slope;
@@ -60,8 +61,8 @@ struct MfmaConvArgs {
 };
 
 // producer BatchNorm / ReLU applied to one 16-byte (8-channel) piece while it is staged
-__device__ __forceinline__ uint4 prologue_piece(uint4 v, const float* in_scale, const float* in_shift, int in_act,
-                                                int c) {
+__device__ __forceinline__ uint4 prologue_piece(uint4 v, const float* in_scale, const float* in_shift,
+                                                const float* in_slope, int in_act, int c) {
     if (in_scale || in_act) {
         unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -74,6 +75,9 @@ __device__ __forceinline__ uint4 prologue_piece(uint4 v, const float* in_scale, 
             if (in_act == LEDN_ACT_RELU) {
                 lo = fmaxf(lo, 0.f);
                 hi = fmaxf(hi, 0.f);
+            } else if (in_act == LEDN_ACT_PRELU) {
+                lo = lo > 0.f ? lo : lo * in_slope[c + 2 * i];
+                hi = hi > 0.f ? hi : hi * in_slope[c + 2 * i + 1];
             }
             w[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
         }
@@ -127,7 +131,7 @@ struct PatchStage {
     // thread then transforms its own valid pieces in place (rolled loop: keeps the hot loop's code
     // small; zero padding stays zero, i.e. padding is applied AFTER the prologue)
     __device__ __forceinline__ void commit(unsigned char* s_patch, const float* in_scale, const float* in_shift,
-                                           int in_act, int c0, int tid) const {
+                                           const float* in_slope, int in_act, int c0, int tid) const {
         const int part = tid & 3;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
@@ -144,7 +148,7 @@ struct PatchStage {
                 const int p = (tid >> 2) + j * 64;
                 if (p >= NPIX || !((ok >> j) & 1u)) continue;
                 uint4* slot = reinterpret_cast<uint4*>(s_patch + (long)p * PIXB + part * 16);
-                *slot = prologue_piece(*slot, in_scale, in_shift, in_act, c0 + part * 8);
+                *slot = prologue_piece(*slot, in_scale, in_shift, in_slope, in_act, c0 + part * 8);
             }
         }
     }
@@ -307,7 +311,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     int c0 = 0;
     LEDN_CONV_FETCH(tile, 0);
     while (tile < te) {
-        stage.commit(s_patch, a.in_scale, a.in_shift, a.in_act, c0, tid);
+        stage.commit(s_patch, a.in_scale, a.in_shift, a.in_slope, a.in_act, c0, tid);
         if (!one_chunk) LEDN_CONV_WEIGHTS(c0);
         __syncthreads();
         long ntile = tile;
@@ -489,7 +493,8 @@ bool conv_mfma_supported(const ledn_conv_desc& d) {
     // f32 output: narrow heads only (scalar-store epilogue), no residual (it would be f32 too)
     if (d.dtype_y != LEDN_BF16 && !(d.dtype_y == LEDN_F32 && d.Cout < 8 && !d.res)) return false;
     if (d.dil != 1 || d.xadd) return false;
-    if (d.act_out == LEDN_ACT_SIGMOID || (d.in_act != LEDN_ACT_NONE && d.in_act != LEDN_ACT_RELU)) return false;
+    if (d.act_out == LEDN_ACT_SIGMOID) return false;
+    if (d.in_act != LEDN_ACT_NONE && d.in_act != LEDN_ACT_RELU && !(d.in_act == LEDN_ACT_PRELU && d.in_slope)) return false;
     if (d.groups != 1 && !(d.KH == 1 && d.KW == 1)) return false;   // grouped 1x1: densified weight pack
     if (d.Cin % 16 || (d.Cout % 16 && d.Cout > 8)) return false;   // 16-channel tails are masked
     if (d.KH != d.KW || !((d.KH == 3 && d.pad == 1) || (d.KH == 1 && d.pad == 0))) return false;
@@ -501,7 +506,7 @@ bool conv_mfma_supported(const ledn_conv_desc& d) {
 int conv_mfma(const ledn_conv_desc& d, hipStream_t s) {
     MfmaConvArgs a;
     a.x = (const bf16_t*)d.x; a.wp = (const bf16_t*)d.w_bf16; a.y = (bf16_t*)d.y; a.res = (const bf16_t*)d.res;
-    a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.out_scale = d.out_scale; a.out_shift = d.out_shift;
+    a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_slope = d.in_slope; a.out_scale = d.out_scale; a.out_shift = d.out_shift;
     a.slope = d.slope; a.stat_sum = d.stat_sum; a.stat_sqsum = d.stat_sqsum;
     a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.in_act = d.in_act; a.act_out = d.act_out; a.res_mode = d.res_mode;
@@ -682,6 +687,7 @@ struct MfmaWgradArgs {
     float* dw;
     const float* in_scale;
     const float* in_shift;
+    const float* in_slope;
     long long ws_co, ws_ci, ws_tap;
     int N, H, W, Cin, Ho, Wo, Cout;
     int pad, in_act, groups;
@@ -750,8 +756,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
     } while (0)
     if (t0 < t1) LEDN_WGRAD_FETCH(t0);
     for (long tile = t0; tile < t1; ++tile) {
-        sx.commit(s_x, a.in_scale, a.in_shift, a.in_act, ci0, tid);
-        if (!narrow) sz.commit(s_z, nullptr, nullptr, 0, co0, tid);
+        sx.commit(s_x, a.in_scale, a.in_shift, a.in_slope, a.in_act, ci0, tid);
+        if (!narrow) sz.commit(s_z, nullptr, nullptr, nullptr, 0, co0, tid);
         else szn.commit(s_z, tid);
         __syncthreads();
         if (tile + 1 < t1) LEDN_WGRAD_FETCH(tile + 1);
@@ -901,7 +907,7 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s) {
 int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s) {
     MfmaWgradArgs a;
     a.x = (const bf16_t*)d.x; a.dz = (const bf16_t*)d.dz; a.dw = d.dw;
-    a.in_scale = d.in_scale; a.in_shift = d.in_shift;
+    a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_slope = d.in_slope;
     a.ws_co = d.ws_co; a.ws_ci = d.ws_ci; a.ws_tap = d.ws_tap;
     a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.pad = d.pad; a.in_act = d.in_act; a.groups = d.groups;

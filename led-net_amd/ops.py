@@ -201,7 +201,7 @@ def conv_out_size(h, k, stride, pad, dil):
 
 
 def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, in_shift=None,
-           in_act=ACT_NONE, out_scale=None, out_shift=None, act=ACT_NONE, slope=None, res=None,
+           in_act=ACT_NONE, in_slope=None, out_scale=None, out_shift=None, act=ACT_NONE, slope=None, res=None,
            res_mode=RES_NONE, stats=None, out_dtype=None, transposed=False, out_hw=None, w_bf16=None):
     """Dense/grouped convolution.  x: [N,H,W,Cin]; w: OIHW f32 [Cout_f, Cin_f/groups, KH, KW].
     transposed=True: x is dz [N,Ho_f,Wo_f,Cout_f]; returns dx [N,*out_hw,Cin_f].
@@ -228,11 +228,13 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
         raise LednError('conv2d: residual shape/dtype mismatch')
     if xadd is not None and (xadd.shape != x.shape or xadd.dtype != x.dtype):
         raise LednError('conv2d: xadd shape/dtype mismatch')
-    _check(lib, x, w, y, res, xadd, in_scale, in_shift, out_scale, out_shift, slope, w_bf16)
+    _check(lib, x, w, y, res, xadd, in_scale, in_shift, in_slope, out_scale, out_shift, slope, w_bf16)
+    if in_act == ACT_PRELU and in_slope is None:
+        raise LednError('conv2d: in_act PRELU needs in_slope')
     if w_bf16 is not None and (w_bf16.dtype != torch.bfloat16 or w_bf16.numel() != w.numel() * groups):
         raise LednError('conv2d: w_bf16 must be the bfloat16 pack of w')
     d.x, d.xadd, d.w, d.y, d.res, d.w_bf16 = _p(x), _p(xadd), _p(w), _p(y), _p(res), _p(w_bf16)
-    d.in_scale, d.in_shift = _p(_f32(in_scale, Cin)), _p(_f32(in_shift, Cin))
+    d.in_scale, d.in_shift, d.in_slope = _p(_f32(in_scale, Cin)), _p(_f32(in_shift, Cin)), _p(_f32(in_slope, Cin))
     d.out_scale, d.out_shift = _p(_f32(out_scale, Cout)), _p(_f32(out_shift, Cout))
     d.slope = _p(_f32(slope, Cout))
     if stats is not None:
@@ -313,7 +315,7 @@ def pack_conv_weights(w, mode=0, groups=1):
 
 
 def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None,
-                 in_shift=None, in_act=ACT_NONE, bias=False, dw_out=None, db_out=None):
+                 in_shift=None, in_act=ACT_NONE, in_slope=None, bias=False, dw_out=None, db_out=None):
     """Returns (dw [OIHW f32], db or None) of conv2d(pre(x), w).  dw_out / db_out: contiguous f32
     tensors the gradients are ACCUMULATED into (the trainer's flat gradient buffer) instead of
     fresh zeroed ones."""
@@ -329,10 +331,12 @@ def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None,
         db = db_out if db_out is not None else zeros_f32((Cout,), x.device)
     if tuple(dw.shape) != tuple(w_shape) or dw.dtype != torch.float32 or (db is not None and db.numel() != Cout):
         raise LednError('conv2d_wgrad: gradient buffer shape/dtype mismatch')
-    _check(lib, x, dz, xadd, in_scale, in_shift, dw, db)
+    _check(lib, x, dz, xadd, in_scale, in_shift, in_slope, dw, db)
+    if in_act == ACT_PRELU and in_slope is None:
+        raise LednError('conv2d_wgrad: in_act PRELU needs in_slope')
     d = _lib.WgradDesc()
     d.x, d.xadd, d.dz, d.dw, d.db = _p(x), _p(xadd), _p(dz), _p(dw), _p(db)
-    d.in_scale, d.in_shift = _p(_f32(in_scale, Cin)), _p(_f32(in_shift, Cin))
+    d.in_scale, d.in_shift, d.in_slope = _p(_f32(in_scale, Cin)), _p(_f32(in_shift, Cin)), _p(_f32(in_slope, Cin))
     d.ws_co, d.ws_ci, d.ws_tap = cigf * KH * KW, KH * KW, 1
     d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, Cout
     d.KH, d.KW, d.stride, d.pad, d.dil, d.groups = KH, KW, stride, pad, dil, groups

@@ -98,14 +98,7 @@ class ConvFn(Function):
         dz = _c(dz)
         dx = None
         if ctx.needs_input_grad[0] or (xadd is not None and ctx.needs_input_grad[3]):
-            wp = None
-            cin_f = w.shape[1] * groups     # dgrad kernel: "Cin" = Cout_f (16-multiple), "Cout" = Cin_f
-            if (dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and w.shape[0] % 16 == 0
-                    and (cin_f % 16 == 0 or cin_f <= 8) and ops.mfma_weight_ok(w, groups)
-                    and not (stride == 2 and w.shape[2] == 1)):
-                wp = get_pack(w, 1, groups)
-            dx = ops.conv2d(dz, w, stride=stride, pad=pad, groups=groups, transposed=True,
-                            out_hw=(x.shape[1], x.shape[2]), out_dtype=x.dtype, w_bf16=wp)
+            dx = _conv_dgrad(dz, x, w, stride, pad, groups)
         sw, sb = ctx.sinks
         dw, db = ops.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, pad=pad, groups=groups, xadd=xadd,
                                   bias=has_b, dw_out=sw, db_out=sb)
@@ -146,6 +139,67 @@ class BNActFn(Function):
             res_mode=res_mode, count=count, want_dres=res is not None and ctx.needs_input_grad[4],
             sync=_Env.sync_bn, sinks=ctx.sinks)
         return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None
+
+
+def _conv_dgrad(dz, x, w, stride, pad, groups):
+    """data gradient of conv2d(x, w): MFMA path when the flipped pack applies (see ConvFn.backward)"""
+    wp = None
+    cin_f = w.shape[1] * groups     # dgrad kernel: "Cin" = Cout_f (16-multiple), "Cout" = Cin_f
+    if (dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and w.shape[0] % 16 == 0
+            and (cin_f % 16 == 0 or cin_f <= 8) and ops.mfma_weight_ok(w, groups)
+            and not (stride == 2 and w.shape[2] == 1)):
+        wp = get_pack(w, 1, groups)
+    return ops.conv2d(dz, w, stride=stride, pad=pad, groups=groups, transposed=True,
+                      out_hw=(x.shape[1], x.shape[2]), out_dtype=x.dtype, w_bf16=wp)
+
+
+class BNActConvFn(Function):
+    """z = conv2d(act(BN_train(x)), w) + b with the BatchNorm + activation (none / ReLU / PReLU) folded
+    into the convolution's input staging: act(BN(x)) is never written (one write + one read of the
+    activation less, forward and backward).  backward: dy = dgrad(dz); dw = wgrad(pre(x), dz) with the
+    same prologue; then the BatchNorm/activation backward on (x, dy)."""
+    ACTS = (ACT_NONE, ACT_RELU, ACT_PRELU)
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, w, b, stats_in, bn, act, stride, pad, groups, stats_out, out_dtype):
+        Cc = x.shape[-1]
+        count = x.numel() // Cc
+        if stats_in is None:
+            stats_in = ops.zeros_f32((2, Cc), x.device)
+            ops.channel_stats(x, stats=(stats_in[0], stats_in[1]))
+        if _Env.sync_bn is not None:
+            _Env.sync_bn(stats_in)
+            count *= _Env.world
+        scale, shift, mean, invstd = ops.bn_finalize((stats_in[0], stats_in[1]), count, gamma, beta,
+                                                     bn.running_mean, bn.running_var, BN_MOMENTUM, bn.eps)
+        wp = None
+        if x.dtype == torch.bfloat16 and ops.mfma_weight_ok(w, groups) and out_dtype in (None, torch.bfloat16):
+            wp = get_pack(w, 0, groups)
+        st = (stats_out[0], stats_out[1]) if stats_out is not None else None
+        z = ops.conv2d(x, w, stride=stride, pad=pad, groups=groups, in_scale=scale, in_shift=shift, in_act=act,
+                       in_slope=slope, out_shift=b, stats=st, out_dtype=out_dtype, w_bf16=wp)
+        ctx.save_for_backward(x, w, scale, shift, mean, invstd, slope)
+        ctx.cfg = (act, count, stride, pad, groups, b is not None)
+        ctx.sinks = (_Sinks.get(gamma), _Sinks.get(beta), _Sinks.get(slope), _Sinks.get(w), _Sinks.get(b))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w, scale, shift, mean, invstd, slope = ctx.saved_tensors
+        act, count, stride, pad, groups, has_b = ctx.cfg
+        sg, sb_, ss, sw, sbias = ctx.sinks
+        dz = _c(dz)
+        dy = _conv_dgrad(dz, x, w, stride, pad, groups)
+        dw, db = ops.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, pad=pad, groups=groups, in_scale=scale,
+                                  in_shift=shift, in_act=act, in_slope=slope, bias=has_b, dw_out=sw, db_out=sbias)
+        dx, _, dgamma, dbeta, dslope = T.bn_act_bwd(x, dy, scale=scale, shift=shift, mean=mean, invstd=invstd,
+                                                     act=act, slope=slope, count=count, sync=_Env.sync_bn,
+                                                     sinks=(sg, sb_, ss))
+        return (dx, dgamma, dbeta, dslope, None if sw is not None else dw, None if sbias is not None else db,
+                None, None, None, None, None, None, None, None)
+
+
+FUSE_BN_INTO_CONV = True    # BNActConvFn where a BatchNorm(+act) output feeds exactly one convolution
 
 
 class ActFn(Function):
@@ -394,6 +448,9 @@ def conv_module(m, x, act_override=None, res=None, res_mode=RES_NONE, out_dtype=
     """blocks.ConvModule in training mode."""
     act = _ACT[m.act] if act_override is None else act_override
     if m.norm_first:
+        if FUSE_BN_INTO_CONV and act in BNActConvFn.ACTS:
+            return BNActConvFn.apply(x, m.bn.weight, m.bn.bias, None, m.conv.weight, m.conv.bias, None, m.bn, act,
+                                     m.stride, m.padding, 1, None, out_dtype)
         y = bn_act(x, m.bn, act)
         return ConvFn.apply(y, m.conv.weight, m.conv.bias, None, m.stride, m.padding, 1, None, out_dtype)
     return conv_bn_act(x, m.conv, m.bn if m.with_norm else None, act, res=res, res_mode=res_mode,
@@ -401,13 +458,24 @@ def conv_module(m, x, act_override=None, res=None, res_mode=RES_NONE, out_dtype=
 
 
 def basic_block(m, x, final_relu=False):
-    out = conv_module(m.conv1, x)
     if m.downsample is not None:
         res = conv_bn_act(x, m.downsample[0], m.downsample[1])
     else:
         res = x
     act = ACT_RELU if (m.act_out or final_relu) else ACT_NONE
-    return conv_module(m.conv2, out, act_override=act, res=res, res_mode=RES_ADD)
+    c1, c2 = m.conv1, m.conv2
+    if (FUSE_BN_INTO_CONV and not c1.norm_first and not c2.norm_first and c1.with_norm and c2.with_norm
+            and _ACT[c1.act] in BNActConvFn.ACTS):
+        # conv1 -> [BN1 + ReLU folded into conv2's input staging] -> conv2 -> BN2 (+res) -> act
+        st1 = _stats(c1.conv.out_channels, x)
+        z1 = ConvFn.apply(x, c1.conv.weight, c1.conv.bias, None, c1.conv.stride[0], c1.conv.padding[0],
+                          c1.conv.groups, st1, None)
+        st2 = _stats(c2.conv.out_channels, x)
+        z2 = BNActConvFn.apply(z1, c1.bn.weight, c1.bn.bias, None, c2.conv.weight, c2.conv.bias, st1, c1.bn,
+                               _ACT[c1.act], c2.conv.stride[0], c2.conv.padding[0], c2.conv.groups, st2, None)
+        return BNActFn.apply(z2, c2.bn.weight, c2.bn.bias, None, res, st2, c2.bn, act, RES_ADD, None)
+    out = conv_module(c1, x)
+    return conv_module(c2, out, act_override=act, res=res, res_mode=RES_ADD)
 
 
 def sesp(m, x):
@@ -417,12 +485,22 @@ def sesp(m, x):
     w2 = DwPackFn.apply(False, *[d.conv.weight for d in m.spp_dw_v2])
     st = _stats(m.nOut, x)
     z = DwFn.apply(p, w2, 1, -1, [d + 1 for d in m.dil], m.n, False, st)
-    cat = bn_act(z, m.br_after_cat.bn, ACT_PRELU, slope=m.br_after_cat.act.weight, stats=st)
+    exp = m.conv_1x1_exp
     if m.stride == 2 and not m.spatial:
-        return conv_bn_act(cat, m.conv_1x1_exp.conv, m.conv_1x1_exp.bn, res=AvgPoolFn.apply(x), res_mode=RES_ADD)
-    res = x if (m.stride == 1 and m.nIn == m.nOut) else None
-    return conv_bn_act(cat, m.conv_1x1_exp.conv, m.conv_1x1_exp.bn, ACT_PRELU, slope=m.module_act.weight,
-                       res=res, res_mode=RES_ADD if res is not None else RES_NONE)
+        act3, slope3, res = ACT_NONE, None, AvgPoolFn.apply(x)
+    else:
+        act3, slope3 = ACT_PRELU, m.module_act.weight
+        res = x if (m.stride == 1 and m.nIn == m.nOut) else None
+    rm = RES_ADD if res is not None else RES_NONE
+    if FUSE_BN_INTO_CONV:
+        # BN(cat) + PReLU folded into the expansion conv's input staging
+        st3 = _stats(exp.conv.out_channels, x)
+        z3 = BNActConvFn.apply(z, m.br_after_cat.bn.weight, m.br_after_cat.bn.bias, m.br_after_cat.act.weight,
+                               exp.conv.weight, exp.conv.bias, st, m.br_after_cat.bn, ACT_PRELU,
+                               exp.conv.stride[0], exp.conv.padding[0], exp.conv.groups, st3, None)
+        return BNActFn.apply(z3, exp.bn.weight, exp.bn.bias, slope3, res, st3, exp.bn, act3, rm, None)
+    cat = bn_act(z, m.br_after_cat.bn, ACT_PRELU, slope=m.br_after_cat.act.weight, stats=st)
+    return conv_bn_act(cat, exp.conv, exp.bn, act3, slope=slope3, res=res, res_mode=rm)
 
 
 def cespb(m, x):
