@@ -143,12 +143,40 @@ struct PatchStage {
             *reinterpret_cast<uint4*>(s_patch + (long)p * PIXB + part * 16) = q;
         }
         if (in_scale || in_act) {
+            // the thread's eight channels are the same for all its pieces: their parameters are loaded
+            // ONCE per commit (the first version re-read them from global memory for every piece)
+            float sc[8], sh[8], sl[8];
+            const int c = c0 + part * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                sc[i] = 1.f; sh[i] = 0.f; sl[i] = 0.f;
+            }
+            if (in_scale) {
+                ld8(in_scale + c, sc);
+                ld8(in_shift + c, sh);
+            }
+            if (in_act == LEDN_ACT_PRELU) ld8(in_slope + c, sl);
+            else if (in_act == LEDN_ACT_NONE) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sl[i] = 1.f;     // act(v) = max(v,0) + sl * min(v,0)
+            }
 #pragma unroll 1
             for (int j = 0; j < NL; ++j) {
                 const int p = (tid >> 2) + j * 64;
                 if (p >= NPIX || !((ok >> j) & 1u)) continue;
                 uint4* slot = reinterpret_cast<uint4*>(s_patch + (long)p * PIXB + part * 16);
-                *slot = prologue_piece(*slot, in_scale, in_shift, in_slope, in_act, c0 + part * 8);
+                const uint4 v4 = *slot;
+                unsigned w[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+                    lo = lo * sc[2 * i] + sh[2 * i];
+                    hi = hi * sc[2 * i + 1] + sh[2 * i + 1];
+                    lo = fmaxf(lo, 0.f) + sl[2 * i] * fminf(lo, 0.f);
+                    hi = fmaxf(hi, 0.f) + sl[2 * i + 1] * fminf(hi, 0.f);
+                    w[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                }
+                *slot = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
     }
