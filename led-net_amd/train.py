@@ -199,7 +199,10 @@ class BNActConvFn(Function):
                 None, None, None, None, None, None, None, None)
 
 
-FUSE_BN_INTO_CONV = True    # BNActConvFn where a BatchNorm(+act) output feeds exactly one convolution
+import os as _os
+# BNActConvFn where a BatchNorm(+act) output feeds exactly one convolution: 0 = off, 1 = the norm->act->conv
+# modules of LEDHead only, 2 = also BasicBlock conv1->conv2 and the SESP expansion (LEDN_FUSE_BN_CONV)
+FUSE_BN_INTO_CONV = int(_os.environ.get('LEDN_FUSE_BN_CONV', '1'))   # measured: 0, 1, 2 within 0.3 % of each other (r01q)
 
 
 class ActFn(Function):
@@ -464,7 +467,7 @@ def basic_block(m, x, final_relu=False):
         res = x
     act = ACT_RELU if (m.act_out or final_relu) else ACT_NONE
     c1, c2 = m.conv1, m.conv2
-    if (FUSE_BN_INTO_CONV and not c1.norm_first and not c2.norm_first and c1.with_norm and c2.with_norm
+    if (FUSE_BN_INTO_CONV >= 2 and not c1.norm_first and not c2.norm_first and c1.with_norm and c2.with_norm
             and _ACT[c1.act] in BNActConvFn.ACTS):
         # conv1 -> [BN1 + ReLU folded into conv2's input staging] -> conv2 -> BN2 (+res) -> act
         st1 = _stats(c1.conv.out_channels, x)
@@ -492,7 +495,7 @@ def sesp(m, x):
         act3, slope3 = ACT_PRELU, m.module_act.weight
         res = x if (m.stride == 1 and m.nIn == m.nOut) else None
     rm = RES_ADD if res is not None else RES_NONE
-    if FUSE_BN_INTO_CONV:
+    if FUSE_BN_INTO_CONV >= 2:
         # BN(cat) + PReLU folded into the expansion conv's input staging
         st3 = _stats(exp.conv.out_channels, x)
         z3 = BNActConvFn.apply(z, m.br_after_cat.bn.weight, m.br_after_cat.bn.bias, m.br_after_cat.act.weight,

@@ -87,6 +87,25 @@ def test_sesp_train_golden(be, name):
     _check_block(fx, m, TR.sesp)
 
 
+@pytest.mark.parametrize('name', [train_names('g1_')[0], train_names('g4')[0], train_names('g11_')[0], train_names('g11_')[-1]])
+def test_bn_folded_into_conv_golden(be, name, monkeypatch):
+    """train.FUSE_BN_INTO_CONV = 2: BatchNorm + (P)ReLU folded into the consuming convolution's input
+    staging in BasicBlock (conv1 -> conv2) and SESP (cat -> expansion), forward and backward, against
+    the same golden fixtures as the unfused path (the default folds the LEDHead modules only)."""
+    from led_net_amd.blocks import SESP, BasicBlock
+    from led_net_amd import train as TR
+    monkeypatch.setattr(TR, 'FUSE_BN_INTO_CONV', 2)
+    fx = Fixture(name)
+    kw = fx.meta['kwargs']
+    if name.startswith('g11_'):
+        m = BasicBlock(kw['in_channels'], kw['channels'], kw['stride'], kw.get('downsample', False),
+                       kw.get('act_out', True))
+        _check_block(fx, m, TR.basic_block)
+    else:
+        m = SESP(kw['nIn'], kw['nOut'], kw['stride'], 4, kw.get('r_lim', 7), kw['Spatial'])
+        _check_block(fx, m, TR.sesp)
+
+
 @pytest.mark.parametrize('name', train_names('g5_'))
 def test_getb_train_golden(be, name):
     from led_net_amd.blocks import GETB
