@@ -90,6 +90,12 @@ typedef struct {
     const float* in_slope; /* [Cin] when in_act == PRELU (pre(x) = prelu(x*in_scale+in_shift, in_slope)) */
 } ledn_conv_desc;
 int ledn_conv2d(const ledn_conv_desc* d, void* stream);
+/* ledn_conv2d, but when the kernel produced its channel statistics as per-workgroup partial rows
+ * ([rows][2][Cout] f32 in the workspace) the summing launch is skipped and the rows are handed to the
+ * caller (*rows > 0), who must pass them to ledn_bn_finalize_rows BEFORE any other ledn call on this
+ * workspace; *rows == 0: stat_sum / stat_sqsum are complete as with ledn_conv2d.  Saves one launch
+ * per conv + BatchNorm pair in training (BatchNorm statistics of nn.BatchNorm2d in train mode). */
+int ledn_conv2d_deferred_stats(const ledn_conv_desc* d, float** part, int* rows, void* stream);
 /* Pure query, no launch: 1 if ledn_conv2d would run this descriptor on conv_mfma_kernel (matrix
  * cores), 0 if on conv_direct_kernel (VALU).  bench.py names the kernel in its roofline with it. */
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d);
@@ -229,6 +235,12 @@ typedef struct {
     int C, act, res_mode;
     int dtype_x, dtype_y;
 } ledn_affine_desc;
+/* ledn_bn_finalize from statistic rows part[rows][2][C] (see ledn_conv2d_deferred_stats): sums the rows and
+ * finalizes in one launch; sum / sqsum (optional) receive the totals. */
+int ledn_bn_finalize_rows(const float* part, int rows, double count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                          float* shift, float* mean, float* invstd, float* sum, float* sqsum, int C,
+                          void* stream);
 int ledn_affine_act(const ledn_affine_desc* d, void* stream);
 
 /* Planar-to-interleaved input transform (the step in front of the stem):

@@ -16,6 +16,10 @@ int pack_conv_weights_impl(const float* w, void* out, int Cout, int Cin, int KH,
 int wgrad_validate(const ledn_wgrad_desc& d);
 int conv_wgrad_direct(const ledn_wgrad_desc& d, hipStream_t s);
 int dwconv_impl(const ledn_dw_desc& d, hipStream_t s);
+int bn_finalize_rows_impl(const float* part, int rows, double count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                          float* shift, float* mean, float* invstd, float* sum, float* sqsum, int C,
+                          hipStream_t s);
 int im2col_stem_planar_impl(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
                             const float* scale, const float* shift, const int* map, hipStream_t s);
 int dw_pack_impl(const ledn_dwpack_desc& d, float* packed, hipStream_t s);
@@ -75,6 +79,8 @@ static Workspace g_ws = {nullptr, 0};
 Workspace& workspace() { return g_ws; }
 static Options g_opt = {512, 512};
 Options& options() { return g_opt; }
+static DeferredStats g_defer = {false, nullptr, 0};
+DeferredStats& deferred_stats() { return g_defer; }
 }  // namespace ledn
 
 using namespace ledn;
@@ -106,6 +112,31 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
     if (rc != LEDN_OK) return rc;
     if (conv_mfma_supported(*d)) return conv_mfma(*d, S(stream));
     return conv_direct(*d, S(stream));
+}
+
+int ledn_conv2d_deferred_stats(const ledn_conv_desc* d, float** part, int* rows, void* stream) {
+    if (!d || !part || !rows) return LEDN_EINVAL;
+    *part = nullptr;
+    *rows = 0;
+    DeferredStats& ds = deferred_stats();
+    ds.want = true;
+    ds.part = nullptr;
+    ds.rows = 0;
+    const int rc = ledn_conv2d(d, stream);
+    ds.want = false;
+    if (rc == LEDN_OK && ds.part) {
+        *part = ds.part;
+        *rows = ds.rows;
+    }
+    return rc;
+}
+
+int ledn_bn_finalize_rows(const float* part, int rows, double count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                          float* shift, float* mean, float* invstd, float* sum, float* sqsum, int C,
+                          void* stream) {
+    return bn_finalize_rows_impl(part, rows, count, gamma, beta, running_mean, running_var, momentum, eps, scale,
+                                 shift, mean, invstd, sum, sqsum, C, S(stream));
 }
 
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d) { return d && conv_mfma_supported(*d) ? 1 : 0; }

@@ -255,6 +255,14 @@ struct Options {
     int wgrad_workgroups;
 };
 Options& options();
+// ledn_conv2d_deferred_stats: the MFMA conv leaves its per-workgroup statistic rows [rows][2][C] in the
+// workspace (no finish launch) and reports them here; ledn_bn_finalize_rows sums them itself
+struct DeferredStats {
+    bool want;
+    float* part;
+    int rows;
+};
+DeferredStats& deferred_stats();
 // out_j[c] += sum_b part[b*K + j*C + c], j < nout (K = nout*C)
 int finish_partials(const float* part, int nblk, int C, int nout, float* o0, float* o1, float* o2,
                     hipStream_t s);

@@ -266,6 +266,71 @@ int nchw_to_nhwc_impl(const void* x, int dtype_x, void* y, int dtype_y, int N, i
     return check_launch();
 }
 
+// BatchNorm finalize straight from the producer's per-workgroup statistic rows part[rows][2][C]
+// (one launch instead of finish_partials + bn_finalize).  Workgroup = 2 channels: thread = (one of
+// the 4 sums, one of 64 row slots), 4 independent loads in flight, LDS reduction over the slots.
+__global__ void __launch_bounds__(256) bn_finalize_rows_kernel(const float* part, int rows, double count,
+                                                               const float* gamma, const float* beta,
+                                                               float* running_mean, float* running_var,
+                                                               float momentum, float eps, float* scale,
+                                                               float* shift, float* mean_o, float* invstd_o,
+                                                               float* sum_o, float* sqsum_o, int C) {
+    __shared__ float s_red[256];
+    const int o = threadIdx.x & 3, slot = threadIdx.x >> 2;
+    const int ch = o & 1, kind = o >> 1;
+    const int c = blockIdx.x * 2 + ch;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+        const float* src = part + (long)kind * C + c;
+        const long rs = 2L * C;
+        int r = slot;
+        for (; r + 192 < rows; r += 256) {
+            a0 += src[(long)r * rs];
+            a1 += src[(long)(r + 64) * rs];
+            a2 += src[(long)(r + 128) * rs];
+            a3 += src[(long)(r + 192) * rs];
+        }
+        for (; r < rows; r += 64) a0 += src[(long)r * rs];
+    }
+    s_red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    for (int st = 128; st >= 4; st >>= 1) {
+        if (threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < 2 && c < C) {      // thread = channel ch: s_red[ch] = sum, s_red[2 + ch] = sum of squares
+        const float sm = s_red[threadIdx.x], sq = s_red[2 + threadIdx.x];
+        if (sum_o) sum_o[c] = sm;
+        if (sqsum_o) sqsum_o[c] = sq;
+        const double m = (double)sm / count;
+        double var = (double)sq / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float sc = g * invstd;
+        scale[c] = sc;
+        shift[c] = b - (float)m * sc;
+        if (mean_o) mean_o[c] = (float)m;
+        if (invstd_o) invstd_o[c] = invstd;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+int bn_finalize_rows_impl(const float* part, int rows, double count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                          float* shift, float* mean, float* invstd, float* sum, float* sqsum, int C,
+                          hipStream_t s) {
+    LEDN_REQUIRE(part && rows > 0 && scale && shift && C > 0 && count > 0);
+    LEDN_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    LEDN_LAUNCH(bn_finalize_rows_kernel, dim3((unsigned)cdiv(C, 2)), dim3(256), 0, s, part, rows, count, gamma,
+                beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, sum, sqsum, C);
+    return check_launch();
+}
+
 int bn_finalize_impl(const float* sum, const float* sqsum, double count, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, float momentum,
                      float eps, float* scale, float* shift, float* mean, float* invstd, int C,

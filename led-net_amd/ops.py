@@ -4,6 +4,7 @@ All activations are dense NHWC torch tensors (float32 or bfloat16); torch is
 used for device memory and the current HIP stream only.  Every function checks
 shapes/dtypes/devices before handing raw pointers to the library.
 """
+import ctypes as C
 import math
 
 import torch
@@ -202,7 +203,8 @@ def conv_out_size(h, k, stride, pad, dil):
 
 def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, in_shift=None,
            in_act=ACT_NONE, in_slope=None, out_scale=None, out_shift=None, act=ACT_NONE, slope=None, res=None,
-           res_mode=RES_NONE, stats=None, out_dtype=None, transposed=False, out_hw=None, w_bf16=None):
+           res_mode=RES_NONE, stats=None, out_dtype=None, transposed=False, out_hw=None, w_bf16=None,
+           defer_stats=False):
     """Dense/grouped convolution.  x: [N,H,W,Cin]; w: OIHW f32 [Cout_f, Cin_f/groups, KH, KW].
     transposed=True: x is dz [N,Ho_f,Wo_f,Cout_f]; returns dx [N,*out_hw,Cin_f].
     w_bf16: pack_conv_weights(w, mode=int(transposed)) -- enables the MFMA path for bf16."""
@@ -245,6 +247,17 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
     d.KH, d.KW, d.stride, d.pad, d.dil, d.groups = KH, KW, stride, pad, dil, groups
     d.in_act, d.act_out, d.res_mode = in_act, act, res_mode if res is not None else RES_NONE
     d.dtype_x, d.dtype_y, d.transposed = _dt(x), _dt(y), int(transposed)
+    if defer_stats and stats is not None:
+        # statistics may stay per-workgroup rows in the workspace: the caller's bn_finalize (the very next
+        # ledn call) sums them -- see PendingRows
+        part, rows = C.c_void_p(), C.c_int(0)
+        _run(lib, 'ledn_conv2d_deferred_stats', x, d, C.byref(part), C.byref(rows), work=_TIMING is not None and (
+            f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}',
+            _nb(x, xadd, y, res, w), 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW,
+            'conv_mfma_kernel' if lib.cdll.ledn_conv2d_uses_mfma(d) else 'conv_direct_kernel'))
+        if rows.value > 0:
+            PendingRows.put(stats[0], part.value, rows.value, lib)
+        return y
     _run(lib, 'ledn_conv2d', x, d, work=_TIMING is not None and (
         f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}',
         _nb(x, xadd, y, res, w), 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW,
@@ -412,6 +425,29 @@ def channel_stats(x, xadd=None, stats=None):
     return stats
 
 
+class PendingRows:
+    """Hand-off of deferred convolution statistics (conv2d(defer_stats=True) -> the bn_finalize that
+    follows it): keyed by the statistics buffer; at most one entry is ever pending."""
+    entry = None
+
+    @staticmethod
+    def put(sum_tensor, part_ptr, rows, lib):
+        if PendingRows.entry is not None:
+            raise LednError('deferred statistics of the previous convolution were never finalized')
+        PendingRows.entry = (sum_tensor.data_ptr(), part_ptr, rows, lib)
+
+    @staticmethod
+    def take(sum_tensor, lib):
+        e = PendingRows.entry
+        if e is None:
+            return None
+        if e[0] != sum_tensor.data_ptr() or e[3] is not lib:
+            raise LednError('deferred statistics pending for another buffer: a ledn call came between the '
+                            'convolution and its bn_finalize')
+        PendingRows.entry = None
+        return e[1], e[2]
+
+
 def bn_finalize(stats, count, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     """-> (scale, shift, mean, invstd); updates the running statistics in place."""
     lib = _lib.get_lib()
@@ -419,6 +455,13 @@ def bn_finalize(stats, count, gamma, beta, running_mean=None, running_var=None, 
     dev = stats[0].device
     scale, shift, mean, invstd = (torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(4))
     _check(lib, stats[0], stats[1], gamma, beta, running_mean, running_var)
+    pend = PendingRows.take(stats[0], lib)
+    if pend is not None:
+        _run(lib, 'ledn_bn_finalize_rows', stats[0], pend[0], pend[1], float(count), _p(_f32(gamma, Cc)),
+             _p(_f32(beta, Cc)), _p(_f32(running_mean, Cc)), _p(_f32(running_var, Cc)), momentum, eps,
+             _p(scale), _p(shift), _p(mean), _p(invstd), _p(stats[0]), _p(stats[1]), Cc,
+             work=_TIMING is not None and (f'bnfin_rows C{Cc}', 0, 0, 'bn_finalize_rows_kernel'))
+        return scale, shift, mean, invstd
     _run(lib, 'ledn_bn_finalize', stats[0], _p(stats[0]), _p(stats[1]), float(count), _p(_f32(gamma, Cc)),
          _p(_f32(beta, Cc)), _p(_f32(running_mean, Cc)), _p(_f32(running_var, Cc)), momentum, eps,
          _p(scale), _p(shift), _p(mean), _p(invstd), Cc, work=_TIMING is not None and (f'bnfin C{Cc}', 0, 0))

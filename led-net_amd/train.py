@@ -78,14 +78,15 @@ class ConvFn(Function):
     into `stats` ([2,Cout] f32, zeroed by the caller) by the kernel's epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, b, xadd, stride, pad, groups, stats, out_dtype):
+    def forward(ctx, x, w, b, xadd, stride, pad, groups, stats, out_dtype, defer=False):
         st = (stats[0], stats[1]) if stats is not None else None
         wp = None
         if (xadd is None and x.dtype == torch.bfloat16 and ops.mfma_weight_ok(w, groups)
                 and out_dtype in (None, torch.bfloat16)):
             wp = get_pack(w, 0, groups)
+        # defer: the BatchNorm finalize is the very next ledn call and sums the statistic rows itself
         z = ops.conv2d(x, w, stride=stride, pad=pad, groups=groups, xadd=xadd, out_shift=b, stats=st,
-                       out_dtype=out_dtype, w_bf16=wp)
+                       out_dtype=out_dtype, w_bf16=wp, defer_stats=bool(defer) and _Env.sync_bn is None)
         ctx.save_for_backward(x, w, xadd)
         ctx.cfg = (stride, pad, groups, b is not None)
         ctx.sinks = (_Sinks.get(w), _Sinks.get(b))
@@ -104,7 +105,7 @@ class ConvFn(Function):
                                   bias=has_b, dw_out=sw, db_out=sb)
         return (dx if ctx.needs_input_grad[0] else None, None if sw is not None else dw,
                 None if sb is not None else db,
-                dx if (xadd is not None and ctx.needs_input_grad[3]) else None, None, None, None, None, None)
+                dx if (xadd is not None and ctx.needs_input_grad[3]) else None, None, None, None, None, None, None)
 
 
 class BNActFn(Function):
@@ -177,7 +178,8 @@ class BNActConvFn(Function):
             wp = get_pack(w, 0, groups)
         st = (stats_out[0], stats_out[1]) if stats_out is not None else None
         z = ops.conv2d(x, w, stride=stride, pad=pad, groups=groups, in_scale=scale, in_shift=shift, in_act=act,
-                       in_slope=slope, out_shift=b, stats=st, out_dtype=out_dtype, w_bf16=wp)
+                       in_slope=slope, out_shift=b, stats=st, out_dtype=out_dtype, w_bf16=wp,
+                       defer_stats=st is not None and _Env.sync_bn is None)   # a BNActFn on stats_out follows
         ctx.save_for_backward(x, w, scale, shift, mean, invstd, slope)
         ctx.cfg = (act, count, stride, pad, groups, b is not None)
         ctx.sinks = (_Sinks.get(gamma), _Sinks.get(beta), _Sinks.get(slope), _Sinks.get(w), _Sinks.get(b))
@@ -433,7 +435,7 @@ def relu(x):
 def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE, xadd=None, out_dtype=None):
     st = _stats(conv.out_channels, x) if bn is not None else None
     z = ConvFn.apply(x, conv.weight, conv.bias, xadd, conv.stride[0], conv.padding[0], conv.groups, st,
-                     out_dtype if bn is None else None)
+                     out_dtype if bn is None else None, bn is not None)
     if bn is None:
         assert act == ACT_NONE and res is None
         return z
@@ -559,7 +561,7 @@ def lednet_forward_train(m, x, pre=None):
         # (normalisation folded in; the input needs no gradient) x reshaped weight
         st = _stats(m.channels, x)
         z = ConvFn.apply(ops.im2col_stem_planar(x.contiguous(), s, b, mp), ops.stem_weight_as_1x1(s0.conv.weight),
-                         None, None, 1, 0, 1, st, None)
+                         None, None, 1, 0, 1, st, None, True)
         x1 = BNActFn.apply(z, s0.bn.weight, s0.bn.bias, None, None, st, s0.bn, ACT_RELU, RES_NONE, None)
     else:
         x1 = conv_module(s0, ops.nchw_to_nhwc(x.contiguous(), m.act_dtype, s, b, mp))
@@ -741,6 +743,7 @@ class Trainer:
         (device scalars; no host synchronisation)."""
         self.model.train()
         first = self.table is None
+        ops.PendingRows.entry = None
         self._arena.reset()                  # one fill for every small zeroed scratch of the step
         ops.set_zero_arena(self._arena)
         _Sinks.map = self._sink_map

@@ -207,3 +207,25 @@ def test_im2col_stem_planar_equals_two_step(be, dt, hw):
     got = ops.im2col_stem_planar(D(x), s, b, mp)
     assert got.shape == want.shape and got.dtype == torch.bfloat16
     assert torch.equal(got.cpu().view(torch.int16), want.cpu().view(torch.int16))
+
+
+def test_deferred_conv_statistics_finalize(be):
+    """ledn_conv2d_deferred_stats + ledn_bn_finalize_rows (statistic rows summed inside the finalize
+    launch) against ledn_conv2d + ledn_bn_finalize on the same operands."""
+    from led_net_amd import ops
+    x = r16(torch.randn(2, 32, 40, 70))
+    w = torch.randn(64, 32, 3, 3) / 17.0
+    gamma, beta = torch.rand(64) + 0.5, torch.randn(64) * 0.1
+    wp = ops.pack_conv_weights(D(w), 0)
+    outs = []
+    for defer in (False, True):
+        stats = (D(torch.zeros(64)), D(torch.zeros(64)))
+        rm, rv = D(torch.zeros(64)), D(torch.ones(64))
+        z = ops.conv2d(nhwc(x).bfloat16(), D(w), pad=1, stats=stats, w_bf16=wp, defer_stats=defer)
+        if defer:
+            assert ops.PendingRows.entry is not None, 'this shape must take the partial-row path'
+        sc, sh, mean, invstd = ops.bn_finalize(stats, 2 * 40 * 70, D(gamma), D(beta), rm, rv)
+        assert ops.PendingRows.entry is None
+        outs.append([t.cpu() for t in (z.float(), sc, sh, mean, invstd, rm, rv, stats[0], stats[1])])
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)
