@@ -96,6 +96,11 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream);
  * workspace; *rows == 0: stat_sum / stat_sqsum are complete as with ledn_conv2d.  Saves one launch
  * per conv + BatchNorm pair in training (BatchNorm statistics of nn.BatchNorm2d in train mode). */
 int ledn_conv2d_deferred_stats(const ledn_conv_desc* d, float** part, int* rows, void* stream);
+/* The same hand-off for any statistics producer (ledn_dwconv2d, ledn_channel_stats, ...): bracket ONE
+ * producer call with begin/end; end reports the rows (or rows = 0: the totals are in the producer's
+ * sum / sqsum outputs as usual). */
+int ledn_stats_defer_begin(void);
+int ledn_stats_defer_end(float** part, int* rows);
 /* Pure query, no launch: 1 if ledn_conv2d would run this descriptor on conv_mfma_kernel (matrix
  * cores), 0 if on conv_direct_kernel (VALU).  bench.py names the kernel in its roofline with it. */
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d);

@@ -134,6 +134,8 @@ _PROTOS = {
     'ledn_set_option': ([i32, i64], i32),
     'ledn_conv2d': ([C.POINTER(ConvDesc), vp], i32),
     'ledn_conv2d_uses_mfma': ([C.POINTER(ConvDesc)], i32),
+    'ledn_stats_defer_begin': ([], i32),
+    'ledn_stats_defer_end': ([C.POINTER(C.c_void_p), C.POINTER(i32)], i32),
     'ledn_conv2d_deferred_stats': ([C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.POINTER(i32), vp], i32),
     'ledn_bn_finalize_rows': ([fp, i32, C.c_double, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, fp, fp, fp, fp, i32, vp], i32),
     'ledn_conv2d_wgrad_uses_mfma': ([C.POINTER(WgradDesc)], i32),

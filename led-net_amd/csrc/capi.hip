@@ -114,6 +114,24 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
     return conv_direct(*d, S(stream));
 }
 
+int ledn_stats_defer_begin(void) {
+    DeferredStats& ds = deferred_stats();
+    ds.want = true;
+    ds.part = nullptr;
+    ds.rows = 0;
+    return LEDN_OK;
+}
+int ledn_stats_defer_end(float** part, int* rows) {
+    if (!part || !rows) return LEDN_EINVAL;
+    DeferredStats& ds = deferred_stats();
+    *part = ds.part;
+    *rows = ds.part ? ds.rows : 0;
+    ds.want = false;
+    ds.part = nullptr;
+    ds.rows = 0;
+    return LEDN_OK;
+}
+
 int ledn_conv2d_deferred_stats(const ledn_conv_desc* d, float** part, int* rows, void* stream) {
     if (!d || !part || !rows) return LEDN_EINVAL;
     *part = nullptr;

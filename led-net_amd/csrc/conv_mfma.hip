@@ -492,11 +492,6 @@ static int launch_epi(MfmaConvArgs a, hipStream_t s) {
     const dim3 grid((unsigned)nbx, (unsigned)gy);
     a.part = (EPI != EPI_RAW && a.stat_sum && nbx * WM > 16) ? ws_take(nbx * WM * 2 * a.Cout) : nullptr;
     LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI>), grid, dim3(256), 0, s, a);
-    if (a.part && deferred_stats().want) {   // the caller's BatchNorm finalize sums the rows itself
-        deferred_stats().part = a.part;
-        deferred_stats().rows = (int)(nbx * WM);
-        return check_launch();
-    }
     if (a.part) return finish_partials(a.part, (int)(nbx * WM), a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
     return check_launch();
 }

@@ -96,6 +96,11 @@ __global__ void __launch_bounds__(256) finish_partials_kernel(const float* part,
 
 int finish_partials(const float* part, int nblk, int C, int nout, float* o0, float* o1, float* o2,
                     hipStream_t s) {
+    if (deferred_stats().want && nout == 2 && !o2) {   // (sum, sum of squares) rows: the caller's BatchNorm
+        deferred_stats().part = const_cast<float*>(part);   // finalize sums them (ledn_bn_finalize_rows)
+        deferred_stats().rows = nblk;
+        return check_launch();
+    }
     FinishOuts outs;
     outs.o[0] = o0; outs.o[1] = o1; outs.o[2] = o2;
     long split = cdiv(nblk, 16 * 16);      // <= 16 rows per slot per workgroup

@@ -197,6 +197,21 @@ def _run(lib, name, ref, *args, work=None):
         lib.call(name, *args, stream)
 
 
+def _run_stats(lib, name, ref, stats, defer, *args, work=None):
+    """_run for a statistics producer; defer: its (sum, sumsq) rows stay in the workspace for the
+    bn_finalize that follows immediately (PendingRows)"""
+    if not (defer and stats is not None):
+        return _run(lib, name, ref, *args, work=work)
+    lib.call('ledn_stats_defer_begin')
+    try:
+        _run(lib, name, ref, *args, work=work)
+    finally:
+        part, rows = C.c_void_p(), C.c_int(0)
+        lib.call('ledn_stats_defer_end', C.byref(part), C.byref(rows))
+    if rows.value > 0:
+        PendingRows.put(stats[0], part.value, rows.value, lib)
+
+
 def conv_out_size(h, k, stride, pad, dil):
     return (h + 2 * pad - ((k - 1) * dil + 1)) // stride + 1
 
@@ -247,18 +262,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
     d.KH, d.KW, d.stride, d.pad, d.dil, d.groups = KH, KW, stride, pad, dil, groups
     d.in_act, d.act_out, d.res_mode = in_act, act, res_mode if res is not None else RES_NONE
     d.dtype_x, d.dtype_y, d.transposed = _dt(x), _dt(y), int(transposed)
-    if defer_stats and stats is not None:
-        # statistics may stay per-workgroup rows in the workspace: the caller's bn_finalize (the very next
-        # ledn call) sums them -- see PendingRows
-        part, rows = C.c_void_p(), C.c_int(0)
-        _run(lib, 'ledn_conv2d_deferred_stats', x, d, C.byref(part), C.byref(rows), work=_TIMING is not None and (
-            f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}',
-            _nb(x, xadd, y, res, w), 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW,
-            'conv_mfma_kernel' if lib.cdll.ledn_conv2d_uses_mfma(d) else 'conv_direct_kernel'))
-        if rows.value > 0:
-            PendingRows.put(stats[0], part.value, rows.value, lib)
-        return y
-    _run(lib, 'ledn_conv2d', x, d, work=_TIMING is not None and (
+    _run_stats(lib, 'ledn_conv2d', x, stats, defer_stats, d, work=_TIMING is not None and (
         f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}',
         _nb(x, xadd, y, res, w), 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW,
         'conv_mfma_kernel' if lib.cdll.ledn_conv2d_uses_mfma(d) else 'conv_direct_kernel'))
@@ -362,7 +366,7 @@ def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None,
 
 
 def dwconv2d(x, w_khwc, *, stride=1, pad=-1, dil=(1, 1, 1, 1), group_size=None, out_scale=None,
-             out_shift=None, act=ACT_NONE, slope=None, stats=None, ext1=False, out_dtype=None):
+             out_shift=None, act=ACT_NONE, slope=None, stats=None, ext1=False, out_dtype=None, defer_stats=False):
     """Depthwise conv.  x: [N,H,W,C]; w_khwc: [KH,KW,C] f32."""
     lib = _lib.get_lib()
     N, H, W, Cc = x.shape
@@ -389,7 +393,7 @@ def dwconv2d(x, w_khwc, *, stride=1, pad=-1, dil=(1, 1, 1, 1), group_size=None, 
         d.dil[i] = dil[i] if i < len(dil) else dil[-1]
     d.group_size, d.act_out, d.ext1 = group_size, act, int(ext1)
     d.dtype_x, d.dtype_y = _dt(x), _dt(y)
-    _run(lib, 'ledn_dwconv2d', x, d, work=_TIMING is not None and (f'dw{KH}x{KW} C{Cc} s{stride} {N}x{H}x{W}', _nb(x, y, w_khwc), 2 * y.numel() * KH * KW))
+    _run_stats(lib, 'ledn_dwconv2d', x, stats, defer_stats, d, work=_TIMING is not None and (f'dw{KH}x{KW} C{Cc} s{stride} {N}x{H}x{W}', _nb(x, y, w_khwc), 2 * y.numel() * KH * KW))
     return y
 
 
@@ -412,7 +416,7 @@ def sesp_pyramid(x, w_b33n, dil, stride):
     return y
 
 
-def channel_stats(x, xadd=None, stats=None):
+def channel_stats(x, xadd=None, stats=None, defer_stats=False):
     """x: [..., C] -> (sum[C], sqsum[C]) f32 (accumulated into `stats` when given)."""
     lib = _lib.get_lib()
     Cc = x.shape[-1]
@@ -420,8 +424,8 @@ def channel_stats(x, xadd=None, stats=None):
     if stats is None:
         stats = (zeros_f32(Cc, x.device), zeros_f32(Cc, x.device))
     _check(lib, x, xadd, stats[0], stats[1])
-    _run(lib, 'ledn_channel_stats', x, _p(x), _p(xadd), P, Cc, _dt(x), _p(_f32(stats[0], Cc)),
-         _p(_f32(stats[1], Cc)), work=_TIMING is not None and (f'stats C{Cc} P{P}', _nb(x, xadd), 3 * x.numel()))
+    _run_stats(lib, 'ledn_channel_stats', x, stats, defer_stats, _p(x), _p(xadd), P, Cc, _dt(x), _p(_f32(stats[0], Cc)),
+               _p(_f32(stats[1], Cc)), work=_TIMING is not None and (f'stats C{Cc} P{P}', _nb(x, xadd), 3 * x.numel()))
     return stats
 
 

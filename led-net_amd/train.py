@@ -118,7 +118,7 @@ class BNActFn(Function):
         count = z.numel() // Cc
         if stats is None:
             stats = ops.zeros_f32((2, Cc), z.device)
-            ops.channel_stats(z, stats=(stats[0], stats[1]))
+            ops.channel_stats(z, stats=(stats[0], stats[1]), defer_stats=_Env.sync_bn is None)
         if _Env.sync_bn is not None:
             _Env.sync_bn(stats)
             count *= _Env.world
@@ -167,7 +167,7 @@ class BNActConvFn(Function):
         count = x.numel() // Cc
         if stats_in is None:
             stats_in = ops.zeros_f32((2, Cc), x.device)
-            ops.channel_stats(x, stats=(stats_in[0], stats_in[1]))
+            ops.channel_stats(x, stats=(stats_in[0], stats_in[1]), defer_stats=_Env.sync_bn is None)
         if _Env.sync_bn is not None:
             _Env.sync_bn(stats_in)
             count *= _Env.world
@@ -232,7 +232,9 @@ class DwFn(Function):
     @staticmethod
     def forward(ctx, x, w, stride, pad, dil, group_size, ext1, stats):
         st = (stats[0], stats[1]) if stats is not None else None
-        z = ops.dwconv2d(x, w, stride=stride, pad=pad, dil=dil, group_size=group_size, ext1=ext1, stats=st)
+        # (every DwFn with statistics is followed at once by its BatchNorm finalize: sesp, getb)
+        z = ops.dwconv2d(x, w, stride=stride, pad=pad, dil=dil, group_size=group_size, ext1=ext1, stats=st,
+                         defer_stats=st is not None and _Env.sync_bn is None)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, tuple(dil), group_size, ext1)
         return z
@@ -369,7 +371,7 @@ class MfafTailFn(Function):
             Cc = raw.shape[-1]
             count = raw.numel() // Cc
             stats = ops.zeros_f32((2, Cc), raw.device)
-            ops.channel_stats(raw, stats=(stats[0], stats[1]))
+            ops.channel_stats(raw, stats=(stats[0], stats[1]), defer_stats=_Env.sync_bn is None)
             if _Env.sync_bn is not None:
                 _Env.sync_bn(stats)
                 count *= _Env.world
@@ -488,8 +490,6 @@ def sesp(m, x):
     w1 = DwPackFn.apply(True, *[d.conv.weight for d in m.spp_dw])
     p = PyrFn.apply(o1, w1, m.dil, m.stride)
     w2 = DwPackFn.apply(False, *[d.conv.weight for d in m.spp_dw_v2])
-    st = _stats(m.nOut, x)
-    z = DwFn.apply(p, w2, 1, -1, [d + 1 for d in m.dil], m.n, False, st)
     exp = m.conv_1x1_exp
     if m.stride == 2 and not m.spatial:
         act3, slope3, res = ACT_NONE, None, AvgPoolFn.apply(x)
@@ -497,6 +497,8 @@ def sesp(m, x):
         act3, slope3 = ACT_PRELU, m.module_act.weight
         res = x if (m.stride == 1 and m.nIn == m.nOut) else None
     rm = RES_ADD if res is not None else RES_NONE
+    st = _stats(m.nOut, x)
+    z = DwFn.apply(p, w2, 1, -1, [d + 1 for d in m.dil], m.n, False, st)   # its BN finalize comes next
     if FUSE_BN_INTO_CONV >= 2:
         # BN(cat) + PReLU folded into the expansion conv's input staging
         st3 = _stats(exp.conv.out_channels, x)
