@@ -197,10 +197,14 @@ def _run(lib, name, ref, *args, work=None):
         lib.call(name, *args, stream)
 
 
+import os as _os
+DEFER_STATS = int(_os.environ.get('LEDN_DEFER_STATS', '3'))   # 0 off, 1 convolutions only, 3 all producers
+
+
 def _run_stats(lib, name, ref, stats, defer, *args, work=None):
     """_run for a statistics producer; defer: its (sum, sumsq) rows stay in the workspace for the
     bn_finalize that follows immediately (PendingRows)"""
-    if not (defer and stats is not None):
+    if not (defer and stats is not None and (DEFER_STATS >= 3 or (DEFER_STATS >= 1 and name == 'ledn_conv2d'))):
         return _run(lib, name, ref, *args, work=work)
     lib.call('ledn_stats_defer_begin')
     try:
