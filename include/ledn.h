@@ -320,6 +320,17 @@ typedef struct {
 int ledn_mfaf_gate(const ledn_mfaf_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Evaluation histograms (IoUMetric.intersect_and_union,
+ * mmseg/evaluation/metrics/iou_metric.py:163-199) straight from the uint8 argmax mask the fused
+ * last resize writes (ledn_bilinear argmax) and the int64 label map: over pixels with
+ * label != ignore_index, hist[0][c] += [pred == label == c], hist[1][c] += [pred == c],
+ * hist[2][c] += [label == c] (f32 counts, ACCUMULATED: the caller zeroes; union = [1]+[2]-[0]).
+ * Labels >= num_classes that are not ignore_index are counted nowhere (torch.histc drops them).
+ * num_classes <= 256. */
+int ledn_iou_hist(const unsigned char* pred, const long long* label, long long P, int num_classes,
+                  int ignore_index, float* hist, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * SEAM edge map (prototype tools/speed/ddrnet_speed.py:24-37,282-338; percentile
  * rule: supplementary PDF section 4.2 eq.1).
  *   seg [N,h,w] f32 -> per-image min-max normalise -> Laplacian at strides 1/2/4,

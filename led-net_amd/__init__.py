@@ -12,6 +12,7 @@ from .losses import OhemCrossEntropy  # noqa: F401
 from .segmentor import EncoderDecoder, SegDataSample  # noqa: F401
 from .config import load_config  # noqa: F401
 from .train import Trainer  # noqa: F401
+from .metrics import IoUMetric  # noqa: F401
 
 MODELS.register_module(module=LEDNet)
 MODELS.register_module(module=LEDHead)

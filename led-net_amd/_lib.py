@@ -145,6 +145,7 @@ _PROTOS = {
     'ledn_pack_conv_weights': ([fp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_conv2d_wgrad': ([C.POINTER(WgradDesc), vp], i32),
     'ledn_dwconv2d': ([C.POINTER(DwDesc), vp], i32),
+    'ledn_iou_hist': ([vp, vp, i64, i32, i32, fp, vp], i32),
     'ledn_dw_pack': ([C.POINTER(DwPackDesc), fp, vp], i32),
     'ledn_dw_unpack_grad': ([C.POINTER(DwPackDesc), fp, vp], i32),
     'ledn_sesp_pyramid': ([C.POINTER(PyrDesc), vp], i32),

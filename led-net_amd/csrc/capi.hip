@@ -16,6 +16,8 @@ int pack_conv_weights_impl(const float* w, void* out, int Cout, int Cin, int KH,
 int wgrad_validate(const ledn_wgrad_desc& d);
 int conv_wgrad_direct(const ledn_wgrad_desc& d, hipStream_t s);
 int dwconv_impl(const ledn_dw_desc& d, hipStream_t s);
+int iou_hist_impl(const unsigned char* pred, const long long* label, long long P, int num_classes,
+                  int ignore_index, float* hist, hipStream_t s);
 int bn_finalize_rows_impl(const float* part, int rows, double count, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float momentum, float eps, float* scale,
                           float* shift, float* mean, float* invstd, float* sum, float* sqsum, int C,
@@ -190,6 +192,10 @@ int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream) {
     return conv_wgrad_direct(*d, S(stream));
 }
 
+int ledn_iou_hist(const unsigned char* pred, const long long* label, long long P, int num_classes,
+                  int ignore_index, float* hist, void* stream) {
+    return iou_hist_impl(pred, label, P, num_classes, ignore_index, hist, S(stream));
+}
 int ledn_dwconv2d(const ledn_dw_desc* d, void* stream) { return d ? dwconv_impl(*d, S(stream)) : LEDN_EINVAL; }
 int ledn_dw_pack(const ledn_dwpack_desc* d, float* packed, void* stream) {
     return d ? dw_pack_impl(*d, packed, S(stream)) : LEDN_EINVAL;

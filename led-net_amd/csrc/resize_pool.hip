@@ -262,4 +262,39 @@ int avgpool3x3s2_impl(const void* x, void* y, int N, int H, int W, int C, int Ho
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------
+// evaluation histograms (see include/ledn.h: ledn_iou_hist): LDS counters per workgroup, one
+// global atomic per touched counter per workgroup (f32 counts, exact below 2^24 per image)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) iou_hist_kernel(const unsigned char* pred, const long long* label, long P,
+                                                       int C, int ignore_index, float* hist) {
+    __shared__ unsigned s_h[3 * 256];
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) s_h[i] = 0u;
+    __syncthreads();
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const long long lb = label[p];
+        if (lb == ignore_index) continue;
+        const int pr = pred[p];
+        if (pr < C) {
+            atomicAdd(&s_h[C + pr], 1u);
+            if (pr == lb) atomicAdd(&s_h[pr], 1u);
+        }
+        if (lb >= 0 && lb < C) atomicAdd(&s_h[2 * C + (int)lb], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x)
+        if (s_h[i]) atomicAdd(hist + i, (float)s_h[i]);
+}
+
+int iou_hist_impl(const unsigned char* pred, const long long* label, long long P, int num_classes,
+                  int ignore_index, float* hist, hipStream_t s) {
+    LEDN_REQUIRE(pred && label && hist && P > 0 && num_classes > 0 && num_classes <= 256);
+    long nb = cdiv((long)P, 256 * 16);
+    if (nb > 1024) nb = 1024;
+    LEDN_LAUNCH(iou_hist_kernel, dim3((unsigned)nb), dim3(256), 0, s, pred, label, (long)P, num_classes,
+                ignore_index, hist);
+    return check_launch();
+}
+
 }  // namespace ledn
