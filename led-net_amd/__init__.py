@@ -13,6 +13,7 @@ from .segmentor import EncoderDecoder, SegDataSample  # noqa: F401
 from .config import load_config  # noqa: F401
 from .train import Trainer  # noqa: F401
 from .metrics import IoUMetric  # noqa: F401
+from .checkpoint import init_model, load_checkpoint, save_checkpoint  # noqa: F401
 
 MODELS.register_module(module=LEDNet)
 MODELS.register_module(module=LEDHead)
