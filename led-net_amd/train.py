@@ -841,7 +841,11 @@ class Trainer:
         torch.cuda.current_stream(dev).wait_stream(side)
         self._lr_dev.fill_(self.lr())
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # N > 1: other threads of the process (ProcessGroupNCCL's watchdog) keep calling the runtime while this
+        # thread captures; 'thread_local' confines the capture-safety checks to the capturing thread
+        import os
+        mode = os.environ.get('LEDN_CAPTURE_MODE') or ('thread_local' if self.dist is not None else 'global')
+        with torch.cuda.graph(self._graph, capture_error_mode=mode):
             self._static_out = self.train_step(self._static_in, self._static_samples)
         return self
 
