@@ -1,0 +1,152 @@
+"""Size-independent properties at BASELINE.json's full sizes (configs B and C: 8 / 16 x 3 x 1024 x 1024),
+GPU only -- the oracle finishes small cases in seconds, at these sizes the HIP path is checked through
+properties: batch-split invariance of inference, oracle parity on crops of a full-size convolution,
+order-statistic and selection-count properties of the 16.7 M-pixel OHEM, conservation of the evaluation
+histograms, a full-size training step (finite, gradient buffer re-zeroed, graph replay = eager step)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, 'tests', 'data', 'lednet_test_config.py')
+
+
+def _model(train):
+    import led_net_amd as L
+    torch.manual_seed(304)
+    cfg = L.load_config(CFG)
+    m = L.MODELS.build(cfg['model'])
+    m.set_act_dtype(torch.bfloat16)
+    m.to('cuda:0')
+    m.train(train)
+    return m, cfg
+
+
+def _batch(n, seed=304):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (n, 3, 1024, 1024), dtype=torch.uint8, generator=g)
+    lab = torch.randint(0, 2, (n, 1, 1024, 1024), dtype=torch.int64, generator=g)
+    lab[:, :, :16, :] = 255
+    lab[:, :, :, -16:] = 255
+    return img.cuda(), lab.cuda()
+
+
+def test_inference_batch_split_invariance_config_b():
+    """eval-mode LED-Net at 8 x 3 x 1024 x 1024 bf16: every image's fused logits and argmax mask are the
+    same whether it is computed in the batch or alone (running-statistics BN, per-image SEAM percentile;
+    tiles, persistent-workgroup ranges and stream forks differ between the two runs)."""
+    m, _ = _model(False)
+    img, _ = _batch(8)
+    with torch.no_grad():
+        lg_b, mask_b = m.decode_head.predict_with_mask(m.extract_feat(img))
+        for i in (0, 3, 7):
+            lg_1, mask_1 = m.decode_head.predict_with_mask(m.extract_feat(img[i:i + 1]))
+            # not bit-identical: the MFAF pools are f32 atomics (summation order varies run to run), which moves
+            # bf16 roundings downstream; masks may differ only where the two logits tie within that noise
+            diff = (lg_1[0] - lg_b[i]).abs()
+            scale = float(lg_b[i].abs().max())
+            margin = (lg_b[i][0] - lg_b[i][1]).abs()
+            flips = mask_1[0] != mask_b[i]
+            print(f'image {i}: max |dlogit| {float(diff.max()):.3e} (scale {scale:.2f}), flips {int(flips.sum())}, '
+                  f'largest margin at a flip {float(margin[flips].max()) if flips.any() else 0.0:.3e}')
+            assert float(diff.max()) <= 2e-2 * max(scale, 1.0), i
+            assert int(flips.sum()) <= 1e-3 * flips.numel(), i
+            assert (not flips.any()) or float(margin[flips].max()) <= 2 * float(diff.max()) + 1e-6, i
+    assert mask_b.dtype == torch.uint8 and tuple(mask_b.shape[-2:]) == (1024, 1024)
+    assert 0 < int(mask_b.sum()) < mask_b.numel()          # both classes predicted somewhere
+
+
+def test_full_size_conv_crops_vs_torch_cpu():
+    """MFMA 3x3 convolution at 16 x 256 x 256 x 32 (the stem's layer1 shape) with prologue and statistics:
+    six crops (corners, edges, interior) against torch CPU fp32 on the bf16-rounded operands, and the
+    per-channel statistics against a reduction of the kernel's own output."""
+    from led_net_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(16, 256, 256, 32, generator=g).bfloat16()
+    w = torch.randn(32, 32, 3, 3, generator=g) / 17.0
+    s_in, b_in = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+    xd, wd = x.cuda(), w.cuda()
+    stats = (torch.zeros(32, device='cuda'), torch.zeros(32, device='cuda'))
+    y = ops.conv2d(xd, wd, pad=1, in_scale=s_in.cuda(), in_shift=b_in.cuda(), in_act=ops.ACT_RELU, stats=stats,
+                   w_bf16=ops.pack_conv_weights(wd, 0))
+    yf = y.float()
+    torch.testing.assert_close(stats[0], yf.sum((0, 1, 2)), rtol=2e-3, atol=2.0)      # bf16 output rounding
+    torch.testing.assert_close(stats[1], (yf * yf).sum((0, 1, 2)), rtol=2e-3, atol=2.0)
+    wr = w.bfloat16().float()
+    for n, h0, w0 in [(0, 0, 0), (15, 192, 192), (7, 0, 100), (3, 100, 0), (9, 97, 131), (15, 192, 0)]:
+        hs, ws = max(h0 - 1, 0), max(w0 - 1, 0)
+        he, we = min(h0 + 65, 256), min(w0 + 65, 256)
+        crop = x[n, hs:he, ws:we].float().permute(2, 0, 1)[None]
+        pre = F.relu(crop * s_in.view(1, -1, 1, 1) + b_in.view(1, -1, 1, 1)).bfloat16().float()
+        pad = (1 if w0 == 0 else 0, 1 if we == 256 else 0, 1 if h0 == 0 else 0, 1 if he == 256 else 0)
+        ref = F.conv2d(F.pad(pre, pad), wr)[0].permute(1, 2, 0)
+        ref = ref[:64, :64] if (h0 == 0 and w0 == 0) else ref[(0 if h0 == 0 else 0):, (0 if w0 == 0 else 0):][:64, :64]
+        got = yf[n, h0:h0 + 64, w0:w0 + 64].cpu()
+        torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
+
+
+def test_ohem_order_statistic_at_16m_pixels():
+    """OhemCrossEntropy at N*H*W = 16 777 216 (config C): the radix-select threshold equals
+    max(thres, k-th smallest target probability) for k = min_kept (torch.kthvalue as the independent
+    order statistic), and the selection count is the number of valid pixels below it."""
+    from led_net_amd import ops_train as T
+    g = torch.Generator().manual_seed(9)
+    logits = (torch.randn(16, 1024, 1024, 2, generator=g) * 2).cuda()
+    _, lab = _batch(16, 5)
+    y = lab.squeeze(1).contiguous()
+    for min_kept, thres in ((131072, 0.9), (131072, 0.05), (16000000, 0.9)):
+        out, work = T.ohem_ce_fwd(logits, y, thres, min_kept, 1.0, 255)
+        valid = y != 255
+        prob = torch.softmax(logits, -1).gather(-1, y.clamp(max=1).unsqueeze(-1)).squeeze(-1)[valid]
+        k = min(min_kept, prob.numel() - 1)
+        kth = torch.kthvalue(prob, k + 1).values              # sorted[k], 0-based (ohem_cross_entropy_loss.py:69-74)
+        thr = max(float(kth), thres)
+        assert abs(float(out[2]) - thr) <= 1e-6 * thr, (min_kept, thres, float(out[2]), thr)
+        nsel = int((prob < out[2]).sum())
+        assert int(out[3]) == nsel
+        ce = F.cross_entropy(logits.view(-1, 2), y.view(-1), ignore_index=255, reduction='none')[valid.view(-1)]
+        want = float(ce[prob < out[2]].double().mean())
+        assert abs(float(out[0]) - want) <= 2e-4 * abs(want), (float(out[0]), want)
+
+
+def test_eval_histogram_conservation_full_size():
+    import led_net_amd as L
+    from led_net_amd import metrics as M
+    img, lab = _batch(8, 11)
+    pred = (img[:, 0] > 127).to(torch.uint8)
+    inter, union, ap, al = M.intersect_and_union(pred, lab.squeeze(1).contiguous(), 2, 255)
+    nvalid = int((lab != 255).sum())
+    assert int(ap.sum()) == nvalid and int(al.sum()) == nvalid          # every valid pixel counted once
+    assert torch.all(inter <= torch.minimum(ap, al)) and int(union.sum()) == 2 * nvalid - int(inter.sum())
+    want = int(((pred.long() == lab.squeeze(1)) & (lab.squeeze(1) != 255)).sum())
+    assert int(inter.sum()) == want
+
+
+def test_train_step_config_c_properties():
+    """16 x 3 x 1024 x 1024 bf16 train step: finite losses, every parameter finite and moved, the flat
+    gradient buffer re-zeroed by the SGD kernel, running statistics updated; the captured hipGraph
+    replays the same step (loss within the bf16 / summation-order spread of the eager step)."""
+    import led_net_amd as L
+    m, cfg = _model(True)
+    img, lab = _batch(16)
+    samples = [L.SegDataSample(gt=lab[i]) for i in range(16)]
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    tr = L.Trainer(m, cfg)
+    out = tr.train_step(img, samples)
+    vals = {k: float(v.float().reshape(-1)[0]) for k, v in out.items()}
+    assert all(v == v and abs(v) < 1e4 for v in vals.values()), vals
+    assert 0.0 <= vals['decode.acc_seg'] <= 100.0
+    assert float(tr.flat_grad.abs().max()) == 0.0
+    after = m.state_dict()
+    moved = sum(int(not torch.equal(after[k], before[k])) for k in before if before[k].is_floating_point())
+    assert moved > 0.9 * sum(1 for k in before if before[k].is_floating_point())
+    assert all(bool(torch.isfinite(v).all()) for v in after.values() if v.is_floating_point())
+    tr.capture(img, samples, warmup=1)
+    rep = tr.replay()
+    eager = tr.train_step(img, samples)
+    for k in ('decode.loss_context', 'decode.loss_spatial'):
+        a, b = float(rep[k].float().reshape(-1)[0]), float(eager[k].float().reshape(-1)[0])
+        assert a == a and abs(a - b) <= 0.25 * abs(b) + 1e-3, (k, a, b)    # consecutive steps of one trajectory
