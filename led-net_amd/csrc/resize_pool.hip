@@ -138,7 +138,7 @@ int bilinear_impl(const ledn_resize_desc& d, hipStream_t s) {
 template <typename T, int V>
 __global__ void __launch_bounds__(256) adaptive_avgpool_kernel(const T* x, const T* xadd, float* y, int N,
                                                                int H, int W, int C, int S,
-                                                               int rows_per_block) {
+                                                               int rows_per_block, float* part) {
     __shared__ float s_acc[256 * V];
     const int cell = blockIdx.x;
     const int ox = cell % S, oy = (cell / S) % S, n = cell / (S * S);
@@ -171,13 +171,16 @@ __global__ void __launch_bounds__(256) adaptive_avgpool_kernel(const T* x, const
 #pragma unroll
     for (int v = 0; v < V; ++v) s_acc[threadIdx.x * V + v] = acc[v];
     __syncthreads();
-    if (r0 < r1 && threadIdx.x < cvn) {
+    if (threadIdx.x < cvn && (part || r0 < r1)) {
         const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             float t = 0.f;
             for (int p = 0; p < lanes; ++p) t += s_acc[(p * cvn + cv) * V + v];
-            atomicAdd(y + (long)cell * C + cv * V + v, t * inv);
+            // part: one row of per-cell sums per row chunk, added up in chunk order by finish_partials
+            // (a fixed summation order: inference is bit-reproducible; atomics onto y are not)
+            if (part) part[((long)blockIdx.y * gridDim.x + cell) * C + cv * V + v] = r0 < r1 ? t * inv : 0.f;
+            else atomicAdd(y + (long)cell * C + cv * V + v, t * inv);
         }
     }
 }
@@ -188,25 +191,30 @@ int adaptive_avgpool_impl(const void* x, const void* xadd, float* y, int N, int 
     const int V = C % 4 == 0 ? 4 : 1;
     LEDN_REQUIRE(C / V <= 256);
     const int max_rows = (H + S - 1) / S + 1;                      // tallest adaptive window
-    int chunks = (int)cdiv(2048, (long)N * S * S);                 // aim for >= ~2k workgroups
+    // row chunks per cell: a function of S only, so that an image's sums are added in the same order
+    // whatever the batch size (batch-split invariance of inference, tests/test_full_size.py)
+    int chunks = (int)cdiv(256, (long)S * S);
     if (chunks < 1) chunks = 1;
     if (chunks > max_rows) chunks = max_rows;
     const int rpb = (int)cdiv(max_rows, chunks);
     const dim3 grid((unsigned)(N * S * S), (unsigned)cdiv(max_rows, rpb));
     if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * S * S * C, s) != hipSuccess) return LEDN_ELAUNCH;
+    // <= 256 chunk rows: finish_partials adds each output's row sums in one thread group, in row order
+    float* part = (grid.y > 1 && grid.y <= 256) ? ws_take((long)grid.y * N * S * S * C) : nullptr;
 #define LEDN_AA(T)                                                                                    \
     do {                                                                                              \
         if (V == 4)                                                                                   \
             LEDN_LAUNCH((adaptive_avgpool_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x,          \
-                        (const T*)xadd, y, N, H, W, C, S, rpb);                                       \
+                        (const T*)xadd, y, N, H, W, C, S, rpb, part);                                 \
         else                                                                                          \
             LEDN_LAUNCH((adaptive_avgpool_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x,          \
-                        (const T*)xadd, y, N, H, W, C, S, rpb);                                       \
+                        (const T*)xadd, y, N, H, W, C, S, rpb, part);                                 \
     } while (0)
     if (dtype == LEDN_F32) LEDN_AA(float);
     else if (dtype == LEDN_BF16) LEDN_AA(bf16_t);
     else return LEDN_EINVAL;
 #undef LEDN_AA
+    if (part) return finish_partials(part, (int)grid.y, N * S * S * C, 1, y, nullptr, nullptr, s);
     return check_launch();
 }
 

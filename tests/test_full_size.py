@@ -36,25 +36,20 @@ def _batch(n, seed=304):
 
 def test_inference_batch_split_invariance_config_b():
     """eval-mode LED-Net at 8 x 3 x 1024 x 1024 bf16: every image's fused logits and argmax mask are the
-    same whether it is computed in the batch or alone (running-statistics BN, per-image SEAM percentile;
-    tiles, persistent-workgroup ranges and stream forks differ between the two runs)."""
+    bit-identical whether it is computed in the batch or alone, and from run to run (running-statistics
+    BN, per-image SEAM percentile; tiles, persistent-workgroup ranges and stream forks differ between the runs)."""
     m, _ = _model(False)
     img, _ = _batch(8)
     with torch.no_grad():
         lg_b, mask_b = m.decode_head.predict_with_mask(m.extract_feat(img))
         for i in (0, 3, 7):
             lg_1, mask_1 = m.decode_head.predict_with_mask(m.extract_feat(img[i:i + 1]))
-            # not bit-identical: the MFAF pools are f32 atomics (summation order varies run to run), which moves
-            # bf16 roundings downstream; masks may differ only where the two logits tie within that noise
-            diff = (lg_1[0] - lg_b[i]).abs()
-            scale = float(lg_b[i].abs().max())
-            margin = (lg_b[i][0] - lg_b[i][1]).abs()
-            flips = mask_1[0] != mask_b[i]
-            print(f'image {i}: max |dlogit| {float(diff.max()):.3e} (scale {scale:.2f}), flips {int(flips.sum())}, '
-                  f'largest margin at a flip {float(margin[flips].max()) if flips.any() else 0.0:.3e}')
-            assert float(diff.max()) <= 2e-2 * max(scale, 1.0), i
-            assert int(flips.sum()) <= 1e-3 * flips.numel(), i
-            assert (not flips.any()) or float(margin[flips].max()) <= 2 * float(diff.max()) + 1e-6, i
+            # bit-identical: every reduction of the inference path has a fixed, batch-independent order
+            # (the adaptive pools sum their row chunks in order; no atomics between workgroups)
+            assert torch.equal(lg_1[0], lg_b[i]), (i, float((lg_1[0] - lg_b[i]).abs().max()))
+            assert torch.equal(mask_1[0], mask_b[i]), i
+        lg_2, mask_2 = m.decode_head.predict_with_mask(m.extract_feat(img))      # and run to run
+        assert torch.equal(lg_2, lg_b) and torch.equal(mask_2, mask_b)
     assert mask_b.dtype == torch.uint8 and tuple(mask_b.shape[-2:]) == (1024, 1024)
     assert 0 < int(mask_b.sum()) < mask_b.numel()          # both classes predicted somewhere
 
