@@ -31,6 +31,8 @@ def parse_args():
     p.add_argument('--height', type=int, default=1024)
     p.add_argument('--width', type=int, default=1024)
     p.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    p.add_argument('--graph', action='store_true',
+                   help='replay the predict pass (backbone + head + fused resize/argmax) as one hipGraph per image')
     return p.parse_args()
 
 
@@ -49,12 +51,28 @@ def main():
         model.set_act_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
         g = torch.Generator().manual_seed(304 + run)
         num_warmup, total_iters, pure = 5, 200, 0.0
+        graph = static = None
+        if args.graph:
+            static = torch.zeros((1, 3, args.height, args.width), dtype=torch.uint8, device=dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(3):
+                    model.decode_head.predict_with_mask(model.extract_feat(static))
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph), torch.no_grad():
+                static_out = model.decode_head.predict_with_mask(model.extract_feat(static))   # noqa: F841
         for i in range(total_iters):
             img = torch.randint(0, 256, (1, 3, args.height, args.width), dtype=torch.uint8, generator=g).to(dev)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            with torch.no_grad():
-                model(img, None, mode='predict')
+            if graph is not None:
+                static.copy_(img)
+                graph.replay()
+            else:
+                with torch.no_grad():
+                    model(img, None, mode='predict')
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             if i >= num_warmup:
