@@ -255,7 +255,10 @@ __device__ __forceinline__ float reduce16_over32(const float* v, int lane) {
 // epilogue flavours (compile-time: the runtime-switched version cost a vmcnt(0) drain per store group)
 constexpr int EPI_RAW = 0;        // y = bf16(z)                                  (data gradients)
 constexpr int EPI_RAW_STATS = 1;  // y = bf16(z) + per-channel sum / sum of squares (training forward)
-constexpr int EPI_FULL = 2;       // scale/shift, residual, activation, optional statistics (inference)
+constexpr int EPI_FULL = 2;       // scale/shift, residual, activation + statistics
+constexpr int EPI_FULL_NS = 3;    // the same without statistics (inference: 32 VGPRs less, no spills)
+constexpr bool epi_full(int e) { return e == EPI_FULL || e == EPI_FULL_NS; }
+constexpr bool epi_stats(int e) { return e == EPI_RAW_STATS || e == EPI_FULL; }
 
 // Persistent workgroups: each owns a contiguous range of output tiles and walks the flattened
 // (tile, K-chunk) sequence.  The global loads of step i+1 are issued right after the LDS commit of
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
         }                                                                                             \
     } while (0)
     if (one_chunk) LEDN_CONV_WEIGHTS(0);
-    if (EPI == EPI_FULL) {
+    if (epi_full(EPI)) {
         for (int i = tid; i < NCO; i += 256) {
             const int c = cbw + i;
             s_par[i] = (a.out_scale && c < a.Cout) ? a.out_scale[c] : 1.f;
@@ -321,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
-    constexpr int NST = EPI == EPI_RAW ? 1 : 16;            // per-lane running channel statistics
+    constexpr int NST = epi_stats(EPI) ? 16 : 1;            // per-lane running channel statistics
     float st1[NST], st2[NST];
 #pragma unroll
     for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
@@ -392,14 +395,14 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                         v[j] = acc[m][4 * q + j];
                         acc[m][4 * q + j] = 0.f;
                     }
-                    if (EPI == EPI_FULL) {
+                    if (epi_full(EPI)) {
                         float sc[4], sh[4];
                         ld4(s_par + cl, sc);
                         ld4(s_par + NCO + cl, sh);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[j] + sh[j];
                     }
-                    if (EPI != EPI_RAW) {   // statistics of the BatchNorm input (pre-residual, pre-activation)
+                    if (epi_stats(EPI)) {   // statistics of the BatchNorm input (pre-residual, pre-activation)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float vm = pix_ok ? v[j] : 0.f;
@@ -407,7 +410,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                             st2[4 * q + j] = fmaf(vm, vm, st2[4 * q + j]);
                         }
                     }
-                    if (EPI == EPI_FULL) {
+                    if (epi_full(EPI)) {
                         float ng[4];
                         ld4(s_par + 2 * NCO + cl, ng);
                         if (a.res_mode != LEDN_RES_NONE) {
@@ -461,7 +464,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
 #undef LEDN_CONV_FETCH
 #undef LEDN_CONV_WEIGHTS
 
-    if (EPI != EPI_RAW && a.stat_sum) {   // workgroup-uniform; every lane takes part in the exchange
+    if (epi_stats(EPI) && a.stat_sum) {   // workgroup-uniform; every lane takes part in the exchange
         const float t1 = reduce16_over32(st1, lane), t2 = reduce16_over32(st2, lane);
         const int idx = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
         const int c = cb0 + (idx & 3) + 8 * (idx >> 2) + 4 * lh;
@@ -490,7 +493,7 @@ static int launch_epi(MfmaConvArgs a, hipStream_t s) {
     a.tiles_per_block = (int)cdiv(ntiles, nbx);
     nbx = cdiv(ntiles, a.tiles_per_block);
     const dim3 grid((unsigned)nbx, (unsigned)gy);
-    a.part = (EPI != EPI_RAW && a.stat_sum && nbx * WM > 16) ? ws_take(nbx * WM * 2 * a.Cout) : nullptr;
+    a.part = (epi_stats(EPI) && a.stat_sum && nbx * WM > 16) ? ws_take(nbx * WM * 2 * a.Cout) : nullptr;
     LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI>), grid, dim3(256), 0, s, a);
     if (a.part) return finish_partials(a.part, (int)(nbx * WM), a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
     return check_launch();
@@ -499,7 +502,8 @@ static int launch_epi(MfmaConvArgs a, hipStream_t s) {
 template <int WM, int WN, int MT, int K, int S, int UP>
 static int launch_cfg(const MfmaConvArgs& a, hipStream_t s) {
     const bool raw = !a.out_scale && !a.out_shift && a.act_out == LEDN_ACT_NONE && a.res_mode == LEDN_RES_NONE;
-    if (!raw) return launch_epi<WM, WN, MT, K, S, UP, EPI_FULL>(a, s);
+    if (!raw && a.stat_sum) return launch_epi<WM, WN, MT, K, S, UP, EPI_FULL>(a, s);
+    if (!raw) return launch_epi<WM, WN, MT, K, S, UP, EPI_FULL_NS>(a, s);
     if (a.stat_sum) return launch_epi<WM, WN, MT, K, S, UP, EPI_RAW_STATS>(a, s);
     return launch_epi<WM, WN, MT, K, S, UP, EPI_RAW>(a, s);
 }

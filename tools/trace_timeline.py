@@ -29,7 +29,10 @@ with open(sys.argv[1], newline='') as fh:
 rows.sort()
 # steps are delimited by the single sgd_step_kernel launch of each step
 ends = [i for i, r in enumerate(rows) if r[2] == 'sgd_kernel']
-assert len(ends) >= 4, 'run bench.py --trace-only --mode train (steps are delimited by sgd_kernel)'
+if len(ends) < 4:      # inference: one planar im2col (or layout kernel) per step
+    first = 'im2col_stem_planar_kernel' if any(r[2] == 'im2col_stem_planar_kernel' for r in rows) else 'nchw_to_nhwc_kernel'
+    ends = [i - 1 for i, r in enumerate(rows) if r[2] == first]
+assert len(ends) >= 4, 'run bench.py --trace-only (steps are delimited by sgd_kernel / the first kernel of a pass)'
 lo, hi = ends[-4] + 1, ends[-1] + 1          # the last three steps (graph replays of the timed region)
 seg = rows[lo:hi]
 nsteps = 3
