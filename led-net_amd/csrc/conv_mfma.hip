@@ -658,8 +658,10 @@ __device__ __forceinline__ float ldp(const bf16_t* p) { return bf16_to_f32(p->v)
 // (pixel, quarter) then assembles 8 of the pixel's 32 columns and stores 16 bytes (the four lanes of
 // a pixel write its whole 64-byte row).  (The first version gathered straight from global memory:
 // 32 scattered scalar loads per thread, 1 TB/s.)
-template <typename TX>
-__global__ void __launch_bounds__(256) im2col_stem_planar_kernel(const TX* x, bf16_t* p, int N, int H, int W, int C,
+// (C is a template parameter: the column -> (tap, channel) split divides by it 16 times per thread, and a
+// run-time divisor made the kernel ALU-bound at 1.1 TB/s)
+template <typename TX, int C>
+__global__ void __launch_bounds__(256) im2col_stem_planar_kernel(const TX* x, bf16_t* p, int N, int H, int W,
                                                                  int Ho, int Wo, const float* scale,
                                                                  const float* shift, const int* map) {
     constexpr int PXB = 64, COLS = 2 * PXB + 1;
@@ -706,14 +708,21 @@ int im2col_stem_planar_impl(const void* x, int dtype_x, void* p, int N, int H, i
     LEDN_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1);
     LEDN_REQUIRE((scale == nullptr) == (shift == nullptr));
     const dim3 grid((unsigned)((long)N * Ho * cdiv(Wo, 64)));
-#define LEDN_IP(TX)                                                                                         \
-    LEDN_LAUNCH((im2col_stem_planar_kernel<TX>), grid, dim3(256), 0, s, (const TX*)x, (bf16_t*)p, N, H, W, C, Ho, \
+#define LEDN_IPC(TX, CC)                                                                                    \
+    LEDN_LAUNCH((im2col_stem_planar_kernel<TX, CC>), grid, dim3(256), 0, s, (const TX*)x, (bf16_t*)p, N, H, W, Ho, \
                 Wo, scale, shift, map)
+#define LEDN_IP(TX)                  \
+    do {                             \
+        if (C == 3) LEDN_IPC(TX, 3); \
+        else if (C == 2) LEDN_IPC(TX, 2); \
+        else LEDN_IPC(TX, 1);        \
+    } while (0)
     if (dtype_x == LEDN_U8) LEDN_IP(unsigned char);
     else if (dtype_x == LEDN_F32) LEDN_IP(float);
     else if (dtype_x == LEDN_BF16) LEDN_IP(bf16_t);
     else return LEDN_EINVAL;
 #undef LEDN_IP
+#undef LEDN_IPC
     return check_launch();
 }
 
