@@ -672,17 +672,28 @@ __global__ void __launch_bounds__(256) im2col_stem_planar_kernel(const TX* x, bf
     const int n = blockIdx.x / (wtiles * Ho);
     const int wo0 = wt * PXB;
     const long plane = (long)H * W;
-    for (int e = threadIdx.x; e < C * 3 * COLS; e += blockDim.x) {
-        const int col = e % COLS, r = (e / COLS) % 3, c = e / (3 * COLS);
+    // unconditional loads (out-of-image elements read the plane's first byte and are zeroed): all of a
+    // thread's loads are in flight together instead of a chain of five dependent round trips
+    constexpr int NE = (C * 3 * COLS + 255) / 256;
+    float f[NE];
+    bool ok[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = threadIdx.x + j * 256;
+        const int col = e % COLS, r = (e / COLS) % 3, c = min(e / (3 * COLS), C - 1);
         const int hi = ho * 2 - 1 + r, wi = wo0 * 2 - 1 + col;
-        unsigned short v = 0;
-        if (hi >= 0 && hi < H && wi >= 0 && wi < W) {
-            const int cs = map ? map[c] : c;
-            float f = ldp(x + ((long)n * C + cs) * plane + (long)hi * W + wi);
-            if (scale) f = f * scale[c] + shift[c];
-            v = f32_to_bf16(f);
-        }
-        s_in[e] = v;
+        ok[j] = e < C * 3 * COLS && hi >= 0 && hi < H && wi >= 0 && wi < W;
+        const int cs = map ? map[c] : c;
+        f[j] = ldp(x + ((long)n * C + cs) * plane + (ok[j] ? (long)hi * W + wi : 0L));
+    }
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = threadIdx.x + j * 256;
+        if (e >= C * 3 * COLS) continue;
+        const int c = e / (3 * COLS);
+        float v = f[j];
+        if (scale) v = v * scale[c] + shift[c];
+        s_in[e] = ok[j] ? f32_to_bf16(v) : (unsigned short)0;
     }
     __syncthreads();
     const int q = threadIdx.x & 3, px = threadIdx.x >> 2;
