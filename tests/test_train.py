@@ -278,14 +278,21 @@ def test_direct_gradient_sinks_match_autograd_accumulation(be):
         tol = max(2e-3 * abs(o_ref[k]) + 1e-4, 10 * abs(o_ref2[k] - o_ref[k]))
         assert abs(o_snk[k] - o_ref[k]) <= tol, (k, o_snk[k], o_ref[k], o_ref2[k])
     rel, floor, off = [], [], 0
+    gmax = 0.0
+    spans = []
     for p_ in tr.params:
         n = p_.numel()
         if any(p_ is q for q in tr.live):
-            a, b, c = g_snk[off:off + n], g_ref[off:off + n], g_ref2[off:off + n]
-            den = b.norm().item() + 1e-12
-            rel.append((a - b).norm().item() / den)
-            floor.append((c - b).norm().item() / den)
+            spans.append((off, n))
+            gmax = max(gmax, g_ref[off:off + n].norm().item())
         off += n
+    for off, n in spans:
+        a, b, c = g_snk[off:off + n], g_ref[off:off + n], g_ref2[off:off + n]
+        # analytically-zero gradients (a bias in front of a BatchNorm) are pure rounding noise: measure
+        # them against the largest gradient instead of against themselves
+        den = max(b.norm().item(), 1e-4 * gmax) + 1e-12
+        rel.append((a - b).norm().item() / den)
+        floor.append((c - b).norm().item() / den)
     rel_s, floor_s = sorted(rel), sorted(floor)
     med, worst = rel_s[len(rel_s) // 2], rel_s[-1]
     fmed, fworst = floor_s[len(floor_s) // 2], floor_s[-1]
