@@ -1075,6 +1075,18 @@ __global__ void __launch_bounds__(256) mfaf_combine_kernel(T* dx, T* dr, const T
     }
     for (int k = 0; k < ps.n; ++k) {
         const int S = ps.S[k];
+        if (H % S == 0 && W % S == 0) {
+            // evenly divisible map (every LED-Net size that is a multiple of 128): the windows tile the map,
+            // one cell per pixel -- the general search below costs ~36 integer divisions per pool and made
+            // this kernel ALU-bound (127 us for a 100 MB pass)
+            const int hs = H / S, ws = W / S;
+            const float inv = 1.f / (float)(hs * ws);
+            float t[V];
+            ldv<V>(ps.p[k] + (((long)n * S + y / hs) * S + x / ws) * C + c, t);
+#pragma unroll
+            for (int v = 0; v < V; ++v) a[v] = fmaf(t[v], inv, a[v]);
+            continue;
+        }
         // adaptive windows [floor(i*H/S), ceil((i+1)*H/S)) may overlap: visit every cell containing (y,x)
         int oy0 = (y * S) / H - 1, ox0 = (x * S) / W - 1;
         for (int oy = max(oy0, 0); oy <= min(oy0 + 2, S - 1); ++oy) {

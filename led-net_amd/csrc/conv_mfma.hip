@@ -531,7 +531,6 @@ bool conv_mfma_supported(const ledn_conv_desc& d) {
     if (d.Cin % 16 || (d.Cout % 16 && d.Cout > 8)) return false;   // 16-channel tails are masked
     if (d.KH != d.KW || !((d.KH == 3 && d.pad == 1) || (d.KH == 1 && d.pad == 0))) return false;
     if (d.stride != 1 && d.stride != 2) return false;
-    if (d.transposed && d.stride == 2 && d.KH == 1) return false;
     return true;
 }
 
@@ -552,7 +551,8 @@ int conv_mfma(const ledn_conv_desc& d, hipStream_t s) {
     }
     a.pad = d.KH - 1 - d.pad;   // stride-1 correlation over the (zero-upsampled) dz with flipped taps
     if (d.KH == 3) return d.stride == 1 ? launch_shape<3, 1, 1>(a, s) : launch_shape<3, 1, 2>(a, s);
-    return launch_shape<1, 1, 1>(a, s);
+    // 1x1 stride 2: a 1x1 correlation over the zero-upsampled dz (three of four outputs are zero)
+    return d.stride == 1 ? launch_shape<1, 1, 1>(a, s) : launch_shape<1, 1, 2>(a, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -147,8 +147,7 @@ def _conv_dgrad(dz, x, w, stride, pad, groups):
     wp = None
     cin_f = w.shape[1] * groups     # dgrad kernel: "Cin" = Cout_f (16-multiple), "Cout" = Cin_f
     if (dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and w.shape[0] % 16 == 0
-            and (cin_f % 16 == 0 or cin_f <= 8) and ops.mfma_weight_ok(w, groups)
-            and not (stride == 2 and w.shape[2] == 1)):
+            and (cin_f % 16 == 0 or cin_f <= 8) and ops.mfma_weight_ok(w, groups)):
         wp = get_pack(w, 1, groups)
     return ops.conv2d(dz, w, stride=stride, pad=pad, groups=groups, transposed=True,
                       out_hw=(x.shape[1], x.shape[2]), out_dtype=x.dtype, w_bf16=wp)

@@ -176,9 +176,10 @@ def test_window_attn_and_pool_bwd(be, hw):
     close(dbT.permute(0, 2, 1), bias.grad, 1e-3, 1e-4)
 
 
-def test_mfaf_gate_bwd_and_combine(be):
+@pytest.mark.parametrize('H,W', [(19, 21), (32, 48), (16, 40)])   # ragged / all windows tile / mixed
+def test_mfaf_gate_bwd_and_combine(be, H, W):
     from led_net_amd import ops, ops_train as T
-    N, Cc, H, W = 2, 8, 19, 21
+    N, Cc = 2, 8
     x, r, xl = (torch.randn(N, Cc, H, W, requires_grad=True) for _ in range(3))
     sizes = [4, 8, 16, 1]
     ctx = [torch.randn(N, Cc, s, s, requires_grad=True) for s in sizes]
