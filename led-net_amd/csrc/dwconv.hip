@@ -72,15 +72,23 @@ __global__ void __launch_bounds__(256) dwconv_kernel(ledn_dw_desc d, float* part
                     int hi = ho * d.stride - padh + kh2 * dl;
                     if (hi < 0 || hi >= Hx) continue;
                     if (hi == d.H) hi = d.H - 2;  // ext1 reflect row
-                    for (int kw2 = 0; kw2 < d.KW; ++kw2) {
-                        int wi = wo * d.stride - padw + kw2 * dl;
-                        if (wi < 0 || wi >= Wx) continue;
-                        if (wi == d.W) wi = d.W - 2;
-                        float xv[V], wv[V];
-                        ldv<V>(x + (((long)n * d.H + hi) * d.W + wi) * d.C + c, xv);
-                        ldv<V>(d.w + (long)(kh2 * d.KW + kw2) * d.C + c, wv);
+                    // eight taps of the row at a time, unconditional loads in flight together (the first
+                    // version was a chain of 64 dependent, branch-guarded loads for the GETB 8x8 filter)
+                    for (int kw0 = 0; kw0 < d.KW; kw0 += 8) {
+                        float xv[8][V], wv[8][V];
 #pragma unroll
-                        for (int v = 0; v < V; ++v) acc[v] = fmaf(xv[v], wv[v], acc[v]);
+                        for (int j = 0; j < 8; ++j) {
+                            const int kw2 = kw0 + j;
+                            int wi = wo * d.stride - padw + kw2 * dl;
+                            const bool ok = kw2 < d.KW && wi >= 0 && wi < Wx;
+                            if (wi == d.W) wi = d.W - 2;
+                            ldv_if<V>(x, (((long)n * d.H + hi) * d.W + wi) * d.C + c, ok, xv[j]);
+                            ldv<V>(d.w + (long)(kh2 * d.KW + (kw2 < d.KW ? kw2 : 0)) * d.C + c, wv[j]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+#pragma unroll
+                            for (int v = 0; v < V; ++v) acc[v] = fmaf(xv[j][v], wv[j][v], acc[v]);
                     }
                 }
             }
