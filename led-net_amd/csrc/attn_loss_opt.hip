@@ -22,15 +22,21 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T* qkv, const
                                                              float* dqkv, float* dbiasT, int N, int H,
                                                              int W, int C, int heads, int hh, int ww,
                                                              float* part) {
+    // LDS per wavefront: K, V, Q, dO (16 KB at D = 16) + ONE 64 x 65 score matrix that holds P and is then
+    // overwritten by dS (dV = P^T dO is taken in between), the bias-gradient rows live in registers:
+    // 33 KB -> four wavefronts per CU (the first version kept P, dS and the bias rows in LDS: 66 KB, two
+    // wavefronts per CU, two of the four SIMDs idle).
     constexpr int WS = 8, T2 = 64, TP = 65;
     __shared__ float s_k[T2 * D], s_v[T2 * D], s_q[T2 * D], s_do[T2 * D];
-    __shared__ float s_ds[T2 * TP], s_p[T2 * TP], s_db[T2 * TP];
+    __shared__ float s_p[T2 * TP];
     const int head = blockIdx.y;
     const int t = threadIdx.x;
     const int nwin = N * hh * ww;
     const float scale = rsqrtf((float)D);
     const float* b = biasT + (long)head * T2 * T2 + t;
-    for (int k = 0; k < T2; ++k) s_db[t * TP + k] = 0.f;      // row t is private to lane t
+    float db[T2];                                  // bias-gradient row of query t, summed over this wave's windows
+#pragma unroll
+    for (int k = 0; k < T2; ++k) db[k] = 0.f;
     for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
         const int wx = win % ww, wy = (win / ww) % hh, n = win / (ww * hh);
         const int y = wy * WS + t / WS, x = wx * WS + t % WS;
@@ -40,7 +46,7 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T* qkv, const
         const long src = ((long)n * H + ys) * W + xs;
         const T* p = qkv + src * (3L * C) + head * D;
         float q[D], go[D];
-        __syncthreads();     // the previous window's phase B is done with the LDS operands
+        __syncthreads();     // the previous window's last phase is done with the LDS operands
 #pragma unroll
         for (int j = 0; j < D; j += 4) {
             float kv[4], vv[4];
@@ -61,6 +67,7 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T* qkv, const
             }
         }
         __syncthreads();
+        // ---- A1 (lane = query t): P[t][:] = softmax(q.K^T * scale + bias)
         float m = -3.0e38f;
         for (int k = 0; k < T2; ++k) {
             float dot = 0.f;
@@ -84,31 +91,43 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T* qkv, const
 #pragma unroll
             for (int j = 0; j < D; ++j) dp = fmaf(go[j], s_v[k * D + j], dp);
             s_p[t * TP + k] = pk;
-            s_ds[t * TP + k] = dp;
             rs = fmaf(pk, dp, rs);
         }
+        __syncthreads();
+        // ---- B1 (lane = key t): dV[t] = P[:, t]^T . dO
+        float dv[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) dv[j] = 0.f;
+        for (int i = 0; i < T2; ++i) {
+            const float pk = s_p[i * TP + t];
+#pragma unroll
+            for (int j = 0; j < D; ++j) dv[j] = fmaf(pk, s_do[i * D + j], dv[j]);
+        }
+        __syncthreads();
+        // ---- A2 (lane = query t): dS = P * (dP - rs) overwrites P (dP recomputed: 16 FMAs), dQ, bias rows
         float dq[D];
 #pragma unroll
         for (int j = 0; j < D; ++j) dq[j] = 0.f;
+#pragma unroll
         for (int k = 0; k < T2; ++k) {
-            const float ds = s_p[t * TP + k] * (s_ds[t * TP + k] - rs);
-            s_ds[t * TP + k] = ds;
-            s_db[t * TP + k] += ds;
+            float dp = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) dp = fmaf(go[j], s_v[k * D + j], dp);
+            const float ds = s_p[t * TP + k] * (dp - rs);
+            s_p[t * TP + k] = ds;
+            db[k] += ds;
 #pragma unroll
             for (int j = 0; j < D; ++j) dq[j] = fmaf(ds, s_k[k * D + j], dq[j]);
         }
         __syncthreads();
-        // phase B: lane = key t
-        float dk[D], dv[D];
+        // ---- B2 (lane = key t): dK[t] = scale * dS[:, t]^T . Q
+        float dk[D];
 #pragma unroll
-        for (int j = 0; j < D; ++j) dk[j] = dv[j] = 0.f;
+        for (int j = 0; j < D; ++j) dk[j] = 0.f;
         for (int i = 0; i < T2; ++i) {
-            const float ds = s_ds[i * TP + t], pk = s_p[i * TP + t];
+            const float ds = s_p[i * TP + t];
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                dk[j] = fmaf(ds, s_q[i * D + j], dk[j]);
-                dv[j] = fmaf(pk, s_do[i * D + j], dv[j]);
-            }
+            for (int j = 0; j < D; ++j) dk[j] = fmaf(ds, s_q[i * D + j], dk[j]);
         }
         float* o = dqkv + src * (3L * C) + head * D;
 #pragma unroll
@@ -125,11 +144,11 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T* qkv, const
         }
     }
     // bias-gradient table of this wavefront: dbiasT[head][k][t] (t = query row = lane)
+#pragma unroll
     for (int k = 0; k < T2; ++k) {
-        const float v = s_db[t * TP + k];
         const long idx = (long)head * T2 * T2 + k * T2 + t;
-        if (part) part[(long)blockIdx.x * heads * T2 * T2 + idx] = v;
-        else atomicAdd(dbiasT + idx, v);
+        if (part) part[(long)blockIdx.x * heads * T2 * T2 + idx] = db[k];
+        else atomicAdd(dbiasT + idx, db[k]);
     }
 }
 
