@@ -69,13 +69,20 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T* qkv, const
         __syncthreads();
         // ---- A1 (lane = query t): P[t][:] = softmax(q.K^T * scale + bias)
         float m = -3.0e38f;
-        for (int k = 0; k < T2; ++k) {
-            float dot = 0.f;
+        for (int k0 = 0; k0 < T2; k0 += 8) {
+            float bk[8];                             // eight bias loads in flight (a dependent global load per
+#pragma unroll                                       // score made this loop latency-bound)
+            for (int u = 0; u < 8; ++u) bk[u] = b[(k0 + u) * T2];
 #pragma unroll
-            for (int j = 0; j < D; ++j) dot = fmaf(q[j], s_k[k * D + j], dot);
-            const float sc = dot * scale + b[k * T2];
-            s_p[t * TP + k] = sc;
-            m = fmaxf(m, sc);
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u;
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) dot = fmaf(q[j], s_k[k * D + j], dot);
+                const float sc = dot * scale + bk[u];
+                s_p[t * TP + k] = sc;
+                m = fmaxf(m, sc);
+            }
         }
         float l = 0.f;
         for (int k = 0; k < T2; ++k) {
