@@ -848,6 +848,54 @@ __global__ void __launch_bounds__(256) bilinear_bwd_kernel(const TY* dy, TX* dx,
     stv<V>(dx + pix * C + c, acc);
 }
 
+// exact 2x upsampling (every level of the logit pyramid and the 1/16 -> 1/8 link): a source pixel
+// receives from the 4 x 4 destinations 2s-1 .. 2s+2 only -- sixteen unconditional loads with the
+// same weights and summation order as the general search above (which walks ~36 candidates with a
+// branch each: 125 us for the 134 MB full-resolution logit gradient)
+template <typename TY, typename TX, int V>
+__global__ void __launch_bounds__(256) bilinear_bwd2x_kernel(const TY* dy, TX* dx, int N, int H, int W, int C) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const int cv = C / V;
+    const long total = (long)N * H * W * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long)W * H));
+    float wy[4], wx[4];
+    int yy[4], xx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dv = 2 * y - 1 + j, dh = 2 * x - 1 + j;
+        const bool vy = dv >= 0 && dv < Ho, vx = dh >= 0 && dh < Wo;
+        yy[j] = vy ? dv : 0;
+        xx[j] = vx ? dh : 0;
+        const LerpB ly = lerp_coord_b(yy[j], H, Ho), lx = lerp_coord_b(xx[j], W, Wo);
+        wy[j] = vy ? (ly.i0 == y ? ly.w0 : 0.f) + (ly.i1 == y ? ly.w1 : 0.f) : 0.f;
+        wx[j] = vx ? (lx.i0 == x ? lx.w0 : 0.f) + (lx.i1 == x ? lx.w1 : 0.f) : 0.f;
+    }
+    float g[16][V];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ldv<V>(dy + (((long)n * Ho + yy[j]) * Wo + xx[i]) * C + c, g[j * 4 + i]);
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float wgt = wy[j] * wx[i];
+            if (wgt == 0.f) continue;        // as the general kernel skips them (an inf/nan there must not leak)
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = fmaf(wgt, g[j * 4 + i][v], acc[v]);
+        }
+    stv<V>(dx + pix * C + c, acc);
+}
+
 int bilinear_bwd_impl(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int dtype_dy,
                       int dtype_dx, hipStream_t s) {
     LEDN_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0);
@@ -855,9 +903,12 @@ int bilinear_bwd_impl(const void* dy, void* dx, int N, int H, int W, int C, int 
     const bool v2 = !v4 && C % 2 == 0;
     const long total = (long)N * H * W * (v4 ? C / 4 : (v2 ? C / 2 : C));
     const dim3 grid((unsigned)cdiv(total, 256));
+    const bool x2 = Ho == 2 * H && Wo == 2 * W;
 #define LEDN_K(TY, TX)                                                                                          \
     do {                                                                                                        \
-        if (v4) LEDN_LAUNCH((bilinear_bwd_kernel<TY, TX, 4>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C, Ho, Wo); \
+        if (x2 && v4) LEDN_LAUNCH((bilinear_bwd2x_kernel<TY, TX, 4>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C); \
+        else if (x2 && v2) LEDN_LAUNCH((bilinear_bwd2x_kernel<TY, TX, 2>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C); \
+        else if (v4) LEDN_LAUNCH((bilinear_bwd_kernel<TY, TX, 4>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C, Ho, Wo); \
         else if (v2) LEDN_LAUNCH((bilinear_bwd_kernel<TY, TX, 2>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C, Ho, Wo); \
         else LEDN_LAUNCH((bilinear_bwd_kernel<TY, TX, 1>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C, Ho, Wo); \
     } while (0)

@@ -122,7 +122,8 @@ def test_sesp_pyramid_bwd(be, stride):
 
 
 @pytest.mark.parametrize('src,dst,c', [((9, 17), (18, 34), 4), ((9, 17), (35, 67), 2), ((5, 7), (5, 7), 4),
-                                       ((8, 8), (64, 64), 4), ((16, 12), (7, 5), 1)])
+                                       ((8, 8), (64, 64), 4), ((16, 12), (7, 5), 1), ((13, 6), (26, 12), 2),
+                                       ((1, 3), (2, 6), 2), ((7, 9), (14, 18), 3)])   # exact 2x: V = 4, 2, general
 def test_bilinear_bwd(be, src, dst, c):
     from led_net_amd import ops_train as T
     x = torch.randn(2, c, *src, requires_grad=True)
