@@ -311,7 +311,9 @@ def main():
             for e, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms']):
                 print(f"{v['ms'] / k_steps:9.3f} ms/step  x{v['n'] // k_steps:4d}  {v['bytes'] / max(1e-9, v['ms']) / 1e6:8.1f} GB/s "
                       f"{v['flops'] / max(1e-9, v['ms']) / 1e9:8.2f} TF/s  [kernel] {e}", file=sys.stderr)
-            for (e, sg), v in top[:int(os.environ.get("LEDN_BENCH_VERBOSE", "25")) if os.environ.get("LEDN_BENCH_VERBOSE", "1").isdigit() and int(os.environ.get("LEDN_BENCH_VERBOSE", "1")) > 1 else 25]:
+            verbose = os.environ['LEDN_BENCH_VERBOSE']
+            n_sig = int(verbose) if verbose.isdigit() and int(verbose) > 1 else 25     # signatures listed
+            for (e, sg), v in top[:n_sig]:
                 print(f'{v["ms"] / k_steps:9.3f} ms/step  x{v["n"] // k_steps:3d}  {v["bytes"] * v["n"] / max(1e-9, v["ms"]) / 1e6:8.1f} GB/s '
                       f'{v["flops"] * v["n"] / max(1e-9, v["ms"]) / 1e9:8.2f} TF/s  {e} [{sg}]', file=sys.stderr)
         print(json.dumps(out))
