@@ -159,6 +159,213 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T* qkv, const
     }
 }
 
+// ---------------------------------------------------------------------------
+// Matrix-core variant (bf16, head dim 16, no reflect padding): the five 64 x 64 x 16 products of a
+// (window, head) as v_mfma_f32_32x32x16_bf16.  Everything score-shaped is kept TRANSPOSED,
+// S^T[key j][query i], so that an accumulator lane owns ONE query (column) and its registers run over
+// the keys: the softmax / row-sum reductions are in-lane plus one exchange with lane ^ 32, and the
+// bias-gradient table dbiasT[head][j][i] accumulates in the same register layout across the
+// wavefront's windows.  S^T = K Q^T and dP^T = V dO^T take their fragments straight from global
+// memory (16 B per lane); dQ^T = K^T dS^T uses the accumulator registers as the B operand (the
+// contraction index is permuted consistently on the A side); dV^T = dO^T P and dK^T = Q^T dS need
+// the score matrix transposed, which goes through one 64 x 64 bf16 LDS tile.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) window_attn_bwd_mfma_kernel(const bf16_t* qkv, const float* biasT,
+                                                                  const bf16_t* dout, float* dqkv, float* dbiasT,
+                                                                  int N, int H, int W, int C, int heads, int hh,
+                                                                  int ww, float* part) {
+    constexpr int D = 16, T2 = 64, LP = 72;      // LDS row stride (bf16 elements): 64 + 8 pad
+    __shared__ __attribute__((aligned(16))) unsigned short s_kt[D * LP], s_qt[D * LP], s_dot[D * LP];
+    __shared__ __attribute__((aligned(16))) unsigned short s_m[T2 * LP];
+    const int head = blockIdx.y;
+    const int lane = threadIdx.x, lr = lane & 31, lh = lane >> 5;
+    const int nwin = N * hh * ww;
+    const float scale = rsqrtf((float)D);
+    // bias and its gradient in accumulator layout: [jt][it][reg] <-> key jt*32 + row(reg, lh), query it*32 + lr
+    float bias[2][2][16], db[2][2][16];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, i = it * 32 + lr;
+                bias[jt][it][r] = biasT[(long)head * T2 * T2 + j * T2 + i];
+                db[jt][it][r] = 0.f;
+            }
+    const bf16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const int wx = win % ww, wy = (win / ww) % hh, n = win / (ww * hh);
+        // fragments of tokens lr and 32 + lr (rows of the two 32-row tiles), dims lh*8 .. lh*8+7
+        bf16x8_t kf[2], vf[2], qf[2], dof[2];
+        long tokoff[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int tok = tl * 32 + lr;
+            const long pix = ((long)n * H + wy * 8 + tok / 8) * W + wx * 8 + tok % 8;
+            tokoff[tl] = pix;
+            const bf16_t* p = qkv + pix * (3L * C) + head * D + lh * 8;
+            qf[tl] = *reinterpret_cast<const bf16x8_t*>(p);
+            kf[tl] = *reinterpret_cast<const bf16x8_t*>(p + C);
+            vf[tl] = *reinterpret_cast<const bf16x8_t*>(p + 2 * C);
+            dof[tl] = *reinterpret_cast<const bf16x8_t*>(dout + pix * C + head * D + lh * 8);
+        }
+        __syncthreads();     // previous window's readers of the LDS tiles are done
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {          // transposed copies [dim][token]
+                const int d = lh * 8 + e, tok = tl * 32 + lr;
+                s_kt[d * LP + tok] = (unsigned short)kf[tl][e];
+                s_qt[d * LP + tok] = (unsigned short)qf[tl][e];
+                s_dot[d * LP + tok] = (unsigned short)dof[tl][e];
+            }
+        // ---- S^T = K Q^T, dP^T = V dO^T  (one MFMA per 32 x 32 tile: K = 16)
+        f32x16_t st[2][2], dp[2][2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                f32x16_t z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                st[jt][it] = mfma_32x32x16_bf16(kf[jt], qf[it], z);
+                dp[jt][it] = mfma_32x32x16_bf16(vf[jt], dof[it], z);
+            }
+        // ---- softmax over the keys of each query column, dS^T = P^T * (dP^T - rowsum(P * dP))
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            float m = -3.0e38f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[jt][it][r] = st[jt][it][r] * scale + bias[jt][it][r];
+                    m = fmaxf(m, st[jt][it][r]);
+                }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float l = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[jt][it][r] = __expf(st[jt][it][r] - m);
+                    l += st[jt][it][r];
+                }
+            l += __shfl_xor(l, 32);
+            const float inv = 1.f / l;
+            float rs = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[jt][it][r] *= inv;
+                    rs = fmaf(st[jt][it][r], dp[jt][it][r], rs);
+                }
+            rs += __shfl_xor(rs, 32);
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    dp[jt][it][r] = st[jt][it][r] * (dp[jt][it][r] - rs);     // dS^T
+                    db[jt][it][r] += dp[jt][it][r];
+                }
+        }
+        // ---- P^T -> LDS [j][i] (bf16), dV^T[d][j] = sum_i dO^T[d][i] P[i][j]
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    s_m[(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LP + it * 32 + lr] = f32_to_bf16(st[jt][it][r]);
+        __syncthreads();
+        f32x16_t dvt[2], dkt[2], dqt[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dvt[tl][r] = dkt[tl][r] = dqt[tl][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8_t a = lr < D ? *reinterpret_cast<const bf16x8_t*>(&s_dot[lr * LP + kk * 16 + lh * 8]) : zero8;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(&s_m[(jt * 32 + lr) * LP + kk * 16 + lh * 8]);
+                dvt[jt] = mfma_32x32x16_bf16(a, b, dvt[jt]);
+            }
+        }
+        __syncthreads();
+        // ---- dS^T -> LDS, dK^T[d][j] = sum_i Q^T[d][i] dS[i][j]
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    s_m[(jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LP + it * 32 + lr] = f32_to_bf16(dp[jt][it][r]);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8_t a = lr < D ? *reinterpret_cast<const bf16x8_t*>(&s_qt[lr * LP + kk * 16 + lh * 8]) : zero8;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(&s_m[(jt * 32 + lr) * LP + kk * 16 + lh * 8]);
+                dkt[jt] = mfma_32x32x16_bf16(a, b, dkt[jt]);
+            }
+        }
+        // ---- dQ^T[d][i] = sum_j K^T[d][j] dS^T[j][i]: B straight from the dS^T registers.  k-step (jt, h)
+        // covers keys jt*32 + 16h .. +15 in the accumulator's own order: logical k = lh*8 + e <->
+        // key jt*32 + 16h + (e&3) + 8*(e>>2) + 4*lh, and the A operand (K^T) is gathered in that order.
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x8_t a = zero8;
+                if (lr < D) {
+                    const int j0 = jt * 32 + 16 * h + 4 * lh;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = (short)s_kt[lr * LP + j0 + (e & 3) + 8 * (e >> 2)];
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    bf16x8_t b;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b[e] = (short)f32_to_bf16(dp[jt][it][8 * h + e]);
+                    dqt[it] = mfma_32x32x16_bf16(a, b, dqt[it]);
+                }
+            }
+        // ---- stores: lane (token tl*32 + lr, lh) holds dims 4*lh .. +3 (regs 0-3) and 8 + 4*lh .. +3 (regs 4-7)
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            float* o = dqkv + tokoff[tl] * (3L * C) + head * D + 4 * lh;
+            float t4[4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t4[e] = dqt[tl][4 * g + e] * scale;
+                st4(o + 8 * g, t4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t4[e] = dkt[tl][4 * g + e] * scale;
+                st4(o + C + 8 * g, t4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t4[e] = dvt[tl][4 * g + e];
+                st4(o + 2 * C + 8 * g, t4);
+            }
+        }
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, i = it * 32 + lr;
+                const long idx = (long)head * T2 * T2 + j * T2 + i;
+                if (part) part[(long)blockIdx.x * heads * T2 * T2 + idx] = db[jt][it][r];
+                else atomicAdd(dbiasT + idx, db[jt][it][r]);
+            }
+}
+
 int window_attn_bwd_impl(const void* qkv, const float* biasT, const void* dout, float* dqkv, float* dbiasT,
                          int N, int H, int W, int C, int heads, int ws, int dtype, hipStream_t s) {
     LEDN_REQUIRE(qkv && biasT && dout && dqkv && dbiasT && N > 0 && H > 0 && W > 0 && C > 0 && heads > 0);
@@ -172,6 +379,12 @@ int window_attn_bwd_impl(const void* qkv, const float* biasT, const void* dout, 
     float* part = nb > 8 ? ws_take(nb * heads * 64 * 64) : nullptr;
     if (!part && nb > 32) nb = 32;                            // atomics fallback: <= 32 per table entry
     const dim3 grid((unsigned)nb, (unsigned)heads);
+    if (dtype == LEDN_BF16 && D == 16 && !padded && C % 8 == 0) {   // matrix-core variant
+        LEDN_LAUNCH(window_attn_bwd_mfma_kernel, grid, dim3(64), 0, s, (const bf16_t*)qkv, biasT, (const bf16_t*)dout,
+                    dqkv, dbiasT, N, H, W, C, heads, hh, ww, part);
+        if (part) return finish_partials(part, (int)nb, heads * 64 * 64, 1, dbiasT, nullptr, nullptr, s);
+        return check_launch();
+    }
 #define LEDN_WB(T, DD)                                                                                  \
     do {                                                                                                \
         if (padded)                                                                                     \

@@ -177,6 +177,32 @@ def test_window_attn_and_pool_bwd(be, hw):
     close(dbT.permute(0, 2, 1), bias.grad, 1e-3, 1e-4)
 
 
+@pytest.mark.parametrize('n,hw,heads', [(1, (16, 8), 2), (3, (24, 16), 8)])
+def test_window_attn_bwd_matrix_core(be, n, hw, heads):
+    """window_attn_bwd_mfma_kernel (bf16, head dim 16, windows tile the map): the five 64 x 64 x 16 products
+    on the matrix cores, scores kept transposed in the accumulator layout -- against torch autograd on the
+    bf16-rounded operands (P and dS are rounded to bf16 for the second products: 2e-2 of the gradient scale)."""
+    from led_net_amd import ops_train as T
+    ws, d = 8, 16
+    Cc = heads * d
+    H, W = hw
+    g = torch.Generator().manual_seed(heads)
+    qkv = torch.randn(n, 3 * Cc, H, W, generator=g).bfloat16().float().requires_grad_(True)
+    bias = (torch.randn(heads, 64, 64, generator=g) * 0.5).requires_grad_(True)   # [h][i][j]
+    hh, ww = H // ws, W // ws
+    t = qkv.view(n, 3, heads, d, hh, ws, ww, ws).permute(1, 0, 4, 6, 2, 5, 7, 3).reshape(3, n * hh * ww, heads, 64, d)
+    att = ((t[0] @ t[1].transpose(-2, -1)) * d ** -0.5 + bias.unsqueeze(0)).softmax(-1) @ t[2]
+    att = att.view(n, hh, ww, heads, ws, ws, d).permute(0, 3, 6, 1, 4, 2, 5).reshape(n, Cc, H, W)
+    dout = torch.randn(n, Cc, H, W, generator=g).bfloat16().float()
+    att.backward(dout)
+    biasT = D(bias.detach().permute(0, 2, 1).contiguous())
+    dqkv, dbT = T.window_attn_bwd(nhwc(qkv).bfloat16(), biasT, nhwc(dout).bfloat16(), heads, ws)
+    assert dqkv.dtype == torch.bfloat16
+    sc = float(qkv.grad.abs().max())
+    torch.testing.assert_close(nchw(dqkv.float()), qkv.grad, rtol=3e-2, atol=2e-2 * sc)
+    torch.testing.assert_close(dbT.permute(0, 2, 1).cpu(), bias.grad, rtol=3e-2, atol=2e-2 * float(bias.grad.abs().max()))
+
+
 @pytest.mark.parametrize('H,W', [(19, 21), (32, 48), (16, 40)])   # ragged / all windows tile / mixed
 def test_mfaf_gate_bwd_and_combine(be, H, W):
     from led_net_amd import ops, ops_train as T
