@@ -75,6 +75,121 @@ __global__ void __launch_bounds__(64) window_attn_kernel(const T* qkv, const flo
     for (int j = 0; j < D; j += 4) stv<4>(op + j, o + j);
 }
 
+// Matrix-core variant (bf16, head dim 16, windows tile the map; see window_attn_bwd_mfma_kernel in
+// attn_loss_opt.hip for the layout): S^T = K Q^T with fragments straight from global memory, softmax
+// in-lane over the accumulator registers (+ one exchange with lane ^ 32), O^T = V^T P^T with the
+// probability registers as the B operand and V^T gathered from a 2 KB LDS tile in the matching k order.
+__global__ void __launch_bounds__(64) window_attn_mfma_kernel(const bf16_t* qkv, const float* biasT, bf16_t* out,
+                                                              int N, int H, int W, int C, int heads, int hh,
+                                                              int ww) {
+    constexpr int D = 16, T2 = 64, LP = 72;
+    __shared__ __attribute__((aligned(16))) unsigned short s_vt[D * LP];
+    const int head = blockIdx.y;
+    const int lane = threadIdx.x, lr = lane & 31, lh = lane >> 5;
+    const int nwin = N * hh * ww;
+    const float scale = rsqrtf((float)D);
+    float bias[2][2][16];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bias[jt][it][r] = biasT[(long)head * T2 * T2 + (jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * T2 + it * 32 + lr];
+    const bf16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const int wx = win % ww, wy = (win / ww) % hh, n = win / (ww * hh);
+        bf16x8_t kf[2], vf[2], qf[2];
+        long tokoff[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int tok = tl * 32 + lr;
+            const long pix = ((long)n * H + wy * 8 + tok / 8) * W + wx * 8 + tok % 8;
+            tokoff[tl] = pix;
+            const bf16_t* p = qkv + pix * (3L * C) + head * D + lh * 8;
+            qf[tl] = *reinterpret_cast<const bf16x8_t*>(p);
+            kf[tl] = *reinterpret_cast<const bf16x8_t*>(p + C);
+            vf[tl] = *reinterpret_cast<const bf16x8_t*>(p + 2 * C);
+        }
+        __syncthreads();     // previous window's readers of s_vt are done
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_vt[(lh * 8 + e) * LP + tl * 32 + lr] = (unsigned short)vf[tl][e];
+        f32x16_t st[2][2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                f32x16_t z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                st[jt][it] = mfma_32x32x16_bf16(kf[jt], qf[it], z);
+            }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            float m = -3.0e38f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[jt][it][r] = st[jt][it][r] * scale + bias[jt][it][r];
+                    m = fmaxf(m, st[jt][it][r]);
+                }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float l = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[jt][it][r] = __expf(st[jt][it][r] - m);
+                    l += st[jt][it][r];
+                }
+            l += __shfl_xor(l, 32);
+            const float inv = 1.f / l;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[jt][it][r] *= inv;
+        }
+        __syncthreads();     // V^T tile complete
+        f32x16_t ot[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[it][r] = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x8_t a = zero8;
+                if (lr < D) {
+                    const int j0 = jt * 32 + 16 * h + 4 * lh;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = (short)s_vt[lr * LP + j0 + (e & 3) + 8 * (e >> 2)];
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    bf16x8_t b;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b[e] = (short)f32_to_bf16(st[jt][it][8 * h + e]);
+                    ot[it] = mfma_32x32x16_bf16(a, b, ot[it]);
+                }
+            }
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            bf16_t* o = out + tokoff[tl] * C + head * D + 4 * lh;
+            float t4[4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t4[e] = ot[tl][4 * g + e];
+                st4(o + 8 * g, t4);
+            }
+        }
+    }
+}
+
 int window_attn_impl(const void* qkv, const float* biasT, void* out, int N, int H, int W, int C,
                      int heads, int ws, int dtype, hipStream_t s) {
     LEDN_REQUIRE(qkv && biasT && out && N > 0 && H > 0 && W > 0 && C > 0 && heads > 0);
@@ -82,6 +197,13 @@ int window_attn_impl(const void* qkv, const float* biasT, void* out, int N, int 
     const int D = C / heads;
     const int hh = (H + ws - 1) / ws, ww = (W + ws - 1) / ws;
     LEDN_REQUIRE(hh * ws - H < H && ww * ws - W < W);  // reflect pad must be < size
+    if (dtype == LEDN_BF16 && D == 16 && H % ws == 0 && W % ws == 0 && C % 8 == 0) {   // matrix-core variant
+        long nb = (long)N * hh * ww;
+        if (nb > 512) nb = 512;                          // wavefronts per head, each walks its windows
+        LEDN_LAUNCH(window_attn_mfma_kernel, dim3((unsigned)nb, (unsigned)heads), dim3(64), 0, s, (const bf16_t*)qkv,
+                    biasT, (bf16_t*)out, N, H, W, C, heads, hh, ww);
+        return check_launch();
+    }
     const dim3 grid((unsigned)(N * hh * ww), (unsigned)heads);
 #define LEDN_WA(T, DD)                                                                          \
     LEDN_LAUNCH((window_attn_kernel<T, DD>), grid, dim3(64), 0, s, (const T*)qkv, biasT, (T*)out, N, H, \

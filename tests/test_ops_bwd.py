@@ -196,6 +196,9 @@ def test_window_attn_bwd_matrix_core(be, n, hw, heads):
     dout = torch.randn(n, Cc, H, W, generator=g).bfloat16().float()
     att.backward(dout)
     biasT = D(bias.detach().permute(0, 2, 1).contiguous())
+    from led_net_amd import ops
+    fwd = ops.window_attn(nhwc(qkv).bfloat16(), biasT, heads, ws)          # matrix-core forward of the same op
+    torch.testing.assert_close(nchw(fwd.float()), att.detach(), rtol=2e-2, atol=2e-2 * float(att.abs().max()))
     dqkv, dbT = T.window_attn_bwd(nhwc(qkv).bfloat16(), biasT, nhwc(dout).bfloat16(), heads, ws)
     assert dqkv.dtype == torch.bfloat16
     sc = float(qkv.grad.abs().max())
