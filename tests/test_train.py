@@ -294,8 +294,14 @@ def test_direct_gradient_sinks_match_autograd_accumulation(be):
         rel.append((a - b).norm().item() / den)
         floor.append((c - b).norm().item() / den)
     rel_s, floor_s = sorted(rel), sorted(floor)
-    med, worst = rel_s[len(rel_s) // 2], rel_s[-1]
-    fmed, fworst = floor_s[len(floor_s) // 2], floor_s[-1]
-    print(f'sinks vs autograd: median rel-L2 {med:.2e} worst {worst:.2e}; noise floor {fmed:.2e} / {fworst:.2e}')
-    # a missed or doubled accumulation is rel ~ 1 on that parameter
-    assert med <= max(1e-3, 10 * fmed) and worst <= max(5e-2, 10 * fworst), (med, worst, fmed, fworst)
+    med, p90, worst = rel_s[len(rel_s) // 2], rel_s[int(len(rel_s) * 0.9)], rel_s[-1]
+    fmed, fp90, fworst = floor_s[len(floor_s) // 2], floor_s[int(len(floor_s) * 0.9)], floor_s[-1]
+    print(f'sinks vs autograd: median rel-L2 {med:.2e} p90 {p90:.2e} worst {worst:.2e}; '
+          f'noise floor {fmed:.2e} / {fp90:.2e} / {fworst:.2e}')
+    # The step is chaotic on the GPU (f32 atomics order -> SEAM percentile pixels / ReLU kinks flip between
+    # two passes of the SAME code), so the bound is on the distribution over parameters: a missed or doubled
+    # accumulation is rel ~ 1 on a whole class of parameters (every conv weight, every BN gamma, ...) and
+    # moves the median / 90th percentile; single small-gradient parameters reach ~0.8 by noise alone.
+    assert med <= max(1e-3, 10 * fmed) and p90 <= max(5e-2, 10 * fp90), (med, p90, worst, fmed, fp90, fworst)
+    n_bad, f_bad = sum(r > 0.5 for r in rel), sum(f > 0.5 for f in floor)
+    assert n_bad <= max(4, 3 * f_bad + 2), (n_bad, f_bad)     # a small class (the ~30 PReLU slopes) would show here
