@@ -252,10 +252,15 @@ def test_direct_gradient_sinks_match_autograd_accumulation(be):
     _randomize(model, 5)
     model.to(_DEV[0])
     g = torch.Generator().manual_seed(12)
-    img = torch.randint(0, 256, (2, 3, 320, 320), dtype=torch.uint8, generator=g)
-    lab = torch.randint(0, 2, (2, 1, 320, 320), dtype=torch.int64, generator=g)
+    # batch 8 on the GPU: MFAF's global branch normalises one value per image over the batch, and with two
+    # images that BatchNorm is singular enough (x_hat = +-1) for f32 summation-order noise to swing the whole
+    # upstream gradient by 20-30 % between two passes of the same code (tools/diag_sinks.py); the emulator is
+    # deterministic and keeps the cheap batch of 2
+    nb = 2 if _DEV[0].type == 'cpu' else 8
+    img = torch.randint(0, 256, (nb, 3, 320, 320), dtype=torch.uint8, generator=g)
+    lab = torch.randint(0, 2, (nb, 1, 320, 320), dtype=torch.int64, generator=g)
     lab[:, :, :4, :] = 255
-    samples = [L.SegDataSample(gt=D(lab[i])) for i in range(2)]
+    samples = [L.SegDataSample(gt=D(lab[i])) for i in range(nb)]
     tr = L.Trainer(model, cfg, max_iters=100)
     tr.train_step(D(img), samples)                        # attaches the flat gradient views / sinks
     assert tr._sink_map and float(tr.flat_grad.abs().max()) == 0.0   # SGD re-zeroed the buffer
