@@ -140,8 +140,13 @@ def test_train_step_config_c_properties():
     assert moved > 0.9 * sum(1 for k in before if before[k].is_floating_point())
     assert all(bool(torch.isfinite(v).all()) for v in after.values() if v.is_floating_point())
     tr.capture(img, samples, warmup=1)
-    rep = tr.replay()
-    eager = tr.train_step(img, samples)
+    # the captured graph replays the SAME step as an eager one from the same state
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    mom, it = tr.flat_mom.clone(), tr.iter
+    rep = {k: float(v.float().reshape(-1)[0]) for k, v in tr.replay().items()}
+    m.load_state_dict(state)
+    tr.flat_mom.copy_(mom)
+    tr.iter = it
+    eager = {k: float(v.float().reshape(-1)[0]) for k, v in tr.train_step(img, samples).items()}
     for k in ('decode.loss_context', 'decode.loss_spatial'):
-        a, b = float(rep[k].float().reshape(-1)[0]), float(eager[k].float().reshape(-1)[0])
-        assert a == a and abs(a - b) <= 0.25 * abs(b) + 1e-3, (k, a, b)    # consecutive steps of one trajectory
+        assert rep[k] == rep[k] and abs(rep[k] - eager[k]) <= 2e-2 * abs(eager[k]) + 1e-3, (k, rep[k], eager[k])
