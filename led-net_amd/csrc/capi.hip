@@ -8,6 +8,8 @@ int conv_direct(const ledn_conv_desc& d, hipStream_t s);
 bool conv_mfma_supported(const ledn_conv_desc& d);
 int conv_mfma(const ledn_conv_desc& d, hipStream_t s);
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d);
+bool conv_wgrad_cout2_supported(const ledn_wgrad_desc& d);
+int conv_wgrad_cout2(const ledn_wgrad_desc& d, hipStream_t s);
 int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s);
 int pack_conv_weights_multi_impl(const ledn_pack_entry* table_dev, int n, long long max_elems, hipStream_t s);
 int im2col_stem_impl(const void* x, void* p, int N, int H, int W, int C, int Ho, int Wo, hipStream_t s);
@@ -160,7 +162,9 @@ int ledn_bn_finalize_rows(const float* part, int rows, double count, const float
 }
 
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d) { return d && conv_mfma_supported(*d) ? 1 : 0; }
-int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d) { return d && wgrad_mfma_supported(*d) ? 1 : 0; }
+int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d) {
+    return d && !conv_wgrad_cout2_supported(*d) && wgrad_mfma_supported(*d) ? 1 : 0;
+}
 
 int ledn_pack_conv_weights_multi(const ledn_pack_entry* table_dev, int n, long long max_elems, void* stream) {
     return pack_conv_weights_multi_impl(table_dev, n, max_elems, S(stream));
@@ -183,6 +187,7 @@ int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream) {
     if (!d) return LEDN_EINVAL;
     const int rc = wgrad_validate(*d);
     if (rc != LEDN_OK) return rc;
+    if (conv_wgrad_cout2_supported(*d)) return conv_wgrad_cout2(*d, S(stream));   // two-class heads
     if (wgrad_mfma_supported(*d)) {
         const int r2 = conv_wgrad_mfma(*d, S(stream));
         if (r2 != LEDN_OK || !d->db) return r2;

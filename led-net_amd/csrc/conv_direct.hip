@@ -566,6 +566,127 @@ static bool narrow_ok(const ledn_wgrad_desc& d) {
 int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
                        float* sqsum, hipStream_t s);
 
+// ---------------------------------------------------------------------------
+// Weight gradient of the two-class heads (Cout <= 2: head_x1 / head_x2 3x3 32->2, cls_seg 1x1 64->2,
+// led_head.py:44-51), bf16, stride 1: thread = (input pixel q, 8 input channels).  x[q] is read ONCE
+// (16 bytes, the producer's BatchNorm + ReLU applied in registers); the K*K x 2 gradient values
+// dz[q - tap] that multiply it are 4-byte loads of neighbouring pixels (cache hits: dz is 1/16 of x);
+// K*K x 2 x 8 sums live in registers over the thread's pixels, then an LDS reduction over the 64
+// pixel slots of the workgroup, one partial row per workgroup, finish_partials.  (On the MFMA path
+// 30 of 32 output rows were padding and the narrow dz staging was element-wise: 0.28 ms for the
+// 268 MB x1; this kernel streams x once.)
+// ---------------------------------------------------------------------------
+template <typename TZ, int K>
+__global__ void __launch_bounds__(256) conv_wgrad_cout2_kernel(ledn_wgrad_desc d, float* part) {
+    constexpr int KK = K * K;
+    __shared__ float s_red[256 * 16];
+    const int cgn = d.Cin / 8;                       // channel groups (4 for 32, 8 for 64)
+    const int slots = 256 / cgn;
+    const int slot = threadIdx.x / cgn, cg = threadIdx.x % cgn;
+    const int c = cg * 8;
+    float acc[KK][2][8];
+#pragma unroll
+    for (int t = 0; t < KK; ++t)
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[t][o][i] = 0.f;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = d.in_scale ? d.in_scale[c + i] : 1.f;
+        sh[i] = d.in_shift ? d.in_shift[c + i] : 0.f;
+    }
+    const bf16_t* x = reinterpret_cast<const bf16_t*>(d.x);
+    const TZ* dz = reinterpret_cast<const TZ*>(d.dz);
+    const long npix = (long)d.N * d.H * d.W;
+    const long stride = (long)gridDim.x * slots;
+    if (slot < slots) {
+        for (long q = (long)blockIdx.x * slots + slot; q < npix; q += stride) {
+            const int wi = (int)(q % d.W);
+            const int hi = (int)((q / d.W) % d.H);
+            const int n = (int)(q / ((long)d.W * d.H));
+            float xv[8];
+            ld8(x + q * d.Cin + c, xv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xv[i] = xv[i] * sc[i] + sh[i];
+                if (d.in_act == LEDN_ACT_RELU) xv[i] = fmaxf(xv[i], 0.f);
+            }
+            float g[KK][2];
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {           // output pixel fed by x[q] through tap t
+                const int ho = hi + d.pad - t / K, wo = wi + d.pad - t % K;
+                const bool ok = ho >= 0 && ho < d.Ho && wo >= 0 && wo < d.Wo;
+                const long zo = ok ? (((long)n * d.Ho + ho) * d.Wo + wo) * d.Cout : 0L;
+                const float g0 = ld(dz + zo), g1 = d.Cout > 1 ? ld(dz + zo + 1) : 0.f;
+                g[t][0] = ok ? g0 : 0.f;
+                g[t][1] = ok ? g1 : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < KK; ++t)
+#pragma unroll
+                for (int o = 0; o < 2; ++o)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[t][o][i] = fmaf(xv[i], g[t][o], acc[t][o][i]);
+        }
+    }
+    // reduce over the pixel slots, one tap at a time: s_red[thread][o*8 + i]
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s_red[threadIdx.x * 16 + o * 8 + i] = slot < slots ? acc[t][o][i] : 0.f;
+        __syncthreads();
+        for (int e = threadIdx.x; e < cgn * 16; e += 256) {      // (cg, o, i)
+            const int g_ = e / 16, oi = e % 16;
+            float v = 0.f;
+            for (int sl = 0; sl < slots; ++sl) v += s_red[(sl * cgn + g_) * 16 + oi];
+            const int co = oi / 8, ci = g_ * 8 + oi % 8;
+            if (co < d.Cout) {
+                const long idx = (long)co * d.ws_co + (long)ci * d.ws_ci + (long)t * d.ws_tap;
+                if (part) part[(long)blockIdx.x * ((long)d.Cout * d.Cin * KK) + idx] = v;
+                else atomicAdd(d.dw + idx, v);
+            }
+        }
+    }
+}
+
+static bool cout2_ok(const ledn_wgrad_desc& d) {
+    if (d.Cout > 2 || d.groups != 1 || d.xadd || d.stride != 1 || d.dil != 1) return false;
+    if (d.dtype_x != LEDN_BF16 || (d.Cin != 32 && d.Cin != 64 && d.Cin != 128)) return false;
+    if (d.in_act != LEDN_ACT_NONE && d.in_act != LEDN_ACT_RELU) return false;
+    if (!((d.KH == 3 && d.KW == 3 && d.pad == 1) || (d.KH == 1 && d.KW == 1 && d.pad == 0))) return false;
+    return d.Ho == d.H && d.Wo == d.W;
+}
+
+bool conv_wgrad_cout2_supported(const ledn_wgrad_desc& d) { return cout2_ok(d) && wgrad_natural_strides(d); }
+
+int conv_wgrad_cout2(const ledn_wgrad_desc& d, hipStream_t s) {
+    const long npix = (long)d.N * d.H * d.W;
+    const int slots = 256 / (d.Cin / 8);
+    long nb = cdiv(npix, (long)slots * 16);           // >= 16 pixels per thread
+    if (nb > 1024) nb = 1024;
+    const long numel = (long)d.Cout * d.Cin * d.KH * d.KW;
+    float* part = nb > 4 ? ws_take(nb * numel) : nullptr;
+    if (!part && nb > 16) nb = 16;
+    const dim3 grid((unsigned)nb);
+#define LEDN_C2(TZ)                                                                                   \
+    do {                                                                                              \
+        if (d.KH == 3) LEDN_LAUNCH((conv_wgrad_cout2_kernel<TZ, 3>), grid, dim3(256), 0, s, d, part); \
+        else LEDN_LAUNCH((conv_wgrad_cout2_kernel<TZ, 1>), grid, dim3(256), 0, s, d, part);           \
+    } while (0)
+    if (d.dtype_dz == LEDN_BF16) LEDN_C2(bf16_t);
+    else if (d.dtype_dz == LEDN_F32) LEDN_C2(float);
+    else return LEDN_EINVAL;
+#undef LEDN_C2
+    int rc = part ? finish_partials(part, (int)nb, (int)numel, 1, d.dw, nullptr, nullptr, s) : check_launch();
+    if (rc != LEDN_OK || !d.db) return rc;
+    return channel_stats_impl(d.dz, nullptr, npix, d.Cout, d.dtype_dz, d.db, nullptr, s);
+}
+
 int conv_wgrad_direct(const ledn_wgrad_desc& d, hipStream_t s) {
     if (narrow_ok(d)) {
         int rc;

@@ -229,3 +229,29 @@ def test_deferred_conv_statistics_finalize(be):
         outs.append([t.cpu() for t in (z.float(), sc, sh, mean, invstd, rm, rv, stats[0], stats[1])])
     for a, b in zip(*outs):
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('cin,cout,k,hw,dz_f32', [(32, 2, 3, (21, 45), False), (64, 2, 1, (16, 23), True),
+                                                 (32, 1, 3, (9, 70), False), (128, 2, 3, (12, 12), False)])
+def test_two_class_head_wgrad_kernel(be, cin, cout, k, hw, dz_f32):
+    """conv_wgrad_cout2_kernel (LEDHead's 32->2 / 64->2 layers): x streamed once with the producer's
+    BatchNorm + ReLU applied in registers, against torch autograd on the bf16-rounded operands; bias
+    gradient and accumulation into a caller buffer included."""
+    from led_net_amd import ops
+    pad = k // 2
+    x = r16(torch.randn(3, cin, *hw))
+    s_in, b_in = torch.rand(cin) + 0.5, torch.randn(cin) * 0.1
+    w = (torch.randn(cout, cin, k, k) * 0.1).requires_grad_(True)
+    pre = F.relu(x * s_in.view(1, -1, 1, 1) + b_in.view(1, -1, 1, 1))
+    z = F.conv2d(pre, w, padding=pad)
+    dz = torch.randn_like(z)
+    dz = dz if dz_f32 else r16(dz)
+    z.backward(dz)
+    base = torch.randn_like(w.detach())
+    sink = D(base.clone())
+    dzd = nhwc(dz) if dz_f32 else nhwc(dz).bfloat16()
+    dw, db = ops.conv2d_wgrad(nhwc(x).bfloat16(), dzd, tuple(w.shape), pad=pad, in_scale=D(s_in), in_shift=D(b_in),
+                              in_act=ops.ACT_RELU, bias=True, dw_out=sink)
+    n = 3 * hw[0] * hw[1]
+    torch.testing.assert_close(dw.cpu() - base, w.grad, rtol=2e-3, atol=2e-4 * n ** 0.5 + 1e-3 * float(w.grad.abs().max()))
+    torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3)), rtol=1e-3, atol=1e-3 * n ** 0.5)
