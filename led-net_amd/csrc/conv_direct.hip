@@ -662,7 +662,9 @@ static bool cout2_ok(const ledn_wgrad_desc& d) {
     return d.Ho == d.H && d.Wo == d.W;
 }
 
-bool conv_wgrad_cout2_supported(const ledn_wgrad_desc& d) { return cout2_ok(d) && wgrad_natural_strides(d); }
+// 1x1 only: measured 0.142 -> 0.069 ms for the two 64->2 classifiers; the 3x3 instance (144 accumulators,
+// 214 VGPRs) ran SLOWER than the MFMA narrow path (0.41 vs 0.28 ms at 16 x 512 x 512) and stays there
+bool conv_wgrad_cout2_supported(const ledn_wgrad_desc& d) { return cout2_ok(d) && d.KH == 1 && wgrad_natural_strides(d); }
 
 int conv_wgrad_cout2(const ledn_wgrad_desc& d, hipStream_t s) {
     const long npix = (long)d.N * d.H * d.W;

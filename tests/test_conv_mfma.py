@@ -234,8 +234,8 @@ def test_deferred_conv_statistics_finalize(be):
 @pytest.mark.parametrize('cin,cout,k,hw,dz_f32', [(32, 2, 3, (21, 45), False), (64, 2, 1, (16, 23), True),
                                                  (32, 1, 3, (9, 70), False), (128, 2, 3, (12, 12), False)])
 def test_two_class_head_wgrad_kernel(be, cin, cout, k, hw, dz_f32):
-    """conv_wgrad_cout2_kernel (LEDHead's 32->2 / 64->2 layers): x streamed once with the producer's
-    BatchNorm + ReLU applied in registers, against torch autograd on the bf16-rounded operands; bias
+    """Weight gradients of LEDHead's two-class layers (conv_wgrad_cout2_kernel for the 1x1 classifiers, the MFMA
+    narrow path for the 3x3 heads): x streamed once with the producer's BatchNorm + ReLU applied while staging, against torch autograd on the bf16-rounded operands; bias
     gradient and accumulation into a caller buffer included."""
     from led_net_amd import ops
     pad = k // 2
@@ -253,5 +253,6 @@ def test_two_class_head_wgrad_kernel(be, cin, cout, k, hw, dz_f32):
     dw, db = ops.conv2d_wgrad(nhwc(x).bfloat16(), dzd, tuple(w.shape), pad=pad, in_scale=D(s_in), in_shift=D(b_in),
                               in_act=ops.ACT_RELU, bias=True, dw_out=sink)
     n = 3 * hw[0] * hw[1]
-    torch.testing.assert_close(dw.cpu() - base, w.grad, rtol=2e-3, atol=2e-4 * n ** 0.5 + 1e-3 * float(w.grad.abs().max()))
+    # (the MFMA path rounds act(BN(x)) to bf16 while staging: 2e-2 of the gradient scale)
+    torch.testing.assert_close(dw.cpu() - base, w.grad, rtol=2e-2, atol=2e-4 * n ** 0.5 + 2e-2 * float(w.grad.abs().max()))
     torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3)), rtol=1e-3, atol=1e-3 * n ** 0.5)
