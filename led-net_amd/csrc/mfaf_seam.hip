@@ -79,11 +79,16 @@ __device__ __forceinline__ float seam_lap(const float* seg, int h, int w, int cy
     return acc > 0.f ? acc : 0.f;
 }
 
-__global__ void __launch_bounds__(256) seam_edge_kernel(const float* seg_all, float* edge_all,
-                                                        float* scratch, int h, int w, int kth,
-                                                        float thr, float final_thr) {
-    __shared__ float s_red[2][4];
+// One workgroup of 1024 threads per image (the per-image order statistic needs a workgroup-wide view;
+// at batch 1 this kernel is on the latency path of the whole network: 256 threads and a one-thread
+// 256-bin scan per radix pass took 0.5-0.7 ms).
+constexpr int SEAM_T = 1024;
+__global__ void __launch_bounds__(SEAM_T) seam_edge_kernel(const float* seg_all, float* edge_all,
+                                                           float* scratch, int h, int w, int kth,
+                                                           float thr, float final_thr) {
+    __shared__ float s_red[2][SEAM_T / 64];
     __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_wave[4];
     __shared__ unsigned s_sel[2];  // prefix, remaining rank
     __shared__ float s_thr[3];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -92,9 +97,9 @@ __global__ void __launch_bounds__(256) seam_edge_kernel(const float* seg_all, fl
     float* edge = edge_all + (long)n * hw;
     float* resp = scratch + (long)n * 3 * hw;
 
-    // phase 1
+    // phase 1: min / max of the image
     float mn = 3.0e38f, mx = -3.0e38f;
-    for (int i = tid; i < hw; i += 256) {
+    for (int i = tid; i < hw; i += SEAM_T) {
         const float v = seg[i];
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
@@ -106,12 +111,16 @@ __global__ void __launch_bounds__(256) seam_edge_kernel(const float* seg_all, fl
         s_red[1][tid >> 6] = mx;
     }
     __syncthreads();
-    mn = fminf(fminf(s_red[0][0], s_red[0][1]), fminf(s_red[0][2], s_red[0][3]));
-    mx = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
+    mn = s_red[0][0];
+    mx = s_red[1][0];
+    for (int i = 1; i < SEAM_T / 64; ++i) {
+        mn = fminf(mn, s_red[0][i]);
+        mx = fmaxf(mx, s_red[1][i]);
+    }
     const float den = mx - mn;
 
-    // phase 2
-    for (int i = tid; i < hw; i += 256) {
+    // phase 2: the three Laplacian responses (strides 1 / 2 / 4, nearest-upsampled)
+    for (int i = tid; i < hw; i += SEAM_T) {
         const int y = i / w, x = i % w;
         resp[i] = seam_lap(seg, h, w, y, x, mn, den);
 #pragma unroll
@@ -127,7 +136,7 @@ __global__ void __launch_bounds__(256) seam_edge_kernel(const float* seg_all, fl
     }
     __syncthreads();
 
-    // phase 3
+    // phase 3: k-th smallest response per level (4 x 8-bit radix select)
     if (kth > 0) {
         const int kk = kth > hw ? hw : kth;
         for (int sidx = 0; sidx < 3; ++sidx) {
@@ -138,23 +147,41 @@ __global__ void __launch_bounds__(256) seam_edge_kernel(const float* seg_all, fl
             }
             for (int pass = 0; pass < 4; ++pass) {
                 const int shift = 24 - 8 * pass;
-                s_hist[tid] = 0u;
+                if (tid < 256) s_hist[tid] = 0u;
                 __syncthreads();
                 const unsigned prefix = s_sel[0];
+                const unsigned rank0 = s_sel[1];
                 const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-                for (int i = tid; i < hw; i += 256) {
+                for (int i = tid; i < hw; i += SEAM_T) {
                     const unsigned u = __float_as_uint(r[i]);
                     if ((u & himask) == prefix) atomicAdd(&s_hist[(u >> shift) & 255u], 1u);
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    unsigned rank = s_sel[1], b = 0;
-                    for (; b < 256u; ++b) {
-                        if (rank < s_hist[b]) break;
-                        rank -= s_hist[b];
+                // bucket holding the rank: prefix sum over the 256 bins by the first four wavefronts
+                unsigned mine = 0u, incl = 0u;
+                if (tid < 256) {
+                    mine = s_hist[tid];
+                    incl = mine;
+                    const int lane = tid & 63;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned nbr = __shfl(incl, lane >= o ? lane - o : lane);
+                        if (lane >= o) incl += nbr;
                     }
-                    s_sel[0] = prefix | (b << shift);
-                    s_sel[1] = rank;
+                    if (lane == 63) s_wave[tid >> 6] = incl;
+                }
+                __syncthreads();
+                if (tid < 256) {
+                    for (int i = 0; i < (tid >> 6); ++i) incl += s_wave[i];
+                    const unsigned excl = incl - mine;
+                    const unsigned total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+                    if (rank0 >= excl && rank0 < incl) {            // exactly one thread when rank0 < total
+                        s_sel[0] = prefix | ((unsigned)tid << shift);
+                        s_sel[1] = rank0 - excl;
+                    } else if (rank0 >= total && tid == 255) {      // (cannot happen: rank < count; kept as the
+                        s_sel[0] = prefix | (256u << shift);        //  serial scan's fall-through: b = 256)
+                        s_sel[1] = rank0 - total;
+                    }
                 }
                 __syncthreads();
             }
@@ -166,8 +193,8 @@ __global__ void __launch_bounds__(256) seam_edge_kernel(const float* seg_all, fl
         __syncthreads();
     }
 
-    // phase 4
-    for (int i = tid; i < hw; i += 256) {
+    // phase 4: binarise, fuse, binarise
+    for (int i = tid; i < hw; i += SEAM_T) {
         const float f = 0.6f * (resp[i] > s_thr[0] ? 1.f : 0.f) +
                         0.3f * (resp[hw + i] > s_thr[1] ? 1.f : 0.f) +
                         0.1f * (resp[2 * hw + i] > s_thr[2] ? 1.f : 0.f);
@@ -179,7 +206,7 @@ int seam_edge_impl(const float* seg, float* edge, float* scratch, int N, int h, 
                    float final_thr, hipStream_t s) {
     LEDN_REQUIRE(seg && edge && scratch && N > 0 && h > 0 && w > 0);
     LEDN_REQUIRE(kth >= 0);
-    LEDN_LAUNCH(seam_edge_kernel, dim3((unsigned)N), dim3(256), 0, s, seg, edge, scratch, h, w, kth, thr,
+    LEDN_LAUNCH(seam_edge_kernel, dim3((unsigned)N), dim3(SEAM_T), 0, s, seg, edge, scratch, h, w, kth, thr,
                 final_thr);
     return check_launch();
 }
