@@ -335,13 +335,21 @@ class MFAF(Block):
 
     def forward(self, x, r, out_relu=False):
         assert not self.training
-        xl, aff_l = self._mlp(self.local_att, 0, x, xadd=r)
-        ctx, affs = [], [aff_l]
-        for name, S in self.POOLS:
-            pooled = ops.adaptive_avgpool(x, S, xadd=r)
-            c, aff = self._mlp(getattr(self, name), 1, pooled)
+        # pooled-context chains (pool + two tiny convs each) on auxiliary streams, the local branch on the
+        # main one (see train.mfaf)
+        forks, ctx, affs_ctx = [], [], []
+        for idx, (name, S) in enumerate(self.POOLS):
+            f = ops.Fork(x, 3 + idx, r)
+            with f:
+                pooled = ops.adaptive_avgpool(x, S, xadd=r)
+                c, aff = self._mlp(getattr(self, name), 1, pooled)
+            forks.append((f, c))
             ctx.append(c)
-            affs.append(aff)
+            affs_ctx.append(aff)
+        xl, aff_l = self._mlp(self.local_att, 0, x, xadd=r)
+        for f, c in forks:
+            f.join(c)
+        affs = [aff_l] + affs_ctx
         return ops.mfaf_gate(x, r, xl, ctx, affs, act=ACT_RELU if out_relu else ACT_NONE)
 
 

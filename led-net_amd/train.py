@@ -537,13 +537,22 @@ def mfaf(m, x, r, out_relu=False):
         mid = conv_bn_act(inp, seq[off], seq[off + 1], ACT_RELU)
         c1 = seq[off + 3]
         return ConvFn.apply(mid, c1.weight, c1.bias, None, 1, 0, 1, None, out_dtype), seq[off + 4]
-    xl, bn_l = mlp(m.local_att, 0, xa)
     pooled = MultiPoolFn.apply(xa)
-    raws, bns = [xl], [bn_l]
-    for (name, _), pz in zip(m.POOLS, pooled):
-        c, bn = mlp(getattr(m, name), 1, pz)
-        raws.append(c)
-        bns.append(bn)
+    # the four pooled-context MLPs are chains of tiny launch-bound kernels, independent of each other and of
+    # the local branch: each runs on its own auxiliary stream while the local branch (full-resolution convs)
+    # runs on the main one (forward here, backward through autograd's stream affinity)
+    forks, ctx, bns_ctx = [], [], []
+    for idx, ((name, _), pz) in enumerate(zip(m.POOLS, pooled)):
+        f = ops.Fork(pz, 3 + idx)
+        with f:
+            c, bn = mlp(getattr(m, name), 1, pz)
+        forks.append((f, c))
+        ctx.append(c)
+        bns_ctx.append(bn)
+    xl, bn_l = mlp(m.local_att, 0, xa)
+    for f, c in forks:
+        f.join(c)
+    raws, bns = [xl] + ctx, [bn_l] + bns_ctx
     gb = []
     for bn in bns:
         gb += [bn.weight, bn.bias]
