@@ -154,7 +154,7 @@ class Fork:
     current stream wait for it.  A no-op for host tensors (emulator) and when MULTI_STREAM is off."""
 
     def __init__(self, ref, slot=1, *inputs):
-        self.on = bool(ref.is_cuda and MULTI_STREAM)
+        self.on = bool(ref.is_cuda and MULTI_STREAM and slot > 0)     # slot 0 = stay on the current stream
         if self.on:
             self.main = torch.cuda.current_stream(ref.device)
             self.side = _aux_stream(ref.device, slot)
