@@ -35,6 +35,10 @@ def to_nchw_view(t):
     return t.permute(0, 3, 1, 2)
 
 
+import os as _os
+SEAM_SLOT_EVAL = int(_os.environ.get('LEDN_SEAM_SLOT_EVAL', '2'))   # inference: SEAM edge map on its own stream
+
+
 class LEDNet(Block):
     def __init__(self, in_channels=3, channels=32, ppm_channels=128, norm_cfg=None,
                  align_corners=False, act_cfg=None, init_cfg=None, num_heads=8, window_size=8,
@@ -114,7 +118,7 @@ class LEDNet(Block):
         y = self.stem['4'][1](self.stem['4'][0](y), final_relu=True)           # 2C @1/8
         # The context branch (1/16 .. 1/64 resolution: small launch-bound kernels) and the SEAM edge map
         # run on auxiliary streams between the bilateral fusion points (ops.Fork).
-        with ops.Fork(y, 2) as fe:
+        with ops.Fork(y, SEAM_SLOT_EVAL) as fe:
             edge = self.seam.edge(y)
         # stage 3
         with ops.Fork(y, 1) as f3:

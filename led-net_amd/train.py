@@ -530,6 +530,8 @@ def getb(m, x):
     return ActFn.apply(y, x1, ACT_NONE)
 
 
+CTX_FORKS = int(_os.environ.get('LEDN_CTX_FORKS', '7'))    # bit s: context branch of stage 3+s on the aux stream
+SEAM_SLOT = int(_os.environ.get('LEDN_SEAM_SLOT', '0'))     # stream of the SEAM edge map: 0 = main (measured 895 vs 878 img/s on its own stream)
 MFAF_FORK = int(_os.environ.get('LEDN_MFAF_FORK', '0'))   # measured: 785 vs 876 img/s with the forks in TRAINING (inference gains 4 %: blocks.MFAF)
 
 
@@ -583,12 +585,12 @@ def lednet_forward_train(m, x, pre=None):
     y = basic_block(m.stem['4'][1], basic_block(m.stem['4'][0], y), final_relu=True)
     # context branch and SEAM edge map on auxiliary streams between the fusion points (ops.Fork);
     # autograd runs each backward kernel on the stream of its forward
-    with ops.Fork(y, 2) as fe, torch.no_grad():
+    with ops.Fork(y, SEAM_SLOT) as fe, torch.no_grad():
         # the binarised edge map is piecewise constant: no gradient (ddrnet_speed.py:290-338)
         seg = conv_module(m.seam.conv_1, y.detach(), out_dtype=torch.float32)
         edge = ops.seam_edge(seg, m.seam.percentile, m.seam.fixed_threshold, 0.1)
     # stage 3
-    with ops.Fork(y, 1) as f3:
+    with ops.Fork(y, 1 if CTX_FORKS & 1 else 0) as f3:
         x_c = getb(m.getb1, cespb(m.layer3, y))
         comp = BilinearFn.apply(conv_module(m.compression_1, relu(x_c)), None, out_size, None)
     x_s = cespb(m.layer3_, y)
@@ -597,7 +599,7 @@ def lednet_forward_train(m, x, pre=None):
     x_s = mfaf(m.aff1, x_s, comp)
     c3 = x_s
     # stage 4
-    with ops.Fork(x_c, 1) as f4:
+    with ops.Fork(x_c, 1 if CTX_FORKS & 2 else 0) as f4:
         x_c = cespb(m.layer4, relu(x_c))
         comp = BilinearFn.apply(conv_module(m.compression_2, relu(x_c)), None, out_size, None)
     x_s = cespb(m.layer4_, relu(x_s))
@@ -608,7 +610,7 @@ def lednet_forward_train(m, x, pre=None):
     fe.join(edge)
     x_s = conv_module(m.seam.conv_2, edge, res=x_s, res_mode=RES_GATE, out_dtype=x_s.dtype)
     # stage 5
-    with ops.Fork(x_c, 1) as f5:
+    with ops.Fork(x_c, 1 if CTX_FORKS & 4 else 0) as f5:
         x_c = cespb(m.layer5, relu(x_c))
         x_c = getb(m.getb2, conv_module(m.spp, x_c))
     x_s = sesp(m.layer5_, relu(x_s))
