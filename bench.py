@@ -137,9 +137,34 @@ def cpu_baseline(mode, h, w, budget_s=20.0):
                       f'at batch {bs}, {h}x{w}, fp32, torch CPU ops, {cores} threads'}
 
 
+def launch_ranks(n):
+    """python bench.py --gpus N without a launcher: start `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 bench.py <same arguments>` as a child process, pass its output
+    through and return its exit code.  Fails loudly when the node has fewer than N GPUs."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f'[bench] --gpus {n} requested but this node exposes {have} GPU(s): refusing to run '
+              f'(a 1-rank number must never be reported as an N-rank one)', file=sys.stderr)
+        return 2
+    port = os.environ.get('MASTER_PORT')
+    if not port:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] launching', ' '.join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=None, help='ranks (one per GPU); default: WORLD_SIZE when launched by torch.distributed.run, else 1')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--mode', default=None, choices=['train', 'infer'])
@@ -157,10 +182,20 @@ def main():
     ap.add_argument('--trace-only', action='store_true',
                     help='stop after the timed region (for rocprofv3 timeline traces: no instrumented eager pass, no JSON)')
     args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get('WORLD_SIZE', 1))
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # launched bare (python bench.py --gpus N): become the launcher.  The N ranks are CHILD processes of
+        # torch.distributed.run (the shape of the reference's tools/dist_train.sh:9-18); nothing in this
+        # process has touched the GPU yet (device_count() does not initialise it), and it never will.
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        sys.exit(f'[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with '
+                 f'torch.distributed.run --nproc-per-node {args.gpus} (or run bare: bench.py spawns the ranks itself)')
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group('nccl')
@@ -293,10 +328,15 @@ def main():
             'config': {'workload': (f'LED-Net {H}x{W} train_step (fwd+OHEM-CE+bwd+SGD) batch {bs}/GPU' if mode == 'train'
                                     else f'LED-Net {H}x{W} inference (fwd+fusion+argmax) batch {bs}/GPU'),
                        'global_batch': bs * world, 'parallelism': f'dp{world}',
-                       'batchnorm': ('SyncBN (config): one RCCL all-reduce of [2,C] per BN and direction' if mode == 'train' and not args.local_bn and trainer._all_reduce is not None
+                       'ranks': world, 'images_per_rank_per_step': bs,
+                       'rccl_nranks': (trainer.comm.nranks if mode == 'train' and trainer.comm is not None
+                                       else (dist.get_world_size() if world > 1 else None)),
+                       'batchnorm': ('SyncBN (config): one RCCL all-reduce of [2,C] per BN (or group of BNs ready together) and direction' if mode == 'train' and not args.local_bn and trainer._all_reduce is not None
                                      else 'per-rank statistics'),
                        'collectives': (None if mode != 'train' or trainer._all_reduce is None else
-                                       ('ncclAllReduce on the launch stream (in the graph)' if trainer.comm is not None else 'torch.distributed (eager)')),
+                                       ('ncclAllReduce on the launch streams, one communicator per stream (in the graph); '
+                                        'non-stem gradients exchanged during the stem backward' if trainer.comm is not None
+                                        else 'torch.distributed (eager)')),
                        'kernel_launches_per_step': len(launches) // k_steps,
                        'submission': 'hipGraph replay' if graphed else 'eager launches',
                        'kernel_timing': 'HIP events on the launch streams, instrumented eager pass of the same step right after the timed region',

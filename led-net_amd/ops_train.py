@@ -10,26 +10,34 @@ from .ops import (ACT_NONE, RES_NONE, _DT, LednError, _check, _dt, _f32, _nb, _p
                   conv_out_size)
 
 
-def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
-               res=None, res_mode=RES_NONE, count=None, want_dres=False, sync=None, sinks=None):
-    """Backward of y = act(res_mode(z*scale+shift, res)).
-    BN mode (mean/invstd given): returns (dz, dres, dgamma, dbeta, dslope).
-    Plain mode: returns (dz, dres, None, None, dslope).
-    sync: optional callable all-reducing the [2,C] (sum_g, sum_gx) buffer (SyncBN).
-    sinks: optional (dgamma, dbeta, dslope) ZEROED f32 [C] buffers (any may be None) the kernels
-    reduce straight into (the trainer's gradient views); the matching return value is then None."""
+class _BnBwd:
+    """State of one BatchNorm(+activation, +residual) backward between its two kernels."""
+    __slots__ = ('lib', 'd', 'z', 'bn', 'Cc', 'P', 'local', 'sunk', 'dz', 'dres', 'dslope', 'slope_sunk', 'keep')
+
+
+def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
+                      res=None, res_mode=RES_NONE, count=None, want_dres=False, sinks=None, sync=False):
+    """First half of bn_act_bwd: the per-channel sums (sum g*xhat, sum g) of THIS rank's shard, reduced
+    into the parameter-gradient sinks when given (they ARE d_gamma, d_beta of the local shard -- under
+    SyncBN too: torch.nn.SyncBatchNorm keeps grad_weight / grad_bias local, DDP averages them later),
+    else into zeroed scratch.  -> state for bn_act_bwd_sync / bn_act_bwd_apply."""
     lib = _lib.get_lib()
+    st = _BnBwd()
     Cc = z.shape[-1]
     P = z.numel() // Cc
     bn = mean is not None
     d = _lib.BnBwdDesc()
     sk_g, sk_b, sk_s = sinks if sinks is not None else (None, None, None)
-    if bn and sync is None and sk_g is not None and sk_b is not None:
-        sum_g, sum_gx, sunk = sk_b, sk_g, True
-        _f32(sum_g, Cc), _f32(sum_gx, Cc)
+    sunk = bool(bn and sk_g is not None and sk_b is not None)
+    if sunk and sync and sk_b.data_ptr() != sk_g.data_ptr() + 4 * Cc:
+        sunk = False                       # (never the case for an nn.BatchNorm: weight, bias are adjacent)
+    if sunk:
+        _f32(sk_g, Cc), _f32(sk_b, Cc)
+        sum_gx, sum_g = sk_g, sk_b
+        local = torch.as_strided(sk_g, (2, Cc), (Cc, 1)) if sync else None
     else:
-        sums = _ops.zeros_f32((2, Cc), z.device)
-        sum_g, sum_gx, sunk = sums[0], sums[1], False
+        local = _ops.zeros_f32((2, Cc), z.device)           # [sum g*xhat (d_gamma), sum g (d_beta)]
+        sum_gx, sum_g = local[0], local[1]
     dslope, slope_sunk = None, False
     if slope is not None:
         if sk_s is not None:
@@ -50,11 +58,50 @@ def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT
     d.bn_mode, d.dtype_z, d.dtype_y = int(bn), _dt(z), _dt(dy)
     if bn or slope is not None:
         _run(lib, 'ledn_bn_act_bwd_reduce', z, d, work=_ops._TIMING is not None and (f'bnbwd_reduce C{Cc} P{P}', _nb(z, dy, res), 6 * z.numel()))
-        if bn and sync is not None:
-            sync(sums)
-    _run(lib, 'ledn_bn_act_bwd_apply', z, d, work=_ops._TIMING is not None and (f'bnbwd_apply C{Cc} P{P}', _nb(z, dy, res, dz, dres), 8 * z.numel()))
-    return (dz, dres, (sum_gx if bn and not sunk else None), (sum_g if bn and not sunk else None),
-            None if slope_sunk else dslope)
+    st.lib, st.d, st.z, st.bn, st.Cc, st.P, st.local, st.sunk = lib, d, z, bn, Cc, P, local, sunk
+    st.dz, st.dres, st.dslope, st.slope_sunk = dz, dres, dslope, slope_sunk
+    st.keep = (dy, res, scale, shift, slope, mean, invstd, sum_g, sum_gx, sk_g, sk_b)
+    return st
+
+
+def bn_act_bwd_sync(st, sync):
+    """SyncBN: the apply kernel needs the GLOBAL sums; all-reduce the local ones OUT OF PLACE into scratch
+    (the local sums stay what they are: this rank's parameter gradient)."""
+    if st.bn and sync is not None:
+        glob = _ops.zeros_f32((2, st.Cc), st.z.device)
+        sync.all_reduce(st.local, glob)
+        st.d.sum_gx, st.d.sum_g = glob[0].data_ptr(), glob[1].data_ptr()
+        st.keep += (glob,)
+
+
+def bn_act_bwd_apply(st):
+    """-> (dz, dres, dgamma, dbeta, dslope); a gradient that went into its sink is returned as None."""
+    z, d = st.z, st.d
+    _run(st.lib, 'ledn_bn_act_bwd_apply', z, d, work=_ops._TIMING is not None and (
+        f'bnbwd_apply C{st.Cc} P{st.P}', _nb(z, st.keep[0], st.keep[1], st.dz, st.dres), 8 * z.numel()))
+    give = st.bn and not st.sunk
+    if give and st.keep[9] is not None and st.keep[10] is not None:
+        st.keep[9].add_(st.local[0])       # sinks exist but were not adjacent (see reduce): add the local sums
+        st.keep[10].add_(st.local[1])
+        give = False
+    return (st.dz, st.dres, (st.local[0] if give else None), (st.local[1] if give else None),
+            None if st.slope_sunk else st.dslope)
+
+
+def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
+               res=None, res_mode=RES_NONE, count=None, want_dres=False, sync=None, sinks=None):
+    """Backward of y = act(res_mode(z*scale+shift, res)).
+    BN mode (mean/invstd given): returns (dz, dres, dgamma, dbeta, dslope).
+    Plain mode: returns (dz, dres, None, None, dslope).
+    sync: optional collective object (train._Collective) all-reducing the [2,C] (sum_gx, sum_g) sums (SyncBN);
+    the returned / sunk dgamma, dbeta are always the LOCAL sums (DDP semantics).
+    sinks: optional (dgamma, dbeta, dslope) ZEROED f32 [C] buffers (any may be None) the kernels
+    reduce straight into (the trainer's gradient views); the matching return value is then None."""
+    st = bn_act_bwd_reduce(z, dy, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, slope=slope,
+                           res=res, res_mode=res_mode, count=count, want_dres=want_dres, sinks=sinks,
+                           sync=sync is not None)
+    bn_act_bwd_sync(st, sync)
+    return bn_act_bwd_apply(st)
 
 
 def _dw_desc(x_shape, dz, w_khwc, stride, pad, dil, group_size, ext1, dtype):

@@ -10,6 +10,7 @@ implicit there and explicit here (RCCL via
 torch.distributed on the [2,C] statistic buffers and the flat gradient buffer).
 """
 import math
+import os as _os
 
 import torch
 import torch.nn as nn
@@ -23,8 +24,40 @@ BN_MOMENTUM = 0.1
 
 class _Env:
     """Process-wide training environment (SyncBN collective, world size)."""
-    sync_bn = None      # callable(tensor[2,C]) all-reducing in place, or None
+    sync_bn = None      # _Collective (all_reduce(src, dst), group(ref)) or None
     world = 1
+    grad_ready = None   # callable(tag) fired from the backward by GradReadyFn, or None
+
+
+class _Collective:
+    """Sum all-reduce of small f32 buffers across the data-parallel ranks, on the CURRENT launch stream.
+    commset: rccl.CommSet (one communicator per launch stream: plain stream operations, capturable in the
+    step's hipGraph); else torch.distributed (`dist`: RCCL through ProcessGroupNCCL on the GPU, gloo in the
+    CPU tests)."""
+
+    def __init__(self, commset=None, dist=None):
+        assert (commset is None) != (dist is None)
+        self.commset, self.dist = commset, dist
+
+    def _comm(self, ref, slot=None):
+        return self.commset.get(ops._slot(ref) if slot is None else slot)
+
+    def all_reduce(self, src, dst, slot=None):
+        """dst = sum over ranks of src (dst may be src)."""
+        if self.commset is not None:
+            return self._comm(src, slot).all_reduce(src, dst)
+        if dst is not src:
+            dst.copy_(src)
+        self.dist.all_reduce(dst)
+        return dst
+
+    def group(self, ref, slot=None):
+        """context manager: the all-reduces inside are ONE launch (ncclGroupStart/End); BatchNorms whose
+        statistics are ready together (MFAF's five context BNs) share it."""
+        if self.commset is not None:
+            return self._comm(ref, slot).group()
+        import contextlib
+        return contextlib.nullcontext()
 
 
 def _c(t):
@@ -97,12 +130,12 @@ class ConvFn(Function):
         x, w, xadd = ctx.saved_tensors
         stride, pad, groups, has_b = ctx.cfg
         dz = _c(dz)
+        sw, sb = ctx.sinks
+        dw, db = _conv_wgrad(x, dz, tuple(w.shape), sw, sb, stride=stride, pad=pad, groups=groups, xadd=xadd,
+                             bias=has_b)
         dx = None
         if ctx.needs_input_grad[0] or (xadd is not None and ctx.needs_input_grad[3]):
             dx = _conv_dgrad(dz, x, w, stride, pad, groups)
-        sw, sb = ctx.sinks
-        dw, db = ops.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, pad=pad, groups=groups, xadd=xadd,
-                                  bias=has_b, dw_out=sw, db_out=sb)
         return (dx if ctx.needs_input_grad[0] else None, None if sw is not None else dw,
                 None if sb is not None else db,
                 dx if (xadd is not None and ctx.needs_input_grad[3]) else None, None, None, None, None, None, None)
@@ -120,7 +153,7 @@ class BNActFn(Function):
             stats = ops.zeros_f32((2, Cc), z.device)
             ops.channel_stats(z, stats=(stats[0], stats[1]), defer_stats=_Env.sync_bn is None)
         if _Env.sync_bn is not None:
-            _Env.sync_bn(stats)
+            _Env.sync_bn.all_reduce(stats, stats)
             count *= _Env.world
         scale, shift, mean, invstd = ops.bn_finalize((stats[0], stats[1]), count, gamma, beta,
                                                      bn.running_mean, bn.running_var, BN_MOMENTUM, bn.eps)
@@ -140,6 +173,27 @@ class BNActFn(Function):
             res_mode=res_mode, count=count, want_dres=res is not None and ctx.needs_input_grad[4],
             sync=_Env.sync_bn, sinks=ctx.sinks)
         return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None
+
+
+WGRAD_SLOT = int(_os.environ.get('LEDN_WGRAD_SLOT', '7'))   # auxiliary stream of the weight gradients, 0 = launch stream
+
+
+def _conv_wgrad(x, dz, w_shape, sw, sb, **kw):
+    """Weight (+bias) gradient of a convolution.  With gradient sinks it has no consumer inside the step
+    (it reduces into the flat gradient buffer, read by the exchange / SGD only): it runs on its own HIP
+    stream, concurrently with the data-gradient -> BatchNorm-backward chain that IS the critical path."""
+    if (WGRAD_SLOT and ops.MULTI_STREAM and dz.is_cuda and sw is not None
+            and (sb is not None or not kw.get('bias'))):
+        cur = torch.cuda.current_stream(dz.device)
+        side = ops._aux_stream(dz.device, WGRAD_SLOT)
+        side.wait_stream(cur)
+        for t in (x, dz, *kw.values()):
+            if isinstance(t, torch.Tensor):
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            ops.conv2d_wgrad(x, dz, w_shape, dw_out=sw, db_out=sb, **kw)
+        return None, None
+    return ops.conv2d_wgrad(x, dz, w_shape, dw_out=sw, db_out=sb, **kw)
 
 
 def _conv_dgrad(dz, x, w, stride, pad, groups):
@@ -168,7 +222,7 @@ class BNActConvFn(Function):
             stats_in = ops.zeros_f32((2, Cc), x.device)
             ops.channel_stats(x, stats=(stats_in[0], stats_in[1]), defer_stats=_Env.sync_bn is None)
         if _Env.sync_bn is not None:
-            _Env.sync_bn(stats_in)
+            _Env.sync_bn.all_reduce(stats_in, stats_in)
             count *= _Env.world
         scale, shift, mean, invstd = ops.bn_finalize((stats_in[0], stats_in[1]), count, gamma, beta,
                                                      bn.running_mean, bn.running_var, BN_MOMENTUM, bn.eps)
@@ -190,9 +244,9 @@ class BNActConvFn(Function):
         act, count, stride, pad, groups, has_b = ctx.cfg
         sg, sb_, ss, sw, sbias = ctx.sinks
         dz = _c(dz)
+        dw, db = _conv_wgrad(x, dz, tuple(w.shape), sw, sbias, stride=stride, pad=pad, groups=groups, in_scale=scale,
+                             in_shift=shift, in_act=act, in_slope=slope, bias=has_b)
         dy = _conv_dgrad(dz, x, w, stride, pad, groups)
-        dw, db = ops.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, pad=pad, groups=groups, in_scale=scale,
-                                  in_shift=shift, in_act=act, in_slope=slope, bias=has_b, dw_out=sw, db_out=sbias)
         dx, _, dgamma, dbeta, dslope = T.bn_act_bwd(x, dy, scale=scale, shift=shift, mean=mean, invstd=invstd,
                                                      act=act, slope=slope, count=count, sync=_Env.sync_bn,
                                                      sinks=(sg, sb_, ss))
@@ -200,7 +254,6 @@ class BNActConvFn(Function):
                 None, None, None, None, None, None, None, None)
 
 
-import os as _os
 # BNActConvFn where a BatchNorm(+act) output feeds exactly one convolution: 0 = off, 1 = the norm->act->conv
 # modules of LEDHead only, 2 = also BasicBlock conv1->conv2 and the SESP expansion (LEDN_FUSE_BN_CONV)
 FUSE_BN_INTO_CONV = int(_os.environ.get('LEDN_FUSE_BN_CONV', '1'))   # measured: 0, 1, 2 within 0.3 % of each other (r01q)
@@ -358,6 +411,75 @@ class GetbPoolFn(Function):
         return T.getb_pool_bwd(dout, ctx.ws), dout, None
 
 
+def _bn_stats_group(raws, bns, gammas, betas, given=None):
+    """Batch statistics of several BatchNorms whose inputs are all available: the channel sums of each
+    (given[k]: already accumulated by the producer's epilogue), ONE grouped SyncBN all-reduce for all of
+    them (when data-parallel), then the finalizes.  -> ([(scale, shift, mean, invstd)], [count])"""
+    sync = _Env.sync_bn
+    stats, counts = [], []
+    for k, raw in enumerate(raws):
+        Cc = raw.shape[-1]
+        st = given[k] if given is not None else None
+        if st is None:
+            st = ops.zeros_f32((2, Cc), raw.device)
+            # (deferred rows need the finalize as the very next ledn call: only without the collective, one by one)
+            ops.channel_stats(raw, stats=(st[0], st[1]), defer_stats=False)
+        stats.append(st)
+        counts.append(raw.numel() // Cc * (_Env.world if sync is not None else 1))
+    if sync is not None:
+        with sync.group(raws[0]):
+            for st in stats:
+                sync.all_reduce(st, st)
+    fin = [ops.bn_finalize((st[0], st[1]), counts[k], gammas[k], betas[k], bns[k].running_mean,
+                           bns[k].running_var, BN_MOMENTUM, bns[k].eps) for k, st in enumerate(stats)]
+    return fin, counts
+
+
+def _bn_bwd_group(items):
+    """items: list of kwargs of T.bn_act_bwd_reduce (each with 'z', 'dy').  All reduces, ONE grouped SyncBN
+    all-reduce, all applies.  -> list of (dz, dres, dgamma, dbeta, dslope)."""
+    sync = _Env.sync_bn
+    sts = [T.bn_act_bwd_reduce(it.pop('z'), it.pop('dy'), sync=sync is not None, **it) for it in items]
+    if sync is not None:
+        with sync.group(sts[0].z):
+            for st in sts:
+                T.bn_act_bwd_sync(st, sync)
+    return [T.bn_act_bwd_apply(st) for st in sts]
+
+
+class MultiBNActFn(Function):
+    """n independent y_k = act(BN_train(z_k)) whose inputs are all available (MFAF's five first-level
+    context MLPs): one grouped SyncBN all-reduce per direction instead of n.  Used on the data-parallel
+    path only; numerically the same as n BNActFn."""
+
+    @staticmethod
+    def forward(ctx, n, bns, act, given, *args):
+        zs, gb = args[:n], args[n:]
+        gammas, betas = gb[0::2], gb[1::2]
+        fin, counts = _bn_stats_group(zs, bns, gammas, betas, given)
+        ys, saved = [], []
+        for k, z in enumerate(zs):
+            scale, shift, mean, invstd = fin[k]
+            ys.append(ops.affine_act(z, scale, shift, act=act))
+            saved += [z, scale, shift, mean, invstd]
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (n, act, counts)
+        ctx.sinks = [(_Sinks.get(gammas[k]), _Sinks.get(betas[k]), None) for k in range(n)]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n, act, counts = ctx.cfg
+        sv = ctx.saved_tensors
+        items = [dict(z=sv[5 * k], dy=_c(dys[k]), scale=sv[5 * k + 1], shift=sv[5 * k + 2], mean=sv[5 * k + 3],
+                      invstd=sv[5 * k + 4], act=act, count=counts[k], sinks=ctx.sinks[k]) for k in range(n)]
+        outs = _bn_bwd_group(items)
+        dgb = []
+        for o in outs:
+            dgb += [o[2], o[3]]
+        return (None, None, None, None, *[o[0] for o in outs], *dgb)
+
+
 class MfafTailFn(Function):
     """The five trailing BatchNorms (batch statistics) + sigmoid gate + blend of
     Muti_AFF (classification/model_utils.py:377-400,425-428) in one kernel."""
@@ -365,21 +487,23 @@ class MfafTailFn(Function):
     @staticmethod
     def forward(ctx, x, r, xl, c1, c2, c3, xg, bns, out_relu, *gb):
         raws = [xl, c1, c2, c3, xg]
-        affs, saved, counts = [], [], []
-        for k, raw in enumerate(raws):
-            Cc = raw.shape[-1]
-            count = raw.numel() // Cc
-            stats = ops.zeros_f32((2, Cc), raw.device)
-            ops.channel_stats(raw, stats=(stats[0], stats[1]), defer_stats=_Env.sync_bn is None)
-            if _Env.sync_bn is not None:
-                _Env.sync_bn(stats)
-                count *= _Env.world
-            bn = bns[k]
-            scale, shift, mean, invstd = ops.bn_finalize((stats[0], stats[1]), count, gb[2 * k], gb[2 * k + 1],
-                                                         bn.running_mean, bn.running_var, BN_MOMENTUM, bn.eps)
+        affs, saved = [], []
+        if _Env.sync_bn is not None:
+            fin, counts = _bn_stats_group(raws, bns, gb[0::2], gb[1::2])
+        else:
+            fin, counts = [], []
+            for k, raw in enumerate(raws):
+                Cc = raw.shape[-1]
+                count = raw.numel() // Cc
+                stats = ops.zeros_f32((2, Cc), raw.device)
+                ops.channel_stats(raw, stats=(stats[0], stats[1]), defer_stats=True)
+                bn = bns[k]
+                fin.append(ops.bn_finalize((stats[0], stats[1]), count, gb[2 * k], gb[2 * k + 1],
+                                           bn.running_mean, bn.running_var, BN_MOMENTUM, bn.eps))
+                counts.append(count)
+        for scale, shift, mean, invstd in fin:
             affs.append((scale, shift))
             saved += [scale, shift, mean, invstd]
-            counts.append(count)
         act = ACT_RELU if out_relu else ACT_NONE
         out = ops.mfaf_gate(x, r, xl, [c1, c2, c3, xg], affs, act=act)
         ctx.save_for_backward(x, r, xl, c1, c2, c3, xg, *saved)
@@ -395,14 +519,34 @@ class MfafTailFn(Function):
         affs = [(sv[4 * k], sv[4 * k + 1]) for k in range(5)]
         dx, dr, ds, dctx = T.mfaf_gate_bwd(x, r, xl, [c1, c2, c3, xg], affs, _c(dout), act=ctx.act)
         gys = [ds] + dctx
+        outs = _bn_bwd_group([dict(z=raws[k], dy=gys[k], scale=sv[4 * k], shift=sv[4 * k + 1], mean=sv[4 * k + 2],
+                                   invstd=sv[4 * k + 3], count=ctx.counts[k], sinks=ctx.sinks[k]) for k in range(5)])
         draws, dgb = [], []
-        for k in range(5):
-            dz, _, dgamma, dbeta, _ = T.bn_act_bwd(raws[k], gys[k], scale=sv[4 * k], shift=sv[4 * k + 1],
-                                                    mean=sv[4 * k + 2], invstd=sv[4 * k + 3],
-                                                    count=ctx.counts[k], sync=_Env.sync_bn, sinks=ctx.sinks[k])
-            draws.append(dz)
-            dgb += [dgamma, dbeta]
+        for o in outs:
+            draws.append(o[0])
+            dgb += [o[2], o[3]]
         return (dx, dr, *draws, None, None, *dgb)
+
+
+class GradReadyFn(Function):
+    """Identity.  Its backward runs when every consumer of `x` has delivered its gradient, i.e. when all
+    backward kernels downstream of this point have been issued: the Trainer starts the gradient all-reduce
+    of the parameters behind it (`tag`) there, overlapped with the rest of the backward."""
+
+    @staticmethod
+    def forward(ctx, x, tag):
+        ctx.tag = tag
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if _Env.grad_ready is not None:
+            _Env.grad_ready(ctx.tag)
+        return dy, None
+
+
+def grad_ready(x, tag):
+    return GradReadyFn.apply(x, tag) if (_Env.grad_ready is not None and x.requires_grad) else x
 
 
 class OhemFn(Function):
@@ -543,21 +687,37 @@ def mfaf(m, x, r, out_relu=False):
         c1 = seq[off + 3]
         return ConvFn.apply(mid, c1.weight, c1.bias, None, 1, 0, 1, None, out_dtype), seq[off + 4]
     pooled = MultiPoolFn.apply(xa)
-    # the four pooled-context MLPs are chains of tiny launch-bound kernels, independent of each other and of
-    # the local branch: each runs on its own auxiliary stream while the local branch (full-resolution convs)
-    # runs on the main one (forward here, backward through autograd's stream affinity)
-    forks, ctx, bns_ctx = [], [], []
-    for idx, ((name, _), pz) in enumerate(zip(m.POOLS, pooled)):
-        f = ops.Fork(pz, 3 + idx if MFAF_FORK else 0)
-        with f:
-            c, bn = mlp(getattr(m, name), 1, pz)
-        forks.append((f, c))
-        ctx.append(c)
-        bns_ctx.append(bn)
-    xl, bn_l = mlp(m.local_att, 0, xa)
-    for f, c in forks:
-        f.join(c)
-    raws, bns = [xl] + ctx, [bn_l] + bns_ctx
+    if _Env.sync_bn is not None:
+        # data-parallel: the five first-level BatchNorms (local + four pooled contexts) see their inputs
+        # together -> one grouped SyncBN all-reduce per direction instead of five
+        seqs = [(m.local_att, 0, xa)] + [(getattr(m, name), 1, pz) for (name, _), pz in zip(m.POOLS, pooled)]
+        sts = [_stats(seq[off].out_channels, xa) for seq, off, _ in seqs]
+        zs = [ConvFn.apply(inp, seq[off].weight, seq[off].bias, None, seq[off].stride[0], seq[off].padding[0],
+                           seq[off].groups, st, None, False) for (seq, off, inp), st in zip(seqs, sts)]
+        bns1 = [seq[off + 1] for seq, off, _ in seqs]
+        gb1 = []
+        for bn in bns1:
+            gb1 += [bn.weight, bn.bias]
+        mids = MultiBNActFn.apply(5, bns1, ACT_RELU, sts, *zs, *gb1)
+        raws = [ConvFn.apply(mid, seq[off + 3].weight, seq[off + 3].bias, None, 1, 0, 1, None, None)
+                for mid, (seq, off, _) in zip(mids, seqs)]
+        bns = [seq[off + 4] for seq, off, _ in seqs]
+    else:
+        # the four pooled-context MLPs are chains of tiny launch-bound kernels, independent of each other and of
+        # the local branch: each runs on its own auxiliary stream while the local branch (full-resolution convs)
+        # runs on the main one (forward here, backward through autograd's stream affinity)
+        forks, ctx, bns_ctx = [], [], []
+        for idx, ((name, _), pz) in enumerate(zip(m.POOLS, pooled)):
+            f = ops.Fork(pz, 3 + idx if MFAF_FORK else 0)
+            with f:
+                c, bn = mlp(getattr(m, name), 1, pz)
+            forks.append((f, c))
+            ctx.append(c)
+            bns_ctx.append(bn)
+        xl, bn_l = mlp(m.local_att, 0, xa)
+        for f, c in forks:
+            f.join(c)
+        raws, bns = [xl] + ctx, [bn_l] + bns_ctx
     gb = []
     for bn in bns:
         gb += [bn.weight, bn.bias]
@@ -583,6 +743,7 @@ def lednet_forward_train(m, x, pre=None):
     x2 = conv_module(m.stem['1'], x1)
     y = basic_block(m.stem['2'][1], basic_block(m.stem['2'][0], x2), final_relu=True)
     y = basic_block(m.stem['4'][1], basic_block(m.stem['4'][0], y), final_relu=True)
+    y = grad_ready(y, 'post_stem')     # backward: every parameter gradient outside the stem is complete here
     # context branch and SEAM edge map on auxiliary streams between the fusion points (ops.Fork);
     # autograd runs each backward kernel on the stream of its forward
     with ops.Fork(y, SEAM_SLOT) as fe, torch.no_grad():
@@ -630,6 +791,7 @@ def _base_head(seq, x, out_dtype=None):
 def led_head_forward_train(h, inputs):
     from .lednet import to_nhwc
     c3, c5, x1, x2 = (to_nhwc(t) for t in inputs)
+    x1, x2 = grad_ready(x1, 'post_stem'), grad_ready(x2, 'post_stem')    # (the heads' share of that barrier)
     f32 = torch.float32
     xc = _base_head(h.head, c5)
     xc = ConvFn.apply(xc, h.conv_seg.weight, h.conv_seg.bias, None, 1, 0, 1, None, f32)
@@ -691,9 +853,16 @@ class Trainer:
         self.power, self.eta_min = sched.get('power', power), sched.get('eta_min', eta_min)
         self.iter = 0
         self.world = world_size
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        # gradient layout: [stem | everything else], each in module order.  The stem's backward comes LAST (and is
+        # the long high-resolution part): when it starts, every other parameter gradient is complete
+        # (GradReadyFn 'post_stem') and that tail of the buffer is all-reduced while the stem's backward runs.
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        late = [p for n, p in named if n.startswith('backbone.stem.')]
+        early = [p for n, p in named if not n.startswith('backbone.stem.')]
+        self.params = late + early
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
+        self.n_late = sum(p.numel() for p in late)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_mom = torch.zeros(n, dtype=torch.float32, device=dev)
         self.views, self.moms, off = [], [], 0
@@ -711,11 +880,10 @@ class Trainer:
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         sync = getattr(model.backbone, 'sync_bn', False) or getattr(model.decode_head, 'sync_bn', False)
         _Env.world = world_size
-        # collectives: 'rccl' = ncclAllReduce on the launch stream (rccl.Comm: capturable in the step's
+        # collectives: 'rccl' = ncclAllReduce on the launch streams (rccl.CommSet: capturable in the step's
         # hipGraph), 'torch' = torch.distributed (eager only), default 'auto' = rccl on the GPU when it
         # initialises, else torch.  'rccl' with world_size 1 is the single-GPU self-test of that path.
-        import os
-        mode = collectives or os.environ.get('LEDN_COLLECTIVES', 'auto')
+        mode = collectives or _os.environ.get('LEDN_COLLECTIVES', 'auto')
         self.comm = None
         self.dist = None
         if world_size > 1:
@@ -729,7 +897,10 @@ class Trainer:
         if mode in ('auto', 'rccl') and dev.type == 'cuda' and (world_size > 1 or mode == 'rccl'):
             try:
                 from . import rccl
-                self.comm = rccl.Comm(self.dist.get_rank() if self.dist is not None else 0, world_size, dev)
+                slots = sorted({0} | ({1} if CTX_FORKS else set()) | ({SEAM_SLOT} if SEAM_SLOT else set())
+                               | (set(range(3, 7)) if MFAF_FORK else set()))
+                self.comm = rccl.CommSet(self.dist.get_rank() if self.dist is not None else 0, world_size, dev,
+                                         slots=tuple(slots) + ('grad',))
             except Exception as e:   # noqa: BLE001 -- 'auto': fall back to torch.distributed
                 if mode == 'rccl':
                     raise
@@ -737,12 +908,20 @@ class Trainer:
                 print(f'[led_net_amd] direct RCCL unavailable ({e!r}); collectives through torch.distributed',
                       file=sys.stderr)
         if self.comm is not None:
-            self._all_reduce = self.comm.all_reduce_
+            self.coll = _Collective(commset=self.comm)
         elif self.dist is not None:
-            self._all_reduce = lambda t: self.dist.all_reduce(t)
+            self.coll = _Collective(dist=self.dist)
         else:
-            self._all_reduce = None
-        _Env.sync_bn = self._all_reduce if (sync and self._all_reduce is not None) else None
+            self.coll = None
+        self._sync_bn = self.coll if sync else None
+        self._gstream = torch.cuda.Stream(device=dev) if (self.coll is not None and dev.type == 'cuda') else None
+        self._ready = {}
+        self._early_done = False
+        self.overlap_exchange = bool(int(_os.environ.get('LEDN_OVERLAP_EXCHANGE', '1')))
+
+    @property
+    def _all_reduce(self):      # (bench.py / older callers: "does this trainer exchange gradients")
+        return self.coll
 
     def lr(self):
         """mmengine PolyLR (by iteration): (base-eta_min)*(1-it/max)^power + eta_min."""
@@ -753,39 +932,88 @@ class Trainer:
         for p, v in zip(self.live, self.live_views):
             p.grad = v
 
+    def _enter(self):
+        ops.PendingRows.entry = None
+        self._arena.reset()                  # one fill for every small zeroed scratch of the step
+        ops.set_zero_arena(self._arena)
+        _Sinks.map = self._sink_map
+        _Env.world = self.world
+        _Env.sync_bn = self._sync_bn
+        self._ready, self._early_done = {}, False
+        # the early exchange needs the gradients to land in the flat buffer DURING the backward (sinks)
+        _Env.grad_ready = self._on_grad_ready if (self.coll is not None and self.overlap_exchange
+                                                  and self._sink_map) else None
+
+    def _leave(self):
+        ops.set_zero_arena(None)
+        _Sinks.map = {}
+        _Env.sync_bn = None
+        _Env.grad_ready = None
+
     def train_step(self, inputs, data_samples):
         """forward + loss + backward + gradient all-reduce + SGD; returns the loss dict
         (device scalars; no host synchronisation)."""
         self.model.train()
         first = self.table is None
-        ops.PendingRows.entry = None
-        self._arena.reset()                  # one fill for every small zeroed scratch of the step
-        ops.set_zero_arena(self._arena)
-        _Sinks.map = self._sink_map
-        multi = ops.MULTI_STREAM
-        if self._all_reduce is not None:
-            ops.MULTI_STREAM = False         # collectives of all ranks stay ordered on ONE stream
+        self._enter()
         try:
             return self._train_step(inputs, data_samples, first)
         finally:
-            ops.MULTI_STREAM = multi
-            ops.set_zero_arena(None)
-            _Sinks.map = {}
+            self._leave()
 
     def forward_backward(self, inputs, data_samples):
         """forward + loss + backward only (gradients left in ``flat_grad``; no exchange, no SGD):
         the first half of train_step, for tests and gradient inspection.  Needs one completed
-        train_step (the flat gradient views are attached there)."""
+        train_step (the flat gradient views are attached there).  The gradient buffer is cleared first: the
+        BatchNorm backward reduces its sums INTO the gradient views and reads them back (ops_train.bn_act_bwd),
+        which is only right from zero (train_step gets that from the SGD kernel's re-zeroing)."""
         assert self.table is not None, 'run one train_step first'
         self.model.train()
-        self._arena.reset()
-        ops.set_zero_arena(self._arena)
-        _Sinks.map = self._sink_map
+        self.flat_grad.zero_()
+        self._enter()
+        _Env.grad_ready = None
         try:
             return self._forward_backward(inputs, data_samples, False)
         finally:
-            ops.set_zero_arena(None)
-            _Sinks.map = {}
+            self._leave()
+
+    def _join_side_streams(self):
+        """the launch stream waits for the auxiliary streams that have no consumer inside the step
+        (weight gradients)"""
+        dev = self.flat_grad.device
+        if dev.type == 'cuda' and WGRAD_SLOT:
+            st = ops._AUX.get((dev, WGRAD_SLOT))
+            if st is not None:
+                torch.cuda.current_stream(dev).wait_stream(st)
+
+    def _exchange(self, lo, hi):
+        """all-reduce flat_grad[lo:hi] in buckets on the gradient-exchange stream, after everything queued so
+        far on the launch streams"""
+        if hi <= lo:
+            return
+        dev = self.flat_grad.device
+        if self._gstream is not None:
+            self._gstream.wait_stream(torch.cuda.current_stream(dev))
+            for (d, _slot), st in ops._AUX.items():
+                if d == dev:
+                    self._gstream.wait_stream(st)
+            ctx = torch.cuda.stream(self._gstream)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            for off in range(lo, hi, self.bucket_elems):
+                t = self.flat_grad[off:min(hi, off + self.bucket_elems)]
+                self.coll.all_reduce(t, t, slot='grad')
+
+    def _on_grad_ready(self, tag):
+        """GradReadyFn callback (host side, inside the backward): 'post_stem' fires three times (the stem's
+        output and the two stem tensors the heads read); the third starts the exchange of every
+        non-stem gradient."""
+        self._ready[tag] = self._ready.get(tag, 0) + 1
+        if tag == 'post_stem' and self._ready[tag] == 3 and not self._early_done:
+            self._early_done = True
+            self._exchange(self.n_late, self.flat_grad.numel())
 
     def _forward_backward(self, inputs, data_samples, first):
         if first:
@@ -802,6 +1030,7 @@ class Trainer:
             if 'loss' in k:
                 total = v if total is None else total + v
         total.backward()
+        self._join_side_streams()
         if first:
             # Parameters that never receive a gradient (SEAM conv_1: the binarised edge
             # map is non-differentiable) are skipped, as torch.optim.SGD skips grad=None.
@@ -821,10 +1050,13 @@ class Trainer:
 
     def _train_step(self, inputs, data_samples, first):
         losses = self._forward_backward(inputs, data_samples, first)
-        if self._all_reduce is not None:
-            n = self.flat_grad.numel()
-            for off in range(0, n, self.bucket_elems):
-                self._all_reduce(self.flat_grad[off:off + self.bucket_elems])
+        if self.coll is not None:
+            # what the backward did not already start: the stem's gradients (or everything)
+            self._exchange(0, self.n_late if self._early_done else self.flat_grad.numel())
+            if self._gstream is not None:
+                torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._gstream)
+        if self._lr_dev is not None and not torch.cuda.is_current_stream_capturing():
+            self._lr_dev.fill_(self.lr())       # eager step after a capture(): keep the device-resident rate current
         self.table.step(self.lr(), self.momentum, self.wd, 1.0 / self.world, lr_dev=self._lr_dev)
         self.iter += 1
         # detached: a caller holding the returned losses would otherwise keep the step's autograd graph
@@ -838,6 +1070,10 @@ class Trainer:
     # device-resident learning rate.  With N > 1 ranks the collectives must be stream operations
     # (rccl.Comm): torch.distributed's cannot be captured.
     def capture(self, inputs, data_samples, warmup=3):
+        """Capture one whole step on (inputs, data_samples).  The `warmup` eager steps before the capture are
+        REAL optimizer steps on that batch (allocator / workspace / sink warm-up needs them); self.iter counts
+        them.  Afterwards: replay(), or train_step() (eager) -- both keep the device-resident learning rate
+        current."""
         assert self.dist is None or self.comm is not None, 'graph capture with N > 1 needs the direct RCCL communicator'
         dev = inputs.device
         self._static_in = inputs.clone()
@@ -856,10 +1092,10 @@ class Trainer:
         self._graph = torch.cuda.CUDAGraph()
         # N > 1: other threads of the process (ProcessGroupNCCL's watchdog) keep calling the runtime while this
         # thread captures; 'thread_local' confines the capture-safety checks to the capturing thread
-        import os
-        mode = os.environ.get('LEDN_CAPTURE_MODE') or ('thread_local' if self.dist is not None else 'global')
+        mode = _os.environ.get('LEDN_CAPTURE_MODE') or ('thread_local' if self.dist is not None else 'global')
         with torch.cuda.graph(self._graph, capture_error_mode=mode):
             self._static_out = self.train_step(self._static_in, self._static_samples)
+        self.iter -= 1          # capturing records the step, it does not execute it (PolyLR stays in step)
         return self
 
     def replay(self, inputs=None, data_samples=None):

@@ -62,6 +62,109 @@ def test_ddp_world2_gloo(tmp_path):
     assert x.shape[0] == 4
 
 
+def _cmp_cfg():
+    import led_net_amd as L
+    cfg = L.load_config(os.path.join(ROOT, 'tests', 'data', 'lednet_test_config.py'))
+    for c in cfg['model']['decode_head']['loss_decode']:
+        # every valid pixel selected (p < thres always): the per-rank OHEM means then average to the mean over
+        # the concatenated batch (equal pixel counts per rank), so DDP's gradient mean IS the big-batch gradient
+        c['thres'], c['min_kept'] = 1.5, 1
+    return cfg
+
+
+def _cmp_batch():
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (4, 3, 320, 320), dtype=torch.uint8, generator=g)
+    lab = torch.randint(0, 2, (4, 1, 320, 320), dtype=torch.int64, generator=g)
+    return img, lab
+
+
+def _two_steps(tr, img, samples):
+    """step 1 with learning rate 0 (gradients through autograd's AccumulateGrad; parameters stay identical, the
+    momentum buffer takes the gradient), step 2 with the real rate: gradient sinks, grouped SyncBN collectives
+    and the exchange started from inside the backward -- from IDENTICAL parameters, so the comparison is not
+    swamped by the divergence of an earlier step."""
+    lr = tr.base_lr
+    tr.base_lr = 0.0
+    tr.train_step(img, samples)
+    tr.base_lr = lr
+    tr.train_step(img, samples)
+
+
+def _cmp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import led_net_amd as L
+    from conftest import bind_emu
+    cfg = _cmp_cfg()
+    img, lab = _cmp_batch()
+    per = img.shape[0] // world
+    img, lab = img[rank * per:(rank + 1) * per], lab[rank * per:(rank + 1) * per]
+    with bind_emu():
+        model = L.MODELS.build(cfg['model'])
+        model.load_state_dict(torch.load(os.path.join(out_dir, 'init.pt')))
+        tr = L.Trainer(model, cfg, world_size=world)
+        _two_steps(tr, img, [L.SegDataSample(gt=lab[i]) for i in range(per)])
+        assert tr._early_done, 'the non-stem gradients were not exchanged from inside the backward'
+    if rank == 0:
+        torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, 'world2.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+def test_ddp_world2_equals_world1_on_concatenated_batch(tmp_path):
+    """SyncBN + DDP semantics, end to end: two ranks with two images each must make the same SGD step as ONE
+    process on the four images (BatchNorm statistics over the global batch; BatchNorm gamma/beta gradients =
+    LOCAL sums averaged by the exchange -- not the all-reduced sums, which would train every BatchNorm affine
+    parameter at world x the learning rate; the non-stem gradients exchanged from inside the backward).
+
+    Tolerance: this random-init network on noise images is chaotic in f32 (ReLU / SEAM-percentile / 4-sample
+    BatchNorm flips): the SAME single-process step with the batch merely permuted differs by median 0.8 %,
+    worst 1.5 % of the update norm (measured).  A wrong 1/world or a doubled SyncBN sum is a factor 2."""
+    sys.path.insert(0, ROOT)
+    import led_net_amd as L
+    from conftest import bind_emu
+    cfg = _cmp_cfg()
+    torch.manual_seed(100)
+    img, lab = _cmp_batch()
+    with bind_emu():
+        model = L.MODELS.build(cfg['model'])
+        init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        torch.save(init, tmp_path / 'init.pt')
+        port = 31500 + (os.getpid() % 2000)
+        ctx = mp.spawn(_cmp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=False)
+        tr = L.Trainer(model, cfg, world_size=1)       # meanwhile: the single-process reference
+        _two_steps(tr, img, [L.SegDataSample(gt=lab[i]) for i in range(4)])
+    while not ctx.join():
+        pass
+    one = model.state_dict()
+    two = torch.load(tmp_path / 'world2.pt')
+    rels, ratios = [], {'bn': [], 'other': []}
+    for k, v in one.items():
+        if not v.is_floating_point():
+            continue
+        if 'running_mean' in k:
+            assert (two[k] - v).norm().item() <= 2e-2 * v.norm().item() + 1e-5, k     # global-batch statistics
+            continue
+        upd = (v - init[k]).norm().item()
+        if 'running_' in k or upd < 1e-6:     # (a bias in front of a BatchNorm has zero gradient: noise only)
+            continue
+        rels.append(((two[k] - v).norm().item() / upd, k))
+        bn = v.dim() == 1 and (k.endswith('.weight') or k.endswith('.bias')) and ('.bn.' in k or 'norm' in k or '_att.' in k
+                                                                                   or '.context' in k or '.proj.1.' in k)
+        ratios['bn' if bn else 'other'].append((two[k] - init[k]).norm().item() / upd)
+    rels.sort(reverse=True)
+    for kind, r in ratios.items():
+        r.sort()
+        assert len(r) > 50 and abs(r[len(r) // 2] - 1.0) < 2e-2, (kind, len(r), r[len(r) // 2])
+        assert 0.8 < r[0] and r[-1] < 1.25, (kind, r[0], r[-1])
+    assert rels[len(rels) // 2][0] < 3e-2 and rels[0][0] < 0.25, (rels[len(rels) // 2], rels[:5])
+
+
 @pytest.mark.gpu
 def test_rccl_in_graph_single_rank():
     """The N > 1 step keeps its collectives inside the hipGraph by issuing ncclAllReduce on the launch
@@ -88,6 +191,8 @@ def test_rccl_in_graph_single_rank():
         model = copy.deepcopy(base).to(dev)
         tr = L.Trainer(model, cfg, max_iters=100, collectives=mode)
         assert (tr.comm is not None) == (mode == 'rccl')
+        if mode == 'rccl':
+            assert tr.comm.nranks == 1 and set(tr.comm.comms) >= {0, 1, 'grad'}
         out = tr.train_step(img, samples)           # one eager step from identical weights
         torch.cuda.synchronize()
         res.append(({k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()},
