@@ -44,7 +44,9 @@ int ledn_set_workspace(void* ptr, long long nfloats);
  * the default.  Results never depend on them beyond f32 summation order. */
 enum {
     LEDN_OPT_CONV_WORKGROUPS = 0,   /* persistent workgroups of the MFMA conv (default 512) */
-    LEDN_OPT_WGRAD_WORKGROUPS = 1   /* pixel-range workgroups of the MFMA weight gradient (default 512) */
+    LEDN_OPT_WGRAD_WORKGROUPS = 1,  /* pixel-range workgroups of the MFMA weight gradient (default 512) */
+    LEDN_OPT_STREAM_FAST = 2        /* 1 (default): 16-B-per-lane streaming kernels (csrc/stream_fast.hip) for the bf16
+                                       elementwise / BatchNorm passes; 0: the generic kernels (A/B measurements) */
 };
 int ledn_set_option(int option, long long value);
 

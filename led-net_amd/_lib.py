@@ -17,6 +17,7 @@ OK, EINVAL, ELAUNCH = 0, 1, 2
 F32, BF16, U8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_GATE = 0, 1, 2
+OPT_CONV_WORKGROUPS, OPT_WGRAD_WORKGROUPS, OPT_STREAM_FAST = 0, 1, 2
 
 vp, fp, i32, i64 = C.c_void_p, C.c_void_p, C.c_int, C.c_longlong
 
@@ -224,6 +225,8 @@ def get_lib():
         return _override
     if _hip is None:
         _hip = Library(HIP_LIB_PATH, is_hip=True)
+        if os.environ.get('LEDN_STREAM_FAST') == '0':      # A/B measurements: the generic streaming kernels
+            _hip.set_option(OPT_STREAM_FAST, 0)
     return _hip
 
 

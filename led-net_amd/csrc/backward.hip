@@ -205,6 +205,10 @@ static long bn_rows(const ledn_bnbwd_desc& d) {
 int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
     const int rc = bnbwd_validate(d, false);
     if (rc != LEDN_OK) return rc;
+    if (options().stream_fast && d.act != LEDN_ACT_SIGMOID) {
+        const int rf = bn_act_bwd_reduce_fast(d, s);
+        if (rf >= 0) return rf;
+    }
     long nb = cdiv(d.P, bn_rows(d) * 8);
     float* part = nullptr;
     if (nb > 2048) nb = 2048;
@@ -219,6 +223,10 @@ int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
 int bn_act_bwd_apply_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
     const int rc = bnbwd_validate(d, true);
     if (rc != LEDN_OK) return rc;
+    if (options().stream_fast && d.act != LEDN_ACT_SIGMOID) {
+        const int rf = bn_act_bwd_apply_fast(d, s);
+        if (rf >= 0) return rf;
+    }
     long nb = cdiv(d.P, bn_rows(d) * 4);
     if (nb > 4096) nb = 4096;
     const dim3 grid((unsigned)nb);

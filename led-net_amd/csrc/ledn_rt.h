@@ -253,6 +253,7 @@ inline float* ws_take(long nfloats) {
 struct Options {
     int conv_workgroups;
     int wgrad_workgroups;
+    int stream_fast;
 };
 Options& options();
 // ledn_conv2d_deferred_stats: the MFMA conv leaves its per-workgroup statistic rows [rows][2][C] in the
@@ -266,6 +267,12 @@ DeferredStats& deferred_stats();
 // out_j[c] += sum_b part[b*K + j*C + c], j < nout (K = nout*C)
 int finish_partials(const float* part, int nblk, int C, int nout, float* o0, float* o1, float* o2,
                     hipStream_t s);
+// stream_fast.hip: -1 = not handled (the generic kernel takes the call)
+int affine_act_fast(const ledn_affine_desc& d, hipStream_t s);
+int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s);
+int bn_act_bwd_apply_fast(const ledn_bnbwd_desc& d, hipStream_t s);
+int channel_stats_fast(const void* x, const void* xadd, long long P, int C, int dtype, float* sum, float* sqsum,
+                       hipStream_t s);
 
 }  // namespace ledn
 

@@ -114,6 +114,10 @@ int finish_partials(const float* part, int nblk, int C, int nout, float* o0, flo
 int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
                        float* sqsum, hipStream_t s) {
     LEDN_REQUIRE(x && sum && P > 0 && C > 0);
+    if (options().stream_fast) {
+        const int rc = channel_stats_fast(x, xadd, P, C, dtype, sum, sqsum, s);
+        if (rc >= 0) return rc;
+    }
     // 8 B per lane (4 x bf16): measured faster than 16 B per lane here -- twice the threads in flight
     // beat the wider access on these 33..270 MB tensors (r01l: 16 B/lane cost +15..30 %)
     const int V = (C % 4 == 0) ? 4 : 1;
@@ -212,6 +216,10 @@ int affine_act_impl(const ledn_affine_desc& d, hipStream_t s) {
     LEDN_REQUIRE((d.scale == nullptr) == (d.shift == nullptr));
     LEDN_REQUIRE(d.res_mode == LEDN_RES_NONE || d.res != nullptr);
     LEDN_REQUIRE(d.act != LEDN_ACT_PRELU || d.slope != nullptr);
+    if (options().stream_fast && d.act != LEDN_ACT_SIGMOID) {
+        const int rc = affine_act_fast(d, s);
+        if (rc >= 0) return rc;
+    }
     const bool v4 = d.C % 4 == 0;
     const bool v8 = false;   // 16 B per lane measured slower than 8 B per lane (see channel_stats_impl)
     const int cvn = v8 ? d.C / 8 : (v4 ? d.C / 4 : d.C);

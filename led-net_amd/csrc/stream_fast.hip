@@ -1,0 +1,401 @@
+// stream_fast.hip -- the elementwise / per-channel-reduction passes of the train step at the streaming rate
+// of the chip: BatchNorm apply + residual + activation (affine_act), BatchNorm backward (reduce, apply),
+// channel statistics; bf16 activations, channel count a power of two in 8..512.
+//
+// Calibration (tools/micro/stream_cal.hip, MI355X): a plain copy-like kernel moves 33 MB in + 33 MB out in
+// 10 us and 2 x 33 MB in + 33 MB out in 15 us (6.5-7 TB/s: tensors of this size live in the 256 MB
+// Infinity Cache between producer and consumer), provided every lane issues 16-byte accesses and has ALL its
+// loads in flight before the first use.  The generic kernels in norm_act.hip / backward.hip (8 B per lane, one
+// dependent load -> compute -> store round trip per loop trip) ran the same shapes in 22 / 38 us.
+//
+// Shape of every kernel here: a workgroup of 256 lanes owns 256*UNR consecutive 8-channel vectors (16 B of
+// bf16); 256 is a multiple of C/8, so a lane keeps ONE channel group for all its vectors and the per-channel
+// coefficients sit in registers (staged through LDS once per workgroup); the UNR loads of each operand are
+// issued back to back, unconditionally (tail lanes re-read vector 0), then consumed.
+#include "ledn_rt.h"
+
+namespace ledn {
+
+constexpr int SF_MAXC = 512;
+
+__host__ __device__ inline bool sf_pow2(int c) { return c > 0 && (c & (c - 1)) == 0; }
+static inline bool sf_channels_ok(int C) { return sf_pow2(C) && C >= 8 && C <= SF_MAXC; }
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* o) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 ldraw(const void* base, long vec) {
+    return reinterpret_cast<const uint4*>(base)[vec];
+}
+
+// ===========================================================================
+// y = act(res_mode(x [+ xadd] * scale + shift, res))        (ledn_affine_act, all bf16)
+// ===========================================================================
+template <int ACT, int RES, bool HAS_XADD, int UNR>
+__global__ void __launch_bounds__(256) affine_fast_kernel(ledn_affine_desc d, long nvec) {
+    __shared__ float s_par[3][SF_MAXC];
+    for (int c = threadIdx.x; c < d.C; c += 256) {
+        s_par[0][c] = d.scale ? d.scale[c] : 1.f;
+        s_par[1][c] = d.shift ? d.shift[c] : 0.f;
+        s_par[2][c] = d.slope ? d.slope[c] : 0.f;
+    }
+    __syncthreads();
+    const int c0 = (int)(threadIdx.x % (unsigned)(d.C >> 3)) * 8;
+    float sc[8], sh[8], sl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = s_par[0][c0 + i];
+        sh[i] = s_par[1][c0 + i];
+        sl[i] = ACT == LEDN_ACT_PRELU ? s_par[2][c0 + i] : 0.f;
+    }
+    const long base = (long)blockIdx.x * (256 * UNR) + threadIdx.x;
+    uint4 xr[UNR], ar[UNR], rr[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const long i = base + u * 256;
+        const long j = i < nvec ? i : 0;
+        xr[u] = ldraw(d.x, j);
+        if (HAS_XADD) ar[u] = ldraw(d.xadd, j);
+        if (RES != LEDN_RES_NONE) rr[u] = ldraw(d.res, j);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const long i = base + u * 256;
+        if (i >= nvec) break;
+        float v[8];
+        unpack8(xr[u], v);
+        if (HAS_XADD) {
+            float a[8];
+            unpack8(ar[u], a);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += a[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + sh[k];
+        if (RES != LEDN_RES_NONE) {
+            float r[8];
+            unpack8(rr[u], r);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = RES == LEDN_RES_ADD ? v[k] + r[k] : v[k] * r[k] + r[k];
+        }
+        if (ACT != LEDN_ACT_NONE) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = act_apply(ACT, v[k], sl[k]);
+        }
+        st8(reinterpret_cast<bf16_t*>(d.y) + i * 8, v);
+    }
+}
+
+// dispatch helpers: runtime (act, res_mode) -> template instance
+#define SF_ACT_SWITCH(ACTV, BODY)                                                 \
+    switch (ACTV) {                                                               \
+        case LEDN_ACT_NONE: { constexpr int A_ = LEDN_ACT_NONE; BODY; } break;    \
+        case LEDN_ACT_RELU: { constexpr int A_ = LEDN_ACT_RELU; BODY; } break;    \
+        case LEDN_ACT_RELU6: { constexpr int A_ = LEDN_ACT_RELU6; BODY; } break;  \
+        case LEDN_ACT_PRELU: { constexpr int A_ = LEDN_ACT_PRELU; BODY; } break;  \
+        default: return -1;                                                       \
+    }
+#define SF_RES_SWITCH(RESV, BODY)                                                 \
+    switch (RESV) {                                                               \
+        case LEDN_RES_NONE: { constexpr int R_ = LEDN_RES_NONE; BODY; } break;    \
+        case LEDN_RES_ADD: { constexpr int R_ = LEDN_RES_ADD; BODY; } break;      \
+        case LEDN_RES_GATE: { constexpr int R_ = LEDN_RES_GATE; BODY; } break;    \
+        default: return -1;                                                       \
+    }
+
+// -> LEDN_OK when handled, -1 when the generic kernel must take the call
+int affine_act_fast(const ledn_affine_desc& d, hipStream_t s) {
+    if (d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16 || !sf_channels_ok(d.C)) return -1;
+    const long nvec = d.P * d.C / 8;
+    if (nvec < 4096) return -1;
+    constexpr int UNR = 4;
+    const dim3 grid((unsigned)cdiv(nvec, 256 * UNR));
+    if (d.xadd) {
+        if (d.act != LEDN_ACT_NONE || d.res_mode != LEDN_RES_NONE) return -1;
+        LEDN_LAUNCH((affine_fast_kernel<LEDN_ACT_NONE, LEDN_RES_NONE, true, UNR>), grid, dim3(256), 0, s, d, nvec);
+        return check_launch();
+    }
+    SF_ACT_SWITCH(d.act, SF_RES_SWITCH(d.res_mode,
+        LEDN_LAUNCH((affine_fast_kernel<A_, R_, false, UNR>), grid, dim3(256), 0, s, d, nvec)));
+    return check_launch();
+}
+
+// ===========================================================================
+// BatchNorm (+ residual / gate) + activation backward, all bf16
+//   t  = res_mode(z*sc + sh, res);  g = dy * act'(t)  (gate: gv = g*res, gres = g*(z*sc+sh+1))
+//   reduce: sum gv, sum gv*xhat, sum dslope          xhat = (z - mean) * invstd
+//   apply : dz = sc*(gv - mean_g - xhat*mean_gx) = sc*gv + A*z + B,
+//           A = -sc*mean_gx*invstd,  B = -sc*mean_g - A*mean      (no BatchNorm: A = B = 0)
+// ===========================================================================
+struct BnG {
+    float gv[8], gres[8], dsl[8];
+};
+template <int ACT, int RES>
+__device__ __forceinline__ void bn_g8(const float* z, const float* dy, const float* r, const float* sc,
+                                      const float* sh, const float* sl, BnG& o) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float v = z[k] * sc[k] + sh[k];
+        float t = v;
+        if (RES == LEDN_RES_ADD) t = v + r[k];
+        else if (RES == LEDN_RES_GATE) t = v * r[k] + r[k];
+        const float gt = ACT == LEDN_ACT_NONE ? dy[k] : dy[k] * act_grad(ACT, t, sl[k]);
+        if (ACT == LEDN_ACT_PRELU) o.dsl[k] = t <= 0.f ? dy[k] * t : 0.f;
+        if (RES == LEDN_RES_GATE) {
+            o.gv[k] = gt * r[k];
+            o.gres[k] = gt * (v + 1.f);
+        } else {
+            o.gv[k] = gt;
+            o.gres[k] = gt;
+        }
+    }
+}
+
+template <int ACT, int RES, bool HAS_DRES, int UNR>
+__global__ void __launch_bounds__(256) bn_apply_fast_kernel(ledn_bnbwd_desc d, long nvec) {
+    __shared__ float s_par[5][SF_MAXC];     // sc, sh, sl, A, B
+    const float invn = (float)(1.0 / d.count);
+    for (int c = threadIdx.x; c < d.C; c += 256) {
+        const float sc = d.scale ? d.scale[c] : 1.f;
+        s_par[0][c] = sc;
+        s_par[1][c] = d.shift ? d.shift[c] : 0.f;
+        s_par[2][c] = d.slope ? d.slope[c] : 0.f;
+        float A = 0.f, B = 0.f;
+        if (d.bn_mode) {
+            const float mg = d.sum_g[c] * invn, mgx = d.sum_gx[c] * invn;
+            A = -sc * mgx * d.invstd[c];
+            B = -sc * mg - A * d.mean[c];
+        }
+        s_par[3][c] = A;
+        s_par[4][c] = B;
+    }
+    __syncthreads();
+    const int c0 = (int)(threadIdx.x % (unsigned)(d.C >> 3)) * 8;
+    float sc[8], sh[8], sl[8], A[8], B[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = s_par[0][c0 + k];
+        sh[k] = s_par[1][c0 + k];
+        sl[k] = ACT == LEDN_ACT_PRELU ? s_par[2][c0 + k] : 0.f;
+        A[k] = s_par[3][c0 + k];
+        B[k] = s_par[4][c0 + k];
+    }
+    const long base = (long)blockIdx.x * (256 * UNR) + threadIdx.x;
+    uint4 zr[UNR], gr[UNR], rr[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const long i = base + u * 256;
+        const long j = i < nvec ? i : 0;
+        zr[u] = ldraw(d.z, j);
+        gr[u] = ldraw(d.dy, j);
+        if (RES != LEDN_RES_NONE) rr[u] = ldraw(d.res, j);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const long i = base + u * 256;
+        if (i >= nvec) break;
+        float z[8], dy[8], r[8];
+        unpack8(zr[u], z);
+        unpack8(gr[u], dy);
+        if (RES != LEDN_RES_NONE) unpack8(rr[u], r);
+        BnG g;
+        bn_g8<ACT, RES>(z, dy, r, sc, sh, sl, g);
+        float dz[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dz[k] = fmaf(sc[k], g.gv[k], fmaf(A[k], z[k], B[k]));
+        st8(reinterpret_cast<bf16_t*>(d.dz) + i * 8, dz);
+        if (HAS_DRES) st8(reinterpret_cast<bf16_t*>(d.dres) + i * 8, g.gres);
+    }
+}
+
+int bn_act_bwd_apply_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
+    if (d.dtype_z != LEDN_BF16 || d.dtype_y != LEDN_BF16 || !sf_channels_ok(d.C)) return -1;
+    const long nvec = d.P * d.C / 8;
+    if (nvec < 4096) return -1;
+    const bool has_dres = d.dres != nullptr;
+    if (has_dres && d.res_mode == LEDN_RES_NONE) return -1;
+    constexpr int UNR = 4;
+    const dim3 grid((unsigned)cdiv(nvec, 256 * UNR));
+    if (has_dres) {
+        SF_ACT_SWITCH(d.act, SF_RES_SWITCH(d.res_mode,
+            LEDN_LAUNCH((bn_apply_fast_kernel<A_, R_, R_ != LEDN_RES_NONE, UNR>), grid, dim3(256), 0, s, d, nvec)));
+    } else {
+        SF_ACT_SWITCH(d.act, SF_RES_SWITCH(d.res_mode,
+            LEDN_LAUNCH((bn_apply_fast_kernel<A_, R_, false, UNR>), grid, dim3(256), 0, s, d, nvec)));
+    }
+    return check_launch();
+}
+
+// reduce: lane (row r, channel group cg) owns UNR pixels r, r + rows, ... of its workgroup's chunk (all loads
+// first, ONE trip: workgroups start and retire continuously, so the loads of one overlap the arithmetic of
+// another -- this kernel is as much VALU- as memory-bound: ~7-12 VALU operations per element at 39 T op/s
+// are 3-5 us on a 33 MB tensor); workgroup totals -> part[block][3][C] (finish_partials adds them up).
+// sum g*xhat is accumulated as sum g*(z - mean) and scaled by invstd once per workgroup.
+template <int ACT, int RES, int UNR>
+__global__ void __launch_bounds__(256) bn_reduce_fast_kernel(ledn_bnbwd_desc d, float* part) {
+    __shared__ float s_par[5][SF_MAXC];     // sc, sh, sl, mean, invstd
+    __shared__ float s_red[3][256 * 8];
+    for (int c = threadIdx.x; c < d.C; c += 256) {
+        s_par[0][c] = d.scale ? d.scale[c] : 1.f;
+        s_par[1][c] = d.shift ? d.shift[c] : 0.f;
+        s_par[2][c] = d.slope ? d.slope[c] : 0.f;
+        s_par[3][c] = d.bn_mode ? d.mean[c] : 0.f;
+        s_par[4][c] = d.bn_mode ? d.invstd[c] : 0.f;
+    }
+    __syncthreads();
+    const int cvn = d.C >> 3, rows = 256 / cvn;
+    const int cg = (int)(threadIdx.x % (unsigned)cvn), r = (int)(threadIdx.x / (unsigned)cvn);
+    const int c0 = cg * 8;
+    float sc[8], sh[8], sl[8], mean[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = s_par[0][c0 + k];
+        sh[k] = s_par[1][c0 + k];
+        sl[k] = ACT == LEDN_ACT_PRELU ? s_par[2][c0 + k] : 0.f;
+        mean[k] = s_par[3][c0 + k];
+    }
+    float a[8], b[8], e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = b[k] = e[k] = 0.f;
+    const long stride = (long)gridDim.x * rows;
+    for (long p0 = (long)blockIdx.x * rows + r; p0 < d.P; p0 += UNR * stride) {
+        uint4 zr[UNR], gr[UNR], rr[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long p = p0 + u * stride;
+            const long j = (p < d.P ? p : p0) * cvn + cg;
+            zr[u] = ldraw(d.z, j);
+            gr[u] = ldraw(d.dy, j);
+            if (RES != LEDN_RES_NONE) rr[u] = ldraw(d.res, j);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (p0 + u * stride >= d.P) break;
+            float z[8], dy[8], rv[8];
+            unpack8(zr[u], z);
+            unpack8(gr[u], dy);
+            if (RES != LEDN_RES_NONE) unpack8(rr[u], rv);
+            BnG g;
+            bn_g8<ACT, RES>(z, dy, rv, sc, sh, sl, g);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a[k] += g.gv[k];
+                b[k] = fmaf(g.gv[k], z[k] - mean[k], b[k]);
+                if (ACT == LEDN_ACT_PRELU) e[k] += g.dsl[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s_red[0][threadIdx.x * 8 + k] = a[k];
+        s_red[1][threadIdx.x * 8 + k] = b[k];
+        s_red[2][threadIdx.x * 8 + k] = e[k];
+    }
+    __syncthreads();
+    // output (kind j, channel c): sum over the workgroup's rows; all 256 lanes take part
+    for (int o = threadIdx.x; o < 3 * d.C; o += 256) {
+        const int j = o / d.C, c = o % d.C;
+        const float* src = s_red[j] + (c >> 3) * 8 + (c & 7);
+        float t0 = 0.f, t1 = 0.f;
+        int rr2 = 0;
+        for (; rr2 + 1 < rows; rr2 += 2) {
+            t0 += src[rr2 * cvn * 8];
+            t1 += src[(rr2 + 1) * cvn * 8];
+        }
+        if (rr2 < rows) t0 += src[rr2 * cvn * 8];
+        float t = t0 + t1;
+        if (j == 1) t *= s_par[4][c];
+        part[(long)blockIdx.x * 3 * d.C + o] = t;
+    }
+}
+
+int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
+    if (d.dtype_z != LEDN_BF16 || d.dtype_y != LEDN_BF16 || !sf_channels_ok(d.C)) return -1;
+    if (d.P * d.C / 8 < 4096) return -1;
+    constexpr int UNR = 4;
+    const int rows = 256 / (d.C >> 3);
+    long nb = cdiv(d.P, (long)rows * UNR);           // one trip per lane up to 2048 workgroups
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    float* part = ws_take(nb * 3 * d.C);
+    if (!part) return -1;
+    const dim3 grid((unsigned)nb);
+    SF_ACT_SWITCH(d.act, SF_RES_SWITCH(d.res_mode,
+        LEDN_LAUNCH((bn_reduce_fast_kernel<A_, R_, UNR>), grid, dim3(256), 0, s, d, part)));
+    return finish_partials(part, (int)nb, d.C, 3, d.sum_g, d.sum_gx, d.dslope, s);
+}
+
+// ===========================================================================
+// per-channel sum / sum of squares of x [+ xadd], bf16
+// ===========================================================================
+template <bool HAS_XADD, int UNR>
+__global__ void __launch_bounds__(256) stats_fast_kernel(const void* x, const void* xadd, long P, int C, float* part) {
+    __shared__ float s_red[2][256 * 8];
+    const int cvn = C >> 3, rows = 256 / cvn;
+    const int cg = (int)(threadIdx.x % (unsigned)cvn), r = (int)(threadIdx.x / (unsigned)cvn);
+    float a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = b[k] = 0.f;
+    const long stride = (long)gridDim.x * rows;
+    for (long p0 = (long)blockIdx.x * rows + r; p0 < P; p0 += UNR * stride) {
+        uint4 xr[UNR], ar[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long p = p0 + u * stride;
+            const long j = (p < P ? p : p0) * cvn + cg;
+            xr[u] = ldraw(x, j);
+            if (HAS_XADD) ar[u] = ldraw(xadd, j);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (p0 + u * stride >= P) break;
+            float v[8];
+            unpack8(xr[u], v);
+            if (HAS_XADD) {
+                float w[8];
+                unpack8(ar[u], w);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += w[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a[k] += v[k];
+                b[k] = fmaf(v[k], v[k], b[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s_red[0][threadIdx.x * 8 + k] = a[k];
+        s_red[1][threadIdx.x * 8 + k] = b[k];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * C; o += 256) {
+        const int j = o / C, c = o % C;
+        const float* src = s_red[j] + (c >> 3) * 8 + (c & 7);
+        float t = 0.f;
+        for (int rr2 = 0; rr2 < rows; ++rr2) t += src[rr2 * cvn * 8];
+        part[(long)blockIdx.x * 2 * C + o] = t;
+    }
+}
+
+int channel_stats_fast(const void* x, const void* xadd, long long P, int C, int dtype, float* sum, float* sqsum,
+                       hipStream_t s) {
+    if (dtype != LEDN_BF16 || !sf_channels_ok(C) || !sqsum) return -1;
+    if (P * C / 8 < 4096) return -1;
+    constexpr int UNR = 4;
+    const int rows = 256 / (C >> 3);
+    long nb = cdiv((long)P, (long)rows * UNR * 2);
+    if (nb > 1024) nb = 1024;
+    float* part = ws_take(nb * 2 * C);
+    if (!part) return -1;
+    const dim3 grid((unsigned)nb);
+    if (xadd) LEDN_LAUNCH((stats_fast_kernel<true, UNR>), grid, dim3(256), 0, s, x, xadd, (long)P, C, part);
+    else LEDN_LAUNCH((stats_fast_kernel<false, UNR>), grid, dim3(256), 0, s, x, xadd, (long)P, C, part);
+    return finish_partials(part, (int)nb, C, 2, sum, sqsum, nullptr, s);
+}
+
+}  // namespace ledn

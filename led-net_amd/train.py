@@ -175,7 +175,7 @@ class BNActFn(Function):
         return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None
 
 
-WGRAD_SLOT = int(_os.environ.get('LEDN_WGRAD_SLOT', '7'))   # auxiliary stream of the weight gradients, 0 = launch stream
+WGRAD_SLOT = int(_os.environ.get('LEDN_WGRAD_SLOT', '0'))   # auxiliary stream of the weight gradients, 0 = launch stream (measured r02n: 782 img/s on its own stream vs 892 on the launch stream)
 
 
 def _conv_wgrad(x, dz, w_shape, sw, sb, **kw):

@@ -1,0 +1,128 @@
+"""csrc/stream_fast.hip (16-B-per-lane streaming kernels of the bf16 BatchNorm / activation passes) against
+(a) the generic kernels behind the same C-ABI entry (LEDN_OPT_STREAM_FAST toggled) and (b) plain torch fp32
+math on the same bf16 inputs.  Shapes include a ragged tail (vector count not a multiple of the 1024 vectors a
+workgroup owns) and every residual / activation mode.  Emulator on CPU; the same tests on the MI355X (-m gpu)."""
+import pytest
+import torch
+
+OPT_STREAM_FAST = 2
+BF = torch.bfloat16
+
+
+def _toggle(on):
+    from led_net_amd import _lib
+    _lib.get_lib().set_option(OPT_STREAM_FAST, 1 if on else 0)
+
+
+def _both(fn):
+    """fn() under the fast kernels and under the generic ones"""
+    try:
+        _toggle(True)
+        a = fn()
+        _toggle(False)
+        b = fn()
+    finally:
+        _toggle(True)
+    return a, b
+
+
+def _rnd(be, *shape, scale=1.0, shift=0.0):
+    return be((torch.randn(*shape) * scale + shift).to(BF))
+
+
+SHAPES = [(2, 33, 31, 64), (1, 40, 52, 16), (3, 17, 23, 128), (2, 24, 40, 512), (1, 129, 67, 32)]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('act,res_mode,xadd', [('relu', 'add', False), ('prelu', 'add', False), (None, 'gate', False),
+                                               ('relu6', None, False), (None, None, True), ('prelu', None, False)])
+def test_affine_act_fast(be, shape, act, res_mode, xadd):
+    from led_net_amd import ops
+    torch.manual_seed(3)
+    C = shape[-1]
+    x, res, xa = _rnd(be, *shape, scale=2), _rnd(be, *shape), _rnd(be, *shape)
+    sc, sh, sl = be(torch.rand(C) + 0.5), be(torch.randn(C)), be(torch.rand(C) * 0.3)
+    A = {'relu': ops.ACT_RELU, 'relu6': ops.ACT_RELU6, None: ops.ACT_NONE, 'prelu': ops.ACT_PRELU}[act]
+    R = {'add': ops.RES_ADD, 'gate': ops.RES_GATE, None: ops.RES_NONE}[res_mode]
+
+    def run():
+        return ops.affine_act(x, sc, sh, act=A, slope=sl if act == 'prelu' else None, res=res if res_mode else None,
+                              res_mode=R, xadd=xa if xadd else None)
+    fast, gen = _both(run)
+    v = x.float() + (xa.float() if xadd else 0)
+    v = v * sc + sh
+    if res_mode == 'add':
+        v = v + res.float()
+    elif res_mode == 'gate':
+        v = v * res.float() + res.float()
+    if act == 'relu':
+        v = v.clamp(min=0)
+    elif act == 'relu6':
+        v = v.clamp(0, 6)
+    elif act == 'prelu':
+        v = torch.where(v > 0, v, v * sl)
+    # bf16 output: one rounding of the same fp32 value -> at most 1 ulp from torch, identical between the kernels
+    # up to fma contraction (1 ulp on rare elements)
+    torch.testing.assert_close(fast.float().cpu(), v.cpu(), rtol=1e-2, atol=1e-2)
+    assert (fast.float() - gen.float()).abs().max().item() <= 2e-2 * max(1.0, v.abs().max().item())
+    assert (fast != gen).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('act,res_mode', [('relu', 'add'), ('prelu', 'add'), (None, 'gate'), ('relu6', None),
+                                          ('prelu', None), (None, None)])
+def test_bn_act_bwd_fast(be, shape, act, res_mode):
+    from led_net_amd import ops, ops_train as T
+    torch.manual_seed(4)
+    C = shape[-1]
+    z, dy, res = _rnd(be, *shape, scale=2, shift=0.5), _rnd(be, *shape), _rnd(be, *shape)
+    gamma, beta, sl = be(torch.rand(C) + 0.5), be(torch.randn(C)), be(torch.rand(C) * 0.3)
+    A = {'relu': ops.ACT_RELU, 'relu6': ops.ACT_RELU6, None: ops.ACT_NONE, 'prelu': ops.ACT_PRELU}[act]
+    R = {'add': ops.RES_ADD, 'gate': ops.RES_GATE, None: ops.RES_NONE}[res_mode]
+    P = z.numel() // C
+
+    def run():
+        st = ops.channel_stats(z)
+        scale, shift, mean, invstd = ops.bn_finalize(st, P, gamma, beta)
+        out = T.bn_act_bwd(z, dy, scale=scale, shift=shift, mean=mean, invstd=invstd, act=A,
+                           slope=sl if act == 'prelu' else None, res=res if res_mode else None, res_mode=R,
+                           want_dres=res_mode is not None)
+        return out, (st[0].clone(), st[1].clone())
+    (fast, st_f), (gen, st_g) = _both(run)
+    # statistics: f32 sums of the same bf16 values in a different order
+    for a, b in zip(st_f, st_g):
+        torch.testing.assert_close(a.cpu(), b.cpu(), rtol=1e-4, atol=1e-2)
+    # torch reference on the same bf16 inputs, fp32 math
+    zf = z.float().cpu().requires_grad_(True)
+    rf = res.float().cpu().requires_grad_(True)
+    g_, b_, s_ = (t.float().cpu().requires_grad_(True) for t in (gamma, beta, sl))
+    zz = zf.reshape(-1, C)
+    mean, var = zz.mean(0), zz.var(0, unbiased=False)
+    v = (zf - mean) / torch.sqrt(var + 1e-5) * g_ + b_
+    t = v + rf if res_mode == 'add' else (v * rf + rf if res_mode == 'gate' else v)
+    y = {'relu': lambda a: a.clamp(min=0), 'relu6': lambda a: a.clamp(0, 6), None: lambda a: a,
+         'prelu': lambda a: torch.where(a > 0, a, a * s_)}[act](t)
+    y.backward(dy.float().cpu())
+    names = ['dz', 'dres', 'dgamma', 'dbeta', 'dslope']
+    want = [zf.grad, rf.grad if res_mode else None, g_.grad, b_.grad, s_.grad if act == 'prelu' else None]
+    for n, f, g, w in zip(names, fast, gen, want):
+        if w is None:
+            continue
+        f, g = f.float().cpu(), g.float().cpu()
+        tol = 3e-2 * w.abs().max().item() + 1e-3      # bf16 outputs / f32 reductions of bf16 products
+        assert (f - w).abs().max().item() <= tol, (n, (f - w).abs().max().item(), tol)
+        assert (f - g).abs().max().item() <= tol, (n, 'fast vs generic', (f - g).abs().max().item(), tol)
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_channel_stats_fast(be, shape):
+    from led_net_amd import ops
+    torch.manual_seed(5)
+    x, xa = _rnd(be, *shape, scale=2, shift=0.3), _rnd(be, *shape)
+    for add in (None, xa):
+        (f0, f1), (g0, g1) = _both(lambda: tuple(t.clone() for t in ops.channel_stats(x, xadd=add)))
+        v = (x.float() + (add.float() if add is not None else 0)).reshape(-1, shape[-1]).double().cpu()
+        torch.testing.assert_close(f0.double().cpu(), v.sum(0), rtol=1e-4, atol=2e-2)
+        torch.testing.assert_close(f1.double().cpu(), (v * v).sum(0), rtol=1e-4, atol=2e-2)
+        torch.testing.assert_close(f0.cpu(), g0.cpu(), rtol=1e-4, atol=2e-2)
+        torch.testing.assert_close(f1.cpu(), g1.cpu(), rtol=1e-4, atol=2e-2)

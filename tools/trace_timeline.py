@@ -25,7 +25,9 @@ def base(k):
 rows = []
 with open(sys.argv[1], newline='') as fh:
     for r in csv.DictReader(fh):
-        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), base(r['Kernel_Name'])))
+        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), base(r['Kernel_Name']),
+                     (int(r.get('Grid_Size_X') or r.get('Grid_Size') or 0), int(r.get('Grid_Size_Y') or 1),
+                      int(r.get('Workgroup_Size_X') or r.get('Workgroup_Size') or 0))))
 rows.sort()
 # steps are delimited by the single sgd_step_kernel launch of each step
 ends = [i for i, r in enumerate(rows) if r[2] == 'sgd_kernel']
@@ -38,7 +40,7 @@ seg = rows[lo:hi]
 nsteps = 3
 t0, t1 = seg[0][0], max(r[1] for r in seg)
 ev = []
-for s, e, k in seg:
+for s, e, k, _g in seg:
     ev.append((s, 1, k))
     ev.append((e, -1, k))
 ev.sort()
@@ -70,7 +72,7 @@ print(f'steps analysed: {nsteps}, kernels/step: {len(seg) / nsteps:.0f}, wall {w
 print(f'idle {idle / nsteps / 1e6:.3f} ms  one-kernel {one / nsteps / 1e6:.3f} ms  overlapped {multi / nsteps / 1e6:.3f} ms')
 tot = defaultdict(float)
 cnt = defaultdict(int)
-for s, e, k in seg:
+for s, e, k, _g in seg:
     tot[k] += e - s
     cnt[k] += 1
 print('--- exclusive time (ms/step), total duration, launches/step')
@@ -79,3 +81,17 @@ for k, v in sorted(excl.items(), key=lambda kv: -kv[1])[:28]:
 print('--- idle gaps following a kernel (ms/step)')
 for k, v in sorted(gap_after.items(), key=lambda kv: -kv[1])[:10]:
     print(f'{v / nsteps / 1e6:8.3f}  x{cnt[k] / nsteps:6.1f}  {k}')
+
+# ---- per launch shape (kernel, grid): average duration and average start-to-next-start interval (the cost on a
+# serial chain: duration + the gap before the next kernel starts)
+shape_t, shape_i, shape_n = defaultdict(float), defaultdict(float), defaultdict(int)
+for i, (s0, e0, k, g) in enumerate(seg):
+    key = (k, g)
+    shape_t[key] += e0 - s0
+    shape_n[key] += 1
+    if i + 1 < len(seg):
+        shape_i[key] += max(0, seg[i + 1][0] - s0)
+print('--- by launch shape: ms/step, launches/step, avg us, avg start-to-next-start us, kernel (grid x, grid y, wg)')
+for key, v in sorted(shape_t.items(), key=lambda kv: -kv[1])[:int(sys.argv[2]) if len(sys.argv) > 2 else 70]:
+    n_ = shape_n[key]
+    print(f'{v / nsteps / 1e6:8.3f}  x{n_ / nsteps:6.1f}  {v / n_ / 1e3:8.1f}  {shape_i[key] / n_ / 1e3:8.1f}  {key[0]} {key[1]}')
