@@ -129,9 +129,13 @@ int ledn_im2col_stem(const void* x, void* p, int N, int H, int W, int C, int Ho,
 /* The same patches straight from the planar input batch (NCHW uint8 / f32 / bf16) with the
  * SegDataPreProcessor normalisation and channel map (data_preprocessor.py:98-151) applied on the
  * way: p[.., (kh*3+kw)*C + c] = bf16(x[n, map[c], hi, wi] * scale[c] + shift[c]).  Fuses
- * ledn_nchw_to_nhwc + ledn_im2col_stem (the NHWC copy of the input is never written). */
+ * ledn_nchw_to_nhwc + ledn_im2col_stem (the NHWC copy of the input is never written).
+ * valid_hw (optional, int32 [N][2]): image n holds data in rows < valid_hw[2n], columns < valid_hw[2n+1] only;
+ * the rest of the H x W plane is batch padding and reads as pad_val IN THE NORMALISED DOMAIN (stack_batch pads
+ * after the normalisation, mmseg/utils/misc.py:77-93, data_preprocessor.py:121-133; pad_val = 0 there). */
 int ledn_im2col_stem_planar(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
-                            const float* scale, const float* shift, const int* map, void* stream);
+                            const float* scale, const float* shift, const int* map, const int* valid_hw,
+                            float pad_val, void* stream);
 
 /* Weight (and bias) gradient of the same convolution:
  *   dw(co,ci,tap) += sum_{n,ho,wo} pre(x)[n, ho*s-pad+kh*dil, .., ci] * dz[n,ho,wo,co]
@@ -254,9 +258,11 @@ int ledn_affine_act(const ledn_affine_desc* d, void* stream);
  *   y[n,h,w,c] = x[n, map[c], h, w] * scale[c] + shift[c]
  * x: [N][C][H][W] u8 / f32 / bf16, y: [N][H][W][C] f32 / bf16; map NULL = identity.
  * Replaces: SegDataPreProcessor's BGR->RGB flip and (x-mean)/std
- * (mmseg/models/data_preprocessor.py:117-127) plus the NCHW->NHWC re-layout. */
+ * (mmseg/models/data_preprocessor.py:117-127) plus the NCHW->NHWC re-layout; valid_hw / pad_val as in
+ * ledn_im2col_stem_planar (the batch padding of stack_batch, applied after the normalisation). */
 int ledn_nchw_to_nhwc(const void* x, int dtype_x, void* y, int dtype_y, int N, int C, int H, int W,
-                      const float* scale, const float* shift, const int* map, void* stream);
+                      const float* scale, const float* shift, const int* map, const int* valid_hw, float pad_val,
+                      void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Resampling.
@@ -284,6 +290,13 @@ int ledn_adaptive_avgpool(const void* x, const void* xadd, float* y, int N, int 
 /* 3x3 stride-2 pad-1 average pool, count_include_pad (nn_layers/eesp.py:74,111). */
 int ledn_avgpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo,
                       int dtype, void* stream);
+/* k x k average pool, stride s, zero padding p counted in the divisor (nn.AvgPool2d defaults): the pooling
+ * pyramid of DAPPM / PAPPM (mmseg/models/utils/ppm.py:66-70: (5,2,2), (9,4,4), (17,8,8)).
+ * Ho = (H + 2p - k)/s + 1 (floor).  _bwd: dx = adjoint (gather form). */
+int ledn_avgpool2d(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad,
+                   int dtype, void* stream);
+int ledn_avgpool2d_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int k, int stride,
+                       int pad, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * GETB (backbones/UNetFormer_GETB.py:97-206).

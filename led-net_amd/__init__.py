@@ -9,11 +9,11 @@ from .registry import BACKBONES, HEADS, LOSSES, MODELS, SEGMENTORS, register_int
 from .lednet import LEDNet
 from .led_head import LEDHead
 from .losses import OhemCrossEntropy  # noqa: F401
-from .segmentor import EncoderDecoder, SegDataSample  # noqa: F401
+from .segmentor import EncoderDecoder, SegDataPreProcessor, SegDataSample  # noqa: F401
 from .config import load_config  # noqa: F401
 from .train import Trainer  # noqa: F401
 from .metrics import IoUMetric  # noqa: F401
-from .checkpoint import init_model, load_checkpoint, save_checkpoint  # noqa: F401
+from .checkpoint import init_model, load_checkpoint, resume, save_checkpoint  # noqa: F401
 
 MODELS.register_module(module=LEDNet)
 MODELS.register_module(module=LEDHead)

@@ -142,7 +142,7 @@ _PROTOS = {
     'ledn_conv2d_wgrad_uses_mfma': ([C.POINTER(WgradDesc)], i32),
     'ledn_pack_conv_weights_multi': ([vp, i32, i64, vp], i32),
     'ledn_im2col_stem': ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
-    'ledn_im2col_stem_planar': ([vp, i32, vp, i32, i32, i32, i32, i32, i32, fp, fp, vp, vp], i32),
+    'ledn_im2col_stem_planar': ([vp, i32, vp, i32, i32, i32, i32, i32, i32, fp, fp, vp, vp, C.c_float, vp], i32),
     'ledn_pack_conv_weights': ([fp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_conv2d_wgrad': ([C.POINTER(WgradDesc), vp], i32),
     'ledn_dwconv2d': ([C.POINTER(DwDesc), vp], i32),
@@ -153,9 +153,11 @@ _PROTOS = {
     'ledn_channel_stats': ([vp, vp, i64, i32, i32, fp, fp, vp], i32),
     'ledn_bn_finalize': ([fp, fp, C.c_double, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, fp, fp, i32, vp], i32),
     'ledn_affine_act': ([C.POINTER(AffineDesc), vp], i32),
-    'ledn_nchw_to_nhwc': ([vp, i32, vp, i32, i32, i32, i32, i32, fp, fp, vp, vp], i32),
+    'ledn_nchw_to_nhwc': ([vp, i32, vp, i32, i32, i32, i32, i32, fp, fp, vp, vp, C.c_float, vp], i32),
     'ledn_bilinear': ([C.POINTER(ResizeDesc), vp], i32),
     'ledn_adaptive_avgpool': ([vp, vp, fp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_avgpool2d': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_avgpool2d_bwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_avgpool3x3s2': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_window_attn': ([vp, fp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_getb_pool': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),

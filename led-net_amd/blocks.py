@@ -79,11 +79,12 @@ class ConvModule(Block):
     Call sites: basic_block.py:43-57, ddrnet.py:68-105,123-138, led_head.py:87-94."""
 
     def __init__(self, cin, cout, k, stride=1, padding=0, act='relu', with_norm=True,
-                 order=('conv', 'norm', 'act'), bias='auto'):
+                 order=('conv', 'norm', 'act'), bias='auto', groups=1):
         super().__init__()
         if bias == 'auto':
             bias = not with_norm
-        self.conv = nn.Conv2d(cin, cout, k, stride, padding, bias=bias)
+        self.conv = nn.Conv2d(cin, cout, k, stride, padding, groups=groups, bias=bias)
+        self.groups = groups
         self.norm_first = order.index('norm') < order.index('conv')
         if with_norm:
             self.bn = nn.BatchNorm2d(cin if self.norm_first else cout)
@@ -102,16 +103,16 @@ class ConvModule(Block):
             # norm -> act -> conv: BN+act become the conv's input prologue
             s, b = self.cached('fold', lambda: fold_bn(self.bn))
             ps, pb, pact = post if post is not None else (None, self.conv.bias, ACT_NONE)
-            return ops.conv2d(x, w, stride=self.stride, pad=self.padding, in_scale=s, in_shift=b,
-                              in_act=act, out_scale=ps, out_shift=pb, act=pact, out_dtype=out_dtype,
-                              w_bf16=packed(self, w, x))
+            return ops.conv2d(x, w, stride=self.stride, pad=self.padding, groups=self.groups, in_scale=s, in_shift=b,
+                              in_act=act, out_scale=ps, out_shift=pb, act=pact, out_dtype=out_dtype, res=res,
+                              res_mode=res_mode, w_bf16=packed(self, w, x, 0, self.groups))
         if self.with_norm:
             s, b = self.cached('fold', lambda: fold_bn(self.bn, self.conv.bias))
         else:
             s, b = None, self.conv.bias
-        return ops.conv2d(x, w, stride=self.stride, pad=self.padding, in_act=in_act, xadd=xadd,
+        return ops.conv2d(x, w, stride=self.stride, pad=self.padding, groups=self.groups, in_act=in_act, xadd=xadd,
                           out_scale=s, out_shift=b, act=act, res=res, res_mode=res_mode,
-                          out_dtype=out_dtype, w_bf16=packed(self, w, x))
+                          out_dtype=out_dtype, w_bf16=packed(self, w, x, 0, self.groups))
 
 
 class BasicBlock(Block):
@@ -227,12 +228,75 @@ class SESP(Block):
 
 
 class CESPB(nn.Sequential):
-    """Cascade of two SESP blocks (PDF p.17); growth in the stride-1 block
-    because SESP(stride=2, Spatial=False) needs nIn == nOut (eesp.py:110-111)."""
+    """Cascade of `depth` SESP blocks (PDF p.17 "stage-wise cascade of ESP blocks"; the count is not published:
+    default 2).  Growth in the first (stride-1) block, the stride in the last one, because
+    SESP(stride=2, Spatial=False) needs nIn == nOut (eesp.py:110-111)."""
 
-    def __init__(self, nIn, nOut, stride, spatial):
+    def __init__(self, nIn, nOut, stride, spatial, depth=2):
         r = 7 if spatial else 9
-        super().__init__(SESP(nIn, nOut, 1, 4, r, spatial), SESP(nOut, nOut, stride, 4, r, spatial))
+        if depth < 1:
+            raise ValueError('CESPB depth must be >= 1')
+        if depth == 1:
+            if stride == 2 and not spatial and nIn != nOut:
+                raise ValueError('a one-block CESPB cannot grow channels at stride 2: SESP(stride=2, Spatial=False) '
+                                 'needs nIn == nOut (eesp.py:110-111); use depth >= 2 on the context branch')
+            blocks = [SESP(nIn, nOut, stride, 4, r, spatial)]
+        else:
+            blocks = ([SESP(nIn, nOut, 1, 4, r, spatial)] + [SESP(nOut, nOut, 1, 4, r, spatial) for _ in range(depth - 2)]
+                      + [SESP(nOut, nOut, stride, 4, r, spatial)])
+        super().__init__(*blocks)
+
+
+class PPM(Block):
+    """DAPPM / PAPPM pooling pyramid (mmseg/models/utils/ppm.py:11-192) as the selectable context tail of LEDNet
+    (the `ppm_channels` slot of the DDRNet skeleton, ddrnet.py:118-119).  Child names = the reference's
+    (`scales.{i}[.1]`, `processes[.{i}]`, `compression`, `shortcut`, each a norm -> act -> conv ConvModule without
+    bias), so a checkpoint of the reference modules loads unchanged."""
+    NAC = ('norm', 'act', 'conv')
+
+    def __init__(self, cin, branch, cout, kind='pappm', num_scales=5, kernel_sizes=(5, 9, 17), strides=(2, 4, 8),
+                 paddings=(2, 4, 8)):
+        super().__init__()
+        if kind not in ('dappm', 'pappm'):
+            raise ValueError(f'unknown pooling pyramid {kind!r}')
+        self.kind, self.num_scales = kind, num_scales
+        self.pools = list(zip(kernel_sizes, strides, paddings))[:num_scales - 2]
+        cm = lambda ci, co, k, pad=0, g=1: ConvModule(ci, co, k, 1, pad, act='relu', order=self.NAC, bias=False, groups=g)  # noqa: E731
+        scales = [cm(cin, branch, 1)]
+        for k, st, pd in self.pools:
+            scales.append(nn.Sequential(nn.AvgPool2d(k, st, pd), cm(cin, branch, 1)))
+        scales.append(nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), cm(cin, branch, 1)))
+        self.scales = nn.ModuleList(scales)
+        if kind == 'dappm':
+            self.processes = nn.ModuleList(cm(branch, branch, 3, 1) for _ in range(num_scales - 1))
+        else:
+            self.processes = cm(branch * (num_scales - 1), branch * (num_scales - 1), 3, 1, num_scales - 1)
+        self.compression = cm(branch * num_scales, cout, 1)
+        self.shortcut = cm(cin, cout, 1)
+
+    def pooled(self, x, i):
+        """input of scales[i] (i >= 1): the k/s/p average pool or, for the last scale, the global mean"""
+        if i < self.num_scales - 1:
+            return ops.avgpool2d(x, *self.pools[i - 1])
+        g = ops.adaptive_avgpool(x, 1)
+        return g if g.dtype == x.dtype else ops.affine_act(g, out_dtype=x.dtype)
+
+    def forward(self, x):
+        assert not self.training, 'training path: see train.ppm'
+        hw = x.shape[1:3]
+        x_ = self.scales[0](x)
+        n = self.num_scales
+        if self.kind == 'dappm':
+            feats = [x_]
+            for i in range(1, n):
+                up = ops.bilinear(self.scales[i][1](self.pooled(x, i)), hw, add=feats[i - 1])
+                feats.append(self.processes[i - 1](up))
+            cat = torch.cat(feats, dim=-1)
+        else:
+            ups = [ops.bilinear(self.scales[i][1](self.pooled(x, i)), hw, add=x_) for i in range(1, n)]
+            cat = torch.cat([x_, self.processes(torch.cat(ups, dim=-1))], dim=-1)
+        # (torch.cat along the channels of <= 1/64-resolution maps: data movement of a few hundred KB)
+        return self.compression(cat, res=self.shortcut(x), res_mode=RES_ADD)
 
 
 # --------------------------------------------------------------------------- #

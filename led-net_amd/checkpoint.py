@@ -37,10 +37,28 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False):
     return ckpt
 
 
-def save_checkpoint(model, filename, meta=None):
-    """mmengine layout: {'meta': ..., 'state_dict': cpu tensors}."""
+def save_checkpoint(model, filename, meta=None, trainer=None):
+    """mmengine layout: {'meta': ..., 'state_dict': cpu tensors} and, with a Trainer, what mmengine's
+    CheckpointHook adds for --resume: 'optimizer' (torch.optim.SGD.state_dict(): the momentum buffers, indexed
+    by position in model.parameters()) and 'param_schedulers' (the PolyLR position)."""
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    torch.save({'meta': dict(meta or {}), 'state_dict': sd}, filename)
+    ckpt = {'meta': dict(meta or {}), 'state_dict': sd}
+    if trainer is not None:
+        ckpt['optimizer'] = trainer.optimizer_state_dict()
+        ckpt['param_schedulers'] = [trainer.scheduler_state_dict()]
+        ckpt['meta'].setdefault('iter', trainer.iter)
+    torch.save(ckpt, filename)
+
+
+def resume(trainer, ckpt):
+    """restore the optimizer / schedule state of a checkpoint dict (as returned by load_checkpoint) into a
+    Trainer; weights-only checkpoints restart with zero momentum (and say so)."""
+    if 'optimizer' in ckpt:
+        trainer.load_optimizer_state_dict(ckpt['optimizer'], ckpt.get('param_schedulers'), ckpt.get('meta', {}).get('iter'))
+    else:
+        warnings.warn('checkpoint has no optimizer state: resuming the weights only (momentum restarts at zero)')
+        trainer.iter = int(ckpt.get('meta', {}).get('iter', trainer.iter))
+    return trainer
 
 
 def init_model(config, checkpoint=None, device='cuda:0'):

@@ -25,7 +25,8 @@ int bn_finalize_rows_impl(const float* part, int rows, double count, const float
                           float* shift, float* mean, float* invstd, float* sum, float* sqsum, int C,
                           hipStream_t s);
 int im2col_stem_planar_impl(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
-                            const float* scale, const float* shift, const int* map, hipStream_t s);
+                            const float* scale, const float* shift, const int* map, const int* valid_hw, float pad_val,
+                            hipStream_t s);
 int dw_pack_impl(const ledn_dwpack_desc& d, float* packed, hipStream_t s);
 int dw_unpack_grad_impl(const ledn_dwpack_desc& d, const float* dpacked, hipStream_t s);
 int sesp_pyramid_impl(const ledn_pyr_desc& d, hipStream_t s);
@@ -38,7 +39,12 @@ int bn_finalize_impl(const float* sum, const float* sqsum, double count, const f
 int affine_act_impl(const ledn_affine_desc& d, hipStream_t s);
 int bilinear_impl(const ledn_resize_desc& d, hipStream_t s);
 int nchw_to_nhwc_impl(const void* x, int dtype_x, void* y, int dtype_y, int N, int C, int H, int W,
-                      const float* scale, const float* shift, const int* map, hipStream_t s);
+                      const float* scale, const float* shift, const int* map, const int* valid_hw, float pad_val,
+                      hipStream_t s);
+int avgpool2d_impl(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int k, int st, int pad,
+                   int dtype, hipStream_t s);
+int avgpool2d_bwd_impl(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int k, int st, int pad,
+                       int dtype, hipStream_t s);
 int adaptive_avgpool_impl(const void* x, const void* xadd, float* y, int N, int H, int W, int C, int S,
                           int dtype, hipStream_t s);
 int avgpool3x3s2_impl(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int dtype,
@@ -172,8 +178,9 @@ int ledn_pack_conv_weights_multi(const ledn_pack_entry* table_dev, int n, long l
 }
 
 int ledn_im2col_stem_planar(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
-                            const float* scale, const float* shift, const int* map, void* stream) {
-    return im2col_stem_planar_impl(x, dtype_x, p, N, H, W, C, Ho, Wo, scale, shift, map, S(stream));
+                            const float* scale, const float* shift, const int* map, const int* valid_hw,
+                            float pad_val, void* stream) {
+    return im2col_stem_planar_impl(x, dtype_x, p, N, H, W, C, Ho, Wo, scale, shift, map, valid_hw, pad_val, S(stream));
 }
 int ledn_im2col_stem(const void* x, void* p, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
     return im2col_stem_impl(x, p, N, H, W, C, Ho, Wo, S(stream));
@@ -228,8 +235,17 @@ int ledn_affine_act(const ledn_affine_desc* d, void* stream) {
     return d ? affine_act_impl(*d, S(stream)) : LEDN_EINVAL;
 }
 int ledn_nchw_to_nhwc(const void* x, int dtype_x, void* y, int dtype_y, int N, int C, int H, int W,
-                      const float* scale, const float* shift, const int* map, void* stream) {
-    return nchw_to_nhwc_impl(x, dtype_x, y, dtype_y, N, C, H, W, scale, shift, map, S(stream));
+                      const float* scale, const float* shift, const int* map, const int* valid_hw, float pad_val,
+                      void* stream) {
+    return nchw_to_nhwc_impl(x, dtype_x, y, dtype_y, N, C, H, W, scale, shift, map, valid_hw, pad_val, S(stream));
+}
+int ledn_avgpool2d(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad,
+                   int dtype, void* stream) {
+    return avgpool2d_impl(x, y, N, H, W, C, Ho, Wo, k, stride, pad, dtype, S(stream));
+}
+int ledn_avgpool2d_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int k, int stride,
+                       int pad, int dtype, void* stream) {
+    return avgpool2d_bwd_impl(dy, dx, N, H, W, C, Ho, Wo, k, stride, pad, dtype, S(stream));
 }
 int ledn_bilinear(const ledn_resize_desc* d, void* stream) { return d ? bilinear_impl(*d, S(stream)) : LEDN_EINVAL; }
 int ledn_adaptive_avgpool(const void* x, const void* xadd, float* y, int N, int H, int W, int C, int Sz,

@@ -663,7 +663,8 @@ __device__ __forceinline__ float ldp(const bf16_t* p) { return bf16_to_f32(p->v)
 template <typename TX, int C>
 __global__ void __launch_bounds__(256) im2col_stem_planar_kernel(const TX* x, bf16_t* p, int N, int H, int W,
                                                                  int Ho, int Wo, const float* scale,
-                                                                 const float* shift, const int* map) {
+                                                                 const float* shift, const int* map,
+                                                                 const int* valid_hw, float pad_val) {
     constexpr int PXB = 64, COLS = 2 * PXB + 1;
     __shared__ unsigned short s_in[3 * 3 * COLS];             // [c][row][col], zero outside the image
     const int wtiles = (Wo + PXB - 1) / PXB;
@@ -676,13 +677,16 @@ __global__ void __launch_bounds__(256) im2col_stem_planar_kernel(const TX* x, bf
     // thread's loads are in flight together instead of a chain of five dependent round trips
     constexpr int NE = (C * 3 * COLS + 255) / 256;
     float f[NE];
-    bool ok[NE];
+    bool ok[NE], data[NE];
+    // batch padding (stack_batch): rows >= vh / columns >= vw of image n read as pad_val (normalised domain)
+    const int vh = valid_hw ? valid_hw[2 * n] : H, vw = valid_hw ? valid_hw[2 * n + 1] : W;
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
         const int e = threadIdx.x + j * 256;
         const int col = e % COLS, r = (e / COLS) % 3, c = min(e / (3 * COLS), C - 1);
         const int hi = ho * 2 - 1 + r, wi = wo0 * 2 - 1 + col;
         ok[j] = e < C * 3 * COLS && hi >= 0 && hi < H && wi >= 0 && wi < W;
+        data[j] = hi < vh && wi < vw;
         const int cs = map ? map[c] : c;
         f[j] = ldp(x + ((long)n * C + cs) * plane + (ok[j] ? (long)hi * W + wi : 0L));
     }
@@ -693,6 +697,7 @@ __global__ void __launch_bounds__(256) im2col_stem_planar_kernel(const TX* x, bf
         const int c = e / (3 * COLS);
         float v = f[j];
         if (scale) v = v * scale[c] + shift[c];
+        v = data[j] ? v : pad_val;
         s_in[e] = ok[j] ? f32_to_bf16(v) : (unsigned short)0;
     }
     __syncthreads();
@@ -714,14 +719,15 @@ __global__ void __launch_bounds__(256) im2col_stem_planar_kernel(const TX* x, bf
 }
 
 int im2col_stem_planar_impl(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
-                            const float* scale, const float* shift, const int* map, hipStream_t s) {
+                            const float* scale, const float* shift, const int* map, const int* valid_hw,
+                            float pad_val, hipStream_t s) {
     LEDN_REQUIRE(x && p && N > 0 && H > 0 && W > 0 && C > 0 && 9 * C <= 32);
     LEDN_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1);
     LEDN_REQUIRE((scale == nullptr) == (shift == nullptr));
     const dim3 grid((unsigned)((long)N * Ho * cdiv(Wo, 64)));
 #define LEDN_IPC(TX, CC)                                                                                    \
     LEDN_LAUNCH((im2col_stem_planar_kernel<TX, CC>), grid, dim3(256), 0, s, (const TX*)x, (bf16_t*)p, N, H, W, Ho, \
-                Wo, scale, shift, map)
+                Wo, scale, shift, map, valid_hw, pad_val)
 #define LEDN_IP(TX)                  \
     do {                             \
         if (C == 3) LEDN_IPC(TX, 3); \

@@ -248,27 +248,31 @@ __device__ __forceinline__ float ld(const unsigned char* p) { return (float)*p; 
 template <typename TX, typename TY>
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const TX* x, TY* y, int N, int C, int H, int W,
                                                            const float* scale, const float* shift,
-                                                           const int* map) {
+                                                           const int* map, const int* valid_hw, float pad_val) {
     const long plane = (long)H * W;
     const long total = (long)N * plane;
     const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= total) return;
     const long n = pix / plane, hw = pix % plane;
+    // batch padding (stack_batch): outside the image's valid extent the value is pad_val (normalised domain)
+    const bool data = !valid_hw || ((int)(hw / W) < valid_hw[2 * n] && (int)(hw % W) < valid_hw[2 * n + 1]);
     for (int c = 0; c < C; ++c) {
         const int cs = map ? map[c] : c;
         float v = ld(x + (n * C + cs) * plane + hw);
         if (scale) v = v * scale[c] + shift[c];
-        st(y + pix * C + c, v);
+        st(y + pix * C + c, data ? v : pad_val);
     }
 }
 
 int nchw_to_nhwc_impl(const void* x, int dtype_x, void* y, int dtype_y, int N, int C, int H, int W,
-                      const float* scale, const float* shift, const int* map, hipStream_t s) {
+                      const float* scale, const float* shift, const int* map, const int* valid_hw, float pad_val,
+                      hipStream_t s) {
     LEDN_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0);
     LEDN_REQUIRE((scale == nullptr) == (shift == nullptr));
     const dim3 grid((unsigned)cdiv((long)N * H * W, 256));
 #define LEDN_L(TX, TY) \
-    LEDN_LAUNCH((nchw_to_nhwc_kernel<TX, TY>), grid, dim3(256), 0, s, (const TX*)x, (TY*)y, N, C, H, W, scale, shift, map)
+    LEDN_LAUNCH((nchw_to_nhwc_kernel<TX, TY>), grid, dim3(256), 0, s, (const TX*)x, (TY*)y, N, C, H, W, scale, shift, map, \
+                valid_hw, pad_val)
     if (dtype_x == LEDN_F32 && dtype_y == LEDN_F32) LEDN_L(float, float);
     else if (dtype_x == LEDN_F32 && dtype_y == LEDN_BF16) LEDN_L(float, bf16_t);
     else if (dtype_x == LEDN_BF16 && dtype_y == LEDN_BF16) LEDN_L(bf16_t, bf16_t);

@@ -270,6 +270,108 @@ int avgpool3x3s2_impl(const void* x, void* y, int N, int H, int W, int C, int Ho
     return check_launch();
 }
 
+// ---- k x k / stride s / pad p average pool, zero padding counted in the divisor (nn.AvgPool2d defaults:
+// count_include_pad=True, ceil_mode=False): the pooling pyramid of DAPPM / PAPPM (utils/ppm.py:66-70)
+template <typename T, int V>
+__global__ void __launch_bounds__(256) avgpool2d_kernel(const T* x, T* y, int N, int H, int W, int C, int Ho,
+                                                        int Wo, int k, int st, int pad) {
+    const int cv = C / V;
+    const long total = (long)N * Ho * Wo * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int n = (int)(pix / ((long)Wo * Ho));
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    const int h0 = max(ho * st - pad, 0), h1 = min(ho * st - pad + k, H);
+    const int w0 = max(wo * st - pad, 0), w1 = min(wo * st - pad + k, W);
+    for (int hi = h0; hi < h1; ++hi)
+        for (int wi = w0; wi < w1; ++wi) {
+            float xv[V];
+            ldv<V>(x + (((long)n * H + hi) * W + wi) * C + c, xv);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] += xv[v];
+        }
+    const float inv = 1.f / (float)(k * k);
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] *= inv;
+    stv<V>(y + pix * C + c, acc);
+}
+
+int avgpool2d_impl(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int k, int st, int pad,
+                   int dtype, hipStream_t s) {
+    LEDN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && st > 0 && pad >= 0 && 2 * pad <= k);
+    LEDN_REQUIRE(Ho == (H + 2 * pad - k) / st + 1 && Wo == (W + 2 * pad - k) / st + 1 && Ho > 0 && Wo > 0);
+    const bool v4 = C % 4 == 0;
+    const long total = (long)N * Ho * Wo * (v4 ? C / 4 : C);
+    const dim3 grid((unsigned)cdiv(total, 256));
+#define LEDN_AP(T)                                                                                          \
+    do {                                                                                                    \
+        if (v4) LEDN_LAUNCH((avgpool2d_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, k, st, pad); \
+        else LEDN_LAUNCH((avgpool2d_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x, (T*)y, N, H, W, C, Ho, Wo, k, st, pad);    \
+    } while (0)
+    if (dtype == LEDN_F32) LEDN_AP(float);
+    else if (dtype == LEDN_BF16) LEDN_AP(bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_AP
+    return check_launch();
+}
+
+// adjoint in gather form: dx[y,x] = 1/k^2 * sum of dy over the windows that contain (y,x)
+template <typename T, int V>
+__global__ void __launch_bounds__(256) avgpool2d_bwd_kernel(const T* dy, T* dx, int N, int H, int W, int C, int Ho,
+                                                            int Wo, int k, int st, int pad) {
+    const int cv = C / V;
+    const long total = (long)N * H * W * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * V;
+    const long pix = idx / cv;
+    const int xx = (int)(pix % W);
+    const int yy = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long)W * H));
+    // windows ho with ho*st - pad <= yy < ho*st - pad + k
+    const int ho1 = min((yy + pad) / st, Ho - 1), wo1 = min((xx + pad) / st, Wo - 1);
+    const int ho0 = max((yy + pad - k + st) / st, 0), wo0 = max((xx + pad - k + st) / st, 0);
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    for (int ho = ho0; ho <= ho1; ++ho)
+        for (int wo = wo0; wo <= wo1; ++wo) {
+            float g[V];
+            ldv<V>(dy + (((long)n * Ho + ho) * Wo + wo) * C + c, g);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] += g[v];
+        }
+    const float inv = 1.f / (float)(k * k);
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] *= inv;
+    stv<V>(dx + pix * C + c, acc);
+}
+
+int avgpool2d_bwd_impl(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int k, int st, int pad,
+                       int dtype, hipStream_t s) {
+    LEDN_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && st > 0 && pad >= 0 && 2 * pad <= k);
+    LEDN_REQUIRE(Ho == (H + 2 * pad - k) / st + 1 && Wo == (W + 2 * pad - k) / st + 1 && Ho > 0 && Wo > 0);
+    const bool v4 = C % 4 == 0;
+    const long total = (long)N * H * W * (v4 ? C / 4 : C);
+    const dim3 grid((unsigned)cdiv(total, 256));
+#define LEDN_AP(T)                                                                                          \
+    do {                                                                                                    \
+        if (v4) LEDN_LAUNCH((avgpool2d_bwd_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)dy, (T*)dx, N, H, W, C, Ho, Wo, k, st, pad); \
+        else LEDN_LAUNCH((avgpool2d_bwd_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)dy, (T*)dx, N, H, W, C, Ho, Wo, k, st, pad);    \
+    } while (0)
+    if (dtype == LEDN_F32) LEDN_AP(float);
+    else if (dtype == LEDN_BF16) LEDN_AP(bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_AP
+    return check_launch();
+}
+
 // ---------------------------------------------------------------------------
 // evaluation histograms (see include/ledn.h: ledn_iou_hist): LDS counters per workgroup, one
 // global atomic per touched counter per workgroup (f32 counts, exact below 2^24 per image)

@@ -96,12 +96,26 @@ class LEDHead(Block):
         """decode_head.py:266-284 -> N x num_classes x H x W fused logits."""
         return self.fuse_predict(*self.forward_nhwc(inputs))
 
+    def predict_nhwc(self, inputs):
+        """fused logits in NHWC f32 (EncoderDecoder.postprocess_result crops / resizes them per image)"""
+        xc, h1, h2 = self.forward_nhwc(inputs)
+        size = (2 * h1.shape[1], 2 * h1.shape[2])
+        r = ops.bilinear(xc, tuple(math.ceil(s / 4) for s in size), add=h2)
+        r = ops.bilinear(r, tuple(math.ceil(s / 2) for s in size), add=h1)
+        return ops.bilinear(r, size)
+
     def predict_with_mask(self, inputs):
         """fused logits and the first-max argmax mask (segmentors/base.py:188) in one pass."""
         return self.fuse_predict(*self.forward_nhwc(inputs), argmax=True)
 
     # ------------------------------------------------------------------ #
     def loss(self, inputs, batch_data_samples, train_cfg=None):
-        """decode_head.py:248-264."""
-        from .train import led_head_loss
-        return led_head_loss(self, inputs, batch_data_samples)
+        """decode_head.py:248-264: forward, then loss_by_feat."""
+        return self.loss_by_feat(self.forward(inputs), batch_data_samples)
+
+    def loss_by_feat(self, seg_logits, batch_data_samples):
+        """led_head.py:101-146: (context, spatial, head_x1, head_x2) logits (NCHW, as ``forward`` returns them in
+        training) -> the two fused pyramids at the label size, OHEM-CE on each (loss_decode[0] / [1]) and the
+        top-1 accuracy of the context logits; keys ``loss_context``, ``loss_spatial``, ``acc_seg``."""
+        from .train import led_head_loss_by_feat
+        return led_head_loss_by_feat(self, seg_logits, batch_data_samples)

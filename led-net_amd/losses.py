@@ -3,7 +3,8 @@
 Mirrors mmseg/models/losses/ohem_cross_entropy_loss.py:11-94 (constructor
 arguments, ``loss_name`` property, selection semantics) and
 losses/accuracy.py:6-60 (top-1, ignore_index).  The arithmetic runs in the
-fused HIP kernels of csrc/ohem.hip.
+fused HIP kernels of csrc/attn_loss_opt.hip (ohem_*: softmax prob + CE, exact k-th
+smallest by radix select, masked mean, backward).
 """
 import torch.nn as nn
 

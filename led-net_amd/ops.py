@@ -287,9 +287,18 @@ def im2col_stem(x):
     return p
 
 
-def im2col_stem_planar(x, scale=None, shift=None, chan_map=None):
+def _valid_hw(valid, N, ref):
+    if valid is None:
+        return None
+    if valid.dtype != torch.int32 or tuple(valid.shape) != (N, 2) or valid.device != ref.device:
+        raise LednError('valid_hw must be an int32 [N, 2] tensor on the input\'s device')
+    return valid
+
+
+def im2col_stem_planar(x, scale=None, shift=None, chan_map=None, valid=None, pad_val=0.0):
     """x: [N,C,H,W] uint8/float32/bfloat16 planar batch -> [N,Ho,Wo,32] bf16 patches of the 3x3/s2/p1 stem
-    conv with y = x[map[c]]*scale[c]+shift[c] applied (= im2col_stem(nchw_to_nhwc(x, bf16, ...)))."""
+    conv with y = x[map[c]]*scale[c]+shift[c] applied (= im2col_stem(nchw_to_nhwc(x, bf16, ...))).
+    valid: int32 [N,2] (rows, columns) holding image data; the rest is batch padding = pad_val."""
     lib = _lib.get_lib()
     N, Cc, H, W = x.shape
     dtx = {torch.float32: F32, torch.bfloat16: BF16, torch.uint8: _lib.U8}.get(x.dtype)
@@ -299,9 +308,9 @@ def im2col_stem_planar(x, scale=None, shift=None, chan_map=None):
         raise LednError('im2col_stem_planar: chan_map must be int32[C]')
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     p = torch.empty((N, Ho, Wo, 32), dtype=torch.bfloat16, device=x.device)
-    _check(lib, x, p, scale, shift, chan_map)
+    _check(lib, x, p, scale, shift, chan_map, _valid_hw(valid, N, x))
     _run(lib, 'ledn_im2col_stem_planar', x, _p(x), dtx, _p(p), N, H, W, Cc, Ho, Wo, _p(_f32(scale, Cc)),
-         _p(_f32(shift, Cc)), _p(chan_map),
+         _p(_f32(shift, Cc)), _p(chan_map), _p(valid), float(pad_val),
          work=_TIMING is not None and (f'im2col_stem_planar {N}x{H}x{W}', _nb(x, p), 0, 'im2col_stem_planar_kernel'))
     return p
 
@@ -494,8 +503,9 @@ def affine_act(x, scale=None, shift=None, *, act=ACT_NONE, slope=None, res=None,
     return y
 
 
-def nchw_to_nhwc(x, out_dtype, scale=None, shift=None, chan_map=None):
-    """x: [N,C,H,W] uint8/float32/bfloat16 -> [N,H,W,C] out_dtype, y = x[map[c]]*scale[c]+shift[c]."""
+def nchw_to_nhwc(x, out_dtype, scale=None, shift=None, chan_map=None, valid=None, pad_val=0.0):
+    """x: [N,C,H,W] uint8/float32/bfloat16 -> [N,H,W,C] out_dtype, y = x[map[c]]*scale[c]+shift[c];
+    valid / pad_val: batch padding as in im2col_stem_planar."""
     lib = _lib.get_lib()
     N, Cc, H, W = x.shape
     dtx = {torch.float32: F32, torch.bfloat16: BF16, torch.uint8: _lib.U8}.get(x.dtype)
@@ -504,9 +514,9 @@ def nchw_to_nhwc(x, out_dtype, scale=None, shift=None, chan_map=None):
     y = torch.empty((N, H, W, Cc), dtype=out_dtype, device=x.device)
     if chan_map is not None and (chan_map.dtype != torch.int32 or chan_map.numel() != Cc):
         raise LednError('nchw_to_nhwc: chan_map must be int32[C]')
-    _check(lib, x, y, scale, shift, chan_map)
+    _check(lib, x, y, scale, shift, chan_map, _valid_hw(valid, N, x))
     _run(lib, 'ledn_nchw_to_nhwc', x, _p(x), dtx, _p(y), _DT[out_dtype], N, Cc, H, W, _p(_f32(scale, Cc)),
-         _p(_f32(shift, Cc)), _p(chan_map), work=_TIMING is not None and (f'nchw2nhwc {N}x{Cc}x{H}x{W}', _nb(x, y), 2 * x.numel()))
+         _p(_f32(shift, Cc)), _p(chan_map), _p(valid), float(pad_val), work=_TIMING is not None and (f'nchw2nhwc {N}x{Cc}x{H}x{W}', _nb(x, y), 2 * x.numel()))
     return y
 
 
@@ -537,6 +547,31 @@ def adaptive_avgpool(x, S, xadd=None):
     _run(lib, 'ledn_adaptive_avgpool', x, _p(x), _p(xadd), _p(y), N, H, W, Cc, S, _dt(x),
          work=_TIMING is not None and (f'apool S{S} C{Cc} {N}x{H}x{W}', _nb(x, xadd, y), x.numel()))
     return y
+
+
+def avgpool2d(x, k, stride, pad):
+    """nn.AvgPool2d(k, stride, pad) (zero padding counted in the divisor) on NHWC x."""
+    lib = _lib.get_lib()
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if Ho <= 0 or Wo <= 0:
+        raise LednError(f'avgpool2d: a {k}x{k} window (pad {pad}) does not fit a {H}x{W} map')
+    y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    _check(lib, x, y)
+    _run(lib, 'ledn_avgpool2d', x, _p(x), _p(y), N, H, W, Cc, Ho, Wo, k, stride, pad, _dt(x),
+         work=_TIMING is not None and (f'avgpool{k}s{stride} C{Cc} {N}x{H}x{W}', _nb(x, y), k * k * y.numel()))
+    return y
+
+
+def avgpool2d_bwd(dy, in_hw, k, stride, pad):
+    lib = _lib.get_lib()
+    N, Ho, Wo, Cc = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device)
+    _check(lib, dy, dx)
+    _run(lib, 'ledn_avgpool2d_bwd', dy, _p(dy), _p(dx), N, H, W, Cc, Ho, Wo, k, stride, pad, _dt(dy),
+         work=_TIMING is not None and (f'avgpool{k}s{stride}_bwd C{Cc} {N}x{H}x{W}', _nb(dy, dx), k * k * dx.numel()))
+    return dx
 
 
 def avgpool3x3s2(x):

@@ -599,10 +599,12 @@ def conv_module(m, x, act_override=None, res=None, res_mode=RES_NONE, out_dtype=
     act = _ACT[m.act] if act_override is None else act_override
     if m.norm_first:
         if FUSE_BN_INTO_CONV and act in BNActConvFn.ACTS:
-            return BNActConvFn.apply(x, m.bn.weight, m.bn.bias, None, m.conv.weight, m.conv.bias, None, m.bn, act,
-                                     m.stride, m.padding, 1, None, out_dtype)
-        y = bn_act(x, m.bn, act)
-        return ConvFn.apply(y, m.conv.weight, m.conv.bias, None, m.stride, m.padding, 1, None, out_dtype)
+            z = BNActConvFn.apply(x, m.bn.weight, m.bn.bias, None, m.conv.weight, m.conv.bias, None, m.bn, act,
+                                  m.stride, m.padding, m.conv.groups, None, out_dtype)
+        else:
+            z = ConvFn.apply(bn_act(x, m.bn, act), m.conv.weight, m.conv.bias, None, m.stride, m.padding,
+                             m.conv.groups, None, out_dtype)
+        return z if res is None else ActFn.apply(z, res, ACT_NONE)      # (res_mode ADD: the PPM shortcut)
     return conv_bn_act(x, m.conv, m.bn if m.with_norm else None, act, res=res, res_mode=res_mode,
                        out_dtype=out_dtype)
 
@@ -654,7 +656,57 @@ def sesp(m, x):
 
 
 def cespb(m, x):
-    return sesp(m[1], sesp(m[0], x))
+    for blk in m:
+        x = sesp(blk, x)
+    return x
+
+
+class AvgPool2dFn(Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        ctx.cfg = ((x.shape[1], x.shape[2]), k, stride, pad)
+        return ops.avgpool2d(x, k, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.avgpool2d_bwd(_c(dy), *ctx.cfg), None, None, None
+
+
+class GlobalPoolFn(Function):
+    """x -> its per-image channel means [N,1,1,C] in x's dtype (AdaptiveAvgPool2d((1,1)))."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        g = ops.adaptive_avgpool(x, 1)
+        return g if g.dtype == x.dtype else ops.affine_act(g, out_dtype=x.dtype)
+
+    @staticmethod
+    def backward(ctx, dg):
+        dx = torch.zeros(ctx.shape, dtype=ctx.dtype, device=dg.device)
+        dg = _c(dg)
+        T.mfaf_bwd_combine(dx, None, None, [dg if dg.dtype == torch.float32 else ops.affine_act(dg, out_dtype=torch.float32)])
+        return dx
+
+
+def ppm(m, x):
+    """blocks.PPM (DAPPM / PAPPM, utils/ppm.py:119-129,178-192) in training mode."""
+    hw = (x.shape[1], x.shape[2])
+    n = m.num_scales
+    x_ = conv_module(m.scales[0], x)
+
+    def up(i):
+        pooled = AvgPool2dFn.apply(x, *m.pools[i - 1]) if i < n - 1 else GlobalPoolFn.apply(x)
+        return conv_module(m.scales[i][1], pooled)
+    if m.kind == 'dappm':
+        feats = [x_]
+        for i in range(1, n):
+            feats.append(conv_module(m.processes[i - 1], BilinearFn.apply(up(i), feats[i - 1], hw, None)))
+        cat = torch.cat(feats, dim=-1)
+    else:
+        ups = [BilinearFn.apply(up(i), x_, hw, None) for i in range(1, n)]
+        cat = torch.cat([x_, conv_module(m.processes, torch.cat(ups, dim=-1))], dim=-1)
+    return conv_module(m.compression, cat, res=conv_module(m.shortcut, x), res_mode=RES_ADD)
 
 
 def getb(m, x):
@@ -729,17 +781,17 @@ def lednet_forward_train(m, x, pre=None):
     from .lednet import to_nchw_view
     H, W = x.shape[2:]
     out_size = (math.ceil(H / 8), math.ceil(W / 8))
-    s, b, mp = pre if pre is not None else (None, None, None)
+    s, b, mp, valid, pad_val = (tuple(pre) + (None, 0.0))[:5] if pre is not None else (None, None, None, None, 0.0)
     s0 = m.stem['0']
     if m.act_dtype == torch.bfloat16 and 9 * m.in_channels <= 32 and m.channels % 32 == 0:
         # stem as a K=32 GEMM on the MFMA path: im2col patches straight from the planar batch
         # (normalisation folded in; the input needs no gradient) x reshaped weight
         st = _stats(m.channels, x)
-        z = ConvFn.apply(ops.im2col_stem_planar(x.contiguous(), s, b, mp), ops.stem_weight_as_1x1(s0.conv.weight),
+        z = ConvFn.apply(ops.im2col_stem_planar(x.contiguous(), s, b, mp, valid, pad_val), ops.stem_weight_as_1x1(s0.conv.weight),
                          None, None, 1, 0, 1, st, None, True)
         x1 = BNActFn.apply(z, s0.bn.weight, s0.bn.bias, None, None, st, s0.bn, ACT_RELU, RES_NONE, None)
     else:
-        x1 = conv_module(s0, ops.nchw_to_nhwc(x.contiguous(), m.act_dtype, s, b, mp))
+        x1 = conv_module(s0, ops.nchw_to_nhwc(x.contiguous(), m.act_dtype, s, b, mp, valid, pad_val))
     x2 = conv_module(m.stem['1'], x1)
     y = basic_block(m.stem['2'][1], basic_block(m.stem['2'][0], x2), final_relu=True)
     y = basic_block(m.stem['4'][1], basic_block(m.stem['4'][0], y), final_relu=True)
@@ -752,7 +804,9 @@ def lednet_forward_train(m, x, pre=None):
         edge = ops.seam_edge(seg, m.seam.percentile, m.seam.fixed_threshold, 0.1)
     # stage 3
     with ops.Fork(y, 1 if CTX_FORKS & 1 else 0) as f3:
-        x_c = getb(m.getb1, cespb(m.layer3, y))
+        x_c = cespb(m.layer3, y)
+        if m.getb_stage3:
+            x_c = getb(m.getb1, x_c)
         comp = BilinearFn.apply(conv_module(m.compression_1, relu(x_c)), None, out_size, None)
     x_s = cespb(m.layer3_, y)
     f3.join(x_c, comp)
@@ -773,7 +827,7 @@ def lednet_forward_train(m, x, pre=None):
     # stage 5
     with ops.Fork(x_c, 1 if CTX_FORKS & 4 else 0) as f5:
         x_c = cespb(m.layer5, relu(x_c))
-        x_c = getb(m.getb2, conv_module(m.spp, x_c))
+        x_c = getb(m.getb2, conv_module(m.spp, x_c)) if m.context_tail == 'getb' else ppm(m.spp, x_c)
     x_s = sesp(m.layer5_, relu(x_s))
     f5.join(x_c)
     c5 = BilinearFn.apply(x_c, x_s, out_size, None)
@@ -819,9 +873,17 @@ def ohem_loss(crit, score, target):
     return loss
 
 
-def led_head_loss(h, inputs, batch_data_samples):
-    xc, xs, h1, h2 = led_head_forward_train(h, inputs)
-    label = torch.stack([ds.gt_sem_seg.data for ds in batch_data_samples], dim=0)   # N x 1 x H x W
+def led_head_loss_by_feat(h, seg_logits, batch_data_samples):
+    """LEDHead.loss_by_feat (led_head.py:101-146) on the four NCHW(-view) training logits."""
+    from .lednet import to_nhwc
+    xc, xs, h1, h2 = (to_nhwc(t, torch.float32) for t in seg_logits)
+    labels = [ds.gt_sem_seg.data for ds in batch_data_samples]
+    base = labels[0]._base if labels[0]._base is not None else None
+    if (base is not None and base.dim() == 4 and base.shape[0] == len(labels) and base.is_contiguous()
+            and all(lb._base is base and lb.data_ptr() == base[i].data_ptr() for i, lb in enumerate(labels))):
+        label = base                      # the samples are views of ONE resident N x 1 x H x W batch: no copy
+    else:
+        label = torch.stack(labels, dim=0)
     hw = label.shape[2:]
     y = label.squeeze(1).contiguous()
     ctx = fuse_loss(xc, h1, h2, hw)
@@ -830,6 +892,13 @@ def led_head_loss(h, inputs, batch_data_samples):
     l0, out0 = OhemFn.apply(ctx, y, c0.thresh, c0.min_kept, c0.loss_weight, c0.ignore_label)
     l1, _ = OhemFn.apply(spa, y, c1.thresh, c1.min_kept, c1.loss_weight, c1.ignore_label)
     return {'loss_context': l0, 'loss_spatial': l1, 'acc_seg': out0[1:2]}
+
+
+def led_head_loss(h, inputs, batch_data_samples):
+    """LEDHead.loss: forward (training) + loss_by_feat (NHWC tensors passed straight through)"""
+    from .lednet import to_nchw_view
+    return led_head_loss_by_feat(h, tuple(to_nchw_view(t) for t in led_head_forward_train(h, inputs)),
+                                 batch_data_samples)
 
 
 # --------------------------------------------------------------------------- #
@@ -922,6 +991,43 @@ class Trainer:
     @property
     def _all_reduce(self):      # (bench.py / older callers: "does this trainer exchange gradients")
         return self.coll
+
+    # ------------------------------------------------------------------ #
+    # resume: what mmengine's CheckpointHook stores besides the weights (`optimizer` = OptimWrapper.state_dict() =
+    # torch.optim.SGD.state_dict() over model.parameters() order, `param_schedulers` = [PolyLR.state_dict()])
+    def optimizer_state_dict(self):
+        """torch.optim.SGD-format state: parameter index = position in ``model.parameters()``; a momentum
+        buffer only for parameters that have received a gradient (SGD creates its state lazily)."""
+        order = list(self.model.parameters())
+        pos = {id(p): i for i, p in enumerate(self.params)}
+        live = {id(p) for p in getattr(self, 'live', [])} if self.table is not None else set()
+        state = {}
+        for i, p in enumerate(order):
+            if id(p) in live:
+                state[i] = {'momentum_buffer': self.moms[pos[id(p)]].detach().clone().cpu()}
+        group = dict(lr=self.lr(), momentum=self.momentum, dampening=0, weight_decay=self.wd, nesterov=False,
+                     maximize=False, foreach=None, differentiable=False, fused=None, initial_lr=self.base_lr,
+                     params=list(range(len(order))))
+        return {'state': state, 'param_groups': [group]}
+
+    def scheduler_state_dict(self):
+        return {'last_step': self.iter, 'begin': 0, 'end': self.max_iters, 'power': self.power, 'eta_min': self.eta_min,
+                'total_iters': self.max_iters, 'base_values': [self.base_lr], 'by_epoch': False}
+
+    def load_optimizer_state_dict(self, opt_sd, schedulers=None, iter=None):
+        """restore the momentum buffers (and the schedule position) saved by optimizer_state_dict /
+        an mmengine checkpoint of the same model"""
+        order = list(self.model.parameters())
+        pos = {id(p): i for i, p in enumerate(self.params)}
+        for i, st in opt_sd.get('state', {}).items():
+            p = order[int(i)]
+            buf = st.get('momentum_buffer')
+            if buf is not None and id(p) in pos:
+                self.moms[pos[id(p)]].copy_(buf.to(self.flat_mom.device, torch.float32).view_as(p))
+        if schedulers:
+            self.iter = int(schedulers[0].get('last_step', self.iter))
+        if iter is not None:
+            self.iter = int(iter)
 
     def lr(self):
         """mmengine PolyLR (by iteration): (base-eta_min)*(1-it/max)^power + eta_min."""
@@ -1077,9 +1183,12 @@ class Trainer:
         assert self.dist is None or self.comm is not None, 'graph capture with N > 1 needs the direct RCCL communicator'
         dev = inputs.device
         self._static_in = inputs.clone()
-        self._static_lab = [ds.gt_sem_seg.data.clone() for ds in data_samples]
+        # ONE resident N x 1 x H x W label batch; the samples are views of it (led_head_loss_by_feat then needs
+        # no per-step torch.stack: 134 MB of int64 at 16 x 1024 x 1024)
+        self._static_lab = torch.stack([ds.gt_sem_seg.data for ds in data_samples], dim=0)
         from .segmentor import SegDataSample
-        self._static_samples = [SegDataSample(gt=t) for t in self._static_lab]
+        self._static_samples = [SegDataSample(gt=self._static_lab[i], metainfo=dict(getattr(ds, 'metainfo', {}) or {}))
+                                for i, ds in enumerate(data_samples)]
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -1102,8 +1211,8 @@ class Trainer:
         """one captured step; new inputs are copied into the static buffers first."""
         if inputs is not None and inputs is not self._static_in:
             self._static_in.copy_(inputs)
-            for dst, ds in zip(self._static_lab, data_samples):
-                dst.copy_(ds.gt_sem_seg.data)
+            for i, ds in enumerate(data_samples):
+                self._static_lab[i].copy_(ds.gt_sem_seg.data)
         self._lr_dev.fill_(self.lr())
         self._graph.replay()
         self.iter += 1

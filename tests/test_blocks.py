@@ -159,3 +159,83 @@ def test_whole_network_predict_vs_oracle(be, hw):
     t = model(D(img), mode='tensor')
     assert [tuple(a.shape[1:]) for a in t] == [(2, math.ceil(hw[0] / 8), math.ceil(hw[1] / 8)),
                                                (2, hw[0] // 2, hw[1] // 2), (2, hw[0] // 4, hw[1] // 4)]
+
+
+@pytest.mark.parametrize('name', eval_names('g14_'))
+def test_ppm_eval_golden(be, name):
+    """blocks.PPM (DAPPM / PAPPM) on the HIP kernels vs the fixtures generated from utils/ppm.py"""
+    from led_net_amd.blocks import PPM
+    fx = Fixture(name)
+    kw = fx.meta['kwargs']
+    m = PPM(kw['in_channels'], kw['branch_channels'], kw['out_channels'], fx.meta['kind'].lower(), kw['num_scales']).eval()
+    m.load_state_dict(fx.sd, strict=True)
+    m.to(_DEV[0])
+    close(nchw(m(nhwc(fx.ins['x']))), fx.outs['y'], 5e-4, 5e-5)
+
+
+VARIANTS = [
+    dict(context_tail='pappm'),
+    dict(context_tail='dappm'),
+    dict(cespb_depth=(1, 3)),
+    dict(seam_mode='fixed', seam_threshold=0.1),
+    dict(getb_stage3=False),
+]
+
+
+@pytest.mark.parametrize('flags', VARIANTS, ids=lambda f: '-'.join(f'{k}={v}' for k, v in f.items()))
+def test_reconstruction_flags_vs_oracle(be, flags):
+    """every open choice of the backbone reconstruction is a constructor flag (CESPB cascade depth,
+    the context tail -- GETB or the DAPPM / PAPPM pooling pyramid --, SEAM binarisation rule, GETB placement);
+    each variant: inference features + fused logits and the training-mode loss against the oracle with the same
+    flags."""
+    import led_net_amd as L
+    torch.manual_seed(304)
+    cfg = L.load_config(os.path.join(os.path.dirname(__file__), 'data', 'lednet_test_config.py'))
+    cfg['model']['backbone'].update(flags)
+    for c in cfg['model']['decode_head']['loss_decode']:
+        c['min_kept'] = 5000
+    model = L.MODELS.build(cfg['model']).eval()
+    _randomize(model, 2)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(_DEV[0])
+    okw = dict(cespb_depth=model.backbone.cespb_depth, context_tail=model.backbone.context_tail,
+               getb_stage3=model.backbone.getb_stage3,
+               seam_threshold=('p80' if model.backbone.seam_mode == 'percentile' else flags.get('seam_threshold', 0.1)))
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (2, 3, 320, 320), dtype=torch.uint8, generator=g)
+    lab = torch.randint(0, 2, (2, 1, 320, 320), generator=g)
+    x = spec.preprocess(img)
+    with torch.no_grad():
+        want_logits, want_mask = spec.predict(x, sd, **okw)
+        out = model(D(img), mode='predict')
+    logits = torch.stack([o.seg_logits.data for o in out]).cpu()
+    close(logits, want_logits, 2e-3, 5e-4)
+    mask = torch.cat([o.pred_sem_seg.data for o in out]).long().cpu()
+    margin = (want_logits[:, 0] - want_logits[:, 1]).abs()
+    assert ((mask != want_mask) & (margin > 1e-3)).sum().item() == 0
+    model.train()
+    sd_t = {k: v.clone() for k, v in sd.items()}
+    want = spec.loss(x, lab, sd_t, loss_cfg=((0.9, 5000, 1.0), (0.9, 5000, 0.4)), **okw)
+    got = model(D(img), [L.SegDataSample(gt=D(lab)[i]) for i in range(2)], mode='loss')
+    for k in want:
+        # (random-init net on noise: a SEAM pixel within rounding of its hard threshold flips the whole gate at
+        #  that pixel -- the fixed-threshold variant moved the loss by 2.5e-3; a mis-wired variant is >> 1e-2)
+        assert abs(float(got[k].detach().reshape(-1)[0]) - float(want[k])) <= 1e-2 * abs(float(want[k])) + 1e-4, k
+    # the state_dict surface of the variant is the reference's for the pooling pyramids (utils/ppm.py child names)
+    if flags.get('context_tail') in ('pappm', 'dappm'):
+        keys = set(sd)
+        assert 'backbone.spp.scales.0.conv.weight' in keys and 'backbone.spp.scales.4.1.bn.weight' in keys
+        assert 'backbone.spp.compression.conv.weight' in keys and 'backbone.spp.shortcut.bn.running_mean' in keys
+        assert ('backbone.spp.processes.conv.weight' in keys) == (flags['context_tail'] == 'pappm')
+        assert ('backbone.spp.processes.3.conv.weight' in keys) == (flags['context_tail'] == 'dappm')
+        assert not any(k.startswith('backbone.getb2.') for k in keys)
+
+
+def test_reconstruction_flag_errors():
+    import led_net_amd as L
+    with pytest.raises(ValueError):
+        L.LEDNet(context_tail='aspp')
+    with pytest.raises(ValueError):
+        L.LEDNet(cespb_depth=1)          # the context branch cannot grow channels and stride in one SESP
+    with pytest.raises(ValueError):
+        L.LEDNet(seam_mode='otsu')

@@ -55,3 +55,48 @@ def test_checkpoint_ddp_prefix_bare_dict_and_old_meta(tmp_path):
     assert any('missing keys' in str(x.message) for x in w)
     with pytest.raises(RuntimeError):
         L.load_checkpoint(b, p2, strict=True)
+
+
+def test_resume_restores_momentum_and_schedule(tmp_path):
+    """tools/train.py --resume: the checkpoint carries mmengine's 'optimizer' (torch.optim.SGD.state_dict() layout over
+    model.parameters() order) and 'param_schedulers'; a fresh Trainer resumed from it holds the same momentum buffers
+    and PolyLR position, and torch.optim.SGD itself accepts the optimizer state."""
+    import led_net_amd as L
+    from conftest import bind_emu
+    torch.manual_seed(5)
+    cfg = L.load_config(CFG)
+    for c in cfg['model']['decode_head']['loss_decode']:
+        c['min_kept'] = 5000
+    g = torch.Generator().manual_seed(9)
+    img = torch.randint(0, 256, (2, 3, 320, 320), dtype=torch.uint8, generator=g)
+    lab = torch.randint(0, 2, (2, 1, 320, 320), generator=g)
+    with bind_emu():
+        a = L.MODELS.build(cfg['model'])
+        ta = L.Trainer(a, cfg, max_iters=100)
+        samples = [L.SegDataSample(gt=lab[i]) for i in range(2)]
+        ta.train_step(img, samples)
+        ta.train_step(img, samples)
+        path = str(tmp_path / 'iter_2.pth')
+        L.save_checkpoint(a, path, meta=dict(iter=2), trainer=ta)
+        ck = torch.load(path, weights_only=False)
+        assert {'meta', 'state_dict', 'optimizer', 'param_schedulers'} <= set(ck)
+        opt = ck['optimizer']
+        n_params = len(list(a.parameters()))
+        assert opt['param_groups'][0]['params'] == list(range(n_params)) and opt['param_groups'][0]['momentum'] == 0.9
+        # parameters that never get a gradient (SEAM conv_1: non-differentiable edge map) have no state, as in torch
+        assert 0 < len(opt['state']) < n_params
+        b = L.MODELS.build(cfg['model'])
+        ckb = L.load_checkpoint(b, path)
+        tb = L.resume(L.Trainer(b, cfg, max_iters=100), ckb)
+        assert tb.iter == 2 and abs(tb.lr() - ta.lr()) < 1e-12
+        pa = {id(p): i for i, p in enumerate(ta.params)}
+        for p_a, p_b, (name, _) in zip(a.parameters(), b.parameters(), a.named_parameters()):
+            ma = ta.moms[pa[id(p_a)]]
+            mb = tb.moms[{id(p): i for i, p in enumerate(tb.params)}[id(p_b)]]
+            assert torch.equal(ma, mb), name
+        assert ta.flat_mom.abs().sum() > 0
+    # format check against the real thing
+    sgd = torch.optim.SGD(b.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    sgd.load_state_dict(opt)
+    k = next(iter(opt['state']))
+    assert torch.equal(sgd.state[list(b.parameters())[k]]['momentum_buffer'], opt['state'][k]['momentum_buffer'])

@@ -133,6 +133,17 @@ def test_basic_block_train_golden(be, name):
     _check_block(fx, m, TR.basic_block)
 
 
+@pytest.mark.parametrize('name', train_names('g14_'))
+def test_ppm_train_golden(be, name):
+    """DAPPM / PAPPM context tail in training mode: output, input gradient, every parameter gradient, running stats"""
+    from led_net_amd.blocks import PPM
+    from led_net_amd import train as TR
+    fx = Fixture(name)
+    kw = fx.meta['kwargs']
+    m = PPM(kw['in_channels'], kw['branch_channels'], kw['out_channels'], fx.meta['kind'].lower(), kw['num_scales'])
+    _check_block(fx, m, TR.ppm)
+
+
 def test_led_head_train_golden(be):
     """LEDHead.forward (train) + loss_by_feat: logits, losses, accuracy, grads wrt the
     four backbone features and every head parameter (fixture g10, mmcv shim)."""

@@ -9,6 +9,7 @@ every 50 iterations, checkpoints in mmengine layout (iter_N.pth).  Datasets/augm
     python -m torch.distributed.run --nproc-per-node 8 tools/train.py CONFIG --launcher pytorch
 """
 import argparse
+import ast
 import glob
 import os
 import os.path as osp
@@ -57,8 +58,8 @@ def main():
         for part in parts[:-1]:
             node = node[int(part)] if isinstance(node, list) else node[part]
         try:
-            val = eval(val, {}, {})       # numbers / tuples / None, as mmengine's DictAction
-        except Exception:                 # noqa: BLE001 -- plain string
+            val = ast.literal_eval(val)   # numbers / tuples / lists / None / booleans, as mmengine's DictAction
+        except (ValueError, SyntaxError):  # plain string
             pass
         node[parts[-1]] = val
     work_dir = args.work_dir or osp.join('./work_dirs', osp.splitext(osp.basename(args.config))[0])
@@ -66,14 +67,17 @@ def main():
     torch.manual_seed(304)
     model = L.MODELS.build(cfg['model'])
     model.set_act_dtype(torch.float32 if args.f32 else torch.bfloat16)
-    start = 0
+    start, ckpt = 0, None
     if args.resume:
         cks = sorted(glob.glob(osp.join(work_dir, 'iter_*.pth')), key=lambda f: int(osp.basename(f)[5:-4]))
         if cks:
-            start = L.load_checkpoint(model, cks[-1])['meta'].get('iter', 0)
+            ckpt = L.load_checkpoint(model, cks[-1])
+            start = ckpt['meta'].get('iter', 0)
             print(f'resumed from {cks[-1]} (iter {start})')
     model.to(dev)
     trainer = L.Trainer(model, cfg, world_size=world, max_iters=None)
+    if ckpt is not None:
+        L.resume(trainer, ckpt)           # momentum buffers + PolyLR position (mmengine 'optimizer' / 'param_schedulers')
     trainer.iter = start
     max_iters = args.max_iters or trainer.max_iters
     g = torch.Generator().manual_seed(304 + rank)
@@ -92,7 +96,7 @@ def main():
             print(f'Iter(train) [{it + 1:6d}/{max_iters}]  lr: {trainer.lr():.4e}  time: {dt:.4f}  '
                   + '  '.join(f'{k}: {v:.4f}' for k, v in vals.items()), flush=True)
         if rank == 0 and ((args.save_interval and (it + 1) % args.save_interval == 0) or it + 1 == max_iters):
-            L.save_checkpoint(model, osp.join(work_dir, f'iter_{it + 1}.pth'),
+            L.save_checkpoint(model, osp.join(work_dir, f'iter_{it + 1}.pth'), trainer=trainer,
                               meta=dict(iter=it + 1, dataset_meta=dict(classes=('background', 'foreground'), palette=None)))
     if rank == 0:
         n = max_iters - start
