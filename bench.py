@@ -43,15 +43,26 @@ def synthetic_batch(n, h, w, dev, seed=304):
     return img.to(dev), lab.to(dev)
 
 
-def build_model(dev, dtype, train):
+def build_model(dev, dtype, train, backbone_flags=None):
     import led_net_amd as L
     torch.manual_seed(304)
     cfg = L.load_config(os.path.join(ROOT, 'tests', 'data', 'lednet_test_config.py'))
+    cfg['model']['backbone'].update(backbone_flags or {})
     model = L.MODELS.build(cfg['model'])
     model.set_act_dtype(torch.bfloat16 if dtype == 'bf16' else torch.float32)
     model.to(dev)
     model.train(train)
     return model, cfg
+
+
+def pmc_record(kernel, mode, dtype):
+    """the committed PMC record of `kernel` (profiles/pmc_traffic_<mode>_<dtype>.json) or {}"""
+    path = os.path.join(ROOT, 'profiles', f'pmc_traffic_{mode}_{dtype}.json')
+    try:
+        with open(path) as fh:
+            return json.load(fh)['kernels'].get(kernel) or {}
+    except (OSError, ValueError, KeyError):
+        return {}
 
 
 def pmc_traffic(kernel, mode, dtype):
@@ -179,6 +190,7 @@ def main():
                          'with --gpus 1, rccl runs the one-rank self-test of that path (SyncBN + gradient all-reduce in the graph)')
     ap.add_argument('--local-bn', action='store_true',
                     help='N>1: per-rank BatchNorm statistics instead of the config\'s SyncBN (one all-reduce per BN and direction)')
+    ap.add_argument('--backbone', default='', help="reconstruction flags of LEDNet as key=value,... (e.g. cespb_depth=(2,3),context_tail='pappm'); default: the survey's contract")
     ap.add_argument('--trace-only', action='store_true',
                     help='stop after the timed region (for rocprofv3 timeline traces: no instrumented eager pass, no JSON)')
     args = ap.parse_args()
@@ -208,7 +220,12 @@ def main():
     mode = args.mode or ('train' if has_train else 'infer')
     bs = args.batch or (16 if mode == 'train' else 8)
     H, W = args.height, args.width
-    model, cfg = build_model(dev, args.dtype, mode == 'train')
+    import ast
+    flags = {}
+    for kv in filter(None, __import__('re').split(r',(?![^(]*\))', args.backbone)):
+        k, v = kv.split('=', 1)
+        flags[k.strip()] = ast.literal_eval(v.strip())
+    model, cfg = build_model(dev, args.dtype, mode == 'train', flags)
     if args.local_bn:
         model.backbone.sync_bn = model.decode_head.sync_bn = False
     img, lab = synthetic_batch(bs, H, W, dev, seed=304 + rank)
@@ -310,6 +327,7 @@ def main():
             roof = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=round(gbs / HBM_PEAK_GBS, 5))
         roof['traffic'] = pmc_traffic(kname, mode, args.dtype)
+        roof['mfma_busy'] = pmc_record(kname, mode, args.dtype).get('mfma_busy_frac')   # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), same PMC collection
         roof.update(kernel=kname, avg_us=round(avg_ms * 1e3, 2), launches_per_step=f['n'] // k_steps,
                     alg_bytes_per_launch=f['bytes'] // f['n'], alg_flops_per_launch=f['flops'] // f['n'],
                     alg_gbs=round(gbs, 1), alg_tflops=round(tfl, 3), mfma_frac=round(tfl / peak_t, 5),
@@ -325,7 +343,7 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic',
-            'config': {'workload': (f'LED-Net {H}x{W} train_step (fwd+OHEM-CE+bwd+SGD) batch {bs}/GPU' if mode == 'train'
+            'config': {'backbone_flags': flags or None, 'workload': (f'LED-Net {H}x{W} train_step (fwd+OHEM-CE+bwd+SGD) batch {bs}/GPU' if mode == 'train'
                                     else f'LED-Net {H}x{W} inference (fwd+fusion+argmax) batch {bs}/GPU'),
                        'global_batch': bs * world, 'parallelism': f'dp{world}',
                        'ranks': world, 'images_per_rank_per_step': bs,

@@ -47,8 +47,11 @@ class LEDNet(Block):
         """The first seven arguments are the reference config's (cfg :24-30).  The rest are the choices of the
         reconstruction, each with the documented default:
           num_heads, window_size  GETB attention (prototype: dim 128, 8 heads, 8x8 windows, ddrnet_speed.py:81-83)
-          cespb_depth    SESP blocks cascaded per CESPB: int or (spatial branch, context branch); the paper gives no
-                         count (PDF p.17) -> 2.  The context branch needs >= 2 (growth and stride cannot share a block)
+          cespb_depth    SESP blocks cascaded per CESPB: int or (spatial branch, context branch).  The paper gives no
+                         count (PDF p.17); the survey's contract fixes the default at 2.  (2, 3) is the
+                         setting that reproduces the PUBLISHED PARAMETER COUNT: 1.6636 M against 1.661 M (+0.16 %;
+                         2 gives 1.534 M = 92.3 %, 3 gives 1.669 M: tests/count_complexity.py).
+                         The context branch needs >= 2 (growth and stride cannot share a block)
           context_tail   'getb' (default: 1x1 16C -> ppm_channels + GETB; PDF p.18 reports pooling pyramids hurt),
                          'pappm' or 'dappm' (utils/ppm.py: the DDRNet slot `ppm_channels` names, ddrnet.py:118-119)
           seam_mode      'percentile' (default, per-image seam_percentile: PDF section 4.2 eq.1) or 'fixed'

@@ -1,6 +1,14 @@
 """bf16 activation storage (MFMA conv engine active): whole network vs the fp32 CPU
-oracle.  Tolerances are bf16-level: activations are rounded to 8 significant bits
-after every layer (accumulation stays fp32)."""
+oracle.  Activations are rounded to 8 significant bits after every layer (accumulation,
+BatchNorm statistics, the logit pyramid and the loss stay fp32).
+
+STATED TOLERANCE of the bf16 path (the dtype of the headline bench), = measured on the MI355X
+(tools/measure_parity.py, 3 seeds x 2 x 512 x 512, r02w) with 2x headroom:
+  max |logit error|  <= 3.5 % of the logit scale (max |logit|)     measured 0.7-1.6 %
+  mean |logit error| <= 0.5 % of the logit scale                   measured 0.16-0.24 %
+  argmax: no disagreement where the oracle's class margin exceeds 5 % of the scale (measured 0),
+          <= 1e-4 of the pixels where it exceeds 1 % (measured <= 1.9e-5); every flip lies within
+          2 x max |logit error| of a tie.  (f32 activations: masks bit-exact, tests/test_parity_argmax.py.)"""
 import os
 
 import pytest
@@ -46,10 +54,12 @@ def test_predict_bf16_vs_oracle(be):
     mask = torch.cat([o.pred_sem_seg.data for o in out]).long().cpu()
     scale = want.abs().max().item()
     err = (logits - want).abs()
-    assert err.max().item() < 0.08 * scale and err.mean().item() < 0.01 * scale, (err.max().item(), err.mean().item(), scale)
+    assert err.max().item() < 0.035 * scale and err.mean().item() < 0.005 * scale, (err.max().item(), err.mean().item(), scale)
     margin = (want[:, 0] - want[:, 1]).abs()
-    disagree = ((mask != want_mask) & (margin > 0.1 * scale)).float().mean().item()
-    assert disagree < 1e-3, disagree
+    flips = mask != want_mask
+    assert (flips & (margin > 0.05 * scale)).sum().item() == 0
+    assert (flips & (margin > 0.01 * scale)).float().mean().item() <= 1e-4
+    assert (flips & (margin > 2 * err.max())).sum().item() == 0
 
 
 def test_train_step_bf16_vs_oracle(be):

@@ -182,9 +182,11 @@ def test_rccl_in_graph_single_rank():
         c['min_kept'] = 5000
     base = L.MODELS.build(cfg['model'])
     g = torch.Generator().manual_seed(3)
-    img = torch.randint(0, 256, (2, 3, 320, 320), dtype=torch.uint8, generator=g).to(dev)
-    lab = torch.randint(0, 2, (2, 1, 320, 320), dtype=torch.int64, generator=g).to(dev)
-    samples = [L.SegDataSample(gt=lab[i]) for i in range(2)]
+    # (4 images: MFAF's global-pool BatchNorm then sees 4 values per channel; with 2 it is xhat = +-1 and its
+    #  gradient is pure rounding noise that the rest of this chaotic random-init step amplifies)
+    img = torch.randint(0, 256, (4, 3, 320, 320), dtype=torch.uint8, generator=g).to(dev)
+    lab = torch.randint(0, 2, (4, 1, 320, 320), dtype=torch.int64, generator=g).to(dev)
+    samples = [L.SegDataSample(gt=lab[i]) for i in range(4)]
     init = {k: v.detach().float().clone() for k, v in base.state_dict().items()}
     res = []
     for mode in (None, 'rccl'):

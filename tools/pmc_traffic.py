@@ -11,8 +11,13 @@ they do not fit one pass -- MI355X_MICROARCH.md "rocprofv3 PMC slots"), each wit
     64 bytes: it is doubled here (every hot kernel reads 16 B per lane);
   * WRITE_SIZE is exact for 16 B/lane stores and float atomics.
 Kernel names are reduced to the function name (template arguments and the ledn:: namespace
-dropped), the way bench.py names them.  A third pass collects SQ_VALU_MFMA_BUSY_CYCLES and
-SQ_BUSY_CYCLES (MFMA-busy fraction of the same kernels).
+dropped), the way bench.py names them.  A third pass collects SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE:
+  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (N_SIMD x kernel cycles), a fraction in [0, 1] of the matrix-core
+  issue capacity: the counter advances 32 cycles per v_mfma_f32_32x32x16_bf16 on the SIMD that issues it and is
+  summed over the chip's 256 CUs x 4 SIMDs (MI355X_MICROARCH.md, cycle-constants table); kernel cycles =
+  GRBM_GUI_ACTIVE / 8 XCDs when that yields a plausible shader clock (1.0-2.6 GHz against the dispatch's
+  timestamps), else duration x 2.4 GHz.  (Round 1 divided by SQ_BUSY_CYCLES, which is counted per shader
+  engine, and reported "fractions" of 4.8.)
 
 This process never touches the GPU itself: it starts rocprofv3 (with the program directly after
 `--`) as a child and parses the CSV it leaves.
@@ -27,6 +32,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_SIMD, N_XCD, NOMINAL_GHZ = 256 * 4, 8, 2.4      # MI355X: 256 CUs x 4 SIMDs in 8 XCDs
 
 
 def base_name(k):
@@ -63,7 +69,13 @@ def run_pass(counters, outdir, bench_args):
                 a = acc.setdefault(k, {})
                 c = a.setdefault(row['Counter_Name'], [0.0, set()])
                 c[0] += float(row['Counter_Value'])
-                c[1].add(row.get('Dispatch_Id') or row.get('Correlation_Id'))
+                did = row.get('Dispatch_Id') or row.get('Correlation_Id')
+                c[1].add(did)
+                if row.get('Start_Timestamp') and row.get('End_Timestamp'):
+                    d = a.setdefault('__ns__', [0.0, set()])
+                    if did not in d[1]:
+                        d[0] += float(row['End_Timestamp']) - float(row['Start_Timestamp'])
+                        d[1].add(did)
     return {k: {c: (v[0], len(v[1])) for c, v in a.items()} for k, a in acc.items()}
 
 
@@ -83,7 +95,7 @@ def main():
     busy = {}
     if not args.no_mfma_pass:
         try:
-            busy = run_pass(['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'],
+            busy = run_pass(['SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'],
                             os.path.join(args.scratch, tag, 'mfma'), bench_args)
         except SystemExit as e:      # optional evidence; the traffic passes are the required ones
             print(f'[pmc] MFMA-busy pass skipped: {e}', flush=True)
@@ -102,10 +114,19 @@ def main():
         if b and 'SQ_VALU_MFMA_BUSY_CYCLES' in b:
             mf = b['SQ_VALU_MFMA_BUSY_CYCLES'][0]
             rec['sq_valu_mfma_busy_cycles_per_launch'] = round(mf / max(1, b['SQ_VALU_MFMA_BUSY_CYCLES'][1]), 1)
-            if 'SQ_BUSY_CYCLES' in b and b['SQ_BUSY_CYCLES'][0] > 0:
-                rec['mfma_busy_over_sq_busy'] = round(mf / b['SQ_BUSY_CYCLES'][0], 5)
-            if 'GRBM_GUI_ACTIVE' in b and b['GRBM_GUI_ACTIVE'][0] > 0:
-                rec['grbm_gui_active_per_launch'] = round(b['GRBM_GUI_ACTIVE'][0] / max(1, b['GRBM_GUI_ACTIVE'][1]), 1)
+            ns = b.get('__ns__', (0.0, 0))[0]
+            gui = b.get('GRBM_GUI_ACTIVE', (0.0, 0))[0]
+            cycles, how = None, None
+            if gui > 0 and ns > 0 and 1.0 <= gui / N_XCD / ns <= 2.6:
+                cycles, how = gui / N_XCD, 'GRBM_GUI_ACTIVE / 8 XCDs'
+            elif ns > 0:
+                cycles, how = ns * NOMINAL_GHZ, f'dispatch duration x {NOMINAL_GHZ} GHz'
+            elif gui > 0:
+                cycles, how = gui / N_XCD, 'GRBM_GUI_ACTIVE / 8 XCDs (no timestamps)'
+            if cycles:
+                rec['kernel_cycles_per_launch'] = round(cycles / max(1, b['SQ_VALU_MFMA_BUSY_CYCLES'][1]), 1)
+                rec['mfma_busy_frac'] = round(min(1.0, mf / (N_SIMD * cycles)), 5)
+                rec['mfma_busy_cycles_from'] = how
         kernels[k] = rec
     out = dict(command='bench.py ' + ' '.join(bench_args),
                corrections='FETCH_SIZE (KiB) x1024 x2 [gfx950 wide-read undercount]; WRITE_SIZE (KiB) x1024',
@@ -118,7 +139,7 @@ def main():
     for k, r in top:
         print(f"{k:40s} x{r['launches']:4d}  rd {r['hbm_read_bytes_per_launch'] / 1e6:9.2f} MB  "
               f"wr {r['hbm_write_bytes_per_launch'] / 1e6:9.2f} MB  "
-              f"mfma/sq {r.get('mfma_busy_over_sq_busy', float('nan')):.4f}", flush=True)
+              f"mfma busy {r.get('mfma_busy_frac', float('nan')):.4f}", flush=True)
     print(f'[pmc] wrote {path}', flush=True)
 
 

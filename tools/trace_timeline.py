@@ -95,3 +95,16 @@ print('--- by launch shape: ms/step, launches/step, avg us, avg start-to-next-st
 for key, v in sorted(shape_t.items(), key=lambda kv: -kv[1])[:int(sys.argv[2]) if len(sys.argv) > 2 else 70]:
     n_ = shape_n[key]
     print(f'{v / nsteps / 1e6:8.3f}  x{n_ / nsteps:6.1f}  {v / n_ / 1e3:8.1f}  {shape_i[key] / n_ / 1e3:8.1f}  {key[0]} {key[1]}')
+
+# ---- what follows the kernels with the largest trailing gaps (gap = next start - this end, >= 5 us)
+follow = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+for i, (s0, e0, k, g) in enumerate(seg[:-1]):
+    gap = seg[i + 1][0] - e0
+    if gap >= 5000:
+        f = follow[(k, g)][seg[i + 1][2]]
+        f[0] += 1
+        f[1] += gap
+print('--- trailing gaps >= 5 us: kernel (grid) -> next kernel: count/step, mean gap us')
+for key, nxt in sorted(follow.items(), key=lambda kv: -sum(v[1] for v in kv[1].values()))[:12]:
+    for nk, (c, tot_gap) in sorted(nxt.items(), key=lambda kv: -kv[1][1])[:3]:
+        print(f'  {key[0]} {key[1]} -> {nk}: {c / nsteps:.1f}/step, {tot_gap / c / 1e3:.1f} us')
