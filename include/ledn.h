@@ -308,6 +308,13 @@ int ledn_avgpool2d_bwd(const void* dy, void* dx, int N, int H, int W, int C, int
  *   gathered by the host from the (2ws-1)^2 x heads table (:181-187). */
 int ledn_window_attn(const void* qkv, const float* biasT, void* out, int N, int H, int W, int C,
                      int heads, int ws, int dtype, void* stream);
+/* The relative-position bias operand of ledn_window_attn from the module's parameters
+ * (UNetFormer_GETB.py:181-187): biasT[h][j][i] = table[index[i*T + j]][h]; table [R = (2ws-1)^2][heads] f32,
+ * index [T*T] int64 (the module's registered buffer), T = ws*ws.  _bwd: dtable[r][h] += sum of dbiasT over the
+ * token pairs that index row r (gather form, deterministic).  Replaces the host-side index / index_put chain. */
+int ledn_relpos_bias(const float* table, const long long* index, float* biasT, int R, int heads, int T, void* stream);
+int ledn_relpos_bias_bwd(const float* dbiasT, const long long* index, float* dtable, int R, int heads, int T,
+                         void* stream);
 /* out = avgpool_(ws,1)(reflect-pad-bottom(a)) + avgpool_(1,ws)(reflect-pad-right(a)) + local
  * (:197-199); a, local, out: [N,H,W,C]. */
 int ledn_getb_pool(const void* a, const void* local, void* out, int N, int H, int W, int C, int ws,
@@ -389,6 +396,11 @@ typedef struct {
     long long P;
     int C, act, res_mode, bn_mode;
     int dtype_z, dtype_y;
+    /* apply pass, optional: partial gradients already computed for the SAME tensors by another consumer of z / res
+     * (a tensor with several consumers in the forward): dz += dz_add (dtype_z), dres += dres_add (dtype_y).  Replaces
+     * the separate elementwise add of autograd's gradient fan-in. */
+    const void* dz_add;
+    const void* dres_add;
 } ledn_bnbwd_desc;
 int ledn_bn_act_bwd_reduce(const ledn_bnbwd_desc* d, void* stream);
 int ledn_bn_act_bwd_apply(const ledn_bnbwd_desc* d, void* stream);

@@ -83,7 +83,7 @@ class BnBwdDesc(C.Structure):
                 ('mean', fp), ('invstd', fp), ('sum_g', fp), ('sum_gx', fp), ('dslope', fp),
                 ('dz', vp), ('dres', vp), ('count', C.c_double), ('P', i64),
                 ('C', i32), ('act', i32), ('res_mode', i32), ('bn_mode', i32),
-                ('dtype_z', i32), ('dtype_y', i32)]
+                ('dtype_z', i32), ('dtype_y', i32), ('dz_add', vp), ('dres_add', vp)]
 
 
 class DwBwdDesc(C.Structure):
@@ -156,6 +156,8 @@ _PROTOS = {
     'ledn_nchw_to_nhwc': ([vp, i32, vp, i32, i32, i32, i32, i32, fp, fp, vp, vp, C.c_float, vp], i32),
     'ledn_bilinear': ([C.POINTER(ResizeDesc), vp], i32),
     'ledn_adaptive_avgpool': ([vp, vp, fp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ledn_relpos_bias': ([fp, vp, fp, i32, i32, i32, vp], i32),
+    'ledn_relpos_bias_bwd': ([fp, vp, fp, i32, i32, i32, vp], i32),
     'ledn_avgpool2d': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_avgpool2d_bwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_avgpool3x3s2': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),

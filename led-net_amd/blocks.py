@@ -323,9 +323,7 @@ class _GLA(Block):
 
     def bias_t(self):
         """[heads][key j][query i] relative-position bias (:181-187)."""
-        t2 = self.relative_position_index.shape[0]
-        b = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(t2, t2, -1)
-        return b.permute(2, 1, 0).contiguous()
+        return ops.relpos_bias(self.relative_position_bias_table.detach(), self.relative_position_index)
 
 
 class _Mlp(nn.Module):

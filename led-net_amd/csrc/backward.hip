@@ -159,8 +159,22 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(ledn_bnbwd_desc d) {
 #pragma unroll
         for (int i = 0; i < V; ++i)
             dz[i] = d.bn_mode ? prm.sc[i] * (gv[i] - mg[i] - xh[i] * mgx[i]) : gv[i] * prm.sc[i];
+        if (d.dz_add) {
+            float a[V];
+            ldv<V>(reinterpret_cast<const TZ*>(d.dz_add) + off, a);
+#pragma unroll
+            for (int i = 0; i < V; ++i) dz[i] += a[i];
+        }
         stv<V>(reinterpret_cast<TZ*>(d.dz) + off, dz);
-        if (d.dres) stv<V>(reinterpret_cast<TY*>(d.dres) + off, gres);
+        if (d.dres) {
+            if (d.dres_add) {
+                float a[V];
+                ldv<V>(reinterpret_cast<const TY*>(d.dres_add) + off, a);
+#pragma unroll
+                for (int i = 0; i < V; ++i) gres[i] += a[i];
+            }
+            stv<V>(reinterpret_cast<TY*>(d.dres) + off, gres);
+        }
     }
 }
 
@@ -170,7 +184,7 @@ static int bnbwd_validate(const ledn_bnbwd_desc& d, bool apply) {
     LEDN_REQUIRE(d.res_mode == LEDN_RES_NONE || d.res != nullptr);
     LEDN_REQUIRE(d.act != LEDN_ACT_PRELU || d.slope != nullptr);
     LEDN_REQUIRE(!d.bn_mode || (d.mean && d.invstd && d.scale && d.sum_g && d.sum_gx && d.count > 0));
-    if (apply) LEDN_REQUIRE(d.dz != nullptr);
+    if (apply) LEDN_REQUIRE(d.dz != nullptr && (d.dres_add == nullptr || d.dres != nullptr));
     else LEDN_REQUIRE(d.sum_g != nullptr);
     const int V = d.C % 4 == 0 ? 4 : 1;
     LEDN_REQUIRE(d.C / V <= 256);

@@ -45,6 +45,9 @@ int avgpool2d_impl(const void* x, void* y, int N, int H, int W, int C, int Ho, i
                    int dtype, hipStream_t s);
 int avgpool2d_bwd_impl(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int k, int st, int pad,
                        int dtype, hipStream_t s);
+int relpos_bias_impl(const float* table, const long long* index, float* out, int R, int heads, int T, hipStream_t s);
+int relpos_bias_bwd_impl(const float* dbias, const long long* index, float* dtable, int R, int heads, int T,
+                         hipStream_t s);
 int adaptive_avgpool_impl(const void* x, const void* xadd, float* y, int N, int H, int W, int C, int S,
                           int dtype, hipStream_t s);
 int avgpool3x3s2_impl(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int dtype,
@@ -246,6 +249,13 @@ int ledn_avgpool2d(const void* x, void* y, int N, int H, int W, int C, int Ho, i
 int ledn_avgpool2d_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int k, int stride,
                        int pad, int dtype, void* stream) {
     return avgpool2d_bwd_impl(dy, dx, N, H, W, C, Ho, Wo, k, stride, pad, dtype, S(stream));
+}
+int ledn_relpos_bias(const float* table, const long long* index, float* biasT, int R, int heads, int T, void* stream) {
+    return relpos_bias_impl(table, index, biasT, R, heads, T, S(stream));
+}
+int ledn_relpos_bias_bwd(const float* dbiasT, const long long* index, float* dtable, int R, int heads, int T,
+                         void* stream) {
+    return relpos_bias_bwd_impl(dbiasT, index, dtable, R, heads, T, S(stream));
 }
 int ledn_bilinear(const ledn_resize_desc* d, void* stream) { return d ? bilinear_impl(*d, S(stream)) : LEDN_EINVAL; }
 int ledn_adaptive_avgpool(const void* x, const void* xadd, float* y, int N, int H, int W, int C, int Sz,

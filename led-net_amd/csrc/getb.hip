@@ -283,4 +283,55 @@ int getb_pool_impl(const void* a, const void* local, void* out, int N, int H, in
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------
+// relative-position bias of the window attention (UNetFormer_GETB.py:181-187):
+//   biasT[h][j][i] = table[index[i*T + j]][h]      (T = ws*ws tokens, table: (2ws-1)^2 x heads)
+// and its adjoint in gather form (deterministic, no atomics): workgroup r sums dbiasT over the
+// token pairs that index table row r.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) relpos_bias_kernel(const float* table, const long long* index, float* out,
+                                                          int R, int heads, int T) {
+    const long total = (long)heads * T * T;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int i = (int)(idx % T), j = (int)((idx / T) % T), h = (int)(idx / ((long)T * T));
+    const long long r = index[(long)i * T + j];
+    out[idx] = (r >= 0 && r < R) ? table[r * heads + h] : 0.f;
+}
+
+__global__ void __launch_bounds__(256) relpos_bias_bwd_kernel(const float* dbias, const long long* index, float* dtable,
+                                                              int R, int heads, int T) {
+    __shared__ float s_red[256];
+    const int r = blockIdx.x;
+    for (int h = 0; h < heads; ++h) {
+        float acc = 0.f;
+        for (int e = threadIdx.x; e < T * T; e += 256) {
+            const int i = e / T, j = e % T;
+            if (index[e] == r) acc += dbias[((long)h * T + j) * T + i];
+        }
+        s_red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int st = 128; st >= 1; st >>= 1) {
+            if ((int)threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) dtable[(long)r * heads + h] += s_red[0];
+        __syncthreads();
+    }
+}
+
+int relpos_bias_impl(const float* table, const long long* index, float* out, int R, int heads, int T, hipStream_t s) {
+    LEDN_REQUIRE(table && index && out && R > 0 && heads > 0 && T > 0);
+    LEDN_LAUNCH(relpos_bias_kernel, dim3((unsigned)cdiv((long)heads * T * T, 256)), dim3(256), 0, s, table, index, out,
+                R, heads, T);
+    return check_launch();
+}
+
+int relpos_bias_bwd_impl(const float* dbias, const long long* index, float* dtable, int R, int heads, int T,
+                         hipStream_t s) {
+    LEDN_REQUIRE(dbias && index && dtable && R > 0 && heads > 0 && T > 0);
+    LEDN_LAUNCH(relpos_bias_bwd_kernel, dim3((unsigned)R), dim3(256), 0, s, dbias, index, dtable, R, heads, T);
+    return check_launch();
+}
+
 }  // namespace ledn

@@ -154,7 +154,7 @@ __device__ __forceinline__ void bn_g8(const float* z, const float* dy, const flo
     }
 }
 
-template <int ACT, int RES, bool HAS_DRES, int UNR>
+template <int ACT, int RES, bool HAS_DRES, bool HAS_ADD, int UNR>
 __global__ void __launch_bounds__(256) bn_apply_fast_kernel(ledn_bnbwd_desc d, long nvec) {
     __shared__ float s_par[5][SF_MAXC];     // sc, sh, sl, A, B
     const float invn = (float)(1.0 / d.count);
@@ -184,7 +184,9 @@ __global__ void __launch_bounds__(256) bn_apply_fast_kernel(ledn_bnbwd_desc d, l
         B[k] = s_par[4][c0 + k];
     }
     const long base = (long)blockIdx.x * (256 * UNR) + threadIdx.x;
-    uint4 zr[UNR], gr[UNR], rr[UNR];
+    uint4 zr[UNR], gr[UNR], rr[UNR], az[UNR], ar[UNR];
+    // HAS_ADD: partial gradients of z / res from another consumer of the same forward tensor (fan-in folded in)
+    const bool add_z = HAS_ADD && d.dz_add != nullptr, add_r = HAS_ADD && HAS_DRES && d.dres_add != nullptr;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
         const long i = base + u * 256;
@@ -192,6 +194,10 @@ __global__ void __launch_bounds__(256) bn_apply_fast_kernel(ledn_bnbwd_desc d, l
         zr[u] = ldraw(d.z, j);
         gr[u] = ldraw(d.dy, j);
         if (RES != LEDN_RES_NONE) rr[u] = ldraw(d.res, j);
+        if (HAS_ADD) {
+            if (add_z) az[u] = ldraw(d.dz_add, j);
+            if (add_r) ar[u] = ldraw(d.dres_add, j);
+        }
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -206,6 +212,20 @@ __global__ void __launch_bounds__(256) bn_apply_fast_kernel(ledn_bnbwd_desc d, l
         float dz[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) dz[k] = fmaf(sc[k], g.gv[k], fmaf(A[k], z[k], B[k]));
+        if (HAS_ADD) {
+            if (add_z) {
+                float a[8];
+                unpack8(az[u], a);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dz[k] += a[k];
+            }
+            if (add_r) {
+                float a[8];
+                unpack8(ar[u], a);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g.gres[k] += a[k];
+            }
+        }
         st8(reinterpret_cast<bf16_t*>(d.dz) + i * 8, dz);
         if (HAS_DRES) st8(reinterpret_cast<bf16_t*>(d.dres) + i * 8, g.gres);
     }
@@ -219,12 +239,21 @@ int bn_act_bwd_apply_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
     if (has_dres && d.res_mode == LEDN_RES_NONE) return -1;
     constexpr int UNR = 4;
     const dim3 grid((unsigned)cdiv(nvec, 256 * UNR));
-    if (has_dres) {
+    const bool has_add = d.dz_add != nullptr || d.dres_add != nullptr;
+    if (has_add) {      // (one instance per (act, res) with both optional adds resolved at run time: workgroup-uniform)
+        if (has_dres) {
+            SF_ACT_SWITCH(d.act, SF_RES_SWITCH(d.res_mode,
+                LEDN_LAUNCH((bn_apply_fast_kernel<A_, R_, R_ != LEDN_RES_NONE, true, UNR>), grid, dim3(256), 0, s, d, nvec)));
+        } else {
+            SF_ACT_SWITCH(d.act, SF_RES_SWITCH(d.res_mode,
+                LEDN_LAUNCH((bn_apply_fast_kernel<A_, R_, false, true, UNR>), grid, dim3(256), 0, s, d, nvec)));
+        }
+    } else if (has_dres) {
         SF_ACT_SWITCH(d.act, SF_RES_SWITCH(d.res_mode,
-            LEDN_LAUNCH((bn_apply_fast_kernel<A_, R_, R_ != LEDN_RES_NONE, UNR>), grid, dim3(256), 0, s, d, nvec)));
+            LEDN_LAUNCH((bn_apply_fast_kernel<A_, R_, R_ != LEDN_RES_NONE, false, UNR>), grid, dim3(256), 0, s, d, nvec)));
     } else {
         SF_ACT_SWITCH(d.act, SF_RES_SWITCH(d.res_mode,
-            LEDN_LAUNCH((bn_apply_fast_kernel<A_, R_, false, UNR>), grid, dim3(256), 0, s, d, nvec)));
+            LEDN_LAUNCH((bn_apply_fast_kernel<A_, R_, false, false, UNR>), grid, dim3(256), 0, s, d, nvec)));
     }
     return check_launch();
 }

@@ -599,6 +599,31 @@ def window_attn(qkv, biasT, heads, ws=8):
     return out
 
 
+def relpos_bias(table, index):
+    """[heads][key j][query i] relative-position bias from the (2ws-1)^2 x heads table and the module's index buffer."""
+    lib = _lib.get_lib()
+    R, heads = table.shape
+    T = index.shape[0]
+    if index.dtype != torch.int64 or tuple(index.shape) != (T, T):
+        raise LednError('relpos_bias: index must be the int64 [T,T] relative_position_index buffer')
+    out = torch.empty((heads, T, T), dtype=torch.float32, device=table.device)
+    _check(lib, table, index, out)
+    _run(lib, 'ledn_relpos_bias', table, _p(_f32(table)), _p(index), _p(out), R, heads, T,
+         work=_TIMING is not None and (f'relpos_bias h{heads} T{T}', _nb(out), 0))
+    return out
+
+
+def relpos_bias_bwd(dbias, index, dtable):
+    """dtable [R,heads] (f32, accumulated into) += adjoint of relpos_bias"""
+    lib = _lib.get_lib()
+    R, heads = dtable.shape
+    T = index.shape[0]
+    _check(lib, dbias, index, dtable)
+    _run(lib, 'ledn_relpos_bias_bwd', dbias, _p(_f32(dbias, heads * T * T)), _p(index), _p(_f32(dtable)), R, heads, T,
+         work=_TIMING is not None and (f'relpos_bias_bwd h{heads} T{T}', _nb(dbias), 0))
+    return dtable
+
+
 def getb_pool(a, local, ws=8):
     lib = _lib.get_lib()
     N, H, W, Cc = a.shape

@@ -16,7 +16,8 @@ class _BnBwd:
 
 
 def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
-                      res=None, res_mode=RES_NONE, count=None, want_dres=False, sinks=None, sync=False):
+                      res=None, res_mode=RES_NONE, count=None, want_dres=False, sinks=None, sync=False,
+                      dz_add=None, dres_add=None):
     """First half of bn_act_bwd: the per-channel sums (sum g*xhat, sum g) of THIS rank's shard, reduced
     into the parameter-gradient sinks when given (they ARE d_gamma, d_beta of the local shard -- under
     SyncBN too: torch.nn.SyncBatchNorm keeps grad_weight / grad_bias local, DDP averages them later),
@@ -46,8 +47,13 @@ def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, 
             dslope = _ops.zeros_f32(Cc, z.device)
     dz = torch.empty_like(z)
     dres = torch.empty_like(dy) if (want_dres and res_mode != RES_NONE) else None
-    _check(lib, z, dy, res, scale, shift, slope, mean, invstd, sum_g, sum_gx, dslope)
+    if dz_add is not None and (dz_add.shape != z.shape or dz_add.dtype != z.dtype):
+        raise LednError('bn_act_bwd: dz_add must match z')
+    if dres_add is not None and (dres is None or dres_add.shape != dres.shape or dres_add.dtype != dres.dtype):
+        raise LednError('bn_act_bwd: dres_add needs want_dres and must match the residual gradient')
+    _check(lib, z, dy, res, scale, shift, slope, mean, invstd, sum_g, sum_gx, dslope, dz_add, dres_add)
     d.z, d.res, d.dy = _p(z), _p(res), _p(dy)
+    d.dz_add, d.dres_add = _p(dz_add), _p(dres_add)
     d.scale, d.shift, d.slope = _p(_f32(scale, Cc)), _p(_f32(shift, Cc)), _p(_f32(slope, Cc))
     d.mean, d.invstd = _p(_f32(mean, Cc)), _p(_f32(invstd, Cc))
     d.sum_g, d.sum_gx = sum_g.data_ptr(), sum_gx.data_ptr()
@@ -60,7 +66,7 @@ def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, 
         _run(lib, 'ledn_bn_act_bwd_reduce', z, d, work=_ops._TIMING is not None and (f'bnbwd_reduce C{Cc} P{P}', _nb(z, dy, res), 6 * z.numel()))
     st.lib, st.d, st.z, st.bn, st.Cc, st.P, st.local, st.sunk = lib, d, z, bn, Cc, P, local, sunk
     st.dz, st.dres, st.dslope, st.slope_sunk = dz, dres, dslope, slope_sunk
-    st.keep = (dy, res, scale, shift, slope, mean, invstd, sum_g, sum_gx, sk_g, sk_b)
+    st.keep = (dy, res, scale, shift, slope, mean, invstd, sum_g, sum_gx, sk_g, sk_b, dz_add, dres_add)
     return st
 
 
@@ -89,17 +95,19 @@ def bn_act_bwd_apply(st):
 
 
 def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
-               res=None, res_mode=RES_NONE, count=None, want_dres=False, sync=None, sinks=None):
+               res=None, res_mode=RES_NONE, count=None, want_dres=False, sync=None, sinks=None, dz_add=None,
+               dres_add=None):
     """Backward of y = act(res_mode(z*scale+shift, res)).
     BN mode (mean/invstd given): returns (dz, dres, dgamma, dbeta, dslope).
     Plain mode: returns (dz, dres, None, None, dslope).
     sync: optional collective object (train._Collective) all-reducing the [2,C] (sum_gx, sum_g) sums (SyncBN);
     the returned / sunk dgamma, dbeta are always the LOCAL sums (DDP semantics).
+    dz_add / dres_add: partial gradients of z / res from another consumer of the same tensor, added in the apply pass.
     sinks: optional (dgamma, dbeta, dslope) ZEROED f32 [C] buffers (any may be None) the kernels
     reduce straight into (the trainer's gradient views); the matching return value is then None."""
     st = bn_act_bwd_reduce(z, dy, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, slope=slope,
                            res=res, res_mode=res_mode, count=count, want_dres=want_dres, sinks=sinks,
-                           sync=sync is not None)
+                           sync=sync is not None, dz_add=dz_add, dres_add=dres_add)
     bn_act_bwd_sync(st, sync)
     return bn_act_bwd_apply(st)
 

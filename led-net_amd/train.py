@@ -26,6 +26,7 @@ class _Env:
     """Process-wide training environment (SyncBN collective, world size)."""
     sync_bn = None      # _Collective (all_reduce(src, dst), group(ref)) or None
     world = 1
+    head_acc = {}       # gradient fan-in accumulators (_Acc) of the stem tensors LEDHead reads: {'x1': .., 'x2': ..}
     grad_ready = None   # callable(tag) fired from the backward by GradReadyFn, or None
 
 
@@ -62,6 +63,78 @@ class _Collective:
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+class _Acc:
+    """Gradient fan-in without elementwise adds.  A forward tensor with k consumers is handed out as k aliases
+    (FanoutFn).  In the backward each consumer's kernel that can take an addend (data gradient of a convolution:
+    epilogue `res`; BatchNorm backward apply: dz_add / dres_add; average-pool adjoint: add) adds the partial
+    gradient left by the consumers that ran before it and leaves the new partial sum here; FanoutFn.backward
+    returns the last one.  Consumers on another stream, or whose kernel has no addend, simply return their own
+    gradient and are summed the old way.  The _Acc object is handed to the consumers explicitly (`acc=`)."""
+
+    counters = {'chained': 0, 'added': 0}     # diagnostics: fan-ins folded into a kernel / summed by an elementwise add
+
+    def __init__(self):
+        self.buf, self.stream, self.included, self.keep = None, None, set(), []
+
+    @staticmethod
+    def _stream(t):
+        return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+    def take(self, like):
+        """the partial sum so far if the chain can continue on the current stream, else None"""
+        if self.buf is None or self.stream != _Acc._stream(like) or self.buf.shape != like.shape \
+                or self.buf.dtype != like.dtype:
+            return None
+        return self.buf
+
+    def put(self, t, chained):
+        """t: this consumer's output (with the previous partial folded in when `chained`)"""
+        if chained or self.buf is None:
+            self.buf, self.stream = t, _Acc._stream(t)
+            self.included.add(t.data_ptr())
+            self.keep.append(t)      # (alive until FanoutFn.backward: its address must not be reused meanwhile)
+
+
+def _take(acc, like):
+    return acc.take(like) if acc is not None else None
+
+
+class FanoutFn(Function):
+    """x -> k aliases of x, one per consumer (see _Acc)."""
+
+    @staticmethod
+    def forward(ctx, x, k, acc):
+        ctx.acc = acc
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        acc = ctx.acc
+        total = acc.buf
+        for g in gs:
+            if g is None:
+                continue
+            if total is not None and g.data_ptr() in acc.included:
+                _Acc.counters['chained'] += g.data_ptr() != total.data_ptr()
+                continue
+            if total is not None:
+                _Acc.counters['added'] += 1
+            total = g if total is None else total + g        # (consumer outside the chain: other stream / no addend)
+        acc.buf, acc.keep = None, []
+        return total, None, None
+
+
+FANIN_CHAIN = bool(int(_os.environ.get('LEDN_FANIN_CHAIN', '1')))
+
+
+def fanout(x, k):
+    """-> (k aliases of x, the _Acc their consumers share -- or None: plain autograd fan-in)"""
+    if not (FANIN_CHAIN and x.requires_grad and k > 1):
+        return (x,) * k, None
+    acc = _Acc()
+    return FanoutFn.apply(x, k, acc), acc
 
 
 class _Packs:
@@ -111,7 +184,7 @@ class ConvFn(Function):
     into `stats` ([2,Cout] f32, zeroed by the caller) by the kernel's epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, b, xadd, stride, pad, groups, stats, out_dtype, defer=False):
+    def forward(ctx, x, w, b, xadd, stride, pad, groups, stats, out_dtype, defer=False, acc=None):
         st = (stats[0], stats[1]) if stats is not None else None
         wp = None
         if (xadd is None and x.dtype == torch.bfloat16 and ops.mfma_weight_ok(w, groups)
@@ -123,6 +196,7 @@ class ConvFn(Function):
         ctx.save_for_backward(x, w, xadd)
         ctx.cfg = (stride, pad, groups, b is not None)
         ctx.sinks = (_Sinks.get(w), _Sinks.get(b))
+        ctx.acc = acc if xadd is None else None
         return z
 
     @staticmethod
@@ -135,10 +209,10 @@ class ConvFn(Function):
                              bias=has_b)
         dx = None
         if ctx.needs_input_grad[0] or (xadd is not None and ctx.needs_input_grad[3]):
-            dx = _conv_dgrad(dz, x, w, stride, pad, groups)
+            dx = _conv_dgrad(dz, x, w, stride, pad, groups, ctx.acc)
         return (dx if ctx.needs_input_grad[0] else None, None if sw is not None else dw,
                 None if sb is not None else db,
-                dx if (xadd is not None and ctx.needs_input_grad[3]) else None, None, None, None, None, None, None)
+                dx if (xadd is not None and ctx.needs_input_grad[3]) else None, None, None, None, None, None, None, None)
 
 
 class BNActFn(Function):
@@ -146,7 +220,7 @@ class BNActFn(Function):
     the producing kernel) or are reduced here; running stats updated in place."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, slope, res, stats, bn, act, res_mode, out_dtype):
+    def forward(ctx, z, gamma, beta, slope, res, stats, bn, act, res_mode, out_dtype, acc_res=None, acc_z=None):
         Cc = z.shape[-1]
         count = z.numel() // Cc
         if stats is None:
@@ -162,17 +236,27 @@ class BNActFn(Function):
         ctx.save_for_backward(z, res, scale, shift, mean, invstd, slope)
         ctx.cfg = (act, res_mode, count)
         ctx.sinks = (_Sinks.get(gamma), _Sinks.get(beta), _Sinks.get(slope))
+        ctx.acc_res = acc_res if res is not None else None
+        ctx.acc_z = acc_z
         return y
 
     @staticmethod
     def backward(ctx, dy):
         z, res, scale, shift, mean, invstd, slope = ctx.saved_tensors
         act, res_mode, count = ctx.cfg
+        dy = _c(dy)
+        want_dres = res is not None and ctx.needs_input_grad[4]
+        prev = _take(ctx.acc_res, dy) if want_dres else None
+        prev_z = _take(ctx.acc_z, z)
         dz, dres, dgamma, dbeta, dslope = T.bn_act_bwd(
-            z, _c(dy), scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, slope=slope, res=res,
-            res_mode=res_mode, count=count, want_dres=res is not None and ctx.needs_input_grad[4],
-            sync=_Env.sync_bn, sinks=ctx.sinks)
-        return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None
+            z, dy, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, slope=slope, res=res,
+            res_mode=res_mode, count=count, want_dres=want_dres, sync=_Env.sync_bn, sinks=ctx.sinks, dres_add=prev,
+            dz_add=prev_z)
+        if want_dres and ctx.acc_res is not None:
+            ctx.acc_res.put(dres, prev is not None)
+        if ctx.acc_z is not None:
+            ctx.acc_z.put(dz, prev_z is not None)
+        return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None, None, None
 
 
 WGRAD_SLOT = int(_os.environ.get('LEDN_WGRAD_SLOT', '0'))   # auxiliary stream of the weight gradients, 0 = launch stream (measured r02n: 782 img/s on its own stream vs 892 on the launch stream)
@@ -196,15 +280,23 @@ def _conv_wgrad(x, dz, w_shape, sw, sb, **kw):
     return ops.conv2d_wgrad(x, dz, w_shape, dw_out=sw, db_out=sb, **kw)
 
 
-def _conv_dgrad(dz, x, w, stride, pad, groups):
-    """data gradient of conv2d(x, w): MFMA path when the flipped pack applies (see ConvFn.backward)"""
+def _conv_dgrad(dz, x, w, stride, pad, groups, acc=None):
+    """data gradient of conv2d(x, w): MFMA path when the flipped pack applies (see ConvFn.backward).
+    acc: gradient fan-in of x (_Acc): the partial gradient of x's other consumers enters as the epilogue's residual."""
     wp = None
     cin_f = w.shape[1] * groups     # dgrad kernel: "Cin" = Cout_f (16-multiple), "Cout" = Cin_f
     if (dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and w.shape[0] % 16 == 0
             and (cin_f % 16 == 0 or cin_f <= 8) and ops.mfma_weight_ok(w, groups)):
         wp = get_pack(w, 1, groups)
-    return ops.conv2d(dz, w, stride=stride, pad=pad, groups=groups, transposed=True,
-                      out_hw=(x.shape[1], x.shape[2]), out_dtype=x.dtype, w_bf16=wp)
+    # (addend: the MFMA kernel's epilogue residual; f32 activations: the direct kernel's.  The narrow bf16 direct
+    #  kernels have no residual input -- their gradient joins the old way)
+    prev = _take(acc, x) if ((wp is not None and cin_f % 8 == 0) or x.dtype == torch.float32) else None
+    dx = ops.conv2d(dz, w, stride=stride, pad=pad, groups=groups, transposed=True,
+                    out_hw=(x.shape[1], x.shape[2]), out_dtype=x.dtype, w_bf16=wp, res=prev,
+                    res_mode=RES_ADD if prev is not None else RES_NONE)
+    if acc is not None:
+        acc.put(dx, prev is not None)
+    return dx
 
 
 class BNActConvFn(Function):
@@ -215,7 +307,7 @@ class BNActConvFn(Function):
     ACTS = (ACT_NONE, ACT_RELU, ACT_PRELU)
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, slope, w, b, stats_in, bn, act, stride, pad, groups, stats_out, out_dtype):
+    def forward(ctx, x, gamma, beta, slope, w, b, stats_in, bn, act, stride, pad, groups, stats_out, out_dtype, acc=None):
         Cc = x.shape[-1]
         count = x.numel() // Cc
         if stats_in is None:
@@ -236,6 +328,7 @@ class BNActConvFn(Function):
         ctx.save_for_backward(x, w, scale, shift, mean, invstd, slope)
         ctx.cfg = (act, count, stride, pad, groups, b is not None)
         ctx.sinks = (_Sinks.get(gamma), _Sinks.get(beta), _Sinks.get(slope), _Sinks.get(w), _Sinks.get(b))
+        ctx.acc = acc
         return z
 
     @staticmethod
@@ -247,11 +340,14 @@ class BNActConvFn(Function):
         dw, db = _conv_wgrad(x, dz, tuple(w.shape), sw, sbias, stride=stride, pad=pad, groups=groups, in_scale=scale,
                              in_shift=shift, in_act=act, in_slope=slope, bias=has_b)
         dy = _conv_dgrad(dz, x, w, stride, pad, groups)
+        prev = _take(ctx.acc, x)
         dx, _, dgamma, dbeta, dslope = T.bn_act_bwd(x, dy, scale=scale, shift=shift, mean=mean, invstd=invstd,
                                                      act=act, slope=slope, count=count, sync=_Env.sync_bn,
-                                                     sinks=(sg, sb_, ss))
+                                                     sinks=(sg, sb_, ss), dz_add=prev)
+        if ctx.acc is not None:
+            ctx.acc.put(dx, prev is not None)
         return (dx, dgamma, dbeta, dslope, None if sw is not None else dw, None if sbias is not None else db,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 # BNActConvFn where a BatchNorm(+act) output feeds exactly one convolution: 0 = off, 1 = the norm->act->conv
@@ -260,13 +356,15 @@ FUSE_BN_INTO_CONV = int(_os.environ.get('LEDN_FUSE_BN_CONV', '1'))   # measured:
 
 
 class ActFn(Function):
-    """y = act(x [+ xadd]) without normalisation (stage ReLUs, xa = x + r)."""
+    """y = act(x [+ xadd]) without normalisation (stage ReLUs, xa = x + r).  acc: gradient fan-in of x (_Acc)."""
 
     @staticmethod
-    def forward(ctx, x, xadd, act):
+    def forward(ctx, x, xadd, act, acc=None, acc_xadd=None):
         y = ops.affine_act(x, act=act, xadd=xadd)
         ctx.save_for_backward(x, xadd)
         ctx.act = act
+        ctx.acc = acc if (act != ACT_NONE and xadd is None) else None
+        ctx.acc_xadd = acc_xadd if xadd is not None else None
         return y
 
     @staticmethod
@@ -274,10 +372,15 @@ class ActFn(Function):
         x, xadd = ctx.saved_tensors
         dy = _c(dy)
         if ctx.act == ACT_NONE:
-            return dy, (dy if xadd is not None else None), None
+            if ctx.acc_xadd is not None:          # the shortcut's gradient IS dy: first partial of that tensor's fan-in
+                ctx.acc_xadd.put(dy, False)
+            return dy, (dy if xadd is not None else None), None, None, None
         assert xadd is None
-        dz, _, _, _, _ = T.bn_act_bwd(x, dy, act=ctx.act)
-        return dz, None, None
+        prev = _take(ctx.acc, x)
+        dz, _, _, _, _ = T.bn_act_bwd(x, dy, act=ctx.act, dz_add=prev)
+        if ctx.acc is not None:
+            ctx.acc.put(dz, prev is not None)
+        return dz, None, None, None, None
 
 
 class DwFn(Function):
@@ -360,13 +463,19 @@ class BilinearFn(Function):
 
 class AvgPoolFn(Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, acc=None):
         ctx.in_hw = (x.shape[1], x.shape[2])
+        ctx.acc = acc
+        ctx.like = x
         return ops.avgpool3x3s2(x)
 
     @staticmethod
     def backward(ctx, dy):
-        return T.avgpool3x3s2_bwd(_c(dy), ctx.in_hw)
+        prev = _take(ctx.acc, ctx.like)
+        dx = T.avgpool3x3s2_bwd(_c(dy), ctx.in_hw, add=prev)
+        if ctx.acc is not None:
+            ctx.acc.put(dx, prev is not None)
+        return dx, None
 
 
 class MultiPoolFn(Function):
@@ -399,16 +508,68 @@ class WindowAttnFn(Function):
         return dqkv, dbias, None, None
 
 
+class RelPosBiasFn(Function):
+    """table [(2ws-1)^2, heads] -> biasT [heads, T, T] (ledn_relpos_bias); backward straight into the gradient sink"""
+
+    @staticmethod
+    def forward(ctx, table, index):
+        ctx.save_for_backward(index)
+        ctx.shape = tuple(table.shape)
+        ctx.sink = _Sinks.get(table)
+        return ops.relpos_bias(table.detach(), index)
+
+    @staticmethod
+    def backward(ctx, dbias):
+        (index,) = ctx.saved_tensors
+        dt = ctx.sink if ctx.sink is not None else ops.zeros_f32(ctx.shape, dbias.device)
+        ops.relpos_bias_bwd(_c(dbias), index, dt)
+        return (None if ctx.sink is not None else dt), None
+
+
 class GetbPoolFn(Function):
     @staticmethod
-    def forward(ctx, a, local, ws):
+    def forward(ctx, a, local, ws, acc_local=None):
         ctx.ws = ws
+        ctx.acc_local = acc_local
         return ops.getb_pool(a, local, ws)
 
     @staticmethod
     def backward(ctx, dout):
         dout = _c(dout)
-        return T.getb_pool_bwd(dout, ctx.ws), dout, None
+        if ctx.acc_local is not None:             # d local = dout: first partial of n1's gradient fan-in
+            ctx.acc_local.put(dout, False)
+        return T.getb_pool_bwd(dout, ctx.ws), dout, None, None
+
+
+class MfafFrontFn(Function):
+    """xa = x + r and its adaptive average pools to 4x4, 8x8, 16x16, 1x1 (Muti_AFF, classification/model_utils.py:
+    402-423).  Backward: d xa = d(local branch) + the adjoint pools of the four context gradients, and because xa
+    = x + r the same tensor is the gradient of x and of r: ONE kernel (ledn_mfaf_bwd_combine) adds it IN PLACE
+    onto the partial gradients the gate kernel left for x and r (acc_x / acc_r, see _Acc) -- no separate
+    elementwise gradient adds."""
+
+    @staticmethod
+    def forward(ctx, x, r, acc_x, acc_r):
+        xa = ops.affine_act(x, act=ACT_NONE, xadd=r)
+        ctx.like = x.detach()
+        ctx.accs = (acc_x, acc_r)
+        return (xa,) + tuple(ops.adaptive_avgpool(xa, S) for S in MultiPoolFn.SIZES)
+
+    @staticmethod
+    def backward(ctx, dxl, *dps):
+        like = ctx.like
+        acc_x, acc_r = ctx.accs
+        dps = [_c(d) for d in dps]
+        dxl = _c(dxl) if dxl is not None else None
+        px, pr = _take(acc_x, like), _take(acc_r, like)
+        if px is not None and pr is not None and px.data_ptr() != pr.data_ptr():
+            T.mfaf_bwd_combine(px, pr, dxl, dps)          # px += dxa, pr += dxa
+            acc_x.put(px, True)
+            acc_r.put(pr, True)
+            return px, pr, None, None
+        dxa = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
+        T.mfaf_bwd_combine(dxa, None, dxl, dps)
+        return dxa, dxa, None, None
 
 
 def _bn_stats_group(raws, bns, gammas, betas, given=None):
@@ -485,8 +646,9 @@ class MfafTailFn(Function):
     Muti_AFF (classification/model_utils.py:377-400,425-428) in one kernel."""
 
     @staticmethod
-    def forward(ctx, x, r, xl, c1, c2, c3, xg, bns, out_relu, *gb):
+    def forward(ctx, x, r, xl, c1, c2, c3, xg, bns, out_relu, accs, *gb):
         raws = [xl, c1, c2, c3, xg]
+        ctx.accs = accs or (None, None)
         affs, saved = [], []
         if _Env.sync_bn is not None:
             fin, counts = _bn_stats_group(raws, bns, gb[0::2], gb[1::2])
@@ -525,7 +687,10 @@ class MfafTailFn(Function):
         for o in outs:
             draws.append(o[0])
             dgb += [o[2], o[3]]
-        return (dx, dr, *draws, None, None, *dgb)
+        for acc, g in zip(ctx.accs, (dx, dr)):       # first partial gradient of x / r (MfafFrontFn adds d xa onto it)
+            if acc is not None:
+                acc.put(g, False)
+        return (dx, dr, *draws, None, None, None, *dgb)
 
 
 class GradReadyFn(Function):
@@ -573,47 +738,54 @@ def _stats(c, ref):
     return ops.zeros_f32((2, c), ref.device)
 
 
-def relu(x):
-    return ActFn.apply(x, None, ACT_RELU)
+def relu(x, acc=None):
+    return ActFn.apply(x, None, ACT_RELU, acc)
 
 
-def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE, xadd=None, out_dtype=None):
+def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE, xadd=None, out_dtype=None,
+                acc=None, acc_res=None):
+    """acc / acc_res: gradient fan-in (_Acc) of x / res when they are aliases handed out by fanout()"""
     st = _stats(conv.out_channels, x) if bn is not None else None
     z = ConvFn.apply(x, conv.weight, conv.bias, xadd, conv.stride[0], conv.padding[0], conv.groups, st,
-                     out_dtype if bn is None else None, bn is not None)
+                     out_dtype if bn is None else None, bn is not None, acc)
     if bn is None:
         assert act == ACT_NONE and res is None
         return z
-    return BNActFn.apply(z, bn.weight, bn.bias, slope, res, st, bn, act, res_mode, out_dtype)
+    return BNActFn.apply(z, bn.weight, bn.bias, slope, res, st, bn, act, res_mode, out_dtype, acc_res)
 
 
-def bn_act(x, bn, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE, stats=None, out_dtype=None):
-    return BNActFn.apply(x, bn.weight, bn.bias, slope, res, stats, bn, act, res_mode, out_dtype)
+def bn_act(x, bn, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE, stats=None, out_dtype=None, acc_z=None):
+    return BNActFn.apply(x, bn.weight, bn.bias, slope, res, stats, bn, act, res_mode, out_dtype, None, acc_z)
 
 
 _ACT = {None: ACT_NONE, 'relu': ACT_RELU, 'relu6': ACT_RELU6}
 
 
-def conv_module(m, x, act_override=None, res=None, res_mode=RES_NONE, out_dtype=None):
-    """blocks.ConvModule in training mode."""
+def conv_module(m, x, act_override=None, res=None, res_mode=RES_NONE, out_dtype=None, acc=None, acc_res=None):
+    """blocks.ConvModule in training mode (acc / acc_res: see conv_bn_act)."""
     act = _ACT[m.act] if act_override is None else act_override
     if m.norm_first:
         if FUSE_BN_INTO_CONV and act in BNActConvFn.ACTS:
             z = BNActConvFn.apply(x, m.bn.weight, m.bn.bias, None, m.conv.weight, m.conv.bias, None, m.bn, act,
-                                  m.stride, m.padding, m.conv.groups, None, out_dtype)
+                                  m.stride, m.padding, m.conv.groups, None, out_dtype, acc)
         else:
             z = ConvFn.apply(bn_act(x, m.bn, act), m.conv.weight, m.conv.bias, None, m.stride, m.padding,
                              m.conv.groups, None, out_dtype)
         return z if res is None else ActFn.apply(z, res, ACT_NONE)      # (res_mode ADD: the PPM shortcut)
     return conv_bn_act(x, m.conv, m.bn if m.with_norm else None, act, res=res, res_mode=res_mode,
-                       out_dtype=out_dtype)
+                       out_dtype=out_dtype, acc=acc, acc_res=acc_res)
 
 
-def basic_block(m, x, final_relu=False):
-    if m.downsample is not None:
-        res = conv_bn_act(x, m.downsample[0], m.downsample[1])
+def basic_block(m, x, final_relu=False, pre=None):
+    """pre=(x alias, residual alias, acc): the caller already fanned x out (it has further consumers)"""
+    if pre is not None:
+        x, xr, acc = pre
     else:
-        res = x
+        (x, xr), acc = fanout(x, 2)       # consumers: conv1, and the shortcut (identity residual or 1x1 downsample)
+    if m.downsample is not None:
+        res, acc_res = conv_bn_act(xr, m.downsample[0], m.downsample[1], acc=acc), None
+    else:
+        res, acc_res = xr, acc
     act = ACT_RELU if (m.act_out or final_relu) else ACT_NONE
     c1, c2 = m.conv1, m.conv2
     if (FUSE_BN_INTO_CONV >= 2 and not c1.norm_first and not c2.norm_first and c1.with_norm and c2.with_norm
@@ -621,26 +793,31 @@ def basic_block(m, x, final_relu=False):
         # conv1 -> [BN1 + ReLU folded into conv2's input staging] -> conv2 -> BN2 (+res) -> act
         st1 = _stats(c1.conv.out_channels, x)
         z1 = ConvFn.apply(x, c1.conv.weight, c1.conv.bias, None, c1.conv.stride[0], c1.conv.padding[0],
-                          c1.conv.groups, st1, None)
+                          c1.conv.groups, st1, None, False, acc)
         st2 = _stats(c2.conv.out_channels, x)
         z2 = BNActConvFn.apply(z1, c1.bn.weight, c1.bn.bias, None, c2.conv.weight, c2.conv.bias, st1, c1.bn,
                                _ACT[c1.act], c2.conv.stride[0], c2.conv.padding[0], c2.conv.groups, st2, None)
-        return BNActFn.apply(z2, c2.bn.weight, c2.bn.bias, None, res, st2, c2.bn, act, RES_ADD, None)
-    out = conv_module(c1, x)
-    return conv_module(c2, out, act_override=act, res=res, res_mode=RES_ADD)
+        return BNActFn.apply(z2, c2.bn.weight, c2.bn.bias, None, res, st2, c2.bn, act, RES_ADD, None, acc_res)
+    out = conv_module(c1, x, acc=acc)
+    return conv_module(c2, out, act_override=act, res=res, res_mode=RES_ADD, acc_res=acc_res)
 
 
 def sesp(m, x):
-    o1 = conv_bn_act(x, m.proj_1x1.conv, m.proj_1x1.bn, ACT_PRELU, slope=m.proj_1x1.act.weight)
+    residual = (m.stride == 2 and not m.spatial) or (m.stride == 1 and m.nIn == m.nOut)
+    xr, acc = x, None
+    if residual:
+        (x, xr), acc = fanout(x, 2)       # consumers: the projection conv, the block's shortcut
+    o1 = conv_bn_act(x, m.proj_1x1.conv, m.proj_1x1.bn, ACT_PRELU, slope=m.proj_1x1.act.weight, acc=acc)
     w1 = DwPackFn.apply(True, *[d.conv.weight for d in m.spp_dw])
     p = PyrFn.apply(o1, w1, m.dil, m.stride)
     w2 = DwPackFn.apply(False, *[d.conv.weight for d in m.spp_dw_v2])
     exp = m.conv_1x1_exp
     if m.stride == 2 and not m.spatial:
-        act3, slope3, res = ACT_NONE, None, AvgPoolFn.apply(x)
+        act3, slope3, res, acc_res = ACT_NONE, None, AvgPoolFn.apply(xr, acc), None
     else:
         act3, slope3 = ACT_PRELU, m.module_act.weight
-        res = x if (m.stride == 1 and m.nIn == m.nOut) else None
+        res = xr if (m.stride == 1 and m.nIn == m.nOut) else None
+        acc_res = acc if res is not None else None
     rm = RES_ADD if res is not None else RES_NONE
     st = _stats(m.nOut, x)
     z = DwFn.apply(p, w2, 1, -1, [d + 1 for d in m.dil], m.n, False, st)   # its BN finalize comes next
@@ -650,9 +827,9 @@ def sesp(m, x):
         z3 = BNActConvFn.apply(z, m.br_after_cat.bn.weight, m.br_after_cat.bn.bias, m.br_after_cat.act.weight,
                                exp.conv.weight, exp.conv.bias, st, m.br_after_cat.bn, ACT_PRELU,
                                exp.conv.stride[0], exp.conv.padding[0], exp.conv.groups, st3, None)
-        return BNActFn.apply(z3, exp.bn.weight, exp.bn.bias, slope3, res, st3, exp.bn, act3, rm, None)
+        return BNActFn.apply(z3, exp.bn.weight, exp.bn.bias, slope3, res, st3, exp.bn, act3, rm, None, acc_res)
     cat = bn_act(z, m.br_after_cat.bn, ACT_PRELU, slope=m.br_after_cat.act.weight, stats=st)
-    return conv_bn_act(cat, exp.conv, exp.bn, act3, slope=slope3, res=res, res_mode=rm)
+    return conv_bn_act(cat, exp.conv, exp.bn, act3, slope=slope3, res=res, res_mode=rm, acc_res=acc_res)
 
 
 def cespb(m, x):
@@ -711,19 +888,22 @@ def ppm(m, x):
 
 def getb(m, x):
     a = m.attn
-    n1 = bn_act(x, m.norm1)
-    qkv = ConvFn.apply(n1, a.qkv[0].weight, None, None, 1, 0, 1, None, None)
-    att = WindowAttnFn.apply(qkv, a.bias_t(), m.heads, m.ws)
-    mix = GetbPoolFn.apply(att, n1, m.ws)
+    (x_n, x_r), acc_x = fanout(x, 2)                      # consumers: norm1, the attention shortcut
+    n1 = bn_act(x_n, m.norm1, acc_z=acc_x)
+    (n1q, n1l), acc_n1 = fanout(n1, 2)                    # consumers: the qkv conv, the local (pooled) mixing term
+    qkv = ConvFn.apply(n1q, a.qkv[0].weight, None, None, 1, 0, 1, None, None, False, acc_n1)
+    att = WindowAttnFn.apply(qkv, RelPosBiasFn.apply(a.relative_position_bias_table, a.relative_position_index), m.heads, m.ws)
+    mix = GetbPoolFn.apply(att, n1l, m.ws, acc_n1)
     wdw = DwPackFn.apply(False, a.proj[0].weight)
     st = _stats(m.dim, x)
     z = DwFn.apply(mix, wdw, 1, (m.ws - 1) // 2, [1, 1, 1, 1], m.dim, True, st)
     pj = bn_act(z, a.proj[1], stats=st)
-    x1 = ActFn.apply(ConvFn.apply(pj, a.proj[2].weight, None, None, 1, 0, 1, None, None), x, ACT_NONE)
-    n2 = bn_act(x1, m.norm2)
+    x1 = ActFn.apply(ConvFn.apply(pj, a.proj[2].weight, None, None, 1, 0, 1, None, None), x_r, ACT_NONE, None, acc_x)
+    (x1n, x1r), acc_x1 = fanout(x1, 2)                    # consumers: norm2, the MLP shortcut
+    n2 = bn_act(x1n, m.norm2, acc_z=acc_x1)
     h = ActFn.apply(ConvFn.apply(n2, m.mlp.fc1.weight, m.mlp.fc1.bias, None, 1, 0, 1, None, None), None, ACT_RELU6)
     y = ConvFn.apply(h, m.mlp.fc2.weight, m.mlp.fc2.bias, None, 1, 0, 1, None, None)
-    return ActFn.apply(y, x1, ACT_NONE)
+    return ActFn.apply(y, x1r, ACT_NONE, None, acc_x1)
 
 
 CTX_FORKS = int(_os.environ.get('LEDN_CTX_FORKS', '7'))    # bit s: context branch of stage 3+s on the aux stream
@@ -731,14 +911,20 @@ SEAM_SLOT = int(_os.environ.get('LEDN_SEAM_SLOT', '0'))     # stream of the SEAM
 MFAF_FORK = int(_os.environ.get('LEDN_MFAF_FORK', '0'))   # measured: 785 vs 876 img/s with the forks in TRAINING (inference gains 4 %: blocks.MFAF)
 
 
-def mfaf(m, x, r, out_relu=False):
-    xa = ActFn.apply(x, r, ACT_NONE)
+def mfaf(m, x, r, out_relu=False, pre=None):
+    """pre=(x alias for the gate, x alias for xa, acc): the caller already fanned x out (further consumers)"""
+    if pre is not None:
+        x, x_f, acc_x = pre
+    else:
+        (x, x_f), acc_x = fanout(x, 2)
+    (r, r_f), acc_r = fanout(r, 2)
+    front = MfafFrontFn.apply(x_f, r_f, acc_x, acc_r)
+    xa, pooled = front[0], front[1:]
 
     def mlp(seq, off, inp, out_dtype=None):
         mid = conv_bn_act(inp, seq[off], seq[off + 1], ACT_RELU)
         c1 = seq[off + 3]
         return ConvFn.apply(mid, c1.weight, c1.bias, None, 1, 0, 1, None, out_dtype), seq[off + 4]
-    pooled = MultiPoolFn.apply(xa)
     if _Env.sync_bn is not None:
         # data-parallel: the five first-level BatchNorms (local + four pooled contexts) see their inputs
         # together -> one grouped SyncBN all-reduce per direction instead of five
@@ -773,7 +959,7 @@ def mfaf(m, x, r, out_relu=False):
     gb = []
     for bn in bns:
         gb += [bn.weight, bn.bias]
-    return MfafTailFn.apply(x, r, *raws, bns, out_relu, *gb)
+    return MfafTailFn.apply(x, r, *raws, bns, out_relu, (acc_x, acc_r), *gb)
 
 
 def lednet_forward_train(m, x, pre=None):
@@ -792,8 +978,14 @@ def lednet_forward_train(m, x, pre=None):
         x1 = BNActFn.apply(z, s0.bn.weight, s0.bn.bias, None, None, st, s0.bn, ACT_RELU, RES_NONE, None)
     else:
         x1 = conv_module(s0, ops.nchw_to_nhwc(x.contiguous(), m.act_dtype, s, b, mp, valid, pad_val))
-    x2 = conv_module(m.stem['1'], x1)
-    y = basic_block(m.stem['2'][1], basic_block(m.stem['2'][0], x2), final_relu=True)
+    # x1 and x2 also feed LEDHead's head_x1 / head_x2: fan them out here, the head picks its accumulators up
+    # from _Env.head_acc (its consumer is a BNActConvFn whose BatchNorm-backward takes the addend)
+    (x1, x1_head), acc1 = fanout(x1, 2)
+    x2 = conv_module(m.stem['1'], x1, acc=acc1)
+    (x2a, x2b, x2_head), acc2 = fanout(x2, 3)
+    _Env.head_acc = {'x1': (acc1, x1_head.data_ptr()), 'x2': (acc2, x2_head.data_ptr())}
+    x1, x2 = x1_head, x2_head
+    y = basic_block(m.stem['2'][1], basic_block(m.stem['2'][0], None, pre=(x2a, x2b, acc2)), final_relu=True)
     y = basic_block(m.stem['4'][1], basic_block(m.stem['4'][0], y), final_relu=True)
     y = grad_ready(y, 'post_stem')     # backward: every parameter gradient outside the stem is complete here
     # context branch and SEAM edge map on auxiliary streams between the fusion points (ops.Fork);
@@ -810,18 +1002,21 @@ def lednet_forward_train(m, x, pre=None):
         comp = BilinearFn.apply(conv_module(m.compression_1, relu(x_c)), None, out_size, None)
     x_s = cespb(m.layer3_, y)
     f3.join(x_c, comp)
-    x_c = conv_module(m.down_1, relu(x_s), res=x_c, res_mode=RES_ADD)
-    x_s = mfaf(m.aff1, x_s, comp)
-    c3 = x_s
+    (xs_d, xs_t, xs_f), acc_xs = fanout(x_s, 3)       # consumers: relu -> down_1, the MFAF gate, MFAF's xa = x + r
+    x_c = conv_module(m.down_1, relu(xs_d, acc_xs), res=x_c, res_mode=RES_ADD)
+    x_s = mfaf(m.aff1, None, comp, pre=(xs_t, xs_f, acc_xs))
+    (c3, x_s), acc_c3 = fanout(x_s, 2)                # consumers: LEDHead's aux_head (c3), relu -> layer4_
+    _Env.head_acc['c3'] = (acc_c3, c3.data_ptr())
     # stage 4
     with ops.Fork(x_c, 1 if CTX_FORKS & 2 else 0) as f4:
         x_c = cespb(m.layer4, relu(x_c))
         comp = BilinearFn.apply(conv_module(m.compression_2, relu(x_c)), None, out_size, None)
-    x_s = cespb(m.layer4_, relu(x_s))
-    d = conv_module(m.down_2[0], relu(x_s))
+    x_s = cespb(m.layer4_, relu(x_s, acc_c3))
+    (xs_d, xs_t, xs_f), acc_xs = fanout(x_s, 3)
+    d = conv_module(m.down_2[0], relu(xs_d, acc_xs))
     f4.join(x_c, comp)
     x_c = conv_module(m.down_2[1], d, res=x_c, res_mode=RES_ADD)
-    x_s = mfaf(m.aff2, x_s, comp)
+    x_s = mfaf(m.aff2, None, comp, pre=(xs_t, xs_f, acc_xs))
     fe.join(edge)
     x_s = conv_module(m.seam.conv_2, edge, res=x_s, res_mode=RES_GATE, out_dtype=x_s.dtype)
     # stage 5
@@ -837,8 +1032,8 @@ def lednet_forward_train(m, x, pre=None):
 # --------------------------------------------------------------------------- #
 # LEDHead training forward + loss (led_head.py:62-75,101-146)
 # --------------------------------------------------------------------------- #
-def _base_head(seq, x, out_dtype=None):
-    z = conv_module(seq[0], x)
+def _base_head(seq, x, out_dtype=None, acc=None):
+    z = conv_module(seq[0], x, acc=acc)
     return bn_act(z, seq[1], ACT_RELU, out_dtype=out_dtype)
 
 
@@ -849,10 +1044,15 @@ def led_head_forward_train(h, inputs):
     f32 = torch.float32
     xc = _base_head(h.head, c5)
     xc = ConvFn.apply(xc, h.conv_seg.weight, h.conv_seg.bias, None, 1, 0, 1, None, f32)
-    xs = _base_head(h.aux_head, c3)
+    accs, _Env.head_acc = _Env.head_acc, {}
+
+    def acc_of(name, t):      # the backbone's fan-in accumulator of this very tensor (same storage), else None
+        a = accs.get(name)
+        return a[0] if (a is not None and a[1] == t.data_ptr()) else None
+    xs = _base_head(h.aux_head, c3, None, acc_of('c3', c3))
     xs = ConvFn.apply(xs, h.aux_cls_seg.weight, h.aux_cls_seg.bias, None, 1, 0, 1, None, f32)
-    h1 = _base_head(h.head_x1, x1, f32)
-    h2 = _base_head(h.head_x2, x2, f32)
+    h1 = _base_head(h.head_x1, x1, f32, acc_of('x1', x1))
+    h2 = _base_head(h.head_x2, x2, f32, acc_of('x2', x2))
     return xc, xs, h1, h2
 
 

@@ -74,5 +74,12 @@ def test_train_step_bf16_vs_oracle(be):
     for k in ('decode.loss_context', 'decode.loss_spatial', 'decode.acc_seg'):
         a, b = float(got[k].reshape(-1)[0]), float(want[k].reshape(-1)[0])
         assert abs(a - b) <= 0.03 * abs(b) + 1e-3, (k, a, b)
+    from led_net_amd import train as TR
+    TR._Acc.counters.update(chained=0, added=0)
     got2 = tr.train_step(D(img), [L.SegDataSample(gt=D(lab[i])) for i in range(2)])
     assert all(torch.isfinite(v).all() for v in got2.values())
+    # gradient fan-in: the partial gradients of tensors with several consumers are folded into the consumers' backward
+    # kernels (conv data-gradient epilogue, BatchNorm-backward apply, pool adjoints, MFAF combine), not summed by
+    # separate elementwise adds: 11 SESP shortcuts, 4 BasicBlocks, x1 / x2 / c3 heads, 2 x MFAF (x, r), stage ReLUs
+    c = TR._Acc.counters
+    assert c['chained'] >= 15 and c['added'] <= 4, c
