@@ -202,6 +202,11 @@ def main():
         # torch.distributed.run (the shape of the reference's tools/dist_train.sh:9-18); nothing in this
         # process has touched the GPU yet (device_count() does not initialise it), and it never will.
         sys.exit(launch_ranks(args.gpus))
+    # stdout carries exactly ONE line (the JSON, rank 0).  Libraries write there too (librccl prints a version banner
+    # to stdout on its first communicator): for the whole run fd 1 points at stderr, the JSON goes to the saved fd.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -374,7 +379,7 @@ def main():
             for (e, sg), v in top[:n_sig]:
                 print(f'{v["ms"] / k_steps:9.3f} ms/step  x{v["n"] // k_steps:3d}  {v["bytes"] * v["n"] / max(1e-9, v["ms"]) / 1e6:8.1f} GB/s '
                       f'{v["flops"] * v["n"] / max(1e-9, v["ms"]) / 1e9:8.2f} TF/s  {e} [{sg}]', file=sys.stderr)
-        print(json.dumps(out))
+        print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -202,6 +202,15 @@ typedef struct {
 } ledn_dwpack_desc;
 int ledn_dw_pack(const ledn_dwpack_desc* d, float* packed, void* stream);
 int ledn_dw_unpack_grad(const ledn_dwpack_desc* d, const float* dpacked, void* stream);
+/* The same for a whole DEVICE table of banks in one launch (training: once at the start of a step, once at the
+ * end of its backward): dir 0: packed <- filters; dir 1: filter gradients (d.dw) += dpacked, dpacked re-zeroed.
+ * max_elems = the largest n[k] * taps of the table. */
+typedef struct {
+    ledn_dwpack_desc d;
+    float* packed;
+    float* dpacked;
+} ledn_dwpack_entry;
+int ledn_dw_repack_multi(const ledn_dwpack_entry* table_dev, int n, int max_elems, int dir, void* stream);
 
 /* SESP split/transform stage 1 with hierarchical feature fusion:
  *   y[..., b*n + c] = sum_{b' <= b} dw3x3_{dil[b'], stride}(x)[..., c]     b = 0..3

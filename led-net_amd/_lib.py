@@ -55,6 +55,10 @@ class DwPackDesc(C.Structure):
     _fields_ = [('w', fp * 8), ('dw', fp * 8), ('n', i32 * 8), ('nsrc', i32), ('taps', i32), ('stacked', i32)]
 
 
+class DwPackEntry(C.Structure):
+    _fields_ = [('d', DwPackDesc), ('packed', fp), ('dpacked', fp)]
+
+
 class PyrDesc(C.Structure):
     _fields_ = [('x', vp), ('w', fp), ('y', vp),
                 ('N', i32), ('H', i32), ('W', i32), ('n', i32), ('Ho', i32), ('Wo', i32), ('stride', i32),
@@ -148,6 +152,7 @@ _PROTOS = {
     'ledn_dwconv2d': ([C.POINTER(DwDesc), vp], i32),
     'ledn_iou_hist': ([vp, vp, i64, i32, i32, fp, vp], i32),
     'ledn_dw_pack': ([C.POINTER(DwPackDesc), fp, vp], i32),
+    'ledn_dw_repack_multi': ([vp, i32, i32, i32, vp], i32),
     'ledn_dw_unpack_grad': ([C.POINTER(DwPackDesc), fp, vp], i32),
     'ledn_sesp_pyramid': ([C.POINTER(PyrDesc), vp], i32),
     'ledn_channel_stats': ([vp, vp, i64, i32, i32, fp, fp, vp], i32),

@@ -29,6 +29,7 @@ int im2col_stem_planar_impl(const void* x, int dtype_x, void* p, int N, int H, i
                             hipStream_t s);
 int dw_pack_impl(const ledn_dwpack_desc& d, float* packed, hipStream_t s);
 int dw_unpack_grad_impl(const ledn_dwpack_desc& d, const float* dpacked, hipStream_t s);
+int dw_repack_multi_impl(const ledn_dwpack_entry* table_dev, int n, int max_elems, int dir, hipStream_t s);
 int sesp_pyramid_impl(const ledn_pyr_desc& d, hipStream_t s);
 int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
                        float* sqsum, hipStream_t s);
@@ -256,6 +257,9 @@ int ledn_relpos_bias(const float* table, const long long* index, float* biasT, i
 int ledn_relpos_bias_bwd(const float* dbiasT, const long long* index, float* dtable, int R, int heads, int T,
                          void* stream) {
     return relpos_bias_bwd_impl(dbiasT, index, dtable, R, heads, T, S(stream));
+}
+int ledn_dw_repack_multi(const ledn_dwpack_entry* table_dev, int n, int max_elems, int dir, void* stream) {
+    return dw_repack_multi_impl(table_dev, n, max_elems, dir, S(stream));
 }
 int ledn_bilinear(const ledn_resize_desc* d, void* stream) { return d ? bilinear_impl(*d, S(stream)) : LEDN_EINVAL; }
 int ledn_adaptive_avgpool(const void* x, const void* xadd, float* y, int N, int H, int W, int C, int Sz,

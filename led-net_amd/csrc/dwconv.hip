@@ -421,6 +421,39 @@ static int dw_repack(const ledn_dwpack_desc& d, float* packed, const float* dpac
     return check_launch();
 }
 
+// table-driven variant: EVERY depthwise filter bank of the model in one launch (grid.z = bank).
+//   dir 0: packed <- filters (start of a training step)
+//   dir 1: filter gradients += packed gradient, and the packed gradient buffer is re-zeroed (end of the backward)
+__global__ void __launch_bounds__(256) dw_repack_multi_kernel(const ledn_dwpack_entry* table, int dir) {
+    const ledn_dwpack_entry e = table[blockIdx.z];
+    const int k = blockIdx.y;
+    if (k >= e.d.nsrc) return;
+    const int n = e.d.n[k];
+    int c0 = 0, ctot = 0;
+    for (int j = 0; j < e.d.nsrc; ++j) {
+        if (j < k) c0 += e.d.n[j];
+        ctot += e.d.n[j];
+    }
+    const int total = n * e.d.taps;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i / e.d.taps, t = i % e.d.taps;
+        const long pi = e.d.stacked ? ((long)k * e.d.taps + t) * n + c : (long)t * ctot + c0 + c;
+        if (dir == 0) e.packed[pi] = e.d.w[k][i];
+        else {
+            e.d.dw[k][i] += e.dpacked[pi];
+            e.dpacked[pi] = 0.f;
+        }
+    }
+}
+
+int dw_repack_multi_impl(const ledn_dwpack_entry* table_dev, int n, int max_elems, int dir, hipStream_t s) {
+    LEDN_REQUIRE(table_dev && n > 0 && max_elems > 0 && (dir == 0 || dir == 1));
+    long bx = cdiv((long)max_elems, 256);
+    if (bx > 16) bx = 16;
+    LEDN_LAUNCH(dw_repack_multi_kernel, dim3((unsigned)bx, 8u, (unsigned)n), dim3(256), 0, s, table_dev, dir);
+    return check_launch();
+}
+
 int dw_pack_impl(const ledn_dwpack_desc& d, float* packed, hipStream_t s) { return dw_repack(d, packed, nullptr, s); }
 int dw_unpack_grad_impl(const ledn_dwpack_desc& d, const float* dpacked, hipStream_t s) {
     return dw_repack(d, nullptr, dpacked, s);

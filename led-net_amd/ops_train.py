@@ -125,7 +125,7 @@ def _dw_desc(x_shape, dz, w_khwc, stride, pad, dil, group_size, ext1, dtype):
 
 
 def dwconv2d_bwd(x, dz, w_khwc, *, stride=1, pad=-1, dil=(1, 1, 1, 1), group_size=None, ext1=False,
-                 add=None, need_dx=True, need_dw=True):
+                 add=None, need_dx=True, need_dw=True, dw_out=None):
     """-> (dx or None, dw [KH,KW,C] or None)."""
     lib = _lib.get_lib()
     if dz.dtype != x.dtype:
@@ -140,7 +140,11 @@ def dwconv2d_bwd(x, dz, w_khwc, *, stride=1, pad=-1, dil=(1, 1, 1, 1), group_siz
         d.dx = _p(dx)
         _run(lib, 'ledn_dwconv2d_bwd_data', x, d, work=_ops._TIMING is not None and (f'dwbwd_data{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(dz, dx, add), 2 * dz.numel() * KH * KW))
     if need_dw:
-        dw = _ops.zeros_f32(tuple(w_khwc.shape), x.device)
+        # dw_out: an f32 buffer of the bank's shape the gradient is ACCUMULATED into (the trainer's bank-gradient sink)
+        dw = dw_out if dw_out is not None else _ops.zeros_f32(tuple(w_khwc.shape), x.device)
+        if tuple(dw.shape) != tuple(w_khwc.shape) or dw.dtype != torch.float32:
+            raise LednError('dwconv2d_bwd: dw_out shape/dtype mismatch')
+        _check(lib, dw)
         d.dw = _p(dw)
         _run(lib, 'ledn_dwconv2d_bwd_weight', x, d, work=_ops._TIMING is not None and (f'dwbwd_w{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(x, dz) , 2 * dz.numel() * KH * KW))
     return dx, dw
@@ -190,8 +194,8 @@ def dw_unpack_grad(weights, sinks, dpacked, stacked):
          work=_ops._TIMING is not None and (f'dwunpack {tuple(dpacked.shape)}', 12 * dpacked.numel(), 0))
 
 
-def sesp_pyramid_bwd(x, dy, w_b33n, dil, stride):
-    """-> (dx [N,H,W,n], dw [4,3,3,n])."""
+def sesp_pyramid_bwd(x, dy, w_b33n, dil, stride, dw_out=None):
+    """-> (dx [N,H,W,n], dw [4,3,3,n]); dw_out: f32 buffer the weight gradient is accumulated into."""
     lib = _lib.get_lib()
     N, H, W, n = x.shape
     if dy.dtype != x.dtype:
@@ -199,8 +203,10 @@ def sesp_pyramid_bwd(x, dy, w_b33n, dil, stride):
     d = _lib.PyrBwdDesc()
     gsum = torch.empty_like(dy)
     dx = torch.empty_like(x)
-    dw = _ops.zeros_f32(tuple(w_b33n.shape), x.device)
-    _check(lib, x, dy, w_b33n)
+    dw = dw_out if dw_out is not None else _ops.zeros_f32(tuple(w_b33n.shape), x.device)
+    if tuple(dw.shape) != tuple(w_b33n.shape) or dw.dtype != torch.float32:
+        raise LednError('sesp_pyramid_bwd: dw_out shape/dtype mismatch')
+    _check(lib, x, dy, w_b33n, dw)
     d.x, d.dy, d.w, d.gsum, d.dx, d.dw = _p(x), _p(dy), _p(_f32(w_b33n)), _p(gsum), _p(dx), _p(dw)
     d.N, d.H, d.W, d.n, d.Ho, d.Wo, d.stride = N, H, W, n, dy.shape[1], dy.shape[2], stride
     for i in range(4):
@@ -377,3 +383,30 @@ class PackTable:
         lib = _lib.get_lib()
         _run(lib, 'ledn_pack_conv_weights_multi', self.ref, self.table.data_ptr(), self.n, self.max_elems,
              work=_ops._TIMING is not None and (f'packw_multi {self.n} tensors', 0, 0))
+
+
+class DwBankTable:
+    """Device table for ledn_dw_repack_multi: every depthwise filter bank of the model (SESP pyramids and second
+    passes, GETB 8x8) packed from the PyTorch-layout filters by ONE launch per step, and every bank gradient
+    unpacked into the parameters' gradient views (and re-zeroed) by ONE launch at the end of the backward."""
+
+    def __init__(self, banks):
+        """banks: list of (weights [n_k,1,KH,KW] f32 params, gradient sinks (same shapes), stacked, packed, dpacked)"""
+        lib = _lib.get_lib()
+        host = (_lib.DwPackEntry * len(banks))()
+        self.max_elems = 0
+        for i, (weights, sinks, stacked, packed, dpacked) in enumerate(banks):
+            d, _, _ = _dwpack_desc(lib, [w.detach() for w in weights], stacked, sinks)
+            host[i].d = d
+            _check(lib, packed, dpacked)
+            if packed.dtype != torch.float32 or dpacked.shape != packed.shape or dpacked.dtype != torch.float32:
+                raise LednError('DwBankTable: packed / dpacked must be float32 of one shape')
+            host[i].packed, host[i].dpacked = packed.data_ptr(), dpacked.data_ptr()
+            self.max_elems = max(self.max_elems, max(w.numel() for w in weights))
+        self.table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(banks[0][3].device)
+        self.n, self.ref, self.keep = len(banks), banks[0][3], banks
+
+    def run(self, direction):
+        lib = _lib.get_lib()
+        _run(lib, 'ledn_dw_repack_multi', self.ref, self.table.data_ptr(), self.n, self.max_elems, int(direction),
+             work=_ops._TIMING is not None and (f'dw_repack_multi {self.n} banks dir{direction}', 0, 0))
