@@ -252,6 +252,16 @@ __device__ __forceinline__ float reduce16_over32(const float* v, int lane) {
     return r;
 }
 
+// compile-time loop: f(int_c<0>) ... f(int_c<N-1>)
+template <int V> struct int_c { static constexpr int value = V; };
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(int_c<I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
 // epilogue flavours (compile-time: the runtime-switched version cost a vmcnt(0) drain per store group)
 constexpr int EPI_RAW = 0;        // y = bf16(z)                                  (data gradients)
 constexpr int EPI_RAW_STATS = 1;  // y = bf16(z) + per-channel sum / sum of squares (training forward)
@@ -351,23 +361,37 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
         if (ntile < te) LEDN_CONV_FETCH(ntile, nc0);
         // ---- taps x k-steps, all operands from LDS.  A = weights (M = cout), B = pixels (N = 32
         // pixels of a row): the accumulator lane owns ONE pixel and 4 x 4 consecutive channels.
+        // The fragments of product step i+1 (one weight fragment + MT pixel fragments, ds_read_b128 each) are read
+        // BEFORE the MT matrix instructions of step i are issued, so the LDS latency hides behind 4 x 32 cycles of
+        // MFMA.  The compiler's own schedule kept pixel fragments alive across the kh shifts instead (fewer LDS
+        // reads, but ~60 more VGPRs: the statistics flavours spilled 100-180 B per lane) and read most fragments
+        // right in front of their first use.  Measured r03h: 3x3 32->32 forward + statistics 43.6 -> 37.4 us,
+        // 64->64 37.8 -> 33.3 us, no scratch in any flavour.
+        constexpr int NSTEP = KK * (CK / 16);
+        const unsigned char* wbase = s_w + (wn * 32 + lr) * PIXB + lh * 16;
+        const unsigned char* xbase = s_patch + (long)((wm * MT * S) * PC + lr * S) * PIXB + lh * 16;
+        bf16x8_t wf_n, xf_n[MT];
+#define LEDN_FRAGS(i_, wf_, xf_)                                                                          \
+        do {                                                                                              \
+            constexpr int t_ = (i_) / (CK / 16), kk_ = (i_) % (CK / 16), kh_ = t_ / K, kw_ = t_ % K;      \
+            wf_ = *reinterpret_cast<const bf16x8_t*>(wbase + t_ * NCO * PIXB + kk_ * 32);                 \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                \
+                xf_[m] = *reinterpret_cast<const bf16x8_t*>(xbase + (long)((m * S + kh_) * PC + kw_) * PIXB + kk_ * 32); \
+        } while (0)
+        LEDN_FRAGS(0, wf_n, xf_n);
+        static_for<NSTEP>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const bf16x8_t wf = wf_n;
+            bf16x8_t xf[MT];
 #pragma unroll
-        for (int t = 0; t < KK; ++t) {
-            const int kh = t / K, kw = t % K;
+            for (int m = 0; m < MT; ++m) xf[m] = xf_n[m];
+            if constexpr (i + 1 < NSTEP) LEDN_FRAGS(i + 1, wf_n, xf_n);
+            sched_fence();
 #pragma unroll
-            for (int kk = 0; kk < CK / 16; ++kk) {
-                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(s_w + (t * NCO + wn * 32 + lr) * PIXB +
-                                                                       (kk * 16 + lh * 8) * 2);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int row = wm * MT + m;
-                    const unsigned char* xp = s_patch + (long)((row * S + kh) * PC + lr * S + kw) * PIXB +
-                                              (kk * 16 + lh * 8) * 2;
-                    const bf16x8_t xf = *reinterpret_cast<const bf16x8_t*>(xp);
-                    acc[m] = mfma_32x32x16_bf16(wf, xf, acc[m]);
-                }
-            }
-        }
+            for (int m = 0; m < MT; ++m) acc[m] = mfma_32x32x16_bf16(wf, xf[m], acc[m]);
+            sched_fence();
+        });
+#undef LEDN_FRAGS
         __syncthreads();     // patch and chunk weights may be overwritten from here on
 
         if (nc0 == 0) {
@@ -488,7 +512,9 @@ static int launch_epi(MfmaConvArgs a, hipStream_t s) {
     a.tiles_w = (int)cdiv(a.Wo, 32);
     const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
     const long gy = cdiv(a.Cout, WN * 32);
-    long nbx = cdiv(options().conv_workgroups, gy);  // default ~2 resident workgroups per CU
+    long want = options().conv_workgroups;           // default ~2 resident workgroups per CU
+    if (K == 1 && S == 1 && want == 512) want = 768;  // 1x1: three per CU measured faster (r03i: 139 -> 113 us, 32->32 @512^2)
+    long nbx = cdiv(want, gy);
     if (nbx > ntiles) nbx = ntiles;
     a.tiles_per_block = (int)cdiv(ntiles, nbx);
     nbx = cdiv(ntiles, a.tiles_per_block);
