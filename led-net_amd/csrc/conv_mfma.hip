@@ -794,6 +794,45 @@ struct MfmaWgradArgs {
     float* part;      // optional workspace: [gridDim.x][gridDim.y][KK*1024] per-workgroup partial tiles
 };
 
+// the 2*TR k-steps (16 pixels each) of one staged tile for NTW taps: the transposing LDS reads of k-step ks+1 are
+// issued before the NTW matrix instructions of k-step ks
+template <int NTW, int S, int PC, int TR, bool TAPSPLIT, int NT>
+__device__ __forceinline__ void wgrad_ksteps(f32x16_t (&acc)[NT], const unsigned char* s_x, const unsigned char* s_z,
+                                             const int (&tapoff)[NT], int ks0, int kstep, int lh, int q, int colblk,
+                                             int pp) {
+    bf16x4_t fa[2], fb[NTW][2];
+    auto frags = [&](int ks) {
+        const int row = ks >> 1, cb = (ks & 1) * 16;       // pixels (row, cb + 0..15)
+        // A = dz^T: the lane needs 8 pixels cb+8*lh+0..7 of channel colblk*16+l16; B = the x patch at the tap shift
+        const unsigned char* zp = s_z + (long)(row * 32 + cb + lh * 8 + q) * PIXB + (colblk * 16 + pp * 4) * 2;
+        fa[0] = lds_read_tr16(zp);
+        fa[1] = lds_read_tr16(zp + 4 * PIXB);
+        const unsigned char* xp0 = s_x + (long)(row * S * PC + (cb + lh * 8 + q) * S) * PIXB + (colblk * 16 + pp * 4) * 2;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            fb[t][0] = lds_read_tr16(xp0 + tapoff[t]);
+            fb[t][1] = lds_read_tr16(xp0 + tapoff[t] + 4 * S * PIXB);
+        }
+    };
+    if (ks0 < TR * 2) frags(ks0);
+#pragma unroll 2
+    for (int ks = ks0; ks < TR * 2; ks += kstep) {
+        bf16x8_t af, bfv[NTW];
+        af[0] = fa[0][0]; af[1] = fa[0][1]; af[2] = fa[0][2]; af[3] = fa[0][3];
+        af[4] = fa[1][0]; af[5] = fa[1][1]; af[6] = fa[1][2]; af[7] = fa[1][3];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            bfv[t][0] = fb[t][0][0]; bfv[t][1] = fb[t][0][1]; bfv[t][2] = fb[t][0][2]; bfv[t][3] = fb[t][0][3];
+            bfv[t][4] = fb[t][1][0]; bfv[t][5] = fb[t][1][1]; bfv[t][6] = fb[t][1][2]; bfv[t][7] = fb[t][1][3];
+        }
+        if (ks + kstep < TR * 2) frags(ks + kstep);
+        sched_fence();
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = mfma_32x32x16_bf16(af, bfv[t], acc[t]);
+        sched_fence();
+    }
+}
+
 template <int K, int S>
 __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
     constexpr int TR = S == 2 ? 4 : 8;             // output rows per staged tile (TR x 32 pixels = 2*TR k-steps)
@@ -805,7 +844,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char s_mem[LDSB];
     unsigned char* s_x = s_mem;
     unsigned char* s_z = s_mem + XB;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = wave_uniform(tid >> 6);
     const int g16 = lane >> 4, l16 = lane & 15;
     const int colblk = g16 & 1, lh = g16 >> 1;     // channel half (16) and k half (8 pixels)
     const int q = l16 >> 2, pp = l16 & 3;          // tr-read: this lane supplies row q, columns 4pp..4pp+3
@@ -838,6 +877,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
     const long t0 = (long)blockIdx.x * a.tiles_per_block;
     const long t1 = min(ntiles, t0 + a.tiles_per_block);
     const bool narrow = (a.Cout & 7) != 0;   // heads with Cout = 1, 2, 4: element-wise dz staging
+    // (Two register staging sets -- loads two tiles ahead -- measured no faster, r03k: the loop was not waiting on
+    // global memory but on a branch + full LDS wait in front of every matrix instruction; see wgrad_ksteps.)
     PatchStage<PR, PC, S, 1> sx;
     PatchStage<TR, 32, 1, 1> sz;
     NarrowStage<TR * 32> szn;
@@ -860,29 +901,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_mfma_kernel(MfmaWgradArgs a) {
         else szn.commit(s_z, tid);
         __syncthreads();
         if (tile + 1 < t1) LEDN_WGRAD_FETCH(tile + 1);
-        // ---- 2*TR k-steps of 16 pixels (half a row each)
-#pragma unroll 2
-        for (int ks = TAPSPLIT ? 0 : wid; ks < TR * 2; ks += TAPSPLIT ? 1 : 4) {
-            const int row = ks >> 1, cb = (ks & 1) * 16;       // pixels (row, cb + 0..15)
-            // A = dz^T: lane needs 8 pixels cb+8*lh+0..7 of channel colblk*16+l16
-            const unsigned char* zp = s_z + (long)(row * 32 + cb + lh * 8 + q) * PIXB + (colblk * 16 + pp * 4) * 2;
-            const bf16x4_t a_lo = lds_read_tr16(zp);
-            const bf16x4_t a_hi = lds_read_tr16(zp + 4 * PIXB);
-            bf16x8_t af;
-            af[0] = a_lo[0]; af[1] = a_lo[1]; af[2] = a_lo[2]; af[3] = a_lo[3];
-            af[4] = a_hi[0]; af[5] = a_hi[1]; af[6] = a_hi[2]; af[7] = a_hi[3];
-            const unsigned char* xp0 = s_x + (long)(row * S * PC + (cb + lh * 8 + q) * S) * PIXB + (colblk * 16 + pp * 4) * 2;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (TAPSPLIT && wid + 4 * t >= KK) continue;   // wave-uniform
-                const unsigned char* xp = xp0 + tapoff[t];
-                const bf16x4_t b_lo = lds_read_tr16(xp);
-                const bf16x4_t b_hi = lds_read_tr16(xp + 4 * S * PIXB);
-                bf16x8_t bfv;
-                bfv[0] = b_lo[0]; bfv[1] = b_lo[1]; bfv[2] = b_lo[2]; bfv[3] = b_lo[3];
-                bfv[4] = b_hi[0]; bfv[5] = b_hi[1]; bfv[6] = b_hi[2]; bfv[7] = b_hi[3];
-                acc[t] = mfma_32x32x16_bf16(af, bfv, acc[t]);
-            }
+        // wave w owns taps w, w+4, w+8: wave 0 three of them, the others two -- a compile-time count per code path
+        // (a per-tap validity test inside the loop put a branch and a full LDS wait in front of every matrix
+        // instruction, and with the wave index in a vector register the accumulators travelled AGPR <-> VGPR)
+        if constexpr (TAPSPLIT) {
+            if (wid != 0) wgrad_ksteps<NT - 1, S, PC, TR, true>(acc, s_x, s_z, tapoff, 0, 1, lh, q, colblk, pp);
+            else wgrad_ksteps<NT, S, PC, TR, true>(acc, s_x, s_z, tapoff, 0, 1, lh, q, colblk, pp);
+        } else {
+            wgrad_ksteps<NT, S, PC, TR, false>(acc, s_x, s_z, tapoff, wid, 4, lh, q, colblk, pp);
         }
         __syncthreads();
     }

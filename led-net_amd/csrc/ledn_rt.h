@@ -199,6 +199,7 @@ __device__ __forceinline__ f32x16_t mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f
 __device__ __forceinline__ bf16x4_t lds_read_tr16(const void* p) { return emu::lds_read_tr16(p); }
 __device__ __forceinline__ void sched_fence() {}
 __device__ __forceinline__ int opaque(int x) { return x; }
+__device__ __forceinline__ int wave_uniform(int x) { return x; }
 __device__ __forceinline__ void wave_sync() { emu::barrier_wait(LEDN_EMU_CUR->wave_bar); }
 #else
 // value the optimiser must treat as freshly computed: keeps loop-invariant address arithmetic from
@@ -207,6 +208,10 @@ __device__ __forceinline__ int opaque(int x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// a value that is the same in every lane of the wave (wave index, ...) moved to a scalar register: branches on it
+// become scalar branches instead of exec-mask regions (which, around an MFMA, also made the compiler shuttle the
+// accumulator between AGPRs and VGPRs: 32 moves per matrix instruction in the weight-gradient loop)
+__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // orders one wave's LDS accesses across its lanes (the DS unit executes a wave's instructions in
 // order; this keeps the compiler from reordering them).  Every lane of the wave must call.
 __device__ __forceinline__ void wave_sync() {
