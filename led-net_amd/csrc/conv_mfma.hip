@@ -304,6 +304,10 @@ constexpr int EPI_RAW = 0;        // y = bf16(z)                                
 constexpr int EPI_RAW_STATS = 1;  // y = bf16(z) + per-channel sum / sum of squares (training forward)
 constexpr int EPI_FULL = 2;       // scale/shift, residual, activation + statistics
 constexpr int EPI_FULL_NS = 3;    // the same without statistics (inference: 32 VGPRs less, no spills)
+constexpr int EPI_RAW_ACC = 4;    // y = bf16(z) + res, added at the 16-byte store stage: the gradient fan-in of the
+                                  // training backward (the partial gradient of another consumer of the same tensor);
+                                  // EPI_FULL_NS read the addend as 8-byte pieces per accumulator quad and cost as much
+                                  // as the elementwise add it replaced
 constexpr bool epi_full(int e) { return e == EPI_FULL || e == EPI_FULL_NS; }
 constexpr bool epi_stats(int e) { return e == EPI_RAW_STATS || e == EPI_FULL; }
 
@@ -505,11 +509,29 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                 if (vec) {
                     // bf16 tile through the per-wave LDS buffer: every global store is 16 B per lane,
                     // 4 lanes per pixel (whole 64-byte channel rows)
+                    uint4 radd[2];
+                    if (EPI == EPI_RAW_ACC) {    // the addend's two pieces, in flight during the transposition
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int px = (lane >> 2) + 16 * h, piece = lane & 3;
+                            const bool okp = ho < a.Ho && wo0 + px < a.Wo && cb0 + piece * 8 < a.Cout;
+                            radd[h] = *reinterpret_cast<const uint4*>(
+                                a.res + (okp ? (((long)n * a.Ho + ho) * a.Wo + wo0 + px) * a.Cout + cb0 + piece * 8 : 0L));
+                        }
+                    }
                     wave_sync();
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int px = (lane >> 2) + 16 * h, piece = lane & 3;
-                        const uint4 o = *reinterpret_cast<const uint4*>(s_ow + px * PIXB + piece * 16);
+                        uint4 o = *reinterpret_cast<const uint4*>(s_ow + px * PIXB + piece * 16);
+                        if (EPI == EPI_RAW_ACC) {
+                            float fo[8], fr[8];
+                            ld8(reinterpret_cast<const bf16_t*>(&o), fo);
+                            ld8(reinterpret_cast<const bf16_t*>(&radd[h]), fr);
+#pragma unroll
+                            for (int k2 = 0; k2 < 8; ++k2) fo[k2] += fr[k2];
+                            st8(reinterpret_cast<bf16_t*>(&o), fo);
+                        }
                         if (ho < a.Ho && wo0 + px < a.Wo && cb0 + piece * 8 < a.Cout)
                             *reinterpret_cast<uint4*>(a.y + (((long)n * a.Ho + ho) * a.Wo + wo0 + px) * a.Cout + cb0 +
                                                       piece * 8) = o;
@@ -565,6 +587,9 @@ static int launch_epi(MfmaConvArgs a, hipStream_t s) {
 template <int WM, int WN, int MT, int K, int S, int UP>
 static int launch_cfg(const MfmaConvArgs& a, hipStream_t s) {
     const bool raw = !a.out_scale && !a.out_shift && a.act_out == LEDN_ACT_NONE && a.res_mode == LEDN_RES_NONE;
+    if (!a.out_scale && !a.out_shift && a.act_out == LEDN_ACT_NONE && a.res_mode == LEDN_RES_ADD && !a.stat_sum &&
+        (a.Cout & 7) == 0 && !a.y_f32)
+        return launch_epi<WM, WN, MT, K, S, UP, EPI_RAW_ACC>(a, s);
     if (!raw && a.stat_sum) return launch_epi<WM, WN, MT, K, S, UP, EPI_FULL>(a, s);
     if (!raw) return launch_epi<WM, WN, MT, K, S, UP, EPI_FULL_NS>(a, s);
     if (a.stat_sum) return launch_epi<WM, WN, MT, K, S, UP, EPI_RAW_STATS>(a, s);

@@ -256,3 +256,27 @@ def test_two_class_head_wgrad_kernel(be, cin, cout, k, hw, dz_f32):
     # (the MFMA path rounds act(BN(x)) to bf16 while staging: 2e-2 of the gradient scale)
     torch.testing.assert_close(dw.cpu() - base, w.grad, rtol=2e-2, atol=2e-4 * n ** 0.5 + 2e-2 * float(w.grad.abs().max()))
     torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3)), rtol=1e-3, atol=1e-3 * n ** 0.5)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,hw', [(32, 32, 3, 1, (20, 37)), (64, 64, 3, 1, (9, 33)), (32, 32, 3, 2, (21, 70)),
+                                                  (64, 64, 1, 1, (12, 40)), (128, 64, 3, 1, (7, 40))])
+def test_mfma_dgrad_accumulates_partial_gradient(be, cin, cout, k, stride, hw):
+    """gradient fan-in folded into the data-gradient kernel: conv2d(transposed, res=partial, RES_ADD) with nothing
+    else in the epilogue runs the store-stage accumulate flavour (EPI_RAW_ACC): bf16(dgrad) + partial, i.e. exactly
+    the separate elementwise add it replaces (one bf16 rounding of the sum)."""
+    from led_net_amd import ops
+    x = r16(torch.randn(2, cin, *hw))
+    w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    pad = k // 2
+    Ho, Wo = ops.conv_out_size(hw[0], k, stride, pad, 1), ops.conv_out_size(hw[1], k, stride, pad, 1)
+    dz = r16(torch.randn(2, cout, Ho, Wo))
+    partial = r16(torch.randn(2, cin, *hw))
+    wp = ops.pack_conv_weights(D(w), 1)
+    plain = ops.conv2d(nhwc(dz).bfloat16(), D(w), stride=stride, pad=pad, transposed=True, out_hw=hw, w_bf16=wp)
+    fused = ops.conv2d(nhwc(dz).bfloat16(), D(w), stride=stride, pad=pad, transposed=True, out_hw=hw, w_bf16=wp,
+                       res=nhwc(partial).bfloat16(), res_mode=ops.RES_ADD)
+    want = (plain.float() + nhwc(partial)).bfloat16()
+    assert torch.equal(fused.cpu(), want.cpu())
+    xg = x.clone().requires_grad_(True)
+    F.conv2d(xg, r16(w), stride=stride, padding=pad).backward(dz)
+    torch.testing.assert_close(nchw(fused), xg.grad + partial, rtol=2e-2, atol=3e-2)
