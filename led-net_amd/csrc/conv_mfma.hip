@@ -316,7 +316,7 @@ constexpr bool epi_stats(int e) { return e == EPI_RAW_STATS || e == EPI_FULL; }
 // step i and fly during its MFMA phase and epilogue.  Because vmcnt retires in order, nothing in
 // the MFMA phase or the RAW epilogues waits on vector memory: the weight fragments of the current
 // K-chunk sit in LDS ([tap][cout][32 ci + 8 pad], zero-filled tails; loaded once when Cin <= 32).
-template <int WM, int WN, int MT, int K, int S, int UP, int EPI>
+template <int WM, int WN, int MT, int K, int S, int UP, int EPI, bool VEC>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     constexpr int TR = WM * MT;
     constexpr int PR = (TR - 1) * S + K, PC = 31 * S + K;
@@ -324,7 +324,6 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     constexpr int NCO = WN * 32;                            // output channels per workgroup
     constexpr int WROWS = KK * NCO;                         // weight rows of one K-chunk
     constexpr int NLW = (WROWS * 4 + 255) / 256;
-    static_assert(PR * PC * PIXB >= 4 * 32 * PIXB, "store-transposition buffers alias the patch");
     __shared__ __attribute__((aligned(16))) unsigned char s_patch[PR * PC * PIXB];
     __shared__ __attribute__((aligned(16))) unsigned char s_w[WROWS * PIXB];
     __shared__ float s_par[3 * NCO];                        // EPI_FULL: out_scale, out_shift, slope
@@ -333,8 +332,15 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     const int lr = lane & 31, lh = lane >> 5;
     const int cbw = blockIdx.y * NCO;                       // first output channel of the workgroup
     const int cb0 = cbw + wn * 32;                          // ... of this wave's N-tile
-    const bool vec = (a.Cout & 7) == 0;                     // 16-byte NHWC stores through LDS
-    unsigned char* s_ow = s_patch + wid * (32 * PIXB);      // per-wave store transposition (after the MFMA phase)
+    // VEC: Cout % 8 == 0, 16-byte NHWC stores through LDS; else the narrow heads (Cout < 8), scalar stores.
+    // Compile-time: as a run-time flag it put a branch around every accumulator quad of the epilogue.
+    constexpr bool vec = VEC;
+    // per-wave store transposition (after the MFMA phase): EG output rows at a time, so that one pair of wave
+    // synchronisations (each a full LDS drain) serves EG rows instead of one -- the epilogue was the longest phase
+    // of a RAW step (cycle counters r03s: 3900 of 10500 cycles, 8 drains per step)
+    constexpr int EG = MT >= 2 ? 2 : 1;
+    static_assert(PR * PC * PIXB >= 4 * EG * 32 * PIXB, "store-transposition buffers alias the patch");
+    unsigned char* s_ow = s_patch + wid * (EG * 32 * PIXB);
 
     const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
     const long tb = (long)blockIdx.x * a.tiles_per_block;
@@ -380,26 +386,37 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
 
-    PatchStage<PR, PC, S, UP> stage;
-#define LEDN_CONV_FETCH(tile_, c0_)                                                                   \
+    // DEEP: two register staging sets, the loads of step i+2 issued while step i computes and step i+1's are still
+    // outstanding (twice the bytes in flight).  Built and measured (r03r): no change (3x3 32->32 data gradient 31.9
+    // vs 32.0 us) -- the per-phase cycle counters (r03s) put the time in the epilogue and the index arithmetic of
+    // fetch / commit, not in waiting for memory.  Kept off: it costs ~28 VGPRs.
+    constexpr bool DEEP = false;
+    PatchStage<PR, PC, S, UP> stage, stage2;
+#define LEDN_CONV_FETCH(st_, tile_, c0_)                                                              \
     do {                                                                                              \
         long b_ = (tile_);                                                                            \
         const int tw_ = (int)(b_ % a.tiles_w); b_ /= a.tiles_w;                                       \
         const int th_ = (int)(b_ % a.tiles_h);                                                        \
-        stage.fetch(a.x, (int)(b_ / a.tiles_h), a.H, a.W, a.Cin, th_ * TR * S - a.pad,                \
-                    tw_ * 32 * S - a.pad, (c0_), tid);                                                \
+        st_.fetch(a.x, (int)(b_ / a.tiles_h), a.H, a.W, a.Cin, th_ * TR * S - a.pad,                  \
+                  tw_ * 32 * S - a.pad, (c0_), tid);                                                  \
     } while (0)
-    long tile = tb;
-    int c0 = 0;
-    LEDN_CONV_FETCH(tile, 0);
-    while (tile < te) {
-        stage.commit(s_patch, a.in_scale, a.in_shift, a.in_slope, a.in_act, c0, tid);
+    // one (tile, K-chunk) step: `stg` holds its patch; afterwards stg is refilled with the step `look` ahead
+    auto do_step = [&](auto& stg, const long tile, const int c0, const int look) {
+        stg.commit(s_patch, a.in_scale, a.in_shift, a.in_slope, a.in_act, c0, tid);
         if (!one_chunk) LEDN_CONV_WEIGHTS(c0);
         __syncthreads();
         long ntile = tile;
         int nc0 = c0 + CK;
         if (nc0 >= a.Cin) { nc0 = 0; ntile = tile + 1; }
-        if (ntile < te) LEDN_CONV_FETCH(ntile, nc0);
+        {
+            long ft = ntile;
+            int fc = nc0;
+            if (look == 2) {
+                fc += CK;
+                if (fc >= a.Cin) { fc = 0; ft += 1; }
+            }
+            if (ft < te) LEDN_CONV_FETCH(stg, ft, fc);
+        }
         // ---- taps x k-steps, all operands from LDS.  A = weights (M = cout), B = pixels (N = 32
         // pixels of a row): the accumulator lane owns ONE pixel and 4 x 4 consecutive channels.
         // The fragments of product step i+1 (one weight fragment + MT pixel fragments, ds_read_b128 each) are read
@@ -445,11 +462,27 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
             const int ho0 = th * TR + wm * MT, wo0 = tw * 32;
             const int wo = wo0 + lr;
             const float hi = a.act_out == LEDN_ACT_RELU6 ? 6.f : 3.0e38f;
+            // the two 16-byte pieces this lane moves per output row: pixel px_h = (lane >> 2) + 16 h, channels
+            // cb0 + 8 (lane & 3) ...; element offset of row ho0 (rows advance by Wo * Cout)
+            const int piece = lane & 3;
+            const bool pc_ok = cb0 + piece * 8 < a.Cout;
+            bool px_ok[2];
+            long yoff[2];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
+            for (int h = 0; h < 2; ++h) {
+                const int px = (lane >> 2) + 16 * h;
+                px_ok[h] = pc_ok && wo0 + px < a.Wo;
+                yoff[h] = (((long)n * a.Ho + ho0) * a.Wo + wo0 + px) * a.Cout + cb0 + piece * 8;
+            }
+            const long row_elems = (long)a.Wo * a.Cout;
+#pragma unroll
+            for (int mg = 0; mg < MT; mg += EG) {
+#pragma unroll
+            for (int m = mg; m < mg + EG; ++m) {
                 const int ho = ho0 + m;
                 const bool pix_ok = ho < a.Ho && wo < a.Wo;
                 const long pix = (((long)n * a.Ho + ho) * a.Wo + wo) * a.Cout;
+                unsigned char* s_om = s_ow + (m - mg) * (32 * PIXB);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int cl = wn * 32 + 8 * q + 4 * lh;         // channel inside the workgroup's slice
@@ -480,7 +513,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                         ld4(s_par + 2 * NCO + cl, ng);
                         if (a.res_mode != LEDN_RES_NONE) {
                             float r[4] = {0.f, 0.f, 0.f, 0.f};
-                            if (vec) {
+                            if constexpr (vec) {
                                 if (pix_ok && c4 < a.Cout) ld4(a.res + pix + c4, r);
                             } else {
 #pragma unroll
@@ -495,8 +528,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], 0.f) + ng[j] * fminf(v[j], 0.f), hi);
                     }
-                    if (vec) {
-                        st4(reinterpret_cast<bf16_t*>(s_ow + lr * PIXB) + 8 * q + 4 * lh, v);
+                    if constexpr (vec) {
+                        st4(reinterpret_cast<bf16_t*>(s_om + lr * PIXB) + 8 * q + 4 * lh, v);
                     } else if (q == 0) {   // narrow heads (Cout < 8): channels 4*lh + j, scalar stores
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -506,43 +539,70 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                             }
                     }
                 }
-                if (vec) {
-                    // bf16 tile through the per-wave LDS buffer: every global store is 16 B per lane,
+            }
+                if constexpr (vec) {
+                    // bf16 rows through the per-wave LDS buffer: every global store is 16 B per lane,
                     // 4 lanes per pixel (whole 64-byte channel rows)
-                    uint4 radd[2];
-                    if (EPI == EPI_RAW_ACC) {    // the addend's two pieces, in flight during the transposition
+                    uint4 radd[EG][2];
+                    if (EPI == EPI_RAW_ACC) {    // the addend's pieces, in flight during the transposition
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int px = (lane >> 2) + 16 * h, piece = lane & 3;
-                            const bool okp = ho < a.Ho && wo0 + px < a.Wo && cb0 + piece * 8 < a.Cout;
-                            radd[h] = *reinterpret_cast<const uint4*>(
-                                a.res + (okp ? (((long)n * a.Ho + ho) * a.Wo + wo0 + px) * a.Cout + cb0 + piece * 8 : 0L));
-                        }
+                        for (int e = 0; e < EG; ++e)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const bool okp = px_ok[h] && ho0 + mg + e < a.Ho;
+                                radd[e][h] = *reinterpret_cast<const uint4*>(a.res + (okp ? yoff[h] + (mg + e) * row_elems : 0L));
+                            }
                     }
                     wave_sync();
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int px = (lane >> 2) + 16 * h, piece = lane & 3;
-                        uint4 o = *reinterpret_cast<const uint4*>(s_ow + px * PIXB + piece * 16);
-                        if (EPI == EPI_RAW_ACC) {
-                            float fo[8], fr[8];
-                            ld8(reinterpret_cast<const bf16_t*>(&o), fo);
-                            ld8(reinterpret_cast<const bf16_t*>(&radd[h]), fr);
+                    for (int e = 0; e < EG; ++e)
 #pragma unroll
-                            for (int k2 = 0; k2 < 8; ++k2) fo[k2] += fr[k2];
-                            st8(reinterpret_cast<bf16_t*>(&o), fo);
+                        for (int h = 0; h < 2; ++h) {
+                            const int px = (lane >> 2) + 16 * h;
+                            uint4 o = *reinterpret_cast<const uint4*>(s_ow + e * (32 * PIXB) + px * PIXB + piece * 16);
+                            if (EPI == EPI_RAW_ACC) {
+                                float fo[8], fr[8];
+                                ld8(reinterpret_cast<const bf16_t*>(&o), fo);
+                                ld8(reinterpret_cast<const bf16_t*>(&radd[e][h]), fr);
+#pragma unroll
+                                for (int k2 = 0; k2 < 8; ++k2) fo[k2] += fr[k2];
+                                st8(reinterpret_cast<bf16_t*>(&o), fo);
+                            }
+                            if (px_ok[h] && ho0 + mg + e < a.Ho)
+                                *reinterpret_cast<uint4*>(a.y + yoff[h] + (mg + e) * row_elems) = o;
                         }
-                        if (ho < a.Ho && wo0 + px < a.Wo && cb0 + piece * 8 < a.Cout)
-                            *reinterpret_cast<uint4*>(a.y + (((long)n * a.Ho + ho) * a.Wo + wo0 + px) * a.Cout + cb0 +
-                                                      piece * 8) = o;
-                    }
                     wave_sync();
                 }
             }
-            if (vec) __syncthreads();   // the transposition buffers alias the patch of the next step
+            if constexpr (vec) __syncthreads();   // the transposition buffers alias the patch of the next step
         }
-        tile = ntile;
-        c0 = nc0;
+    };
+    {
+        long tile = tb;
+        int c0 = 0;
+        auto advance = [&]() {
+            c0 += CK;
+            if (c0 >= a.Cin) { c0 = 0; tile += 1; }
+        };
+        LEDN_CONV_FETCH(stage, tile, 0);
+        if (DEEP) {
+            long t1 = tile;
+            int c1 = CK;
+            if (c1 >= a.Cin) { c1 = 0; t1 += 1; }
+            if (t1 < te) LEDN_CONV_FETCH(stage2, t1, c1);
+            while (tile < te) {
+                do_step(stage, tile, c0, 2);
+                advance();
+                if (!(tile < te)) break;
+                do_step(stage2, tile, c0, 2);
+                advance();
+            }
+        } else {
+            while (tile < te) {
+                do_step(stage, tile, c0, 1);
+                advance();
+            }
+        }
     }
 #undef LEDN_CONV_FETCH
 #undef LEDN_CONV_WEIGHTS
@@ -579,7 +639,8 @@ static int launch_epi(MfmaConvArgs a, hipStream_t s) {
     nbx = cdiv(ntiles, a.tiles_per_block);
     const dim3 grid((unsigned)nbx, (unsigned)gy);
     a.part = (epi_stats(EPI) && a.stat_sum && nbx * WM > 16) ? ws_take(nbx * WM * 2 * a.Cout) : nullptr;
-    LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI>), grid, dim3(256), 0, s, a);
+    if ((a.Cout & 7) == 0) LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI, true>), grid, dim3(256), 0, s, a);
+    else LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI, false>), grid, dim3(256), 0, s, a);
     if (a.part) return finish_partials(a.part, (int)(nbx * WM), a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
     return check_launch();
 }
