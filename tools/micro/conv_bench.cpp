@@ -19,6 +19,10 @@ static const Shape SHAPES[] = {
     {"fwd", 64, 64, 1, 1, 4, 16, 128, 128}, {"dgrad", 64, 64, 1, 1, 4, 16, 128, 128}, {"wgrad", 64, 64, 1, 1, 4, 16, 128, 128},
     {"fwd", 128, 128, 1, 1, 4, 16, 128, 128}, {"fwd", 128, 64, 3, 1, 1, 16, 128, 128}, {"fwd", 64, 16, 1, 1, 4, 16, 128, 128},
     {"fwd", 64, 128, 3, 2, 1, 16, 128, 128}, {"wgrad", 64, 128, 3, 2, 1, 16, 128, 128},
+    // 1x1 stride 1 is layout-agnostic: the same tensors viewed as [N*H*W/512][16][32] make every 16 x 32 tile a
+    // LINEAR 512-pixel chunk of memory instead of 16 segments a row pitch apart
+    {"fwd", 64, 64, 1, 1, 4, 512, 16, 32}, {"dgrad", 64, 64, 1, 1, 4, 512, 16, 32}, {"fwd", 32, 32, 1, 1, 1, 8192, 16, 32},
+    {"fwd", 128, 128, 1, 1, 4, 512, 16, 32}, {"fwd", 64, 16, 1, 1, 4, 512, 16, 32},
 };
 
 int main(int argc, char** argv) {
