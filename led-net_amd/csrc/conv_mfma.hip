@@ -386,21 +386,11 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
 
-<<<<<<< Updated upstream
     // DEEP: two register staging sets, the loads of step i+2 issued while step i computes and step i+1's are still
     // outstanding (twice the bytes in flight).  Built and measured (r03r): no change (3x3 32->32 data gradient 31.9
     // vs 32.0 us) -- the per-phase cycle counters (r03s) put the time in the epilogue and the index arithmetic of
     // fetch / commit, not in waiting for memory.  Kept off: it costs ~28 VGPRs.
     constexpr bool DEEP = false;
-=======
-    // DEEP: two register staging sets, the loads of step i+2 are issued while step i computes and step i+1's are
-    // still outstanding.  Why: the kernel is bound by BYTES IN FLIGHT, not by compute -- PMC r03c: 37-43 % of the
-    // wave cycles in s_waitcnt, and by Little's law 2 workgroups x one 39 KB patch outstanding per CU at the
-    // ~5 us loaded memory latency is ~4 TB/s, which is what the one-ahead version reaches; a plain streaming
-    // kernel keeps ~128 KB per CU outstanding.  Flavours with register room only (the statistics epilogue has
-    // 32 more live registers and would spill).
-    constexpr bool DEEP = (EPI == EPI_RAW || EPI == EPI_RAW_ACC) && MT * WM >= 8;
->>>>>>> Stashed changes
     PatchStage<PR, PC, S, UP> stage, stage2;
 #define LEDN_CONV_FETCH(st_, tile_, c0_)                                                              \
     do {                                                                                              \
@@ -613,36 +603,6 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                 advance();
             }
         }
-<<<<<<< Updated upstream
-=======
-    };
-    {
-        long tile = tb;
-        int c0 = 0;
-        auto advance = [&]() {
-            c0 += CK;
-            if (c0 >= a.Cin) { c0 = 0; tile += 1; }
-        };
-        LEDN_CONV_FETCH(stage, tile, 0);
-        if (DEEP) {
-            long t1 = tile;
-            int c1 = CK;
-            if (c1 >= a.Cin) { c1 = 0; t1 += 1; }
-            if (t1 < te) LEDN_CONV_FETCH(stage2, t1, c1);
-            while (tile < te) {
-                do_step(stage, tile, c0, 2);
-                advance();
-                if (!(tile < te)) break;
-                do_step(stage2, tile, c0, 2);
-                advance();
-            }
-        } else {
-            while (tile < te) {
-                do_step(stage, tile, c0, 1);
-                advance();
-            }
-        }
->>>>>>> Stashed changes
     }
 #undef LEDN_CONV_FETCH
 #undef LEDN_CONV_WEIGHTS
