@@ -448,6 +448,7 @@ class DwPackFn(Function):
     @staticmethod
     def forward(ctx, stacked, *weights):
         ctx.stacked = stacked
+        ctx.set_materialize_grads(False)        # steady state: no gradient arrives (see backward)
         ctx.save_for_backward(*weights)
         ctx.sinks = [_Sinks.get(w) for w in weights]
         key = (tuple(id(w) for w in weights), bool(stacked))
@@ -463,6 +464,8 @@ class DwPackFn(Function):
     @staticmethod
     def backward(ctx, dpacked):
         weights = ctx.saved_tensors
+        if dpacked is None:       # every consumer accumulated into the bank's persistent gradient (_DwBanks.flush)
+            return (None,) + (None,) * len(weights)
         dpacked = _c(dpacked)
         if all(s is not None for s in ctx.sinks):
             T.dw_unpack_grad(weights, ctx.sinks, dpacked, ctx.stacked)
@@ -767,6 +770,7 @@ class OhemFn(Function):
         ctx.save_for_backward(logits, target, work, out)
         ctx.cfg = (loss_weight, ignore_label)
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)        # (no zero tensor for the non-differentiable output)
         loss = out[0].clone()   # 0-dim view copy (4 bytes)
         return loss, out
 
