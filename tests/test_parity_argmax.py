@@ -18,8 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = os.path.join(ROOT, 'tests', 'data', 'lednet_test_config.py')
 
 
-@pytest.mark.parametrize('seed', [1, 2])
-def test_f32_argmax_masks_bit_exact_config_a(seed):
+@pytest.mark.parametrize('seed,batch', [(1, 1), (2, 2)])      # BASELINE config A is 1 x 3 x 512 x 512
+def test_f32_argmax_masks_bit_exact_config_a(seed, batch):
     import led_net_amd as L
     torch.manual_seed(304)
     cfg = L.load_config(CFG)
@@ -28,7 +28,7 @@ def test_f32_argmax_masks_bit_exact_config_a(seed):
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model.to('cuda:0')
     g = torch.Generator().manual_seed(seed)
-    img = torch.randint(0, 256, (2, 3, 512, 512), dtype=torch.uint8, generator=g)
+    img = torch.randint(0, 256, (batch, 3, 512, 512), dtype=torch.uint8, generator=g)
     with torch.no_grad():
         want, want_mask = spec.predict(spec.preprocess(img), sd)
         out = model(img.cuda(), mode='predict')
@@ -38,7 +38,7 @@ def test_f32_argmax_masks_bit_exact_config_a(seed):
     margin = (want[:, 0] - want[:, 1]).abs()
     flips = mask != want_mask
     inside = int((margin <= 1e-5).sum())
-    print(f'f32 predict 2x3x512x512 seed {seed}: max |logit err| {err:.3e}; argmax flips {int(flips.sum())} of {mask.numel()} '
+    print(f'f32 predict {batch}x3x512x512 seed {seed}: max |logit err| {err:.3e}; argmax flips {int(flips.sum())} of {mask.numel()} '
           f'({int((flips & (margin > 1e-5)).sum())} outside the 1e-5 margin band, {inside} pixels inside it)')
     assert err < 1e-4, err
     assert torch.equal(mask[margin > 1e-5], want_mask[margin > 1e-5])
