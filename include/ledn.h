@@ -212,6 +212,40 @@ typedef struct {
 } ledn_dwpack_entry;
 int ledn_dw_repack_multi(const ledn_dwpack_entry* table_dev, int n, int max_elems, int dir, void* stream);
 
+/* Train-time augmentation on the GPU: one launch builds the padded uint8 batch
+ *   out_img [n][3][OH][OW] (BGR planes, as PackSegInputs emits them) and out_seg [n][OH][OW] (int64, may be NULL)
+ * from the decoded source images: resize (cv2 INTER_LINEAR 8-bit fixed point; labels: INTER_NEAREST) -> crop ->
+ * horizontal flip -> PhotoMetricDistortion, with every intermediate 8-bit rounding of the CPU pipeline; pixels
+ * outside the crop extent (ch, cw) get pad_val / seg_pad_val (stack_batch).  The random parameters are drawn on the
+ * host in the reference's numpy.random order (led_net_amd/transforms.py) and passed per image in a device table.
+ * Replaces: RandomResize -> RandomCrop -> RandomFlip -> PhotoMetricDistortion -> PackSegInputs of
+ * configs/_base_/datasets/pascal_voc12.py:6-18 (mmseg/datasets/transforms/transforms.py:208-337, 583-750, 1013-1033,
+ * formatting.py:50-107; mmcv Resize, cv2.resize, cv2.cvtColor for the un-vendored parts).
+ * ledn_aug_crop_hist: per-image class counts hist[n][256] (caller zeroes) of the candidate crop of the resized label
+ * map: RandomCrop's cat_max_ratio test (transforms.py:287-296, np.unique on the crop). */
+typedef struct {
+    const unsigned char* img;   /* source image, uint8 H x W x 3 (BGR as decoded), device memory */
+    const unsigned char* seg;   /* source label map, uint8 H x W, device memory (NULL: no labels) */
+    int H, W;                   /* source size */
+    int RH, RW;                 /* size after the resize (== H, W: no resize) */
+    double sx, sy;              /* cv2's inverse scale: 1 / ((double)RW / W), 1 / ((double)RH / H) */
+    int oy, ox;                 /* crop offset inside the resized image */
+    int ch, cw;                 /* crop extent = valid extent of the output (<= OH, OW) */
+    int flip;                   /* 1: horizontal flip of the crop */
+    int bright_on;
+    float bright_beta;          /* convert(img, beta=...) */
+    int contrast_mode;          /* PhotoMetricDistortion's `mode`: 1 = contrast before saturation, 0 = last */
+    int contrast_on;
+    float contrast_alpha;
+    int sat_on;
+    float sat_alpha;
+    int hue_on;
+    int hue_delta;
+} ledn_aug_entry;
+int ledn_augment_batch(const ledn_aug_entry* table_dev, int n, unsigned char* out_img, long long* out_seg, int OH,
+                       int OW, int pad_val, int seg_pad_val, void* stream);
+int ledn_aug_crop_hist(const ledn_aug_entry* table_dev, int n, int max_pixels, int* hist, void* stream);
+
 /* SESP split/transform stage 1 with hierarchical feature fusion:
  *   y[..., b*n + c] = sum_{b' <= b} dw3x3_{dil[b'], stride}(x)[..., c]     b = 0..3
  * x [N,H,W,n], w [4][3][3][n], y [N,Ho,Wo,4n].

@@ -59,6 +59,14 @@ class DwPackEntry(C.Structure):
     _fields_ = [('d', DwPackDesc), ('packed', fp), ('dpacked', fp)]
 
 
+class AugEntry(C.Structure):          # mirrors ledn_aug_entry field for field
+    _fields_ = [('img', vp), ('seg', vp), ('H', i32), ('W', i32), ('RH', i32), ('RW', i32),
+                ('sx', C.c_double), ('sy', C.c_double), ('oy', i32), ('ox', i32), ('ch', i32), ('cw', i32),
+                ('flip', i32), ('bright_on', i32), ('bright_beta', C.c_float), ('contrast_mode', i32),
+                ('contrast_on', i32), ('contrast_alpha', C.c_float), ('sat_on', i32), ('sat_alpha', C.c_float),
+                ('hue_on', i32), ('hue_delta', i32)]
+
+
 class PyrDesc(C.Structure):
     _fields_ = [('x', vp), ('w', fp), ('y', vp),
                 ('N', i32), ('H', i32), ('W', i32), ('n', i32), ('Ho', i32), ('Wo', i32), ('stride', i32),
@@ -153,6 +161,8 @@ _PROTOS = {
     'ledn_iou_hist': ([vp, vp, i64, i32, i32, fp, vp], i32),
     'ledn_dw_pack': ([C.POINTER(DwPackDesc), fp, vp], i32),
     'ledn_dw_repack_multi': ([vp, i32, i32, i32, vp], i32),
+    'ledn_augment_batch': ([vp, i32, vp, vp, i32, i32, i32, i32, vp], i32),
+    'ledn_aug_crop_hist': ([vp, i32, i32, vp, vp], i32),
     'ledn_dw_unpack_grad': ([C.POINTER(DwPackDesc), fp, vp], i32),
     'ledn_sesp_pyramid': ([C.POINTER(PyrDesc), vp], i32),
     'ledn_channel_stats': ([vp, vp, i64, i32, i32, fp, fp, vp], i32),

@@ -1,0 +1,211 @@
+// augment.hip -- train-time augmentation on the GPU (include/ledn.h: ledn_augment_batch,
+// ledn_aug_crop_hist).  One launch per batch: every output pixel of the padded uint8 batch is produced from the
+// decoded source image by  resize (cv2 INTER_LINEAR, 8-bit fixed point) -> crop -> horizontal flip ->
+// PhotoMetricDistortion  with the intermediate 8-bit roundings of the reference's numpy / cv2 stages, so the
+// result is bit-identical to the CPU pipeline for the same random parameters (drawn on the host in the reference's
+// numpy.random order: led_net_amd/transforms.py).  Label maps take the nearest-neighbour path.
+//   reference: mmseg/datasets/transforms/transforms.py:208-337 (RandomCrop), 583-750 (PhotoMetricDistortion),
+//   1013-1033 (RandomFlip._flip), formatting.py:50-107 (PackSegInputs); mmcv Resize / cv2.resize / cv2.cvtColor.
+// Byte work, HBM/latency-bound: ~12 source bytes read and 3 + 8 bytes written per output pixel.
+#include "ledn_rt.h"
+
+namespace ledn {
+
+// numpy evaluates every float32 operation separately: no contraction into fma here
+#ifdef LEDN_CPU_EMU
+static inline float mul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float add_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float sub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float rint_rn(float a) { return __builtin_rintf(a); }
+static inline float floor_f(float a) { return __builtin_floorf(a); }
+static inline double floor_d(double a) { return __builtin_floor(a); }
+#else
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float rint_rn(float a) { return rintf(a); }
+__device__ __forceinline__ float floor_f(float a) { return floorf(a); }
+__device__ __forceinline__ double floor_d(double a) { return floor(a); }
+#endif
+
+// cv::resize INTER_LINEAR coordinate of destination index d: source indices (s0, s1), 11-bit weights (a0, a1)
+__device__ __forceinline__ void linear_coord(int d, double scale, int src, int& s0, int& s1, int& a0, int& a1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floor_f(f);
+    f = sub_rn(f, (float)s);
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= src - 1) { f = 0.f; s = src - 1; }
+    a1 = (int)rint_rn(mul_rn(f, 2048.f));
+    a0 = (int)rint_rn(mul_rn(sub_rn(1.f, f), 2048.f));
+    s0 = s;
+    s1 = s + 1 < src ? s + 1 : src - 1;
+}
+
+// transforms.py:621-640  convert(): float32(img) * alpha + beta, clip, truncate
+__device__ __forceinline__ int convert_u8(int v, float alpha, float beta) {
+    float x = add_rn(mul_rn((float)v, alpha), beta);
+    x = x < 0.f ? 0.f : (x > 255.f ? 255.f : x);
+    return (int)x;
+}
+
+__device__ __forceinline__ int cv_div_table(int num_shifted, int i, double per) {
+    // saturate_cast<int>(num / (per * i)): the 12-bit division tables of cv2's 8-bit BGR2HSV
+    return i == 0 ? 0 : (int)__builtin_rint((double)num_shifted / (per * (double)i));
+}
+
+__device__ __forceinline__ void bgr2hsv_u8(int b, int g, int r, int& h, int& s, int& v) {
+    v = b > g ? b : g;
+    v = v > r ? v : r;
+    int vmin = b < g ? b : g;
+    vmin = vmin < r ? vmin : r;
+    const int diff = v - vmin;
+    s = (diff * cv_div_table(255 << 12, v, 1.0) + (1 << 11)) >> 12;
+    int hh = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+    hh = (hh * cv_div_table(180 << 12, diff, 6.0) + (1 << 11)) >> 12;
+    h = hh < 0 ? hh + 180 : hh;
+}
+
+__device__ __forceinline__ void hsv2bgr_u8(int hi, int si, int vi, int& b, int& g, int& r) {
+    const float s = mul_rn((float)si, (float)(1.0 / 255.0));
+    const float v = mul_rn((float)vi, (float)(1.0 / 255.0));
+    float fb, fg, fr;
+    if (si == 0) {
+        fb = fg = fr = v;
+    } else {
+        float h = mul_rn((float)hi, (float)(6.0 / 180.0));
+        if (h >= 6.f) h = sub_rn(h, 6.f);
+        int sector = (int)floor_f(h);
+        h = sub_rn(h, (float)sector);
+        if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+        float tab[4];
+        tab[0] = v;
+        tab[1] = mul_rn(v, sub_rn(1.f, s));
+        tab[2] = mul_rn(v, sub_rn(1.f, mul_rn(s, h)));
+        tab[3] = mul_rn(v, sub_rn(1.f, mul_rn(s, sub_rn(1.f, h))));
+        const int sec[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+        fb = tab[sec[sector][0]];
+        fg = tab[sec[sector][1]];
+        fr = tab[sec[sector][2]];
+    }
+    float x;
+    x = rint_rn(mul_rn(fb, 255.f)); b = (int)(x < 0.f ? 0.f : (x > 255.f ? 255.f : x));
+    x = rint_rn(mul_rn(fg, 255.f)); g = (int)(x < 0.f ? 0.f : (x > 255.f ? 255.f : x));
+    x = rint_rn(mul_rn(fr, 255.f)); r = (int)(x < 0.f ? 0.f : (x > 255.f ? 255.f : x));
+}
+
+__device__ __forceinline__ void contrast_u8(const ledn_aug_entry& e, int& b, int& g, int& r) {
+    if (e.contrast_on) {
+        b = convert_u8(b, e.contrast_alpha, 0.f);
+        g = convert_u8(g, e.contrast_alpha, 0.f);
+        r = convert_u8(r, e.contrast_alpha, 0.f);
+    }
+}
+
+// workgroup = 256 consecutive output pixels of image blockIdx.y
+__global__ void __launch_bounds__(256) augment_kernel(const ledn_aug_entry* table, unsigned char* out_img,
+                                                      long long* out_seg, int OH, int OW, int pad_val,
+                                                      int seg_pad_val) {
+    const ledn_aug_entry e = table[blockIdx.y];
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long)OH * OW) return;
+    const int y = (int)(p / OW), x = (int)(p % OW);
+    unsigned char* o = out_img + (long)blockIdx.y * 3 * OH * OW + p;
+    long long* os = out_seg ? out_seg + (long)blockIdx.y * OH * OW + p : nullptr;
+    if (y >= e.ch || x >= e.cw) {         // outside the crop: the batch padding (stack_batch)
+        o[0] = o[(long)OH * OW] = o[2l * OH * OW] = (unsigned char)pad_val;
+        if (os) *os = seg_pad_val;
+        return;
+    }
+    const int ry = e.oy + y, rx = e.ox + (e.flip ? e.cw - 1 - x : x);     // pixel of the resized image
+    int b, g, r;
+    if (e.RH == e.H && e.RW == e.W) {
+        const unsigned char* s = e.img + ((long)ry * e.W + rx) * 3;
+        b = s[0]; g = s[1]; r = s[2];
+    } else {
+        int x0, x1, ax0, ax1, y0, y1, by0, by1;
+        linear_coord(rx, e.sx, e.W, x0, x1, ax0, ax1);
+        linear_coord(ry, e.sy, e.H, y0, y1, by0, by1);
+        const unsigned char* r0 = e.img + (long)y0 * e.W * 3;
+        const unsigned char* r1 = e.img + (long)y1 * e.W * 3;
+        int c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int h0 = r0[x0 * 3 + k] * ax0 + r0[x1 * 3 + k] * ax1;     // horizontal pass, x 2048
+            const int h1 = r1[x0 * 3 + k] * ax0 + r1[x1 * 3 + k] * ax1;
+            int v = (((by0 * (h0 >> 4)) >> 16) + ((by1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            c[k] = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        b = c[0]; g = c[1]; r = c[2];
+    }
+    // PhotoMetricDistortion.transform (transforms.py:708-739)
+    if (e.bright_on) {
+        b = convert_u8(b, 1.f, e.bright_beta);
+        g = convert_u8(g, 1.f, e.bright_beta);
+        r = convert_u8(r, 1.f, e.bright_beta);
+    }
+    if (e.contrast_mode == 1) contrast_u8(e, b, g, r);
+    if (e.sat_on) {
+        int h, s, v;
+        bgr2hsv_u8(b, g, r, h, s, v);
+        s = convert_u8(s, e.sat_alpha, 0.f);
+        hsv2bgr_u8(h, s, v, b, g, r);
+    }
+    if (e.hue_on) {
+        int h, s, v;
+        bgr2hsv_u8(b, g, r, h, s, v);
+        h = (h + e.hue_delta) % 180;
+        if (h < 0) h += 180;              // numpy's % is non-negative
+        hsv2bgr_u8(h, s, v, b, g, r);
+    }
+    if (e.contrast_mode == 0) contrast_u8(e, b, g, r);
+    o[0] = (unsigned char)b;
+    o[(long)OH * OW] = (unsigned char)g;
+    o[2l * OH * OW] = (unsigned char)r;
+    if (os) {
+        int lab = seg_pad_val;
+        if (e.seg) {
+            int sx = (int)floor_d((double)rx * e.sx), sy = (int)floor_d((double)ry * e.sy);
+            sx = sx < e.W - 1 ? sx : e.W - 1;
+            sy = sy < e.H - 1 ? sy : e.H - 1;
+            lab = e.seg[(long)sy * e.W + sx];
+        }
+        *os = lab;
+    }
+}
+
+// class counts of the candidate crop of the resized label map (RandomCrop.crop_bbox's np.unique, transforms.py:287-296)
+__global__ void __launch_bounds__(256) aug_crop_hist_kernel(const ledn_aug_entry* table, int* hist) {
+    __shared__ unsigned s_h[256];
+    const ledn_aug_entry e = table[blockIdx.y];
+    s_h[threadIdx.x] = 0u;
+    __syncthreads();
+    const long P = (long)e.ch * e.cw;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        const int ry = e.oy + (int)(p / e.cw), rx = e.ox + (int)(p % e.cw);
+        int sx = (int)floor_d((double)rx * e.sx), sy = (int)floor_d((double)ry * e.sy);
+        sx = sx < e.W - 1 ? sx : e.W - 1;
+        sy = sy < e.H - 1 ? sy : e.H - 1;
+        atomicAdd(&s_h[e.seg[(long)sy * e.W + sx]], 1u);
+    }
+    __syncthreads();
+    if (s_h[threadIdx.x]) atomicAdd(hist + (long)blockIdx.y * 256 + threadIdx.x, (int)s_h[threadIdx.x]);
+}
+
+int augment_batch_impl(const ledn_aug_entry* table_dev, int n, unsigned char* out_img, long long* out_seg, int OH,
+                       int OW, int pad_val, int seg_pad_val, hipStream_t s) {
+    LEDN_REQUIRE(table_dev && out_img && n > 0 && n <= 65535 && OH > 0 && OW > 0);
+    LEDN_REQUIRE(pad_val >= 0 && pad_val <= 255);
+    LEDN_LAUNCH(augment_kernel, dim3((unsigned)cdiv((long)OH * OW, 256), (unsigned)n), dim3(256), 0, s, table_dev,
+                out_img, out_seg, OH, OW, pad_val, seg_pad_val);
+    return check_launch();
+}
+
+int aug_crop_hist_impl(const ledn_aug_entry* table_dev, int n, int max_pixels, int* hist, hipStream_t s) {
+    LEDN_REQUIRE(table_dev && hist && n > 0 && n <= 65535 && max_pixels > 0);
+    long nb = cdiv((long)max_pixels, 256 * 16);
+    if (nb > 256) nb = 256;
+    LEDN_LAUNCH(aug_crop_hist_kernel, dim3((unsigned)nb, (unsigned)n), dim3(256), 0, s, table_dev, hist);
+    return check_launch();
+}
+
+}  // namespace ledn

@@ -30,6 +30,9 @@ int im2col_stem_planar_impl(const void* x, int dtype_x, void* p, int N, int H, i
 int dw_pack_impl(const ledn_dwpack_desc& d, float* packed, hipStream_t s);
 int dw_unpack_grad_impl(const ledn_dwpack_desc& d, const float* dpacked, hipStream_t s);
 int dw_repack_multi_impl(const ledn_dwpack_entry* table_dev, int n, int max_elems, int dir, hipStream_t s);
+int augment_batch_impl(const ledn_aug_entry* table_dev, int n, unsigned char* out_img, long long* out_seg, int OH,
+                       int OW, int pad_val, int seg_pad_val, hipStream_t s);
+int aug_crop_hist_impl(const ledn_aug_entry* table_dev, int n, int max_pixels, int* hist, hipStream_t s);
 int sesp_pyramid_impl(const ledn_pyr_desc& d, hipStream_t s);
 int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
                        float* sqsum, hipStream_t s);
@@ -260,6 +263,13 @@ int ledn_relpos_bias_bwd(const float* dbiasT, const long long* index, float* dta
 }
 int ledn_dw_repack_multi(const ledn_dwpack_entry* table_dev, int n, int max_elems, int dir, void* stream) {
     return dw_repack_multi_impl(table_dev, n, max_elems, dir, S(stream));
+}
+int ledn_augment_batch(const ledn_aug_entry* table_dev, int n, unsigned char* out_img, long long* out_seg, int OH,
+                       int OW, int pad_val, int seg_pad_val, void* stream) {
+    return augment_batch_impl(table_dev, n, out_img, out_seg, OH, OW, pad_val, seg_pad_val, S(stream));
+}
+int ledn_aug_crop_hist(const ledn_aug_entry* table_dev, int n, int max_pixels, int* hist, void* stream) {
+    return aug_crop_hist_impl(table_dev, n, max_pixels, hist, S(stream));
 }
 int ledn_bilinear(const ledn_resize_desc* d, void* stream) { return d ? bilinear_impl(*d, S(stream)) : LEDN_EINVAL; }
 int ledn_adaptive_avgpool(const void* x, const void* xadd, float* y, int N, int H, int W, int C, int Sz,
