@@ -14,6 +14,7 @@ from .config import load_config  # noqa: F401
 from .train import Trainer  # noqa: F401
 from .metrics import IoUMetric  # noqa: F401
 from .checkpoint import init_model, load_checkpoint, resume, save_checkpoint  # noqa: F401
+from . import transforms  # noqa: F401
 
 MODELS.register_module(module=LEDNet)
 MODELS.register_module(module=LEDHead)

@@ -11,22 +11,18 @@
 
 namespace ledn {
 
-// numpy evaluates every float32 operation separately: no contraction into fma here
-#ifdef LEDN_CPU_EMU
-static inline float mul_rn(float a, float b) { volatile float r = a * b; return r; }
-static inline float add_rn(float a, float b) { volatile float r = a + b; return r; }
-static inline float sub_rn(float a, float b) { volatile float r = a - b; return r; }
-static inline float rint_rn(float a) { return __builtin_rintf(a); }
-static inline float floor_f(float a) { return __builtin_floorf(a); }
-static inline double floor_d(double a) { return __builtin_floor(a); }
-#else
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
-__device__ __forceinline__ float rint_rn(float a) { return rintf(a); }
-__device__ __forceinline__ float floor_f(float a) { return floorf(a); }
-__device__ __forceinline__ double floor_d(double a) { return floor(a); }
+// numpy / cv2 evaluate every floating-point operation separately.  hipcc contracts a * b + c into fma by default
+// (-ffp-contract=fast for device code) and HIP's __fmul_rn / __fadd_rn are plain operators, so contraction is
+// switched off for this translation unit: one fused multiply-add moves an 8-bit result by one level.
+#ifdef __clang__
+#pragma clang fp contract(off)
 #endif
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+__device__ __forceinline__ float rint_rn(float a) { return __builtin_rintf(a); }
+__device__ __forceinline__ float floor_f(float a) { return __builtin_floorf(a); }
+__device__ __forceinline__ double floor_d(double a) { return __builtin_floor(a); }
 
 // cv::resize INTER_LINEAR coordinate of destination index d: source indices (s0, s1), 11-bit weights (a0, a1)
 __device__ __forceinline__ void linear_coord(int d, double scale, int src, int& s0, int& s1, int& a0, int& a1) {
