@@ -245,3 +245,27 @@ def test_augmented_batch_feeds_the_train_step(be):
     assert tuple(data['inputs'].shape) == (2, 3, 320, 320) and data['inputs'].dtype == torch.uint8
     losses = model(data['inputs'], data['data_samples'], mode='loss')
     assert all(torch.isfinite(v).all() for v in losses.values())
+
+
+def test_reference_dataset_pipelines_build():
+    """the train / test pipelines of configs/_base_/datasets/pascal_voc12.py:6-26 (values mirrored here: the GPU box
+    has no /root/reference) build into the GPU Compose with the reference's type names and arguments"""
+    from led_net_amd import transforms as T
+    train_pipeline = [
+        dict(type='LoadImageFromFile'), dict(type='LoadAnnotations'),
+        dict(type='RandomResize', scale=(2048, 512), ratio_range=(0.5, 2.0), keep_ratio=True),
+        dict(type='RandomCrop', crop_size=(512, 512), cat_max_ratio=0.75),
+        dict(type='RandomFlip', prob=0.5), dict(type='PhotoMetricDistortion'), dict(type='PackSegInputs')]
+    test_pipeline = [dict(type='LoadImageFromFile'), dict(type='Resize', scale=(2048, 512), keep_ratio=True),
+                     dict(type='LoadAnnotations'), dict(type='PackSegInputs')]
+    names = [type(t).__name__ for t in T.Compose(train_pipeline).transforms]
+    assert names == ['RandomResize', 'RandomCrop', 'RandomFlip', 'PhotoMetricDistortion', 'PackSegInputs']
+    assert [type(t).__name__ for t in T.Compose(test_pipeline).transforms] == ['Resize', 'PackSegInputs']
+    ref = '/root/reference/configs/LED_Net/LEDNet_80k_cityscapes-1024x1024.py'
+    import os
+    if os.path.exists(ref):            # in the build container: the reference's own file, unchanged
+        import led_net_amd as L
+        cfg = L.load_config(ref)
+        assert [c['type'] for c in cfg['train_pipeline']] == [c['type'] for c in train_pipeline]
+        T.Compose(cfg['train_pipeline'])
+        T.Compose(cfg['test_pipeline'])

@@ -37,6 +37,9 @@ def parse_args():
     p.add_argument('--width', type=int, default=1024)
     p.add_argument('--save-interval', type=int, default=0)
     p.add_argument('--f32', action='store_true')
+    p.add_argument('--augment', action='store_true',
+                   help="run the config's train_pipeline (RandomResize / RandomCrop / RandomFlip / PhotoMetricDistortion) on the "
+                        'GPU over synthetic decoded images (H x 2W uint8 BGR) instead of feeding ready-made crops')
     return p.parse_args()
 
 
@@ -82,12 +85,32 @@ def main():
     max_iters = args.max_iters or trainer.max_iters
     g = torch.Generator().manual_seed(304 + rank)
     bs = args.batch_size
+    pipe = None
+    if args.augment:
+        import numpy as np
+        from led_net_amd import transforms as T
+        pipe_cfg = [dict(c) for c in cfg['train_pipeline']]
+        for c in pipe_cfg:                  # the CLI's crop size wins over the dataset config's
+            if c['type'] == 'RandomCrop':
+                c['crop_size'] = (args.height, args.width)
+            elif c['type'] == 'RandomResize':
+                c['scale'] = (2 * args.width, args.height)
+        pre = cfg['model'].get('data_preprocessor') or {}
+        pipe = T.Compose(pipe_cfg, pad_val=pre.get('pad_val', 0), seg_pad_val=pre.get('seg_pad_val', 255))
+        np.random.seed(304 + rank)
     t0, tlog = time.perf_counter(), time.perf_counter()
     for it in range(start, max_iters):
-        img = torch.randint(0, 256, (bs, 3, args.height, args.width), dtype=torch.uint8, generator=g).to(dev)
-        lab = torch.randint(0, 2, (bs, 1, args.height, args.width), dtype=torch.int64, generator=g)
-        lab[:, :, :16], lab[:, :, -16:], lab[..., :16], lab[..., -16:] = 255, 255, 255, 255
-        lab = lab.to(dev)
+        if pipe is not None:                # "decoded" H x 2W images + label maps -> augmented crops, one launch
+            raw = torch.randint(0, 256, (bs, args.height, 2 * args.width, 3), dtype=torch.uint8, generator=g).to(dev)
+            seg = torch.randint(0, 2, (bs, args.height // 8, args.width // 4), dtype=torch.uint8, generator=g).to(dev)
+            seg = seg.repeat_interleave(8, 1).repeat_interleave(8, 2).contiguous()
+            aug = pipe.batch([dict(img=raw[i], gt_seg_map=seg[i]) for i in range(bs)], out_hw=(args.height, args.width))
+            img, lab = aug['batch'], aug['labels']
+        else:
+            img = torch.randint(0, 256, (bs, 3, args.height, args.width), dtype=torch.uint8, generator=g).to(dev)
+            lab = torch.randint(0, 2, (bs, 1, args.height, args.width), dtype=torch.int64, generator=g)
+            lab[:, :, :16], lab[:, :, -16:], lab[..., :16], lab[..., -16:] = 255, 255, 255, 255
+            lab = lab.to(dev)
         out = trainer.train_step(img, [L.SegDataSample(gt=lab[i]) for i in range(bs)])
         if rank == 0 and ((it + 1) % 50 == 0 or it + 1 == max_iters):
             vals = {k: float(v.float().reshape(-1)[0]) for k, v in out.items()}
