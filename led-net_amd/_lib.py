@@ -244,8 +244,8 @@ def get_lib():
         return _override
     if _hip is None:
         _hip = Library(HIP_LIB_PATH, is_hip=True)
-        if os.environ.get('LEDN_STREAM_FAST') == '0':      # A/B measurements: the generic streaming kernels
-            _hip.set_option(OPT_STREAM_FAST, 0)
+        if os.environ.get('LEDN_STREAM_FAST') is not None:      # A/B measurements: bit 0 = BatchNorm / affine streaming
+            _hip.set_option(OPT_STREAM_FAST, int(os.environ['LEDN_STREAM_FAST']))   # kernels, bit 1 = LDS-tiled depthwise 3x3
     return _hip
 
 

@@ -219,7 +219,7 @@ static long bn_rows(const ledn_bnbwd_desc& d) {
 int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
     const int rc = bnbwd_validate(d, false);
     if (rc != LEDN_OK) return rc;
-    if (options().stream_fast && d.act != LEDN_ACT_SIGMOID) {
+    if ((options().stream_fast & 1) && d.act != LEDN_ACT_SIGMOID) {
         const int rf = bn_act_bwd_reduce_fast(d, s);
         if (rf >= 0) return rf;
     }
@@ -237,7 +237,7 @@ int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
 int bn_act_bwd_apply_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
     const int rc = bnbwd_validate(d, true);
     if (rc != LEDN_OK) return rc;
-    if (options().stream_fast && d.act != LEDN_ACT_SIGMOID) {
+    if ((options().stream_fast & 1) && d.act != LEDN_ACT_SIGMOID) {
         const int rf = bn_act_bwd_apply_fast(d, s);
         if (rf >= 0) return rf;
     }

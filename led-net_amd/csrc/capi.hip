@@ -94,7 +94,7 @@ int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_
 namespace ledn {
 static Workspace g_ws = {nullptr, 0};
 Workspace& workspace() { return g_ws; }
-static Options g_opt = {512, 512, 1};
+static Options g_opt = {512, 512, 3};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3
 Options& options() { return g_opt; }
 static DeferredStats g_defer = {false, nullptr, 0};
 DeferredStats& deferred_stats() { return g_defer; }
@@ -119,7 +119,7 @@ int ledn_set_option(int option, long long value) {
     switch (option) {
         case LEDN_OPT_CONV_WORKGROUPS: options().conv_workgroups = value > 0 ? (int)value : 512; return LEDN_OK;
         case LEDN_OPT_WGRAD_WORKGROUPS: options().wgrad_workgroups = value > 0 ? (int)value : 512; return LEDN_OK;
-        case LEDN_OPT_STREAM_FAST: options().stream_fast = value != 0; return LEDN_OK;
+        case LEDN_OPT_STREAM_FAST: options().stream_fast = (int)value; return LEDN_OK;
         default: return LEDN_EINVAL;
     }
 }

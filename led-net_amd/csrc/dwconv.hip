@@ -236,6 +236,163 @@ __global__ void __launch_bounds__(256) dw3x3_bf16_kernel(ledn_dw_desc d, const b
     }
 }
 
+// The same 3x3 depthwise conv with the input patch staged in LDS.  The kernel above re-reads every input pixel
+// nine times through the vector L1, whose 32 KB per CU hold a fraction of the three image rows a workgroup's
+// taps span (128 px x 128 B x (2*dil+1) rows): at 1/8 resolution the re-reads fall through to the L2 and the
+// kernel runs at ~1.9 TB/s of algorithmic traffic.  Here a workgroup owns a TH x 32-pixel tile of 32 channels:
+// the (TH + 2*HL) x (32 + 2*HL) patch is fetched ONCE (all 16-byte loads of a lane in flight before the first LDS
+// write, zero fill outside the image), the nine taps are ds_read_b128 (a wave reads 16 consecutive pixels x 64 B:
+// conflict-free), the output is written as 64-byte pixel halves.  Halo re-reads 1.41x (HL = 2, TH = 16).
+// HL = the largest dilation among the workgroup's channel groups (SESP's second stage uses dil + 1: 2 on the
+// spatial branch, 2..5 on the context branch).  Statistics: one partial row per tile.
+template <int FLIP, int HL, int TH>
+__global__ void __launch_bounds__(256) dw3x3_tile_kernel(ledn_dw_desc d, const bf16_t* add, float* part) {
+    constexpr int TW = 32, PW = TW + 2 * HL, PH = TH + 2 * HL, CW = 32, PXB = CW * 2;
+    constexpr int NL = (PH * PW * 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char s_patch[PH * PW * PXB];
+    __shared__ float s_red[2][64 * CW];
+    const int tid = threadIdx.x;
+    const int tx = (d.W + TW - 1) / TW, ty = (d.H + TH - 1) / TH, nch = d.C / CW;
+    const unsigned bid = xcd_block(blockIdx.x, gridDim.x);
+    const int ch = (int)(bid % (unsigned)nch);
+    const unsigned tile = bid / (unsigned)nch;
+    const int txi = (int)(tile % (unsigned)tx), tyi = (int)((tile / (unsigned)tx) % (unsigned)ty);
+    const int n = (int)(tile / (unsigned)(tx * ty));
+    const int y0 = tyi * TH - HL, x0 = txi * TW - HL;
+    const bf16_t* xin = reinterpret_cast<const bf16_t*>(d.x) + (long)n * d.H * d.W * d.C + ch * CW;
+    {
+        uint4 stage[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256, px = e >> 2, q = e & 3;
+            const int gy = y0 + px / PW, gx = x0 + px % PW;
+            const bool ok = e < PH * PW * 4 && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+            stage[i] = ok ? *reinterpret_cast<const uint4*>(xin + ((long)gy * d.W + gx) * d.C + q * 8)
+                          : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256;
+            if (e < PH * PW * 4) *reinterpret_cast<uint4*>(s_patch + (long)e * 16) = stage[i];
+        }
+    }
+    const int cg = tid & 3, pl = tid >> 2;
+    const int c = ch * CW + cg * 8;
+    const int dl = d.dil[c / d.group_size];
+    f32x2_t w[9][4];
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        f32x8_load(d.w + (long)(FLIP ? 8 - t : t) * d.C + c, w[t]);
+        toff[t] = (((t / 3 - 1) * dl) * PW + (t % 3 - 1) * dl) * PXB;
+    }
+    f32x2_t sc[4], sh[4], ng[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = f32x2_t{1.f, 1.f};
+        sh[i] = f32x2_t{0.f, 0.f};
+        ng[i] = d.act_out == LEDN_ACT_NONE ? f32x2_t{1.f, 1.f} : f32x2_t{0.f, 0.f};
+    }
+    if (!FLIP) {
+        if (d.out_scale) f32x8_load(d.out_scale + c, sc);
+        if (d.out_shift) f32x8_load(d.out_shift + c, sh);
+        if (d.act_out == LEDN_ACT_PRELU) f32x8_load(d.slope + c, ng);
+    }
+    const float hi = (!FLIP && d.act_out == LEDN_ACT_RELU6) ? 6.f : 3.0e38f;
+    const bool has_act = !FLIP && d.act_out != LEDN_ACT_NONE;
+    f32x2_t st1[4], st2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st1[i] = st2[i] = f32x2_t{0.f, 0.f};
+    __syncthreads();
+    bf16_t* y = reinterpret_cast<bf16_t*>(d.y) + (long)n * d.H * d.W * d.C + c;
+    const bf16_t* addp = (FLIP && add) ? add + (long)n * d.H * d.W * d.C + c : nullptr;
+    const int lx = pl & 31, gx = txi * TW + lx;
+#pragma unroll 2
+    for (int pass = 0; pass < TH / 2; ++pass) {
+        const int ly = pass * 2 + (pl >> 5), gy = tyi * TH + ly;
+        if (gy >= d.H || gx >= d.W) continue;
+        const unsigned char* ctr = s_patch + ((ly + HL) * PW + lx + HL) * PXB + cg * 16;
+        uint4 raw[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) raw[t] = *reinterpret_cast<const uint4*>(ctr + toff[t]);
+        f32x2_t acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x2_t{0.f, 0.f};
+        const long o = ((long)gy * d.W + gx) * d.C;
+        if (FLIP && addp) bf16x8_unpack(*reinterpret_cast<const uint4*>(addp + o), acc);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            f32x2_t xv[4];
+            bf16x8_unpack(raw[t], xv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = pk_fma(xv[i], w[t][i], acc[i]);
+        }
+        if (!FLIP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i] = pk_fma(acc[i], sc[i], sh[i]);
+                st1[i] += acc[i];
+                st2[i] = pk_fma(acc[i], acc[i], st2[i]);
+            }
+            if (has_act) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i].x = fminf(fmaxf(acc[i].x, 0.f) + ng[i].x * fminf(acc[i].x, 0.f), hi);
+                    acc[i].y = fminf(fmaxf(acc[i].y, 0.f) + ng[i].y * fminf(acc[i].y, 0.f), hi);
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(y + o) = bf16x8_pack(acc);
+    }
+    if (FLIP || !part) return;
+    // per-channel sums of the tile: [64 pixel lanes][32 channels] -> one partial row slice per workgroup
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s_red[0][pl * CW + cg * 8 + 2 * i] = st1[i].x;
+        s_red[0][pl * CW + cg * 8 + 2 * i + 1] = st1[i].y;
+        s_red[1][pl * CW + cg * 8 + 2 * i] = st2[i].x;
+        s_red[1][pl * CW + cg * 8 + 2 * i + 1] = st2[i].y;
+    }
+    __syncthreads();
+    if (tid < 2 * CW) {
+        const int j = tid / CW, cc = tid % CW;
+        float t0 = 0.f, t1 = 0.f;
+        for (int r = 0; r < 64; r += 2) {
+            t0 += s_red[j][r * CW + cc];
+            t1 += s_red[j][(r + 1) * CW + cc];
+        }
+        part[(long)tile * 2 * d.C + (long)j * d.C + ch * CW + cc] = t0 + t1;
+    }
+}
+
+// launches the tiled kernel when it applies (returns the number of partial rows through *rows), else -1
+static int dw3x3_tile_launch(const ledn_dw_desc& d, bool flip, const bf16_t* add, bool want_stats, float** part_out,
+                             long* rows_out, hipStream_t s) {
+    if (d.C % 32 || d.group_size % 8 || d.W < 32 || (long)d.N * d.H * d.W < 16384) return -1;
+    int hl = 0;
+    for (int g = 0; g * d.group_size < d.C; ++g) hl = d.dil[g] > hl ? d.dil[g] : hl;
+    if (hl > 5) return -1;
+    const int TH = hl <= 2 ? 16 : 8;
+    const long tiles = (long)d.N * cdiv(d.H, TH) * cdiv(d.W, 32);
+    const long nb = tiles * (d.C / 32);
+    if (nb > (1L << 30) || tiles > 16384) return -1;
+    float* part = nullptr;
+    if (want_stats) {
+        part = ws_take(tiles * 2 * d.C);
+        if (!part) return -1;
+    }
+    if (hl <= 2) {
+        if (flip) LEDN_LAUNCH((dw3x3_tile_kernel<1, 2, 16>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
+        else LEDN_LAUNCH((dw3x3_tile_kernel<0, 2, 16>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
+    } else {
+        if (flip) LEDN_LAUNCH((dw3x3_tile_kernel<1, 5, 8>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
+        else LEDN_LAUNCH((dw3x3_tile_kernel<0, 5, 8>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
+    }
+    *part_out = part;
+    *rows_out = tiles;
+    return 0;
+}
+
 // shape gate of the vectorised 3x3 kernels (forward and data gradient)
 static bool dw3x3_bf16_ok(int C, int group_size, int KH, int KW, int stride, int pad, int ext1, const int* dil,
                           long numel) {
@@ -255,6 +412,11 @@ int dw3x3_bwd_data_bf16(const ledn_dwbwd_desc& b, hipStream_t s) {   // used by 
     d.N = b.N; d.H = b.H; d.W = b.W; d.C = b.C; d.Ho = b.H; d.Wo = b.W;
     d.KH = d.KW = 3; d.stride = 1; d.pad = b.pad; d.group_size = b.group_size;
     for (int i = 0; i < 4; ++i) d.dil[i] = b.dil[i];
+    if (options().stream_fast & 2) {
+        float* part = nullptr;
+        long rows = 0;
+        if (dw3x3_tile_launch(d, true, (const bf16_t*)b.add, false, &part, &rows, s) == 0) return check_launch();
+    }
     const int rows = 256 / (d.C / 8);
     long nb = cdiv((long)d.N * d.H * d.W, rows * 4);
     if (nb > 2048) nb = 2048;
@@ -284,6 +446,14 @@ int dwconv_impl(const ledn_dw_desc& d, hipStream_t s) {
     if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_BF16 && d.act_out != LEDN_ACT_SIGMOID && d.Ho == d.H &&
         d.Wo == d.W &&
         dw3x3_bf16_ok(d.C, d.group_size, d.KH, d.KW, d.stride, d.pad, d.ext1, d.dil, (long)d.N * d.H * d.W * d.C)) {
+        if (options().stream_fast & 2) {
+            float* partt = nullptr;
+            long rowst = 0;
+            if (dw3x3_tile_launch(d, false, nullptr, d.stat_sum != nullptr, &partt, &rowst, s) == 0) {
+                if (partt) return finish_partials(partt, (int)rowst, d.C, 2, d.stat_sum, d.stat_sqsum, nullptr, s);
+                return check_launch();
+            }
+        }
         const int rows8 = 256 / (d.C / 8);
         long nb8 = cdiv((long)d.N * d.H * d.W, rows8 * 4);
         if (nb8 > 2048) nb8 = 2048;

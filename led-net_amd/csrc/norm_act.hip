@@ -114,7 +114,7 @@ int finish_partials(const float* part, int nblk, int C, int nout, float* o0, flo
 int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int dtype, float* sum,
                        float* sqsum, hipStream_t s) {
     LEDN_REQUIRE(x && sum && P > 0 && C > 0);
-    if (options().stream_fast) {
+    if (options().stream_fast & 1) {
         const int rc = channel_stats_fast(x, xadd, P, C, dtype, sum, sqsum, s);
         if (rc >= 0) return rc;
     }
@@ -216,7 +216,7 @@ int affine_act_impl(const ledn_affine_desc& d, hipStream_t s) {
     LEDN_REQUIRE((d.scale == nullptr) == (d.shift == nullptr));
     LEDN_REQUIRE(d.res_mode == LEDN_RES_NONE || d.res != nullptr);
     LEDN_REQUIRE(d.act != LEDN_ACT_PRELU || d.slope != nullptr);
-    if (options().stream_fast && d.act != LEDN_ACT_SIGMOID) {
+    if ((options().stream_fast & 1) && d.act != LEDN_ACT_SIGMOID) {
         const int rc = affine_act_fast(d, s);
         if (rc >= 0) return rc;
     }

@@ -11,7 +11,7 @@ BF = torch.bfloat16
 
 def _toggle(on):
     from led_net_amd import _lib
-    _lib.get_lib().set_option(OPT_STREAM_FAST, 1 if on else 0)
+    _lib.get_lib().set_option(OPT_STREAM_FAST, 3 if on else 0)
 
 
 def _both(fn):
@@ -126,3 +126,44 @@ def test_channel_stats_fast(be, shape):
         torch.testing.assert_close(f1.double().cpu(), (v * v).sum(0), rtol=1e-4, atol=2e-2)
         torch.testing.assert_close(f0.cpu(), g0.cpu(), rtol=1e-4, atol=2e-2)
         torch.testing.assert_close(f1.cpu(), g1.cpu(), rtol=1e-4, atol=2e-2)
+
+
+# --------------------------------------------------------------------------- LDS-tiled depthwise 3x3 (dwconv.hip)
+def _dw_ref(x, w, dil, group_size):
+    """x [N,H,W,C] f32, w [3,3,C], per-group dilation -> depthwise conv, zero padding = dilation"""
+    import torch.nn.functional as F
+    N, H, W, C = x.shape
+    xs = x.permute(0, 3, 1, 2)
+    outs = []
+    for g in range(C // group_size):
+        sl = slice(g * group_size, (g + 1) * group_size)
+        wg = w[:, :, sl].permute(2, 0, 1).unsqueeze(1)
+        outs.append(F.conv2d(xs[:, sl], wg, padding=dil[g], dilation=dil[g], groups=group_size))
+    return torch.cat(outs, 1).permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize('shape,dil', [((1, 128, 128, 64), (2, 2, 2, 2)), ((1, 70, 250, 64), (2, 3, 4, 5)),
+                                       ((2, 96, 96, 32), (1, 1, 1, 1)), ((1, 64, 300, 128), (2, 3, 4, 5))])
+def test_dw3x3_lds_tile_forward_stats_and_data_gradient(be, shape, dil):
+    """the tiled kernel (>= 16384 pixels, W >= 32, C % 32 == 0) against torch's grouped conv2d: output, the
+    per-channel sum / sum of squares of the epilogue, the flipped-tap data gradient with an addend; ragged tiles"""
+    from led_net_amd import ops, ops_train as T
+    N, H, W, C = shape
+    gs = C // 4
+    g = torch.Generator().manual_seed(H + W + C)
+    x = torch.randn(shape, generator=g).to(torch.bfloat16)
+    w = (0.3 * torch.randn(3, 3, C, generator=g))
+    want = _dw_ref(x.float(), w, dil, gs)
+    st = (torch.zeros(C, device=be.dev), torch.zeros(C, device=be.dev))
+    y = ops.dwconv2d(x.to(be.dev), w.to(be.dev), stride=1, pad=-1, dil=dil, group_size=gs, stats=st)
+    assert y.dtype == torch.bfloat16
+    torch.testing.assert_close(y.float().cpu(), want, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(st[0].cpu(), want.sum((0, 1, 2)), rtol=2e-3, atol=2e-2 * (N * H * W) ** 0.5)
+    torch.testing.assert_close(st[1].cpu(), (want * want).sum((0, 1, 2)), rtol=2e-3, atol=1e-1)
+    # data gradient = correlation with the flipped taps (same dilation) + the fan-in addend
+    dz = torch.randn(shape, generator=g).to(torch.bfloat16)
+    add = torch.randn(shape, generator=g).to(torch.bfloat16)
+    wantdx = _dw_ref(dz.float(), w.flip(0, 1), dil, gs) + add.float()
+    dx, _ = T.dwconv2d_bwd(x.to(be.dev), dz.to(be.dev), w.to(be.dev), stride=1, pad=-1, dil=dil, group_size=gs,
+                           add=add.to(be.dev), need_dw=False)
+    torch.testing.assert_close(dx.float().cpu(), wantdx, rtol=2e-2, atol=3e-2)
