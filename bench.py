@@ -240,6 +240,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    class Watchdog:
+        """N > 1 only: a rank that makes no progress (a collective some peer never joins blocks inside the HIP runtime
+        and cannot be interrupted) ends the job loudly instead of hanging until the driver's limit."""
+
+        def __init__(self, phase, seconds):
+            import threading
+            self.phase, self.seconds, self.done = phase, seconds, threading.Event()
+            self.thread = threading.Thread(target=self._run, daemon=True)
+
+        def _run(self):
+            if not self.done.wait(self.seconds):
+                print(f'[bench] rank {rank}: no progress for {self.seconds} s in phase "{self.phase}" '
+                      f'(collectives={args.collectives or "default"}); aborting. --collectives torch selects the '
+                      f'torch.distributed path (eager launches).', file=sys.stderr, flush=True)
+                os._exit(86)
+
+        def __enter__(self):
+            if world > 1:
+                self.thread.start()
+            return self
+
+        def __exit__(self, *exc):
+            self.done.set()
+            return False
+
     graphed = False
     if mode == 'train':
         trainer = L.Trainer(model, cfg, world_size=world, collectives=args.collectives)
@@ -250,7 +275,8 @@ def main():
         step = eager_step
         if (world == 1 or trainer.comm is not None) and not args.no_graph:
             try:        # whole step (fwd + loss + bwd [+ in-stream RCCL all-reduces] + SGD) as one hipGraph
-                trainer.capture(img, samples)
+                with Watchdog('first steps + graph capture', 420):
+                    trainer.capture(img, samples)
                 step, graphed = (lambda: trainer.replay()), True
             except Exception as e:   # noqa: BLE001 -- report and fall back to eager launches
                 print(f'[bench] graph capture failed, running eager: {e!r}', file=sys.stderr)
@@ -274,14 +300,15 @@ def main():
             except Exception as e:   # noqa: BLE001
                 print(f'[bench] graph capture failed, running eager: {e!r}', file=sys.stderr)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    with Watchdog('warm-up + timed steps', 420):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
     if args.trace_only:
         if rank == 0:
             print(f'[bench] trace-only: {bs * world * args.steps / dt:.1f} images/s', file=sys.stderr)
@@ -292,13 +319,14 @@ def main():
     # an instrumented eager pass of the same step right after the timed region (every rank runs it,
     # the collectives stay matched; rank 0 reports)
     k_steps = min(args.steps, 5)
-    eager_step()
-    barrier()
-    ops.start_timing()
-    for _ in range(k_steps):
+    with Watchdog('instrumented eager pass', 420):
         eager_step()
-    barrier()
-    launches = ops.stop_timing()
+        barrier()
+        ops.start_timing()
+        for _ in range(k_steps):
+            eager_step()
+        barrier()
+        launches = ops.stop_timing()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

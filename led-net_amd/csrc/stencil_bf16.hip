@@ -114,6 +114,9 @@ __device__ __forceinline__ void pyr_stage_weights(const float* w, float* s_w, in
     __syncthreads();
 }
 
+// SAME = all four dilations equal (the spatial branch: [1,1,1,1]): the four branches read the same nine taps, which
+// are then loaded once instead of four times (the re-reads miss the vector L1 at 1/8 resolution and queue on the L2).
+template <bool SAME>
 __global__ void __launch_bounds__(256) pyr_fwd_bf16_kernel(ledn_pyr_desc d) {
     constexpr int V = 8;
     LEDN_DYN_SHARED(float, s_w);   // [36][n]
@@ -135,15 +138,25 @@ __global__ void __launch_bounds__(256) pyr_fwd_bf16_kernel(ledn_pyr_desc d) {
         f32x2_t run[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) run[i] = f32x2_t{0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int dl = d.dil[b];
+        uint4 raw[9];
+        if (SAME) {
+            const int dl = d.dil[0];
             const unsigned mask = tap_mask(yi, xi, dl, d.H, d.W);
-            const int co = opaque(dl * d.n), ro = co * d.W;   // recomputed per pixel: 36 hoisted offsets cost a wave/SIMD
-            uint4 raw[9];
+            const int co = opaque(dl * d.n), ro = co * d.W;
 #pragma unroll
             for (int t = 0; t < 9; ++t)
                 raw[t] = ld_tap(x, base + (unsigned)((t / 3 - 1) * ro + (t % 3 - 1) * co), base, (mask >> t) & 1u);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (!SAME) {
+                const int dl = d.dil[b];
+                const unsigned mask = tap_mask(yi, xi, dl, d.H, d.W);
+                const int co = opaque(dl * d.n), ro = co * d.W;   // recomputed per pixel: 36 hoisted offsets cost a wave/SIMD
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    raw[t] = ld_tap(x, base + (unsigned)((t / 3 - 1) * ro + (t % 3 - 1) * co), base, (mask >> t) & 1u);
+            }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 f32x2_t xv[4], wv[4];
@@ -153,7 +166,7 @@ __global__ void __launch_bounds__(256) pyr_fwd_bf16_kernel(ledn_pyr_desc d) {
                 for (int i = 0; i < 4; ++i) run[i] = pk_fma(xv[i], wv[i], run[i]);
             }
             *reinterpret_cast<uint4*>(y + p * (4L * d.n) + (long)b * d.n + c) = bf16x8_pack(run);
-            sched_fence();   // one branch's nine taps in flight at a time (36 would cost the occupancy)
+            if (!SAME) sched_fence();   // one branch's nine taps in flight at a time (36 would cost the occupancy)
         }
     }
 }
@@ -166,7 +179,10 @@ int pyr_fwd_bf16(const ledn_pyr_desc& d, hipStream_t s) {
     const int rows = 256 / cvn;
     long nb = cdiv((long)d.N * d.Ho * d.Wo, rows * 2);
     if (nb > 2048) nb = 2048;
-    LEDN_LAUNCH(pyr_fwd_bf16_kernel, dim3((unsigned)nb), dim3(256), (size_t)(36 * d.n) * sizeof(float), s, d);
+    if (d.dil[0] == d.dil[1] && d.dil[1] == d.dil[2] && d.dil[2] == d.dil[3])
+        LEDN_LAUNCH(pyr_fwd_bf16_kernel<true>, dim3((unsigned)nb), dim3(256), (size_t)(36 * d.n) * sizeof(float), s, d);
+    else
+        LEDN_LAUNCH(pyr_fwd_bf16_kernel<false>, dim3((unsigned)nb), dim3(256), (size_t)(36 * d.n) * sizeof(float), s, d);
     return check_launch();
 }
 
