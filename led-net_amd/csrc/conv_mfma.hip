@@ -56,6 +56,7 @@ struct MfmaConvArgs {
     int N, H, W, Cin, Ho, Wo, Cout;
     int pad, in_act, act_out, res_mode;
     int tiles_h, tiles_w, tiles_per_block;
+    int tile_stride;        // 0: a workgroup owns a contiguous tile range; > 0: tiles blockIdx.x, + stride, ...
     int y_f32;        // narrow heads (Cout < 8) only: y is float (the logits of LEDHead stay f32)
     float* part;      // optional workspace for the statistics: [gridDim.x * WM][2][Cout]
 };
@@ -343,8 +344,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     unsigned char* s_ow = s_patch + wid * (EG * 32 * PIXB);
 
     const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
-    const long tb = (long)blockIdx.x * a.tiles_per_block;
-    const long te = min(ntiles, tb + a.tiles_per_block);
+    const long tstep = a.tile_stride > 0 ? a.tile_stride : 1;
+    const long tb = a.tile_stride > 0 ? (long)blockIdx.x : (long)blockIdx.x * a.tiles_per_block;
+    const long te = a.tile_stride > 0 ? ntiles : min(ntiles, tb + a.tiles_per_block);
     if (tb >= te) return;                                   // workgroup-uniform
     const bool one_chunk = a.Cin <= CK;
 
@@ -407,13 +409,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
         __syncthreads();
         long ntile = tile;
         int nc0 = c0 + CK;
-        if (nc0 >= a.Cin) { nc0 = 0; ntile = tile + 1; }
+        if (nc0 >= a.Cin) { nc0 = 0; ntile = tile + tstep; }
         {
             long ft = ntile;
             int fc = nc0;
             if (look == 2) {
                 fc += CK;
-                if (fc >= a.Cin) { fc = 0; ft += 1; }
+                if (fc >= a.Cin) { fc = 0; ft += tstep; }
             }
             if (ft < te) LEDN_CONV_FETCH(stg, ft, fc);
         }
@@ -582,13 +584,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
         int c0 = 0;
         auto advance = [&]() {
             c0 += CK;
-            if (c0 >= a.Cin) { c0 = 0; tile += 1; }
+            if (c0 >= a.Cin) { c0 = 0; tile += tstep; }
         };
         LEDN_CONV_FETCH(stage, tile, 0);
         if (DEEP) {
             long t1 = tile;
             int c1 = CK;
-            if (c1 >= a.Cin) { c1 = 0; t1 += 1; }
+            if (c1 >= a.Cin) { c1 = 0; t1 += tstep; }
             if (t1 < te) LEDN_CONV_FETCH(stage2, t1, c1);
             while (tile < te) {
                 do_step(stage, tile, c0, 2);
@@ -637,6 +639,7 @@ static int launch_epi(MfmaConvArgs a, hipStream_t s) {
     if (nbx > ntiles) nbx = ntiles;
     a.tiles_per_block = (int)cdiv(ntiles, nbx);
     nbx = cdiv(ntiles, a.tiles_per_block);
+    a.tile_stride = (options().stream_fast & 4) ? (int)nbx : 0;
     const dim3 grid((unsigned)nbx, (unsigned)gy);
     a.part = (epi_stats(EPI) && a.stat_sum && nbx * WM > 16) ? ws_take(nbx * WM * 2 * a.Cout) : nullptr;
     if ((a.Cout & 7) == 0) LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI, true>), grid, dim3(256), 0, s, a);
@@ -690,7 +693,7 @@ int conv_mfma(const ledn_conv_desc& d, hipStream_t s) {
     a.slope = d.slope; a.stat_sum = d.stat_sum; a.stat_sqsum = d.stat_sqsum;
     a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout;
     a.in_act = d.in_act; a.act_out = d.act_out; a.res_mode = d.res_mode;
-    a.tiles_h = a.tiles_w = a.tiles_per_block = 0;
+    a.tiles_h = a.tiles_w = a.tiles_per_block = a.tile_stride = 0;
     a.y_f32 = d.dtype_y == LEDN_F32;
     a.part = nullptr;
     if (!d.transposed) {

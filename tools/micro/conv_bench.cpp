@@ -25,7 +25,10 @@ static const Shape SHAPES[] = {
     {"fwd", 128, 128, 1, 1, 4, 512, 16, 32}, {"fwd", 64, 16, 1, 1, 4, 512, 16, 32},
 };
 
+#include <cstdlib>
 int main(int argc, char** argv) {
+    if (getenv("LEDN_STREAM_FAST")) ledn_set_option(LEDN_OPT_STREAM_FAST, atoi(getenv("LEDN_STREAM_FAST")));
+
     const int only = argc > 1 ? atoi(argv[1]) : -1;
     const int iters = argc > 2 ? atoi(argv[2]) : 30;
     hipStream_t s; CK(hipStreamCreate(&s));
