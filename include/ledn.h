@@ -45,9 +45,11 @@ int ledn_set_workspace(void* ptr, long long nfloats);
 enum {
     LEDN_OPT_CONV_WORKGROUPS = 0,   /* persistent workgroups of the MFMA conv (default 512) */
     LEDN_OPT_WGRAD_WORKGROUPS = 1,  /* pixel-range workgroups of the MFMA weight gradient (default 512) */
-    LEDN_OPT_STREAM_FAST = 2        /* bit mask, default 3.  bit 0: 16-B-per-lane streaming kernels (csrc/stream_fast.hip) for
+    LEDN_OPT_STREAM_FAST = 2        /* bit mask, default 11.  bit 0: 16-B-per-lane streaming kernels (csrc/stream_fast.hip) for
                                        the bf16 elementwise / BatchNorm passes; bit 1: LDS-tiled depthwise 3x3
-                                       (csrc/dwconv.hip); 0: the generic kernels (A/B measurements) */
+                                       (csrc/dwconv.hip); bit 2: MFMA conv tiles handed out round-robin instead of
+                                       as contiguous ranges (off); bit 3: 8-row MFMA conv tiles when a launch has fewer
+                                       16-row tiles than workgroups; 0: the generic kernels (A/B measurements) */
 };
 int ledn_set_option(int option, long long value);
 

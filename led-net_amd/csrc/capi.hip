@@ -94,7 +94,7 @@ int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_
 namespace ledn {
 static Workspace g_ws = {nullptr, 0};
 Workspace& workspace() { return g_ws; }
-static Options g_opt = {512, 512, 3};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3
+static Options g_opt = {512, 512, 11};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3, bit 2 round-robin conv tiles (off), bit 3 8-row conv tiles for under-filled grids
 Options& options() { return g_opt; }
 static DeferredStats g_defer = {false, nullptr, 0};
 DeferredStats& deferred_stats() { return g_defer; }

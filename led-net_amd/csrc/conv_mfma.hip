@@ -367,6 +367,23 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
             if (e_ < WROWS * 4) *reinterpret_cast<uint4*>(s_w + (e_ >> 2) * PIXB + (e_ & 3) * 16) = wv_[j]; \
         }                                                                                             \
     } while (0)
+    // DEEP: two register staging sets, the loads of step i+2 issued while step i computes and step i+1's are still
+    // outstanding (twice the bytes in flight).  Built and measured (r03r): no change (3x3 32->32 data gradient 31.9
+    // vs 32.0 us) -- the per-phase cycle counters (r03s) put the time in the epilogue and the index arithmetic of
+    // fetch / commit, not in waiting for memory.  Kept off: it costs ~28 VGPRs.
+    constexpr bool DEEP = false;
+    PatchStage<PR, PC, S, UP> stage, stage2;
+#define LEDN_CONV_FETCH(st_, tile_, c0_)                                                              \
+    do {                                                                                              \
+        long b_ = (tile_);                                                                            \
+        const int tw_ = (int)(b_ % a.tiles_w); b_ /= a.tiles_w;                                       \
+        const int th_ = (int)(b_ % a.tiles_h);                                                        \
+        st_.fetch(a.x, (int)(b_ / a.tiles_h), a.H, a.W, a.Cin, th_ * TR * S - a.pad,                  \
+                  tw_ * 32 * S - a.pad, (c0_), tid);                                                  \
+    } while (0)
+    // the first patch is requested BEFORE the weights: the two global-memory latencies of the prologue overlap
+    // (every launch pays them once; the small 1/8..1/64-resolution convolutions are little more than their prologue)
+    LEDN_CONV_FETCH(stage, tb, 0);
     if (one_chunk) LEDN_CONV_WEIGHTS(0);
     if (epi_full(EPI)) {
         for (int i = tid; i < NCO; i += 256) {
@@ -388,20 +405,6 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
 
-    // DEEP: two register staging sets, the loads of step i+2 issued while step i computes and step i+1's are still
-    // outstanding (twice the bytes in flight).  Built and measured (r03r): no change (3x3 32->32 data gradient 31.9
-    // vs 32.0 us) -- the per-phase cycle counters (r03s) put the time in the epilogue and the index arithmetic of
-    // fetch / commit, not in waiting for memory.  Kept off: it costs ~28 VGPRs.
-    constexpr bool DEEP = false;
-    PatchStage<PR, PC, S, UP> stage, stage2;
-#define LEDN_CONV_FETCH(st_, tile_, c0_)                                                              \
-    do {                                                                                              \
-        long b_ = (tile_);                                                                            \
-        const int tw_ = (int)(b_ % a.tiles_w); b_ /= a.tiles_w;                                       \
-        const int th_ = (int)(b_ % a.tiles_h);                                                        \
-        st_.fetch(a.x, (int)(b_ / a.tiles_h), a.H, a.W, a.Cin, th_ * TR * S - a.pad,                  \
-                  tw_ * 32 * S - a.pad, (c0_), tid);                                                  \
-    } while (0)
     // one (tile, K-chunk) step: `stg` holds its patch; afterwards stg is refilled with the step `look` ahead
     auto do_step = [&](auto& stg, const long tile, const int c0, const int look) {
         stg.commit(s_patch, a.in_scale, a.in_shift, a.in_slope, a.in_act, c0, tid);
@@ -586,7 +589,6 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
             c0 += CK;
             if (c0 >= a.Cin) { c0 = 0; tile += tstep; }
         };
-        LEDN_CONV_FETCH(stage, tile, 0);
         if (DEEP) {
             long t1 = tile;
             int c1 = CK;
@@ -668,6 +670,11 @@ static int launch_shape(const MfmaConvArgs& a, hipStream_t s) {
         return launch_cfg<4, 1, 1, K, S, UP>(a, s);
     } else {
         if (a.Cout % 64 == 0) return launch_cfg<2, 2, 4, K, S, UP>(a, s);
+        // fewer 16-row tiles than workgroups wanted (1/8-resolution maps, small batches): 8-row tiles double the
+        // parallelism of these latency-bound launches
+        if ((options().stream_fast & 8) &&
+            (long)a.N * cdiv(a.Ho, 16) * cdiv(a.Wo, 32) * cdiv(a.Cout, 32) < (K == 1 ? 768 : 512))
+            return launch_cfg<4, 1, 2, K, S, UP>(a, s);
         return launch_cfg<4, 1, 4, K, S, UP>(a, s);
     }
 }

@@ -11,7 +11,7 @@ BF = torch.bfloat16
 
 def _toggle(on):
     from led_net_amd import _lib
-    _lib.get_lib().set_option(OPT_STREAM_FAST, 3 if on else 0)
+    _lib.get_lib().set_option(OPT_STREAM_FAST, 11 if on else 0)
 
 
 def _both(fn):

@@ -23,6 +23,10 @@ static const Shape SHAPES[] = {
     // LINEAR 512-pixel chunk of memory instead of 16 segments a row pitch apart
     {"fwd", 64, 64, 1, 1, 4, 512, 16, 32}, {"dgrad", 64, 64, 1, 1, 4, 512, 16, 32}, {"fwd", 32, 32, 1, 1, 1, 8192, 16, 32},
     {"fwd", 128, 128, 1, 1, 4, 512, 16, 32}, {"fwd", 64, 16, 1, 1, 4, 512, 16, 32},
+    // under-filled grids (fewer 16-row tiles than workgroups wanted): inference batch 8 and the narrow 1/8-resolution convs
+    {"fwd", 64, 16, 1, 1, 4, 8, 128, 128}, {"fwd", 16, 64, 1, 1, 4, 8, 128, 128}, {"fwd", 64, 32, 1, 1, 1, 8, 128, 128},
+    {"fwd", 64, 32, 3, 1, 1, 8, 128, 128}, {"fwd", 32, 32, 3, 1, 1, 8, 128, 128}, {"dgrad", 64, 16, 1, 1, 4, 16, 128, 128},
+    {"fwd", 16, 64, 1, 1, 4, 16, 128, 128}, {"fwd", 128, 32, 1, 1, 1, 16, 64, 64},
 };
 
 #include <cstdlib>
