@@ -171,19 +171,13 @@ struct PatchStage {
     __device__ __forceinline__ void commit(unsigned char* s_patch, const float* in_scale, const float* in_shift,
                                            const float* in_slope, int in_act, int c0, int tid) const {
         const int part = tid & 3;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int p = (tid >> 2) + j * 64;
-            if (p >= NPIX) continue;
-            const bool valid = ok & (1u << j);
-            uint4 q = v[j];
-            q.x = valid ? q.x : 0u; q.y = valid ? q.y : 0u; q.z = valid ? q.z : 0u; q.w = valid ? q.w : 0u;
-            *reinterpret_cast<uint4*>(s_patch + (long)p * PIXB + part * 16) = q;
-        }
-        if (in_scale || in_act) {
-            // the thread's eight channels are the same for all its pieces: their parameters are loaded
-            // ONCE per commit (the first version re-read them from global memory for every piece)
-            float sc[8], sh[8], sl[8];
+        // input prologue (BatchNorm affine + activation of the producing layer, folded into this convolution): applied
+        // to the staged registers on their way into LDS -- the thread's eight channels are the same for all its pieces,
+        // so their parameters are loaded once per commit.  (The first version wrote the raw patch and re-read, transformed
+        // and re-wrote every slot: the LDS read-modify-write cost what the saved elementwise pass had cost.)
+        const bool pro = in_scale || in_act;
+        float sc[8], sh[8], sl[8];
+        if (pro) {
             const int c = c0 + part * 8;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -198,13 +192,15 @@ struct PatchStage {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) sl[i] = 1.f;     // act(v) = max(v,0) + sl * min(v,0)
             }
-#pragma unroll 1
-            for (int j = 0; j < NL; ++j) {
-                const int p = (tid >> 2) + j * 64;
-                if (p >= NPIX || !((ok >> j) & 1u)) continue;
-                uint4* slot = reinterpret_cast<uint4*>(s_patch + (long)p * PIXB + part * 16);
-                const uint4 v4 = *slot;
-                unsigned w[4] = {v4.x, v4.y, v4.z, v4.w};
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int p = (tid >> 2) + j * 64;
+            if (p >= NPIX) continue;
+            const bool valid = ok & (1u << j);
+            uint4 q = v[j];
+            if (pro) {
+                unsigned w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
@@ -214,8 +210,11 @@ struct PatchStage {
                     hi = fmaxf(hi, 0.f) + sl[2 * i + 1] * fminf(hi, 0.f);
                     w[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
                 }
-                *slot = make_uint4(w[0], w[1], w[2], w[3]);
+                q = make_uint4(w[0], w[1], w[2], w[3]);
             }
+            // (zero padding and tails pad the ACTIVATION, not its pre-image: zero after the prologue)
+            q.x = valid ? q.x : 0u; q.y = valid ? q.y : 0u; q.z = valid ? q.z : 0u; q.w = valid ? q.w : 0u;
+            *reinterpret_cast<uint4*>(s_patch + (long)p * PIXB + part * 16) = q;
         }
     }
 };
