@@ -474,7 +474,11 @@ int ledn_dwconv2d_bwd_weight(const ledn_dwbwd_desc* d, void* stream);
 /* SESP pyramid backward.  g = suffix sums of dy over the 4 branch groups
  * (g_b = sum_{b'>=b} dy_b', the adjoint of the HFF adds, eesp.py:84-91):
  *   ledn_sesp_pyramid_bwd_data  : gsum [N,Ho,Wo,4n] (scratch, written) and dx [N,H,W,n]
- *   ledn_sesp_pyramid_bwd_weight: dw [4][3][3][n] += sum x[pix@tap,dil_b] * gsum_b[pix] */
+ *   ledn_sesp_pyramid_bwd_weight: dw [4][3][3][n] += sum x[pix@tap,dil_b] * gsum_b[pix]
+ * Call bwd_data before bwd_weight with the SAME descriptor (dy must stay valid for both).  gsum is scratch owned by
+ * the pair: on the spatial branch's shape class (bf16, stride 1, dilations 1, >= 16384 pixels) the data gradient reads
+ * dy through an LDS-staged patch with prefix-summed filters and the weight gradient forms the suffix sums from dy
+ * itself -- gsum is then left untouched. */
 typedef struct {
     const void* x;
     const void* dy;

@@ -561,6 +561,8 @@ int dw_bwd_data_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
 
 int dw3x3_bwd_weight_bf16(const ledn_dwbwd_desc& d, hipStream_t s);   // stencil_bf16.hip; -1 = shape not covered
 int pyr_bwd_data_bf16(const ledn_pyrbwd_desc& d, hipStream_t s);
+bool pyr_tile_applies(const ledn_pyrbwd_desc& d);
+int pyr_bwd_data_tile(const ledn_pyrbwd_desc& d, hipStream_t s);
 int pyr_bwd_weight_bf16(const ledn_pyrbwd_desc& d, hipStream_t s);
 
 int dw_bwd_weight_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
@@ -754,6 +756,7 @@ int pyr_bwd_data_impl(const ledn_pyrbwd_desc& d, hipStream_t s) {
     const bool v4 = d.n % 4 == 0;
     const int cvn = v4 ? d.n / 4 : d.n;
     const long npo = (long)d.N * d.Ho * d.Wo;
+    if (pyr_tile_applies(d)) return pyr_bwd_data_tile(d, s);
     if (d.dtype == LEDN_BF16 && v4 && d.stride == 1) {   // suffix sums, then the vectorised gather
         LEDN_LAUNCH((pyr_suffix_kernel<bf16_t, 4>), dim3((unsigned)cdiv(npo * cvn, 256)), dim3(256), 0, s,
                     (const bf16_t*)d.dy, (bf16_t*)d.gsum, npo, d.n);

@@ -186,6 +186,109 @@ int pyr_fwd_bf16(const ledn_pyr_desc& d, hipStream_t s) {
     return check_launch();
 }
 
+// Equal dilations of 1 (the spatial branch), stride 1, large maps: the data gradient straight from dy with the
+// PREFIX-summed filters  dx = sum_b corr(dy_b, flip(W_b)),  W_b = sum_{b' <= b} w_b'  -- no suffix-sum pass over dy
+// (a launch that read and wrote all 4n channels) -- and with the dy patch staged ONCE in LDS: the gather kernel below
+// issues 36 global 16-byte loads per output that miss the 32 KB vector L1 at 1/8 resolution and queue on the L2
+// (85 us for 16 x 128 x 128, n = 32).  Workgroup = 128 lanes = a 8 x 32-pixel tile x 16 channels: patch
+// [10 rows][4 branches][34 px][16 ch] (43.5 KB, three workgroups per CU), lane = (column, 8-channel group, 4 output
+// rows): per branch the 9 x 8 filter values sit in registers and each of the 6 x 3 staged input pieces feeds up to
+// three output rows (18 instead of 36 LDS reads per 4 outputs).
+__global__ void __launch_bounds__(128) pyr_bwd_data_tile_kernel(ledn_pyrbwd_desc d) {
+    constexpr int TW = 32, TH = 8, PW = TW + 2, PH = TH + 2;
+    constexpr int NPIECE = PH * 4 * PW * 2;                 // 16-byte pieces: [py][b][px][half]
+    constexpr int NL = (NPIECE + 127) / 128;
+    __shared__ __attribute__((aligned(16))) unsigned char s_g[NPIECE * 16];
+    __shared__ __attribute__((aligned(16))) float s_w[4 * 9 * 16];
+    const int tid = threadIdx.x;
+    const int tx = (d.W + TW - 1) / TW, ty = (d.H + TH - 1) / TH, nc = d.n / 16;
+    const unsigned bid = xcd_block(blockIdx.x, gridDim.x);
+    const int cgp = (int)(bid % (unsigned)nc);
+    const unsigned tile = bid / (unsigned)nc;
+    const int txi = (int)(tile % (unsigned)tx), tyi = (int)((tile / (unsigned)tx) % (unsigned)ty);
+    const int img = (int)(tile / (unsigned)(tx * ty));
+    const int c0 = cgp * 16, n4 = 4 * d.n;
+    const bf16_t* dy = reinterpret_cast<const bf16_t*>(d.dy) + (long)img * d.H * d.W * n4 + c0;
+    const int y0 = tyi * TH - 1, x0 = txi * TW - 1;
+    {
+        uint4 stage[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 128, half = e & 1, q = e >> 1;
+            const int px = q % PW, rb = q / PW, b = rb & 3, py = rb >> 2;
+            const int gy = y0 + py, gx = x0 + px;
+            const bool ok = e < NPIECE && gy >= 0 && gy < d.H && gx >= 0 && gx < d.W;
+            stage[i] = ok ? *reinterpret_cast<const uint4*>(dy + ((long)gy * d.W + gx) * n4 + b * d.n + half * 8)
+                          : uint4{0u, 0u, 0u, 0u};
+        }
+        for (int i = tid; i < 9 * 16; i += 128) {           // prefix sums of the 16 channels' filters
+            const int t = i >> 4, cc = i & 15;
+            float run = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                run += d.w[(long)(b * 9 + t) * d.n + c0 + cc];
+                s_w[(b * 9 + t) * 16 + cc] = run;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 128;
+            if (e < NPIECE) *reinterpret_cast<uint4*>(s_g + (long)e * 16) = stage[i];
+        }
+    }
+    __syncthreads();
+    const int cg = tid & 1, lx = (tid >> 1) & 31, yg = tid >> 6;
+    f32x2_t acc[4][4];
+#pragma unroll
+    for (int yo = 0; yo < 4; ++yo)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[yo][i] = f32x2_t{0.f, 0.f};
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) {
+        f32x2_t w[9][4];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) f32x8_load(s_w + (b * 9 + t) * 16 + cg * 8, w[t]);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {                        // staged row yg*4 + r = image row (first output row) - 1 + r
+            const unsigned char* row = s_g + ((long)((yg * 4 + r) * 4 + b) * PW + lx) * 32 + cg * 16;
+            f32x2_t in[3][4];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) bf16x8_unpack(*reinterpret_cast<const uint4*>(row + kx * 32), in[kx]);
+#pragma unroll
+            for (int yo = 0; yo < 4; ++yo) {
+                const int ky = r - yo;                       // dx[y] += dy[y + ky - 1][x + kx - 1] * W[(2-ky)*3 + (2-kx)]
+                if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[yo][i] = pk_fma(in[kx][i], w[8 - (ky * 3 + kx)][i], acc[yo][i]);
+            }
+        }
+    }
+    const int gx = txi * TW + lx;
+    bf16_t* dx = reinterpret_cast<bf16_t*>(d.dx) + (long)img * d.H * d.W * d.n + c0 + cg * 8;
+#pragma unroll
+    for (int yo = 0; yo < 4; ++yo) {
+        const int gy = tyi * TH + yg * 4 + yo;
+        if (gy < d.H && gx < d.W) *reinterpret_cast<uint4*>(dx + ((long)gy * d.W + gx) * d.n) = bf16x8_pack(acc[yo]);
+    }
+}
+
+// the tiled data gradient applies (and then nothing reads or writes gsum: the weight gradient forms its suffix sums
+// from dy on the fly -- both entry points decide with this predicate)
+bool pyr_tile_applies(const ledn_pyrbwd_desc& d) {
+    return (options().stream_fast & 2) && d.dtype == LEDN_BF16 && d.stride == 1 && d.n % 16 == 0 && d.n <= 512 &&
+           ((d.n / 8) & (d.n / 8 - 1)) == 0 && d.W >= 32 &&   // (n / 8 a power of two: the bf16 weight-gradient kernel's gate)
+           d.dil[0] == 1 && d.dil[1] == 1 && d.dil[2] == 1 && d.dil[3] == 1 && (long)d.N * d.H * d.W >= 16384 &&
+           (long)d.N * d.H * d.W * d.n * 4 < (1L << 31);
+}
+
+int pyr_bwd_data_tile(const ledn_pyrbwd_desc& d, hipStream_t s) {
+    const long nb = (long)d.N * cdiv(d.H, 8) * cdiv(d.W, 32) * (d.n / 16);
+    LEDN_LAUNCH(pyr_bwd_data_tile_kernel, dim3((unsigned)nb), dim3(128), 0, s, d);
+    return check_launch();
+}
+
 // gsum holds the suffix sums g_b = sum_{b' >= b} dy_b' (pyr_suffix_kernel)
 __global__ void __launch_bounds__(256) pyr_bwd_data_bf16_kernel(ledn_pyrbwd_desc d) {
     constexpr int V = 8;
@@ -244,7 +347,7 @@ int pyr_bwd_data_bf16(const ledn_pyrbwd_desc& d, hipStream_t s) {   // gsum alre
     return check_launch();
 }
 
-__global__ void __launch_bounds__(256) pyr_bwd_weight_bf16_kernel(ledn_pyrbwd_desc d, float* part) {
+__global__ void __launch_bounds__(256) pyr_bwd_weight_bf16_kernel(ledn_pyrbwd_desc d, float* part, bool from_dy) {
     constexpr int V = 8;
     LEDN_DYN_SHARED(float, s_red);   // [4][9*n]
     const int b = blockIdx.y;
@@ -260,7 +363,7 @@ __global__ void __launch_bounds__(256) pyr_bwd_weight_bf16_kernel(ledn_pyrbwd_de
         for (int i = 0; i < 4; ++i) acc[t][i] = f32x2_t{0.f, 0.f};
     {
         const bf16_t* x = reinterpret_cast<const bf16_t*>(d.x);
-        const bf16_t* g = reinterpret_cast<const bf16_t*>(d.gsum);
+        const bf16_t* g = reinterpret_cast<const bf16_t*>(from_dy ? d.dy : d.gsum);
         const long npo = (long)d.N * d.Ho * d.Wo;
         const long ppb = cdiv(cdiv(npo, (long)gridDim.x), (long)rows) * rows;
         const long p0 = (long)xcd_block(blockIdx.x, gridDim.x) * ppb, p1 = min(npo, p0 + ppb);
@@ -276,7 +379,18 @@ __global__ void __launch_bounds__(256) pyr_bwd_weight_bf16_kernel(ledn_pyrbwd_de
                 raw[t] = ld_tap(x, base + (unsigned)(((t / 3 - 1) * dl * d.W + (t % 3 - 1) * dl) * d.n), base,
                                 (mask >> t) & 1u);
             f32x2_t gv[4];
-            bf16x8_unpack(*reinterpret_cast<const uint4*>(g + p * (4L * d.n) + (long)b * d.n + c), gv);
+            if (from_dy) {      // g_b = sum_{b' >= b} dy_b' formed here (the tiled data gradient leaves no gsum behind)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gv[i] = f32x2_t{0.f, 0.f};
+                for (int bb = 3; bb >= b; --bb) {
+                    f32x2_t tv[4];
+                    bf16x8_unpack(*reinterpret_cast<const uint4*>(g + p * (4L * d.n) + (long)bb * d.n + c), tv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gv[i] += tv[i];
+                }
+            } else {
+                bf16x8_unpack(*reinterpret_cast<const uint4*>(g + p * (4L * d.n) + (long)b * d.n + c), gv);
+            }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 f32x2_t xv[4];
@@ -305,7 +419,7 @@ int pyr_bwd_weight_bf16(const ledn_pyrbwd_desc& d, hipStream_t s) {
     float* part = nb > 32 ? ws_take(nb * 36 * d.n) : nullptr;
     if (!part && nb > 128) nb = 128;
     LEDN_LAUNCH(pyr_bwd_weight_bf16_kernel, dim3((unsigned)nb, 4u), dim3(256), (size_t)(36 * d.n) * sizeof(float), s, d,
-                part);
+                part, pyr_tile_applies(d));
     if (part) return finish_partials(part, (int)nb, 36 * d.n, 1, d.dw, nullptr, nullptr, s);
     return check_launch();
 }

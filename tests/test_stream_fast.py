@@ -167,3 +167,29 @@ def test_dw3x3_lds_tile_forward_stats_and_data_gradient(be, shape, dil):
     dx, _ = T.dwconv2d_bwd(x.to(be.dev), dz.to(be.dev), w.to(be.dev), stride=1, pad=-1, dil=dil, group_size=gs,
                            add=add.to(be.dev), need_dw=False)
     torch.testing.assert_close(dx.float().cpu(), wantdx, rtol=2e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize('shape', [(1, 128, 128, 32), (2, 100, 90, 16), (1, 70, 250, 64)])
+def test_pyramid_bwd_lds_tile_equal_dilations(be, shape):
+    """SESP pyramid backward on the spatial branch's shape class (dilations [1,1,1,1], >= 16384 pixels): the tiled
+    data gradient (prefix-summed filters, no suffix pass) and the weight gradient that forms its suffix sums from dy,
+    against torch autograd of the four cumulative depthwise convolutions; ragged tiles"""
+    import torch.nn.functional as F
+    from led_net_amd import ops_train as T
+    N, H, W, n = shape
+    g = torch.Generator().manual_seed(H * W + n)
+    x = torch.randn(N, n, H, W, generator=g).to(torch.bfloat16).float().requires_grad_(True)
+    ws = [(0.3 * torch.randn(n, 1, 3, 3, generator=g)).requires_grad_(True) for _ in range(4)]
+    outs = []
+    for i in range(4):
+        o = F.conv2d(x, ws[i], padding=1, groups=n)
+        outs.append(o if i == 0 else o + outs[-1])
+    y = torch.cat(outs, 1)
+    dy = torch.randn(y.shape, generator=g).to(torch.bfloat16).float()
+    y.backward(dy)
+    wp = torch.stack([w[:, 0].permute(1, 2, 0) for w in ws]).detach().contiguous()
+    to = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(be.dev)     # noqa: E731
+    dx, dw = T.sesp_pyramid_bwd(to(x), to(dy), wp.to(be.dev), [1, 1, 1, 1], 1)
+    torch.testing.assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, rtol=2e-2, atol=6e-2)
+    want_dw = torch.stack([w.grad[:, 0].permute(1, 2, 0) for w in ws])
+    torch.testing.assert_close(dw.cpu(), want_dw, rtol=2e-2, atol=2e-2 * float(want_dw.abs().max()))
