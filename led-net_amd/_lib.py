@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, 'csrc', 'libledn_hip.so')
+HIP_LIB_PATH = os.environ.get('LEDN_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libledn_hip.so')   # (override: A/B of library builds)
 
 OK, EINVAL, ELAUNCH = 0, 1, 2
 F32, BF16, U8 = 0, 1, 2

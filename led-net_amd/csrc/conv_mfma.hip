@@ -175,9 +175,20 @@ struct PatchStage {
         // to the staged registers on their way into LDS -- the thread's eight channels are the same for all its pieces,
         // so their parameters are loaded once per commit.  (The first version wrote the raw patch and re-read, transformed
         // and re-wrote every slot: the LDS read-modify-write cost what the saved elementwise pass had cost.)
-        const bool pro = in_scale || in_act;
+        if (!(in_scale || in_act)) {            // no prologue (most layers): the plain copy, no per-piece branching
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int p = (tid >> 2) + j * 64;
+                if (p >= NPIX) continue;
+                const bool valid = ok & (1u << j);
+                uint4 q = v[j];
+                q.x = valid ? q.x : 0u; q.y = valid ? q.y : 0u; q.z = valid ? q.z : 0u; q.w = valid ? q.w : 0u;
+                *reinterpret_cast<uint4*>(s_patch + (long)p * PIXB + part * 16) = q;
+            }
+            return;
+        }
         float sc[8], sh[8], sl[8];
-        if (pro) {
+        {
             const int c = c0 + part * 8;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -198,22 +209,19 @@ struct PatchStage {
             const int p = (tid >> 2) + j * 64;
             if (p >= NPIX) continue;
             const bool valid = ok & (1u << j);
-            uint4 q = v[j];
-            if (pro) {
-                unsigned w[4] = {q.x, q.y, q.z, q.w};
+            unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
-                    lo = lo * sc[2 * i] + sh[2 * i];
-                    hi = hi * sc[2 * i + 1] + sh[2 * i + 1];
-                    lo = fmaxf(lo, 0.f) + sl[2 * i] * fminf(lo, 0.f);
-                    hi = fmaxf(hi, 0.f) + sl[2 * i + 1] * fminf(hi, 0.f);
-                    w[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
-                }
-                q = make_uint4(w[0], w[1], w[2], w[3]);
+            for (int i = 0; i < 4; ++i) {
+                float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+                lo = lo * sc[2 * i] + sh[2 * i];
+                hi = hi * sc[2 * i + 1] + sh[2 * i + 1];
+                lo = fmaxf(lo, 0.f) + sl[2 * i] * fminf(lo, 0.f);
+                hi = fmaxf(hi, 0.f) + sl[2 * i + 1] * fminf(hi, 0.f);
+                w[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
             }
             // (zero padding and tails pad the ACTIVATION, not its pre-image: zero after the prologue)
-            q.x = valid ? q.x : 0u; q.y = valid ? q.y : 0u; q.z = valid ? q.z : 0u; q.w = valid ? q.w : 0u;
+            uint4 q;
+            q.x = valid ? w[0] : 0u; q.y = valid ? w[1] : 0u; q.z = valid ? w[2] : 0u; q.w = valid ? w[3] : 0u;
             *reinterpret_cast<uint4*>(s_patch + (long)p * PIXB + part * 16) = q;
         }
     }
@@ -380,9 +388,6 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
         st_.fetch(a.x, (int)(b_ / a.tiles_h), a.H, a.W, a.Cin, th_ * TR * S - a.pad,                  \
                   tw_ * 32 * S - a.pad, (c0_), tid);                                                  \
     } while (0)
-    // the first patch is requested BEFORE the weights: the two global-memory latencies of the prologue overlap
-    // (every launch pays them once; the small 1/8..1/64-resolution convolutions are little more than their prologue)
-    LEDN_CONV_FETCH(stage, tb, 0);
     if (one_chunk) LEDN_CONV_WEIGHTS(0);
     if (epi_full(EPI)) {
         for (int i = tid; i < NCO; i += 256) {
@@ -588,6 +593,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
             c0 += CK;
             if (c0 >= a.Cin) { c0 = 0; tile += tstep; }
         };
+        LEDN_CONV_FETCH(stage, tile, 0);   // (requesting it before the weight load measured 1 % slower in inference, r04h)
         if (DEEP) {
             long t1 = tile;
             int c1 = CK;
