@@ -619,16 +619,24 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     if (epi_stats(EPI) && a.stat_sum) {   // workgroup-uniform; every lane takes part in the exchange
         const float t1 = reduce16_over32(st1, lane), t2 = reduce16_over32(st2, lane);
         const int idx = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-        const int c = cb0 + (idx & 3) + 8 * (idx >> 2) + 4 * lh;
-        if ((lane & 1) == 0 && c < a.Cout) {
-            if (a.part) {
-                float* row = a.part + ((long)blockIdx.x * WM + wm) * 2 * a.Cout;
-                row[c] = t1;
-                row[a.Cout + c] = t2;
-            } else {
-                atomicAdd(a.stat_sum + c, t1);
-                atomicAdd(a.stat_sqsum + c, t2);
-            }
+        const int cl = wn * 32 + (idx & 3) + 8 * (idx >> 2) + 4 * lh;      // channel inside the workgroup's slice
+        // the WM waves of a channel slice add up in LDS first: ONE partial row per workgroup (a quarter of the rows
+        // the BatchNorm finalize has to walk: it is a latency chain of row batches)
+        float* s_st = reinterpret_cast<float*>(s_patch);                     // [WM][2][NCO]; the patch is dead here
+        __syncthreads();
+        if ((lane & 1) == 0) {
+            s_st[(wm * 2 + 0) * NCO + cl] = t1;
+            s_st[(wm * 2 + 1) * NCO + cl] = t2;
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * NCO; i += 256) {
+            const int j = i / NCO, cc = i % NCO, c = cbw + cc;
+            if (c >= a.Cout) continue;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += s_st[(w * 2 + j) * NCO + cc];
+            if (a.part) a.part[(long)blockIdx.x * 2 * a.Cout + (long)j * a.Cout + c] = t;
+            else atomicAdd((j ? a.stat_sqsum : a.stat_sum) + c, t);
         }
     }
 }
@@ -648,10 +656,10 @@ static int launch_epi(MfmaConvArgs a, hipStream_t s) {
     nbx = cdiv(ntiles, a.tiles_per_block);
     a.tile_stride = (options().stream_fast & 4) ? (int)nbx : 0;
     const dim3 grid((unsigned)nbx, (unsigned)gy);
-    a.part = (epi_stats(EPI) && a.stat_sum && nbx * WM > 16) ? ws_take(nbx * WM * 2 * a.Cout) : nullptr;
+    a.part = (epi_stats(EPI) && a.stat_sum && nbx > 16) ? ws_take(nbx * 2 * a.Cout) : nullptr;
     if ((a.Cout & 7) == 0) LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI, true>), grid, dim3(256), 0, s, a);
     else LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI, false>), grid, dim3(256), 0, s, a);
-    if (a.part) return finish_partials(a.part, (int)(nbx * WM), a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
+    if (a.part) return finish_partials(a.part, (int)nbx, a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
     return check_launch();
 }
 

@@ -8,6 +8,7 @@ for V in "$@"; do
   i=$((i+1)); [ "$V" = "-" ] && V=""
   ARGS=""; ENVS=""
   for tok in $V; do case $tok in --*) ARGS="$ARGS $tok";; *) ENVS="$ENVS $tok";; esac; done
-  env $ENVS timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $ARGS > $OUT/v$i.json 2> $OUT/v$i.err || { echo "variant $i ($V) failed"; tail -8 $OUT/v$i.err; exit 1; }
+  STEPS="--steps 40 --warmup 5"; case "$ARGS" in *infer*) STEPS="--steps 300 --warmup 20";; esac; case "$ARGS" in *--steps*) STEPS="";; esac
+  env $ENVS timeout -k 10 400 python bench.py $STEPS --no-cpu-baseline $ARGS > $OUT/v$i.json 2> $OUT/v$i.err || { echo "variant $i ($V) failed"; tail -8 $OUT/v$i.err; exit 1; }
   echo "variant $i [$V]: $(python -c "import json,sys; d=json.load(open('$OUT/v$i.json')); print(d['value'], d['unit'], d['ms_per_step'],'ms', d['config'].get('collectives'))")"
 done
