@@ -10,7 +10,7 @@
 
 int main(int argc, char** argv) {
     hipStream_t s; CK(hipStreamCreate(&s));
-    float* ws; CK(hipMalloc(&ws, 128 << 20)); ledn_set_workspace(ws, 32 << 20);
+    float* ws; CK(hipMalloc(&ws, 128 << 20)); CK(hipMemset(ws, 0, 128 << 20)); ledn_set_workspace(ws, 32 << 20);
     const int NSET = 8;
     struct Shape { int C; long P; } shapes[] = {{64, 262144}, {128, 262144}, {32, 1048576}, {16, 262144}, {128, 65536}};
     float *par; CK(hipMalloc(&par, 16 * 512 * 4)); CK(hipMemset(par, 0, 16 * 512 * 4));

@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     const int only = argc > 1 ? atoi(argv[1]) : -1;
     const int iters = argc > 2 ? atoi(argv[2]) : 30;
     hipStream_t s; CK(hipStreamCreate(&s));
-    float* ws; CK(hipMalloc(&ws, 128 << 20)); ledn_set_workspace(ws, 32 << 20);
+    float* ws; CK(hipMalloc(&ws, 128 << 20)); CK(hipMemset(ws, 0, 128 << 20)); ledn_set_workspace(ws, 32 << 20);
     const int NSET = 6;
     float* stats; CK(hipMalloc(&stats, 4096 * 4)); CK(hipMemset(stats, 0, 4096 * 4));
     int idx = -1;
