@@ -37,10 +37,7 @@ int ledn_abi_version(void);
 /* Optional device scratch (f32 words) owned by the caller and used by every later call on ONE
  * stream: cross-workgroup reductions (BN statistics, weight gradients) write per-workgroup
  * partials there and finish with a second tiny kernel instead of same-address atomics.
- * ptr = NULL, nfloats = 0 detaches it (kernels then fall back to atomics).
- * The LAST 1024 words are ticket counters of second stages that run inside the producing kernel (option
- * LEDN_OPT_STREAM_FAST bit 4): they must be ZERO when the buffer is attached; the library leaves them zero after
- * every launch.  Partial rows use the words before them. */
+ * ptr = NULL, nfloats = 0 detaches it (kernels then fall back to atomics). */
 int ledn_set_workspace(void* ptr, long long nfloats);
 
 /* Launch-shape knobs (process-wide; defaults are tuned for a 256-CU MI355X).  value <= 0 restores
@@ -52,9 +49,7 @@ enum {
                                        the bf16 elementwise / BatchNorm passes; bit 1: LDS-tiled depthwise 3x3
                                        (csrc/dwconv.hip); bit 2: MFMA conv tiles handed out round-robin instead of
                                        as contiguous ranges (off); bit 3: 8-row MFMA conv tiles when a launch has fewer
-                                       16-row tiles than workgroups; bit 4: the second stage of the BatchNorm-backward
-                                       reduction inside the reduce kernel (ticket counters, see ledn_set_workspace;
-                                       off by default); 0: the generic kernels (A/B measurements) */
+                                       16-row tiles than workgroups; 0: the generic kernels (A/B measurements) */
 };
 int ledn_set_option(int option, long long value);
 

@@ -219,7 +219,6 @@ class Library:
             if ws is None:
                 import torch
                 ws = self._workspaces[key] = torch.empty(nfloats, dtype=torch.float32, device=device)
-                ws[-1024:].zero_()      # ticket counters of the in-kernel second stages (include/ledn.h: ledn_set_workspace)
             self.call('ledn_set_workspace', ws.data_ptr(), ws.numel())
             self._bound = key
 

@@ -250,88 +250,9 @@ struct Workspace {
     long nfloats;
 };
 Workspace& workspace();
-// The last LEDN_WS_COUNTERS floats of the workspace are ticket counters of the in-kernel second stages
-// (finish_tail): zero when the buffer is attached (the caller's duty), zero again after every launch.
-constexpr long LEDN_WS_COUNTERS = 1024;
 inline float* ws_take(long nfloats) {
     Workspace& w = workspace();
-    return (w.ptr && nfloats <= w.nfloats - LEDN_WS_COUNTERS) ? w.ptr : nullptr;
-}
-inline unsigned* ws_counters() {
-    Workspace& w = workspace();
-    return (w.ptr && w.nfloats > LEDN_WS_COUNTERS) ? reinterpret_cast<unsigned*>(w.ptr + (w.nfloats - LEDN_WS_COUNTERS)) : nullptr;
-}
-
-// ---- second stage of a two-stage reduction inside the producing kernel ---------------------------------------
-// Every lane of every workgroup calls finish_tail() after the workgroup's partial row part[blockIdx.x][K] has been
-// stored.  The last workgroup of each group of `group` consecutive rows (ticket counter) adds the group up into
-// part2[g][K]; the last group to finish adds the group rows into the outputs.  Replaces a separate finish launch on
-// the critical path (~5 us + its gap) by a ~2 us tail that mostly overlaps the other workgroups.  Release / acquire:
-// device-scope fences around the ticket, the rows are read with device-scope loads (the XCDs' L2s are not coherent
-// with each other inside a kernel).
-struct FinishTail {
-    float* part2;
-    unsigned* ctr;          // [1 + groups], zero on entry, zero on exit
-    float* out[3];
-    int C, nout, nblk, group;
-};
-#ifdef LEDN_CPU_EMU
-__device__ __forceinline__ float ld_agent(const float* p) { return *p; }
-__device__ __forceinline__ void fence_agent() {}
-#else
-__device__ __forceinline__ float ld_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void fence_agent() { __threadfence(); }
-#endif
-__device__ __forceinline__ void finish_tail(const float* part, const FinishTail& t, int* s_flag) {
-    const int K = t.C * t.nout, tid = (int)threadIdx.x, nt = (int)blockDim.x;
-    const int g = (int)blockIdx.x / t.group, ngroups = (t.nblk + t.group - 1) / t.group;
-    fence_agent();
-    __syncthreads();
-    if (tid == 0) {
-        const int gsz = t.nblk - g * t.group < t.group ? t.nblk - g * t.group : t.group;
-        *s_flag = atomicAdd(&t.ctr[1 + g], 1u) == (unsigned)(gsz - 1);
-    }
-    __syncthreads();
-    if (!*s_flag) return;
-    fence_agent();
-    {
-        const int r0 = g * t.group, r1 = t.nblk < r0 + t.group ? t.nblk : r0 + t.group;
-        for (int k = tid; k < K; k += nt) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            int r = r0;
-            for (; r + 3 < r1; r += 4) {
-                a0 += ld_agent(part + (long)r * K + k);
-                a1 += ld_agent(part + (long)(r + 1) * K + k);
-                a2 += ld_agent(part + (long)(r + 2) * K + k);
-                a3 += ld_agent(part + (long)(r + 3) * K + k);
-            }
-            for (; r < r1; ++r) a0 += ld_agent(part + (long)r * K + k);
-            t.part2[(long)g * K + k] = (a0 + a1) + (a2 + a3);
-        }
-    }
-    fence_agent();
-    __syncthreads();
-    if (tid == 0) {
-        t.ctr[1 + g] = 0u;
-        *s_flag = atomicAdd(&t.ctr[0], 1u) == (unsigned)(ngroups - 1);
-    }
-    __syncthreads();
-    if (!*s_flag) return;
-    fence_agent();
-    for (int k = tid; k < K; k += nt) {
-        float a0 = 0.f, a1 = 0.f;
-        int gg = 0;
-        for (; gg + 1 < ngroups; gg += 2) {
-            a0 += ld_agent(t.part2 + (long)gg * K + k);
-            a1 += ld_agent(t.part2 + (long)(gg + 1) * K + k);
-        }
-        if (gg < ngroups) a0 += ld_agent(t.part2 + (long)gg * K + k);
-        float* dst = t.out[k / t.C];
-        if (dst) atomicAdd(dst + k % t.C, a0 + a1);
-    }
-    if (tid == 0) t.ctr[0] = 0u;
+    return (w.ptr && nfloats <= w.nfloats) ? w.ptr : nullptr;
 }
 // launch-shape knobs (ledn_set_option)
 struct Options {

@@ -264,8 +264,7 @@ int bn_act_bwd_apply_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
 // are 3-5 us on a 33 MB tensor); workgroup totals -> part[block][3][C] (finish_partials adds them up).
 // sum g*xhat is accumulated as sum g*(z - mean) and scaled by invstd once per workgroup.
 template <int ACT, int RES, int UNR>
-__global__ void __launch_bounds__(256) bn_reduce_fast_kernel(ledn_bnbwd_desc d, float* part, FinishTail tail) {
-    __shared__ int s_flag;
+__global__ void __launch_bounds__(256) bn_reduce_fast_kernel(ledn_bnbwd_desc d, float* part) {
     __shared__ float s_par[5][SF_MAXC];     // sc, sh, sl, mean, invstd
     __shared__ float s_red[3][256 * 8];
     for (int c = threadIdx.x; c < d.C; c += 256) {
@@ -340,7 +339,6 @@ __global__ void __launch_bounds__(256) bn_reduce_fast_kernel(ledn_bnbwd_desc d, 
         if (j == 1) t *= s_par[4][c];
         part[(long)blockIdx.x * 3 * d.C + o] = t;
     }
-    if (tail.ctr) finish_tail(part, tail, &s_flag);
 }
 
 int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
@@ -351,22 +349,11 @@ int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
     long nb = cdiv(d.P, (long)rows * UNR);           // one trip per lane up to 2048 workgroups
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
-    FinishTail tail = {};
-    const int group = 32;
-    const long ngroups = cdiv(nb, group);
-    const bool ticket = (options().stream_fast & 16) && ws_counters() && ngroups + 1 <= LEDN_WS_COUNTERS && nb > group;
-    float* part = ws_take(nb * 3 * d.C + (ticket ? ngroups * 3 * d.C : 0));
+    float* part = ws_take(nb * 3 * d.C);
     if (!part) return -1;
-    if (ticket) {
-        tail.part2 = part + nb * 3 * d.C;
-        tail.ctr = ws_counters();
-        tail.out[0] = d.sum_g; tail.out[1] = d.sum_gx; tail.out[2] = d.dslope;
-        tail.C = d.C; tail.nout = 3; tail.nblk = (int)nb; tail.group = group;
-    }
     const dim3 grid((unsigned)nb);
     SF_ACT_SWITCH(d.act, SF_RES_SWITCH(d.res_mode,
-        LEDN_LAUNCH((bn_reduce_fast_kernel<A_, R_, UNR>), grid, dim3(256), 0, s, d, part, tail)));
-    if (ticket) return check_launch();
+        LEDN_LAUNCH((bn_reduce_fast_kernel<A_, R_, UNR>), grid, dim3(256), 0, s, d, part)));
     return finish_partials(part, (int)nb, d.C, 3, d.sum_g, d.sum_gx, d.dslope, s);
 }
 
