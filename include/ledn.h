@@ -139,6 +139,16 @@ int ledn_im2col_stem(const void* x, void* p, int N, int H, int W, int C, int Ho,
 int ledn_im2col_stem_planar(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
                             const float* scale, const float* shift, const int* map, const int* valid_hw,
                             float pad_val, void* stream);
+/* The whole first stem convolution (3x3, stride 2, pad 1, 3 -> 32; ddrnet.py:123-130) from the planar input batch in
+ * ONE kernel: normalisation + channel map + batch padding (as ledn_im2col_stem_planar), im2col in LDS, K = 32 GEMM on
+ * the matrix cores -- the [pixels][32] patch matrix is never written.  wp: ledn_pack_conv_weights (mode 0) of the
+ * [32][32][1][1] view of the filter (columns (kh*3+kw)*3 + c, zero padded).  y [N,Ho,Wo,32] bf16.
+ * Either out_scale / out_shift / act_out (inference: folded BatchNorm + ReLU) or stat_sum / stat_sqsum (training:
+ * raw z and its per-channel sums, deferred-statistics aware), not both. */
+int ledn_stem_conv(const void* x, int dtype_x, const void* wp, void* y, int N, int H, int W, int C, int Ho, int Wo,
+                   int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
+                   float pad_val, const float* out_scale, const float* out_shift, int act_out, float* stat_sum,
+                   float* stat_sqsum, void* stream);
 
 /* Weight (and bias) gradient of the same convolution:
  *   dw(co,ci,tap) += sum_{n,ho,wo} pre(x)[n, ho*s-pad+kh*dil, .., ci] * dz[n,ho,wo,co]

@@ -27,6 +27,10 @@ int bn_finalize_rows_impl(const float* part, int rows, double count, const float
 int im2col_stem_planar_impl(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
                             const float* scale, const float* shift, const int* map, const int* valid_hw, float pad_val,
                             hipStream_t s);
+int stem_conv_impl(const void* x, int dtype_x, const void* wp, void* y, int N, int H, int W, int C, int Ho, int Wo,
+                   int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
+                   float pad_val, const float* out_scale, const float* out_shift, int act_out, float* stat_sum,
+                   float* stat_sqsum, hipStream_t s);
 int dw_pack_impl(const ledn_dwpack_desc& d, float* packed, hipStream_t s);
 int dw_unpack_grad_impl(const ledn_dwpack_desc& d, const float* dpacked, hipStream_t s);
 int dw_repack_multi_impl(const ledn_dwpack_entry* table_dev, int n, int max_elems, int dir, hipStream_t s);
@@ -260,6 +264,13 @@ int ledn_relpos_bias(const float* table, const long long* index, float* biasT, i
 int ledn_relpos_bias_bwd(const float* dbiasT, const long long* index, float* dtable, int R, int heads, int T,
                          void* stream) {
     return relpos_bias_bwd_impl(dbiasT, index, dtable, R, heads, T, S(stream));
+}
+int ledn_stem_conv(const void* x, int dtype_x, const void* wp, void* y, int N, int H, int W, int C, int Ho, int Wo,
+                   int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
+                   float pad_val, const float* out_scale, const float* out_shift, int act_out, float* stat_sum,
+                   float* stat_sqsum, void* stream) {
+    return stem_conv_impl(x, dtype_x, wp, y, N, H, W, C, Ho, Wo, Cout, in_scale, in_shift, map, valid_hw, pad_val,
+                          out_scale, out_shift, act_out, stat_sum, stat_sqsum, S(stream));
 }
 int ledn_dw_repack_multi(const ledn_dwpack_entry* table_dev, int n, int max_elems, int dir, void* stream) {
     return dw_repack_multi_impl(table_dev, n, max_elems, dir, S(stream));

@@ -890,6 +890,192 @@ __global__ void __launch_bounds__(256) im2col_stem_planar_kernel(const TX* x, bf
                    e8[6] | ((unsigned)e8[7] << 16));
 }
 
+// ---------------------------------------------------------------------------
+// The first stem convolution (3x3, stride 2, 3 -> 32) straight from the planar input batch: normalisation, batch
+// padding, im2col and the K = 32 GEMM in ONE kernel -- the patch matrix [pixels][32] (268 MB at 16 x 1024^2, written
+// by ledn_im2col_stem_planar and read back by the 1x1 MFMA conv: 307 us together) is never materialised.
+// Workgroup = 4 output rows x 64 pixels per tile (tiles dealt round-robin): the 9 x 129 x 3 input window is
+// normalised into LDS as bf16; wave w owns output row w: its two 32-pixel blocks assemble the K-fragment of a pixel
+// from 8 LDS halfwords (k = (kh*3+kw)*3 + c; k >= 27 is zero), weights stay in registers (A operand: cout rows),
+// the accumulator lane owns one pixel and 16 channels, v_permlane32_swap merges the channel quads of lanes l and
+// l + 32 into 16-byte stores (no LDS transposition).  FULL: y = act(acc * out_scale + out_shift) (inference: folded
+// BatchNorm + ReLU); else raw z + per-workgroup statistics rows (training).
+// ---------------------------------------------------------------------------
+struct StemArgs {
+    const void* x;
+    const bf16_t* wp;            // [32 cout][32 k] bf16 (ledn_pack_conv_weights of the [32][32][1][1] view)
+    bf16_t* y;
+    const float *in_scale, *in_shift, *out_scale, *out_shift;
+    const int* map;
+    const int* valid_hw;
+    float* stat_sum;
+    float* stat_sqsum;
+    float* part;
+    int N, H, W, Ho, Wo, act_out;
+    float pad_val;
+};
+
+template <typename TX, bool FULL>
+__global__ void __launch_bounds__(256) stem_conv_kernel(StemArgs a) {
+    constexpr int C = 3, TRO = 4, PXB = 64, COLS = 2 * PXB + 1, ROWS = 2 * TRO + 1;
+    constexpr int NE = (C * ROWS * COLS + 255) / 256;
+    __shared__ unsigned short s_in[C * ROWS * COLS];          // [c][row][col], zero outside the image
+    __shared__ float s_st[4][2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const TX* x = reinterpret_cast<const TX*>(a.x);
+    bf16x8_t wf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.wp + lr * 32 + ks * 16 + lh * 8);
+    int koff[2][8];                                           // LDS offset of column k of the patch row, -1: zero
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + lh * 8 + j, tap = k / C, c = k - tap * C, kh = tap / 3, kw = tap - kh * 3;
+            koff[ks][j] = k < 9 * C ? (c * ROWS + kh) * COLS + kw : -1;
+        }
+    float sc[16], sh[16];
+    if (FULL) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = (i & 3) + 8 * (i >> 2) + 4 * lh;
+            sc[i] = a.out_scale ? a.out_scale[c] : 1.f;
+            sh[i] = a.out_shift ? a.out_shift[c] : 0.f;
+        }
+    }
+    float st1[16], st2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st1[i] = st2[i] = 0.f;
+    const float hi_clip = a.act_out == LEDN_ACT_RELU6 ? 6.f : 3.0e38f;
+    const int tw = (a.Wo + PXB - 1) / PXB, th = (a.Ho + TRO - 1) / TRO;
+    const long ntiles = (long)a.N * th * tw;
+    const long plane = (long)a.H * a.W;
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int txi = (int)(t % tw), tyi = (int)((t / tw) % th), n = (int)(t / ((long)tw * th));
+        const int ho0 = tyi * TRO, wo0 = txi * PXB;
+        const int vh = a.valid_hw ? a.valid_hw[2 * n] : a.H, vw = a.valid_hw ? a.valid_hw[2 * n + 1] : a.W;
+        float f[NE];
+        bool ok[NE], data[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int e = tid + j * 256;
+            const int col = e % COLS, r = (e / COLS) % ROWS, c = min(e / (ROWS * COLS), C - 1);
+            const int hi = ho0 * 2 - 1 + r, wi = wo0 * 2 - 1 + col;
+            ok[j] = e < C * ROWS * COLS && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+            data[j] = hi < vh && wi < vw;
+            const int cs = a.map ? a.map[c] : c;
+            f[j] = ldp(x + ((long)n * C + cs) * plane + (ok[j] ? (long)hi * a.W + wi : 0L));
+        }
+        __syncthreads();                                      // the previous tile's fragments have been read
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int e = tid + j * 256;
+            if (e >= C * ROWS * COLS) continue;
+            const int c = e / (ROWS * COLS);
+            float v = f[j];
+            if (a.in_scale) v = v * a.in_scale[c] + a.in_shift[c];
+            v = data[j] ? v : a.pad_val;
+            s_in[e] = ok[j] ? f32_to_bf16(v) : (unsigned short)0;
+        }
+        __syncthreads();
+        const int ho = ho0 + wid;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int px = mb * 32 + lr, wo = wo0 + px;
+            const int base = (2 * wid) * COLS + 2 * px;
+            f32x16_t acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t xf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[j] = koff[ks][j] >= 0 ? (short)s_in[base + koff[ks][j]] : (short)0;
+                acc = mfma_32x32x16_bf16(wf[ks], xf, acc);
+            }
+            const bool pix_ok = ho < a.Ho && wo < a.Wo;
+            unsigned pk[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = acc[4 * q + j];
+                    if (FULL) {
+                        v[j] = v[j] * sc[4 * q + j] + sh[4 * q + j];
+                        if (a.act_out != LEDN_ACT_NONE) v[j] = fminf(fmaxf(v[j], 0.f), hi_clip);
+                    } else {
+                        const float vm = pix_ok ? v[j] : 0.f;
+                        st1[4 * q + j] += vm;
+                        st2[4 * q + j] = fmaf(vm, vm, st2[4 * q + j]);
+                    }
+                }
+                pk[q][0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                pk[q][1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            }
+            // lanes l / l + 32 hold channels {0-3, 8-11, 16-19, 24-27} (+4): after the swaps l has 0-7 and 16-23,
+            // l + 32 has 8-15 and 24-31
+            permlane32_swap(pk[0][0], pk[1][0]);
+            permlane32_swap(pk[0][1], pk[1][1]);
+            permlane32_swap(pk[2][0], pk[3][0]);
+            permlane32_swap(pk[2][1], pk[3][1]);
+            if (pix_ok) {
+                bf16_t* dst = a.y + (((long)n * a.Ho + ho) * a.Wo + wo) * 32 + 8 * lh;
+                *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+                *reinterpret_cast<uint4*>(dst + 16) = make_uint4(pk[2][0], pk[2][1], pk[3][0], pk[3][1]);
+            }
+        }
+    }
+    if (FULL || !a.stat_sum) return;
+    const float t1 = reduce16_over32(st1, lane), t2 = reduce16_over32(st2, lane);
+    const int idx = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    const int cl = (idx & 3) + 8 * (idx >> 2) + 4 * lh;
+    __syncthreads();
+    if ((lane & 1) == 0) {
+        s_st[wid][0][cl] = t1;
+        s_st[wid][1][cl] = t2;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int j = tid >> 5, c = tid & 31;
+        const float t = (s_st[0][j][c] + s_st[1][j][c]) + (s_st[2][j][c] + s_st[3][j][c]);
+        if (a.part) a.part[(long)blockIdx.x * 64 + j * 32 + c] = t;
+        else atomicAdd((j ? a.stat_sqsum : a.stat_sum) + c, t);
+    }
+}
+
+int stem_conv_impl(const void* x, int dtype_x, const void* wp, void* y, int N, int H, int W, int C, int Ho, int Wo,
+                   int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
+                   float pad_val, const float* out_scale, const float* out_shift, int act_out, float* stat_sum,
+                   float* stat_sqsum, hipStream_t s) {
+    LEDN_REQUIRE(x && wp && y && N > 0 && H > 0 && W > 0 && C == 3 && Cout == 32);
+    LEDN_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1);
+    LEDN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (stat_sum == nullptr) == (stat_sqsum == nullptr));
+    LEDN_REQUIRE(act_out == LEDN_ACT_NONE || act_out == LEDN_ACT_RELU || act_out == LEDN_ACT_RELU6);
+    const bool full = out_scale || out_shift || act_out != LEDN_ACT_NONE;
+    LEDN_REQUIRE(!(full && stat_sum));                        // inference epilogue XOR training statistics
+    StemArgs a;
+    a.x = x; a.wp = (const bf16_t*)wp; a.y = (bf16_t*)y;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
+    a.map = map; a.valid_hw = valid_hw; a.stat_sum = stat_sum; a.stat_sqsum = stat_sqsum;
+    a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.act_out = act_out; a.pad_val = pad_val;
+    const long ntiles = (long)N * cdiv(Ho, 4) * cdiv(Wo, 64);
+    long nb = ntiles < 2048 ? ntiles : 2048;      // (one-shot workgroups measured slower: 198 vs 182 us)
+    a.part = (stat_sum && nb > 16) ? ws_take(nb * 64) : nullptr;
+#define LEDN_STEM(TX)                                                                                      \
+    do {                                                                                                   \
+        if (full) LEDN_LAUNCH((stem_conv_kernel<TX, true>), dim3((unsigned)nb), dim3(256), 0, s, a);       \
+        else LEDN_LAUNCH((stem_conv_kernel<TX, false>), dim3((unsigned)nb), dim3(256), 0, s, a);           \
+    } while (0)
+    if (dtype_x == LEDN_U8) LEDN_STEM(unsigned char);
+    else if (dtype_x == LEDN_F32) LEDN_STEM(float);
+    else if (dtype_x == LEDN_BF16) LEDN_STEM(bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_STEM
+    if (a.part) return finish_partials(a.part, (int)nb, 32, 2, stat_sum, stat_sqsum, nullptr, s);
+    return check_launch();
+}
+
 int im2col_stem_planar_impl(const void* x, int dtype_x, void* p, int N, int H, int W, int C, int Ho, int Wo,
                             const float* scale, const float* shift, const int* map, const int* valid_hw,
                             float pad_val, hipStream_t s) {

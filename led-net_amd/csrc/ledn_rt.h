@@ -176,6 +176,24 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
     T* name = reinterpret_cast<T*>(name##_raw_)
 #endif
 
+// ---- exchange between the two halves of a wave (gfx950: v_permlane32_swap_b32) -------------------------------
+// after the call: a = {a.low, b.low}, b = {a.high, b.high}  (x.low / x.high = the values lanes 0-31 / 32-63 held in x)
+#ifdef LEDN_CPU_EMU
+__device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
+    const bool hi = lane_id() >= 32;
+    const unsigned recv = __shfl_xor(hi ? a : b, 32);
+    if (hi) a = recv;
+    else b = recv;
+}
+#else
+__device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r.x;
+    b = r.y;
+}
+#endif
+
 // ---- XCD-aware block numbering ----------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  xcd_block() renumbers
 // them so that the workgroups resident on one XCD own ONE contiguous eighth of the logical block

@@ -37,6 +37,7 @@ def to_nchw_view(t):
 
 import os as _os
 SEAM_SLOT_EVAL = int(_os.environ.get('LEDN_SEAM_SLOT_EVAL', '2'))   # inference: SEAM edge map on its own stream
+FUSED_STEM = int(_os.environ.get('LEDN_FUSED_STEM', '0'))        # first stem conv as ONE kernel from the planar batch (ledn_stem_conv): parity-green, but 182 us vs 99 + 62 us for im2col + GEMM at 8 x 1024^2 (r04n): off
 
 
 class LEDNet(Block):
@@ -136,7 +137,15 @@ class LEDNet(Block):
         N, _, H, W = x.shape
         out_size = (math.ceil(H / 8), math.ceil(W / 8))                      # ddrnet.py:185
         s, b, m, valid, pad_val = (tuple(pre) + (None, 0.0))[:5] if pre is not None else (None, None, None, None, 0.0)
-        if self.act_dtype == torch.bfloat16 and 9 * self.in_channels <= 32 and self.channels % 32 == 0:
+        if (self.act_dtype == torch.bfloat16 and self.in_channels == 3 and self.channels == 32 and FUSED_STEM
+                and x.dtype in (torch.uint8, torch.float32, torch.bfloat16)):
+            # normalisation + batch padding + im2col + K=32 GEMM + folded BatchNorm + ReLU: one kernel (ledn_stem_conv)
+            from .blocks import fold_bn
+            m0 = self.stem['0']
+            wp = self.cached('stem_wp', lambda: ops.pack_conv_weights(ops.stem_weight_as_1x1(m0.conv.weight.detach()), 0))
+            fs, fb = self.cached('stem_fold', lambda: fold_bn(m0.bn))
+            x1 = ops.stem_conv(x.contiguous(), wp, s, b, m, valid, pad_val, out_scale=fs, out_shift=fb, act=ACT_RELU)
+        elif self.act_dtype == torch.bfloat16 and 9 * self.in_channels <= 32 and self.channels % 32 == 0:
             # planar batch -> im2col patches in one kernel (normalisation folded in), then a K=32 GEMM
             x1 = self._stem0(None, ops.im2col_stem_planar(x.contiguous(), s, b, m, valid, pad_val))
         else:

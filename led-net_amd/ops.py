@@ -315,6 +315,33 @@ def im2col_stem_planar(x, scale=None, shift=None, chan_map=None, valid=None, pad
     return p
 
 
+def stem_conv(x, w_pack, scale=None, shift=None, chan_map=None, valid=None, pad_val=0.0, out_scale=None, out_shift=None,
+              act=ACT_NONE, stats=None, defer_stats=False):
+    """First stem convolution (3x3 s2, 3 -> 32) straight from the planar batch x [N,3,H,W] (uint8 / f32 / bf16):
+    normalisation, channel map, batch padding, im2col and the K = 32 GEMM in one kernel (ledn_stem_conv).
+    w_pack: pack_conv_weights(stem_weight_as_1x1(w), 0).  -> y [N,Ho,Wo,32] bf16."""
+    lib = _lib.get_lib()
+    N, Cc, H, W = x.shape
+    if Cc != 3 or x.dtype not in (torch.uint8, torch.float32, torch.bfloat16):
+        raise LednError('stem_conv: uint8/f32/bf16 input with 3 channels required')
+    if chan_map is not None and (chan_map.dtype != torch.int32 or chan_map.numel() != Cc):
+        raise LednError('stem_conv: chan_map must be int32[C]')
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, Ho, Wo, 32), dtype=torch.bfloat16, device=x.device)
+    _check(lib, x, w_pack, y, scale, shift, chan_map, valid, out_scale, out_shift)
+    dtx = {torch.uint8: _lib.U8, torch.float32: F32, torch.bfloat16: BF16}[x.dtype]
+    valid = _valid_hw(valid, N, x)
+    s0 = s1 = None
+    if stats is not None:
+        _check(lib, stats[0], stats[1])
+        s0, s1 = _p(_f32(stats[0], 32)), _p(_f32(stats[1], 32))
+    _run_stats(lib, 'ledn_stem_conv', x, stats, defer_stats, _p(x), dtx, _p(w_pack), _p(y), N, H, W, Cc, Ho, Wo, 32,
+               _p(_f32(scale, Cc)), _p(_f32(shift, Cc)), _p(chan_map), _p(valid), float(pad_val),
+               _p(_f32(out_scale, 32)), _p(_f32(out_shift, 32)), int(act), s0, s1,
+               work=_TIMING is not None and (f'stem_conv {N}x{H}x{W}', _nb(x, y), 2 * y.numel() * 27, 'stem_conv_kernel'))
+    return y
+
+
 def stem_weight_as_1x1(w):
     """[Cout][3][3][3] OIHW -> [Cout][32][1][1] matching im2col_stem's column order (differentiable)."""
     co, ci, kh, kw = w.shape

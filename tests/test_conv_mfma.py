@@ -280,3 +280,42 @@ def test_mfma_dgrad_accumulates_partial_gradient(be, cin, cout, k, stride, hw):
     xg = x.clone().requires_grad_(True)
     F.conv2d(xg, r16(w), stride=stride, padding=pad).backward(dz)
     torch.testing.assert_close(nchw(fused), xg.grad + partial, rtol=2e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize('shape,valid', [((2, 3, 64, 128), None), ((1, 3, 70, 150), None), ((2, 3, 72, 136), [(72, 136), (50, 101)])])
+def test_fused_stem_conv_equals_im2col_plus_gemm(be, shape, valid):
+    """ledn_stem_conv (normalise + pad + im2col + K=32 MFMA GEMM in one kernel) against the two-kernel path it replaces
+    (ledn_im2col_stem_planar + ledn_conv2d): inference epilogue (folded BatchNorm + ReLU) and training flavour (raw z +
+    per-channel statistics); ragged tiles and per-image valid extents."""
+    from led_net_amd import ops
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g).to(be.dev)
+    w = (0.2 * torch.randn(32, 3, 3, 3, generator=g)).to(be.dev)
+    mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
+    sc, sh = (1.0 / std).to(be.dev), (-mean / std).to(be.dev)
+    cmap = torch.tensor([2, 1, 0], dtype=torch.int32, device=be.dev)
+    vt = torch.tensor(valid, dtype=torch.int32, device=be.dev) if valid is not None else None
+    w1 = ops.stem_weight_as_1x1(w)
+    wp = ops.pack_conv_weights(w1, 0)
+    patches = ops.im2col_stem_planar(x, sc, sh, cmap, vt, 0.25)
+    osc, osh = (0.5 + torch.rand(32, generator=g)).to(be.dev), (0.1 * torch.randn(32, generator=g)).to(be.dev)
+    want = ops.conv2d(patches, w1, out_scale=osc, out_shift=osh, act=ops.ACT_RELU, w_bf16=wp)
+    got = ops.stem_conv(x, wp, sc, sh, cmap, vt, 0.25, out_scale=osc, out_shift=osh, act=ops.ACT_RELU)
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    torch.testing.assert_close(got.float().cpu(), want.float().cpu(), rtol=1e-2, atol=1e-2)
+    st_w = (torch.zeros(32, device=be.dev), torch.zeros(32, device=be.dev))
+    st_g = (torch.zeros(32, device=be.dev), torch.zeros(32, device=be.dev))
+    zw = ops.conv2d(patches, w1, stats=st_w, w_bf16=wp)
+    zg = ops.stem_conv(x, wp, sc, sh, cmap, vt, 0.25, stats=st_g)
+    torch.testing.assert_close(zg.float().cpu(), zw.float().cpu(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(st_g[0].cpu(), st_w[0].cpu(), rtol=1e-3, atol=1e-2 * zw.float().abs().sum().item() / 32 / 100)
+    torch.testing.assert_close(st_g[1].cpu(), st_w[1].cpu(), rtol=1e-3, atol=1e-1)
+    # and against plain torch: conv2d(normalised input, zero padding)
+    xn = x.float().cpu()[:, [2, 1, 0]] * sc.cpu().view(1, 3, 1, 1) + sh.cpu().view(1, 3, 1, 1)
+    if valid is not None:
+        for i, (vh, vw) in enumerate(valid):
+            xn[i, :, vh:, :] = 0.25
+            xn[i, :, :, vw:] = 0.25
+    ref = torch.nn.functional.conv2d(xn, w.cpu(), stride=2, padding=1).permute(0, 2, 3, 1)
+    torch.testing.assert_close(zg.float().cpu(), ref, rtol=3e-2, atol=3e-2)
