@@ -184,6 +184,7 @@ def main():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-seconds', type=float, default=20.0, help='budget of the bounded CPU-oracle sample')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--collectives', default=None, choices=['auto', 'rccl', 'torch'],
                     help='N>1: rccl = ncclAllReduce on the launch stream (graph-capturable), torch = torch.distributed (eager); '
@@ -397,7 +398,7 @@ def main():
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(mode, H, W)
+            out['cpu_baseline'] = cpu_baseline(mode, H, W, args.cpu_baseline_seconds)
         if os.environ.get('LEDN_BENCH_VERBOSE'):
             for e, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms']):
                 print(f"{v['ms'] / k_steps:9.3f} ms/step  x{v['n'] // k_steps:4d}  {v['bytes'] / max(1e-9, v['ms']) / 1e6:8.1f} GB/s "
