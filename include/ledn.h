@@ -564,6 +564,15 @@ int ledn_ohem_ce_bwd(const float* logits, const long long* target, long long P, 
                      int ignore_label, const float* work, const float* out, const float* dloss,
                      float loss_weight, float* dlogits, void* stream);
 long long ledn_ohem_work_floats(long long P);
+/* The same loss on logits that are the bilinear (align_corners=False) resize of src [N,Hs,Ws,2] (f32) to H x W, without
+ * materialising them: LEDHead.loss_by_feat's resize of each fused output to the label size (led_head.py:132-138)
+ * folded into the loss.  target [N,H,W]; work: ledn_ohem_work_floats(N*H*W); out as ledn_ohem_ce_fwd.
+ * ledn_ohem_ce_up_bwd (exact 2x only: H = 2 Hs, W = 2 Ws): dsrc [N,Hs,Ws,2] = resize^T(dlogits), dlogits never written. */
+int ledn_ohem_ce_up_fwd(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target, float thres,
+                        long long min_kept, float loss_weight, int ignore_label, float* work, float* out, void* stream);
+int ledn_ohem_ce_up_bwd(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target,
+                        int ignore_label, const float* work, const float* out, const float* dloss, float loss_weight,
+                        float* dsrc, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * SGD with momentum and weight decay over a table of tensors (torch.optim.SGD

@@ -675,6 +675,148 @@ int ohem_ce_bwd_impl(const float* logits, const long long* target, long long P, 
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------
+// OHEM-CE on logits that are the bilinear (align_corners=False) upsampling of src [N,Hs,Ws,2] to H x W, without
+// materialising them: LEDHead.loss_by_feat resizes each fused output to the label size right in front of the loss
+// (led_head.py:132-138); at 16 x 1024^2 that tensor and its gradient are 134 MB each, written once and read twice.
+// Forward: ohem_prob with the four-tap interpolation in front (any ratio).  Backward (exact 2x): a workgroup owns a
+// 16 x 16 tile of src; the softmax gradients of its 34 x 34 children are formed once in LDS, then every src pixel
+// gathers its 4 x 4 children with the interpolation weights (the adjoint of the resize), so neither dlogits nor a
+// scatter with atomics exists.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void up_logits2(const float* src, int Ws, const Lerp& ly, const Lerp& lx, float& l0, float& l1) {
+    const float2 v00 = *reinterpret_cast<const float2*>(src + ((long)ly.i0 * Ws + lx.i0) * 2);
+    const float2 v01 = *reinterpret_cast<const float2*>(src + ((long)ly.i0 * Ws + lx.i1) * 2);
+    const float2 v10 = *reinterpret_cast<const float2*>(src + ((long)ly.i1 * Ws + lx.i0) * 2);
+    const float2 v11 = *reinterpret_cast<const float2*>(src + ((long)ly.i1 * Ws + lx.i1) * 2);
+    l0 = ly.w0 * (lx.w0 * v00.x + lx.w1 * v01.x) + ly.w1 * (lx.w0 * v10.x + lx.w1 * v11.x);
+    l1 = ly.w0 * (lx.w0 * v00.y + lx.w1 * v01.y) + ly.w1 * (lx.w0 * v10.y + lx.w1 * v11.y);
+}
+
+__global__ void __launch_bounds__(256) ohem_prob_up_kernel(const float* src, int N, int Hs, int Ws, int H, int W,
+                                                           const long long* target, int ignore_label, float* work) {
+    __shared__ unsigned s_hist[OH_BINS];
+    __shared__ unsigned s_cnt[2];
+    const long P = (long)N * H * W;
+    const OhemWork w = ohem_work(work, P);
+    for (int i = threadIdx.x; i < OH_BINS; i += blockDim.x) s_hist[i] = 0u;
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const long long tg = target[p];
+        if (tg == ignore_label) {
+            w.prob[p] = 2.0f;
+            w.loss[p] = 0.f;
+            continue;
+        }
+        const int x = (int)(p % W), y = (int)((p / W) % H), n = (int)(p / ((long)W * H));
+        float lg[2];
+        up_logits2(src + (long)n * Hs * Ws * 2, Ws, lerp_coord(y, Hs, H), lerp_coord(x, Ws, W), lg[0], lg[1]);
+        const int am = lg[1] > lg[0] ? 1 : 0;
+        const float mx = lg[am];
+        const float se = __expf(lg[0] - mx) + __expf(lg[1] - mx);
+        const float lt = lg[(int)tg] - mx;
+        const float pr = __expf(lt) / se;
+        w.prob[p] = pr;
+        w.loss[p] = __logf(se) - lt;
+        atomicAdd(&s_hist[oh_bin(__float_as_uint(pr), 0)], 1u);
+        atomicAdd(&s_cnt[0], 1u);
+        if (am == (int)tg) atomicAdd(&s_cnt[1], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < OH_BINS; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&w.hist[i], s_hist[i]);
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&w.state[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+int ohem_ce_up_fwd_impl(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target, float thres,
+                        long long min_kept, float loss_weight, int ignore_label, float* work, float* out,
+                        hipStream_t s) {
+    LEDN_REQUIRE(src && target && work && out && N > 0 && Hs > 0 && Ws > 0 && H > 0 && W > 0);
+    const long long P = (long long)N * H * W;
+    LEDN_REQUIRE(P < (1LL << 31) && min_kept >= 1);
+    const OhemWork w = ohem_work(work, P);
+    if (hipMemsetAsync(w.hist, 0, sizeof(unsigned) * (3 * OH_BINS + 16), s) != hipSuccess) return LEDN_ELAUNCH;
+    const dim3 grid((unsigned)(cdiv(P, 256) < 2048 ? cdiv(P, 256) : 2048));
+    LEDN_LAUNCH(ohem_prob_up_kernel, grid, dim3(256), 0, s, src, N, Hs, Ws, H, W, target, ignore_label, work);
+    LEDN_LAUNCH(ohem_scan_kernel, dim3(1), dim3(256), 0, s, work, (long)P, 0, min_kept, thres);
+    LEDN_LAUNCH(ohem_hist_kernel, grid, dim3(256), 0, s, work, (long)P, 1);
+    LEDN_LAUNCH(ohem_scan_kernel, dim3(1), dim3(256), 0, s, work, (long)P, 1, min_kept, thres);
+    LEDN_LAUNCH(ohem_hist_kernel, grid, dim3(256), 0, s, work, (long)P, 2);
+    LEDN_LAUNCH(ohem_scan_kernel, dim3(1), dim3(256), 0, s, work, (long)P, 2, min_kept, thres);
+    LEDN_LAUNCH(ohem_reduce_kernel, grid, dim3(256), 0, s, work, (long)P);
+    LEDN_LAUNCH(ohem_final_kernel, dim3(1), dim3(1), 0, s, work, (long)P, loss_weight, out);
+    return check_launch();
+}
+
+__global__ void __launch_bounds__(256) ohem_bwd_up2_kernel(const float* src, int N, int Hs, int Ws,
+                                                           const long long* target, int ignore_label,
+                                                           const float* work, const float* out, const float* dloss,
+                                                           float loss_weight, float* dsrc) {
+    constexpr int T = 16, CH = 2 * T + 2;                   // src tile, children per side
+    __shared__ float2 s_g[CH * CH];
+    const int H = 2 * Hs, W = 2 * Ws;
+    const int tw = (Ws + T - 1) / T, th = (Hs + T - 1) / T;
+    const int bj = blockIdx.x % tw, bi = (blockIdx.x / tw) % th, n = blockIdx.x / (tw * th);
+    const int i0 = bi * T, j0 = bj * T;
+    const float* prob = work;
+    const float thr = out[2];
+    const float coef = dloss[0] * loss_weight / out[3];
+    const float* sn = src + (long)n * Hs * Ws * 2;
+    for (int k = threadIdx.x; k < CH * CH; k += 256) {
+        const int y = 2 * i0 - 1 + k / CH, x = 2 * j0 - 1 + k % CH;
+        float2 g = make_float2(0.f, 0.f);
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const long p = ((long)n * H + y) * W + x;
+            const long long tg = target[p];
+            if (tg != ignore_label && prob[p] < thr) {
+                float l0, l1;
+                up_logits2(sn, Ws, lerp_coord(y, Hs, H), lerp_coord(x, Ws, W), l0, l1);
+                const float mx = fmaxf(l0, l1);
+                const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx), inv = 1.f / (e0 + e1);
+                g.x = coef * (e0 * inv - (tg == 0 ? 1.f : 0.f));
+                g.y = coef * (e1 * inv - (tg == 1 ? 1.f : 0.f));
+            }
+        }
+        s_g[k] = g;
+    }
+    __syncthreads();
+    const int a = threadIdx.x / T, b = threadIdx.x % T, i = i0 + a, j = j0 + b;
+    if (i >= Hs || j >= Ws) return;
+    float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+        const int y = 2 * i - 1 + dy;
+        if (y < 0 || y >= H) continue;
+        const Lerp ly = lerp_coord(y, Hs, H);
+        const float wy = (ly.i0 == i ? ly.w0 : 0.f) + (ly.i1 == i ? ly.w1 : 0.f);
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const int x = 2 * j - 1 + dx;
+            if (x < 0 || x >= W) continue;
+            const Lerp lx = lerp_coord(x, Ws, W);
+            const float wgt = wy * ((lx.i0 == j ? lx.w0 : 0.f) + (lx.i1 == j ? lx.w1 : 0.f));
+            const float2 g = s_g[(2 * a + dy) * CH + 2 * b + dx];
+            acc.x += wgt * g.x;
+            acc.y += wgt * g.y;
+        }
+    }
+    *reinterpret_cast<float2*>(dsrc + (((long)n * Hs + i) * Ws + j) * 2) = acc;
+}
+
+int ohem_ce_up_bwd_impl(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target,
+                        int ignore_label, const float* work, const float* out, const float* dloss, float loss_weight,
+                        float* dsrc, hipStream_t s) {
+    LEDN_REQUIRE(src && target && work && out && dloss && dsrc && N > 0 && Hs > 0 && Ws > 0);
+    LEDN_REQUIRE(H == 2 * Hs && W == 2 * Ws);               // the fused adjoint is written for the exact 2x resize
+    const long nb = (long)N * cdiv(Hs, 16) * cdiv(Ws, 16);
+    LEDN_REQUIRE(nb < (1L << 31));
+    LEDN_LAUNCH(ohem_bwd_up2_kernel, dim3((unsigned)nb), dim3(256), 0, s, src, N, Hs, Ws, target, ignore_label, work, out,
+                dloss, loss_weight, dsrc);
+    return check_launch();
+}
+
 // ===========================================================================
 // multi-tensor SGD: grid = (chunks, tensors)
 // ===========================================================================

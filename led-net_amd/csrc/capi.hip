@@ -88,6 +88,12 @@ long long ohem_work_floats(long long P);
 int ohem_ce_fwd_impl(const float* logits, const long long* target, long long P, int C, float thres,
                      long long min_kept, float loss_weight, int ignore_label, float* work, float* out,
                      hipStream_t s);
+int ohem_ce_up_fwd_impl(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target, float thres,
+                        long long min_kept, float loss_weight, int ignore_label, float* work, float* out,
+                        hipStream_t s);
+int ohem_ce_up_bwd_impl(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target,
+                        int ignore_label, const float* work, const float* out, const float* dloss, float loss_weight,
+                        float* dsrc, hipStream_t s);
 int ohem_ce_bwd_impl(const float* logits, const long long* target, long long P, int C, int ignore_label,
                      const float* work, const float* out, const float* dloss, float loss_weight,
                      float* dlogits, hipStream_t s);
@@ -352,6 +358,15 @@ int ledn_ohem_ce_fwd(const float* logits, const long long* target, long long P, 
                      void* stream) {
     return ohem_ce_fwd_impl(logits, target, P, C, thres, min_kept, loss_weight, ignore_label, work, out,
                             S(stream));
+}
+int ledn_ohem_ce_up_fwd(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target, float thres,
+                        long long min_kept, float loss_weight, int ignore_label, float* work, float* out, void* stream) {
+    return ohem_ce_up_fwd_impl(src, N, Hs, Ws, H, W, target, thres, min_kept, loss_weight, ignore_label, work, out, S(stream));
+}
+int ledn_ohem_ce_up_bwd(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target,
+                        int ignore_label, const float* work, const float* out, const float* dloss, float loss_weight,
+                        float* dsrc, void* stream) {
+    return ohem_ce_up_bwd_impl(src, N, Hs, Ws, H, W, target, ignore_label, work, out, dloss, loss_weight, dsrc, S(stream));
 }
 int ledn_ohem_ce_bwd(const float* logits, const long long* target, long long P, int C, int ignore_label,
                      const float* work, const float* out, const float* dloss, float loss_weight,

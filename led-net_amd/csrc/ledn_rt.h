@@ -194,6 +194,25 @@ __device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
 }
 #endif
 
+// F.interpolate(mode='bilinear', align_corners=False) source coordinates
+// (ATen area_pixel_compute_source_index: scale*(dst+0.5)-0.5 clamped at 0).
+struct Lerp {
+    int i0, i1;
+    float w0, w1;
+};
+__device__ __forceinline__ Lerp lerp_coord(int dst, int in, int out) {
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    Lerp l;
+    l.i0 = (int)src;
+    if (l.i0 > in - 1) l.i0 = in - 1;
+    l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
 // ---- XCD-aware block numbering ----------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  xcd_block() renumbers
 // them so that the workgroups resident on one XCD own ONE contiguous eighth of the logical block

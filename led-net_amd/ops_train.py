@@ -332,6 +332,42 @@ def ohem_ce_bwd(logits, target, work, out, dloss, loss_weight, ignore_label=255)
     return dl
 
 
+def ohem_ce_up_fwd(src, target, thres, min_kept, loss_weight, ignore_label=255):
+    """OHEM-CE on bilinear(src -> target's H x W) without materialising the resized logits.
+    src [N,Hs,Ws,2] f32, target [N,H,W] int64 -> (out[4], work)."""
+    lib = _lib.get_lib()
+    if src.dtype != torch.float32 or target.dtype != torch.int64 or src.dim() != 4 or src.shape[-1] != 2:
+        raise LednError('ohem_ce_up: src f32 [N,Hs,Ws,2] and int64 target required')
+    N, Hs, Ws, _ = src.shape
+    if target.dim() != 3 or target.shape[0] != N:
+        raise LednError('ohem_ce_up: target [N,H,W] required')
+    H, W = int(target.shape[1]), int(target.shape[2])
+    P = N * H * W
+    work = torch.empty(lib.cdll.ledn_ohem_work_floats(P), dtype=torch.float32, device=src.device)
+    out = torch.empty(4, dtype=torch.float32, device=src.device)
+    _check(lib, src, target, work, out)
+    _run(lib, 'ledn_ohem_ce_up_fwd', src, _p(src), N, Hs, Ws, H, W, _p(target), thres, int(min_kept), loss_weight,
+         ignore_label, _p(work), _p(out),
+         work=_ops._TIMING is not None and (f'ohem_up_fwd P{P}', _nb(src, target) + 5 * 8 * P, 40 * P))
+    return out, work
+
+
+def ohem_ce_up_bwd(src, target, work, out, dloss, loss_weight, ignore_label=255):
+    """-> dsrc [N,Hs,Ws,2]: the adjoint of the exact 2x resize applied to the loss gradient (never materialised)."""
+    lib = _lib.get_lib()
+    N, Hs, Ws, _ = src.shape
+    H, W = int(target.shape[1]), int(target.shape[2])
+    if H != 2 * Hs or W != 2 * Ws:
+        raise LednError('ohem_ce_up_bwd: exact 2x resize only')
+    dsrc = torch.empty_like(src)
+    dloss = dloss.reshape(1).to(torch.float32).contiguous()
+    _check(lib, src, target, work, out, dloss, dsrc)
+    _run(lib, 'ledn_ohem_ce_up_bwd', src, _p(src), N, Hs, Ws, H, W, _p(target), ignore_label, _p(work), _p(out),
+         _p(dloss), loss_weight, _p(dsrc),
+         work=_ops._TIMING is not None and (f'ohem_up_bwd P{N * H * W}', _nb(src, target, dsrc) + 4 * N * H * W, 30 * N * H * W))
+    return dsrc
+
+
 class SgdTable:
     """Device table of (param, grad, momentum) pointers for ledn_sgd_step."""
 

@@ -1106,12 +1106,16 @@ def led_head_forward_train(h, inputs):
     return xc, xs, h1, h2
 
 
-def fuse_loss(logit, h1, h2, hw):
-    """led_head.py:106-138: floor(size/4), floor(size/2), size; NHWC f32."""
+def fuse_loss_half(logit, h1, h2, hw):
+    """led_head.py:106-131: the fusion pyramid up to floor(size/2); NHWC f32."""
     H, W = hw
     r = BilinearFn.apply(logit, h2, (H // 4, W // 4), None)
-    r = BilinearFn.apply(r, h1, (H // 2, W // 2), None)
-    return BilinearFn.apply(r, None, (H, W), None)
+    return BilinearFn.apply(r, h1, (H // 2, W // 2), None)
+
+
+def fuse_loss(logit, h1, h2, hw):
+    """led_head.py:106-138: floor(size/4), floor(size/2), size; NHWC f32."""
+    return BilinearFn.apply(fuse_loss_half(logit, h1, h2, hw), None, tuple(hw), None)
 
 
 def ohem_loss(crit, score, target):
@@ -1121,6 +1125,28 @@ def ohem_loss(crit, score, target):
     loss, _ = OhemFn.apply(lg, target.contiguous(), crit.thresh, crit.min_kept, crit.loss_weight,
                            crit.ignore_label)
     return loss
+
+
+class OhemUpFn(Function):
+    """OhemCrossEntropy on resize(src -> label size) with the resize folded into the loss kernels (exact 2x)."""
+
+    @staticmethod
+    def forward(ctx, src, target, thres, min_kept, loss_weight, ignore_label):
+        out, work = T.ohem_ce_up_fwd(src, target, thres, min_kept, loss_weight, ignore_label)
+        ctx.save_for_backward(src, target, work, out)
+        ctx.cfg = (loss_weight, ignore_label)
+        ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
+        loss = out[0].clone()
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, dloss, _dout):
+        src, target, work, out = ctx.saved_tensors
+        return T.ohem_ce_up_bwd(src, target, work, out, dloss, ctx.cfg[0], ctx.cfg[1]), None, None, None, None, None
+
+
+FUSE_LOSS_RESIZE = int(_os.environ.get('LEDN_FUSE_LOSS_RESIZE', '1'))
 
 
 def led_head_loss_by_feat(h, seg_logits, batch_data_samples):
@@ -1136,9 +1162,17 @@ def led_head_loss_by_feat(h, seg_logits, batch_data_samples):
         label = torch.stack(labels, dim=0)
     hw = label.shape[2:]
     y = label.squeeze(1).contiguous()
+    c0, c1 = h.loss_decode[0], h.loss_decode[1]
+    H, W = hw
+    if FUSE_LOSS_RESIZE and H % 2 == 0 and W % 2 == 0 and xc.shape[-1] == 2:
+        # the last (exact 2x) resize of each fused output runs inside the loss kernels: the full-resolution logits
+        # and their gradient are never written
+        ctx2, spa2 = fuse_loss_half(xc, h1, h2, hw), fuse_loss_half(xs, h1, h2, hw)
+        l0, out0 = OhemUpFn.apply(ctx2, y, c0.thresh, c0.min_kept, c0.loss_weight, c0.ignore_label)
+        l1, _ = OhemUpFn.apply(spa2, y, c1.thresh, c1.min_kept, c1.loss_weight, c1.ignore_label)
+        return {'loss_context': l0, 'loss_spatial': l1, 'acc_seg': out0[1:2]}
     ctx = fuse_loss(xc, h1, h2, hw)
     spa = fuse_loss(xs, h1, h2, hw)
-    c0, c1 = h.loss_decode[0], h.loss_decode[1]
     l0, out0 = OhemFn.apply(ctx, y, c0.thresh, c0.min_kept, c0.loss_weight, c0.ignore_label)
     l1, _ = OhemFn.apply(spa, y, c1.thresh, c1.min_kept, c1.loss_weight, c1.ignore_label)
     return {'loss_context': l0, 'loss_spatial': l1, 'acc_seg': out0[1:2]}

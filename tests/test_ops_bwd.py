@@ -335,3 +335,37 @@ def test_two_stage_reductions_large(be):
     dxp, dwp = T.sesp_pyramid_bwd(nhwc(xp), nhwc(dyp), D(wpk), [1, 2, 3, 4], 1)
     close(nchw(dxp), xp.grad, 2e-3, 2e-4)
     close(dwp, torch.stack([w.grad[:, 0].permute(1, 2, 0) for w in wq]), 2e-3, 2e-2)
+
+
+@pytest.mark.parametrize('shape', [(2, 24, 40), (1, 33, 17), (2, 16, 16)])
+def test_ohem_with_folded_2x_resize_equals_resize_then_ohem(be, shape):
+    """ledn_ohem_ce_up_fwd / _bwd (LEDHead.loss_by_feat's last resize folded into the loss kernels, led_head.py:132-138)
+    against the unfused chain bilinear -> OhemCrossEntropy and its autograd adjoint: loss, accuracy, threshold, the
+    selection count and the gradient at the half-resolution logits; tiles with ragged edges, ignored labels."""
+    from led_net_amd import ops, ops_train as T
+    N, Hs, Ws = shape
+    H, W = 2 * Hs, 2 * Ws
+    g = torch.Generator().manual_seed(Hs * Ws)
+    src = (2.0 * torch.randn(N, Hs, Ws, 2, generator=g)).to(be.dev)
+    tgt = torch.randint(0, 2, (N, H, W), generator=g)
+    tgt[:, :3] = 255
+    tgt = tgt.to(be.dev)
+    kept = max(1, N * H * W // 5)
+    full = ops.bilinear(src, (H, W))
+    out_w, work_w = T.ohem_ce_fwd(full, tgt, 0.7, kept, 0.4)
+    out_g, work_g = T.ohem_ce_up_fwd(src, tgt, 0.7, kept, 0.4)
+    torch.testing.assert_close(out_g.cpu(), out_w.cpu(), rtol=1e-5, atol=1e-6)
+    dloss = torch.tensor([1.7], device=be.dev)
+    dfull = T.ohem_ce_bwd(full, tgt, work_w, out_w, dloss, 0.4)
+    want = T.bilinear_bwd(dfull, (Hs, Ws))
+    got = T.ohem_ce_up_bwd(src, tgt, work_g, out_g, dloss, 0.4)
+    torch.testing.assert_close(got.cpu(), want.cpu(), rtol=1e-4, atol=1e-7)
+    # and torch autograd through F.interpolate + the selected-pixel cross entropy
+    s = src.detach().cpu().clone().requires_grad_(True)
+    up = F.interpolate(s.permute(0, 3, 1, 2), size=(H, W), mode='bilinear', align_corners=False)
+    prob = torch.softmax(up, 1).gather(1, tgt.cpu().clamp(max=1).unsqueeze(1)).squeeze(1)
+    sel = (tgt.cpu() != 255) & (prob < float(out_w[2]))
+    ce = F.cross_entropy(up, tgt.cpu().clamp(max=1), reduction='none')
+    loss = 0.4 * (ce * sel).sum() / sel.sum()
+    (1.7 * loss).backward()
+    torch.testing.assert_close(got.cpu(), s.grad, rtol=2e-3, atol=2e-6)
