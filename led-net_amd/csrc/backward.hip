@@ -921,6 +921,57 @@ __global__ void __launch_bounds__(256) bilinear_bwd2x_kernel(const TY* dy, TX* d
     stv<V>(dx + pix * C + c, acc);
 }
 
+// Large upsampling ratios (the 1/64 -> 1/8 and 1/32 -> 1/8 context links: ~18 x 18 destinations per source pixel):
+// the thread-per-source-pixel search above is a serial chain of ~300 dependent candidate steps (119 us for
+// 16 x 16 x 16 x 128 <- 128 x 128).  Here a workgroup owns ONE source pixel: lane = (4-channel group, one of
+// 256 / (C/4) destination-row slots), the slots split the candidate rows, an LDS reduction adds them up.  Same
+// weights, candidates and per-row summation order as the search kernel.
+template <typename TY, typename TX>
+__global__ void __launch_bounds__(256) bilinear_bwd_wide_kernel(const TY* dy, TX* dx, int N, int H, int W, int C,
+                                                                int Ho, int Wo) {
+    constexpr int V = 4;
+    __shared__ float s_red[256 * V];
+    const int cv = C / V, slots = 256 / cv;
+    const int cg = threadIdx.x % cv, slot = threadIdx.x / cv, c = cg * V;
+    const long pix = blockIdx.x;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    int ylo, yhi, xlo, xhi;
+    dst_range(y, H, Ho, ylo, yhi);
+    dst_range(x, W, Wo, xlo, xhi);
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    if (slot < slots) {
+        for (int dyy = ylo + slot; dyy <= yhi; dyy += slots) {
+            const LerpB ly = lerp_coord_b(dyy, H, Ho);
+            const float wy = (ly.i0 == y ? ly.w0 : 0.f) + (ly.i1 == y ? ly.w1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int dxx = xlo; dxx <= xhi; ++dxx) {
+                const LerpB lx = lerp_coord_b(dxx, W, Wo);
+                const float wx = (lx.i0 == x ? lx.w0 : 0.f) + (lx.i1 == x ? lx.w1 : 0.f);
+                if (wx == 0.f) continue;
+                float g[V];
+                ldv<V>(dy + (((long)n * Ho + dyy) * Wo + dxx) * C + c, g);
+                const float wgt = wy * wx;
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[v] = fmaf(wgt, g[v], acc[v]);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) s_red[threadIdx.x * V + v] = acc[v];
+    __syncthreads();
+    if (threadIdx.x < cv) {
+        float t[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) t[v] = 0.f;
+        for (int sl = 0; sl < slots; ++sl)
+#pragma unroll
+            for (int v = 0; v < V; ++v) t[v] += s_red[(sl * cv + threadIdx.x) * V + v];
+        stv<V>(dx + pix * C + threadIdx.x * V, t);
+    }
+}
+
 int bilinear_bwd_impl(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int dtype_dy,
                       int dtype_dx, hipStream_t s) {
     LEDN_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0);
@@ -929,9 +980,13 @@ int bilinear_bwd_impl(const void* dy, void* dx, int N, int H, int W, int C, int 
     const long total = (long)N * H * W * (v4 ? C / 4 : (v2 ? C / 2 : C));
     const dim3 grid((unsigned)cdiv(total, 256));
     const bool x2 = Ho == 2 * H && Wo == 2 * W;
+    // >= 4x and few source pixels: one workgroup per source pixel (see bilinear_bwd_wide_kernel)
+    const bool wide = v4 && !x2 && Ho >= 4 * H && Wo >= 4 * W && C / 4 <= 256 && (long)N * H * W <= (1L << 20) &&
+                      (options().stream_fast & 2);
 #define LEDN_K(TY, TX)                                                                                          \
     do {                                                                                                        \
-        if (x2 && v4) LEDN_LAUNCH((bilinear_bwd2x_kernel<TY, TX, 4>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C); \
+        if (wide) LEDN_LAUNCH((bilinear_bwd_wide_kernel<TY, TX>), dim3((unsigned)((long)N * H * W)), dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C, Ho, Wo); \
+        else if (x2 && v4) LEDN_LAUNCH((bilinear_bwd2x_kernel<TY, TX, 4>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C); \
         else if (x2 && v2) LEDN_LAUNCH((bilinear_bwd2x_kernel<TY, TX, 2>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C); \
         else if (v4) LEDN_LAUNCH((bilinear_bwd_kernel<TY, TX, 4>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C, Ho, Wo); \
         else if (v2) LEDN_LAUNCH((bilinear_bwd_kernel<TY, TX, 2>), grid, dim3(256), 0, s, (const TY*)dy, (TX*)dx, N, H, W, C, Ho, Wo); \

@@ -369,3 +369,14 @@ def test_ohem_with_folded_2x_resize_equals_resize_then_ohem(be, shape):
     loss = 0.4 * (ce * sel).sum() / sel.sum()
     (1.7 * loss).backward()
     torch.testing.assert_close(got.cpu(), s.grad, rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize('src,dst,c', [((4, 4), (32, 32), 128), ((8, 6), (32, 24), 64), ((3, 5), (17, 29), 8)])
+def test_bilinear_bwd_large_ratio(be, src, dst, c):
+    """>= 4x upsampling adjoint: one workgroup per source pixel, destination rows split over lane slots"""
+    from led_net_amd import ops_train as T
+    x = torch.randn(2, c, *src, requires_grad=True)
+    y = F.interpolate(x, size=dst, mode='bilinear', align_corners=False)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    close(nchw(T.bilinear_bwd(nhwc(dy), src)), x.grad, 1e-4, 1e-5)
