@@ -380,3 +380,22 @@ def test_bilinear_bwd_large_ratio(be, src, dst, c):
     dy = torch.randn_like(y)
     y.backward(dy)
     close(nchw(T.bilinear_bwd(nhwc(dy), src)), x.grad, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize('dt_x,dt_z', [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16),
+                                       (torch.float32, torch.float32)])
+@pytest.mark.parametrize('k', [3, 1])
+def test_conv_wgrad_single_input_channel(be, dt_x, dt_z, k):
+    """1 -> 64 weight gradient (SEAM conv_2): thread = (pixel slot, 8 output channels) kernel; bias gradient"""
+    from led_net_amd import ops
+    g = torch.Generator().manual_seed(3 + k)
+    x = torch.randn(2, 1, 37, 41, generator=g).to(dt_x).float().requires_grad_(False)
+    w = torch.randn(64, 1, k, k, generator=g).requires_grad_(True)
+    b = torch.zeros(64, requires_grad=True)
+    y = F.conv2d(x, w, b, padding=k // 2)
+    dz = torch.randn(y.shape, generator=g).to(dt_z).float()
+    y.backward(dz)
+    dw, db = ops.conv2d_wgrad(nhwc(x).to(dt_x), nhwc(dz).to(dt_z), (64, 1, k, k), pad=k // 2, bias=True)
+    tol = 1e-4 if dt_z == torch.float32 and dt_x == torch.float32 else 2e-3
+    close(dw, w.grad, tol, tol * float(w.grad.abs().max()))
+    close(db, b.grad, tol, tol * float(b.grad.abs().max()))
