@@ -365,6 +365,148 @@ __global__ void __launch_bounds__(256) dw3x3_tile_kernel(ledn_dw_desc d, const b
     }
 }
 
+// GETB's 8x8 depthwise convolution (UNetFormer_GETB.py:118,201-204: reflect-extended by one row / column, zero
+// padding 3) with the input patch in LDS.  The generic kernel walks 8 rows x 8 taps of global loads per output as a
+// serial chain (134 us for 16 x 64 x 64 x 128: the exposed tail of the context branch on the auxiliary stream); the
+// arithmetic is ~10 us.  Workgroup = 8 x 32 outputs x 32 channels: (8+7) x (32+7) patch, 80-byte pixel rows (two-way
+// bank conflicts at most), the 64 x 32 filter values in LDS; lane = (8-channel group, 4 adjacent outputs, row): per
+// filter row the 11 pixels its four outputs share are read once and unpacked once (sliding window), the eight taps'
+// filter values come as two broadcast 16-byte reads each.  FLIP = 1: the data gradient with respect to the
+// reflect-EXTENDED map (flipped taps, padding 4); the fold of row H / column W into H-2 / W-2 is the caller's.
+template <int FLIP>
+__global__ void __launch_bounds__(256) dw8x8_tile_kernel(ledn_dw_desc d, float* part, int pad_lo) {
+    constexpr int TH = 8, TW = 32, K = 8, PH = TH + K - 1, PW = TW + K - 1, CW = 32, PXB = 80;
+    constexpr int NL = (PH * PW * 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char s_patch[PH * PW * PXB];
+    __shared__ __attribute__((aligned(16))) float s_w[K * K * CW];
+    float(*s_red)[64 * CW] = reinterpret_cast<float(*)[64 * CW]>(s_patch);     // statistics exchange: the patch is dead then
+    const int tid = threadIdx.x;
+    const int tx = (d.Wo + TW - 1) / TW, ty = (d.Ho + TH - 1) / TH, nch = d.C / CW;
+    const unsigned bid = xcd_block(blockIdx.x, gridDim.x);
+    const int ch = (int)(bid % (unsigned)nch);
+    const unsigned tile = bid / (unsigned)nch;
+    const int txi = (int)(tile % (unsigned)tx), tyi = (int)((tile / (unsigned)tx) % (unsigned)ty);
+    const int n = (int)(tile / (unsigned)(tx * ty));
+    const int y0 = tyi * TH - pad_lo, x0 = txi * TW - pad_lo;
+    const int Hx = d.H + (d.ext1 ? 1 : 0), Wx = d.W + (d.ext1 ? 1 : 0);
+    const bf16_t* xin = reinterpret_cast<const bf16_t*>(d.x) + (long)n * d.H * d.W * d.C + ch * CW;
+    {
+        uint4 stage[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256, px = e >> 2, q = e & 3;
+            int gy = y0 + px / PW, gx = x0 + px % PW;
+            const bool ok = e < PH * PW * 4 && gy >= 0 && gy < Hx && gx >= 0 && gx < Wx;
+            if (gy == d.H) gy = d.H - 2;                    // the reflected row / column (ext1)
+            if (gx == d.W) gx = d.W - 2;
+            stage[i] = ok ? *reinterpret_cast<const uint4*>(xin + ((long)gy * d.W + gx) * d.C + q * 8)
+                          : uint4{0u, 0u, 0u, 0u};
+        }
+        for (int i = tid; i < K * K * CW; i += 256) {
+            const int t = i / CW, cc = i % CW;
+            s_w[i] = d.w[(long)(FLIP ? K * K - 1 - t : t) * d.C + ch * CW + cc];
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256;
+            if (e < PH * PW * 4) *reinterpret_cast<uint4*>(s_patch + (long)(e >> 2) * PXB + (e & 3) * 16) = stage[i];
+        }
+    }
+    __syncthreads();
+    const int cg = tid & 3, xg = (tid >> 2) & 7, r = tid >> 5;
+    f32x2_t acc[4][4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[o][i] = f32x2_t{0.f, 0.f};
+#pragma unroll 1
+    for (int kh = 0; kh < K; ++kh) {
+        const unsigned char* row = s_patch + ((r + kh) * PW + 4 * xg) * PXB + cg * 16;
+        f32x2_t xr[11][4];
+#pragma unroll
+        for (int j = 0; j < 11; ++j) bf16x8_unpack(*reinterpret_cast<const uint4*>(row + j * PXB), xr[j]);
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            f32x2_t w[4];
+            f32x8_load(s_w + (kh * K + kw) * CW + cg * 8, w);
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[o][i] = pk_fma(xr[o + kw][i], w[i], acc[o][i]);
+        }
+    }
+    const int c = ch * CW + cg * 8;
+    f32x2_t sc[4], sh[4], ng[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = f32x2_t{1.f, 1.f};
+        sh[i] = f32x2_t{0.f, 0.f};
+        ng[i] = d.act_out == LEDN_ACT_NONE ? f32x2_t{1.f, 1.f} : f32x2_t{0.f, 0.f};
+    }
+    if (!FLIP) {
+        if (d.out_scale) f32x8_load(d.out_scale + c, sc);
+        if (d.out_shift) f32x8_load(d.out_shift + c, sh);
+        if (d.act_out == LEDN_ACT_PRELU) f32x8_load(d.slope + c, ng);
+    }
+    const float hi = (!FLIP && d.act_out == LEDN_ACT_RELU6) ? 6.f : 3.0e38f;
+    const bool has_act = !FLIP && d.act_out != LEDN_ACT_NONE;
+    f32x2_t st1[4], st2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st1[i] = st2[i] = f32x2_t{0.f, 0.f};
+    const int gy = tyi * TH + r;
+    bf16_t* y = reinterpret_cast<bf16_t*>(d.y) + (long)n * d.Ho * d.Wo * d.C + c;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int gx = txi * TW + 4 * xg + o;
+        if (gy >= d.Ho || gx >= d.Wo) continue;
+        if (!FLIP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[o][i] = pk_fma(acc[o][i], sc[i], sh[i]);
+                st1[i] += acc[o][i];
+                st2[i] = pk_fma(acc[o][i], acc[o][i], st2[i]);
+            }
+            if (has_act) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[o][i].x = fminf(fmaxf(acc[o][i].x, 0.f) + ng[i].x * fminf(acc[o][i].x, 0.f), hi);
+                    acc[o][i].y = fminf(fmaxf(acc[o][i].y, 0.f) + ng[i].y * fminf(acc[o][i].y, 0.f), hi);
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(y + ((long)gy * d.Wo + gx) * d.C) = bf16x8_pack(acc[o]);
+    }
+    if (FLIP || !part) return;
+    const int pl = tid >> 2;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s_red[0][pl * CW + cg * 8 + 2 * i] = st1[i].x;
+        s_red[0][pl * CW + cg * 8 + 2 * i + 1] = st1[i].y;
+        s_red[1][pl * CW + cg * 8 + 2 * i] = st2[i].x;
+        s_red[1][pl * CW + cg * 8 + 2 * i + 1] = st2[i].y;
+    }
+    __syncthreads();
+    if (tid < 2 * CW) {
+        const int j = tid / CW, cc = tid % CW;
+        float t0 = 0.f, t1 = 0.f;
+        for (int q = 0; q < 64; q += 2) {
+            t0 += s_red[j][q * CW + cc];
+            t1 += s_red[j][(q + 1) * CW + cc];
+        }
+        part[(long)tile * 2 * d.C + (long)j * d.C + ch * CW + cc] = t0 + t1;
+    }
+}
+
+static bool dw8x8_tile_ok(const ledn_dw_desc& d) {
+    if (!(options().stream_fast & 2)) return false;
+    if (d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16 || d.KH != 8 || d.KW != 8 || d.stride != 1 || d.pad != 3) return false;
+    if (d.C % 32 || d.Ho != d.H || d.Wo != d.W || !d.ext1 || d.act_out == LEDN_ACT_SIGMOID) return false;
+    for (int g = 0; g * d.group_size < d.C; ++g)
+        if (d.dil[g] != 1) return false;
+    return (long)d.N * d.H * d.W >= 4096 && (long)d.N * d.H * d.W * d.C < (1L << 31);
+}
+
 // launches the tiled kernel when it applies (returns the number of partial rows through *rows), else -1
 static int dw3x3_tile_launch(const ledn_dw_desc& d, bool flip, const bf16_t* add, bool want_stats, float** part_out,
                              long* rows_out, hipStream_t s) {
@@ -442,6 +584,16 @@ int dwconv_impl(const ledn_dw_desc& d, hipStream_t s) {
         const int pw = d.pad >= 0 ? d.pad : d.dil[g] * (d.KW - 1) / 2;
         LEDN_REQUIRE(d.Ho == (Hx + 2 * ph - ((d.KH - 1) * d.dil[g] + 1)) / d.stride + 1);
         LEDN_REQUIRE(d.Wo == (Wx + 2 * pw - ((d.KW - 1) * d.dil[g] + 1)) / d.stride + 1);
+    }
+    if (dw8x8_tile_ok(d)) {
+        const long tiles = (long)d.N * cdiv(d.Ho, 8) * cdiv(d.Wo, 32);
+        float* part = nullptr;
+        if (d.stat_sum) part = ws_take(tiles * 2 * d.C);
+        if (!d.stat_sum || part) {
+            LEDN_LAUNCH((dw8x8_tile_kernel<0>), dim3((unsigned)(tiles * (d.C / 32))), dim3(256), 0, s, d, part, 3);
+            if (part) return finish_partials(part, (int)tiles, d.C, 2, d.stat_sum, d.stat_sqsum, nullptr, s);
+            return check_launch();
+        }
     }
     if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_BF16 && d.act_out != LEDN_ACT_SIGMOID && d.Ho == d.H &&
         d.Wo == d.W &&

@@ -193,3 +193,24 @@ def test_pyramid_bwd_lds_tile_equal_dilations(be, shape):
     torch.testing.assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, rtol=2e-2, atol=6e-2)
     want_dw = torch.stack([w.grad[:, 0].permute(1, 2, 0) for w in ws])
     torch.testing.assert_close(dw.cpu(), want_dw, rtol=2e-2, atol=2e-2 * float(want_dw.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(1, 64, 64, 128), (2, 40, 70, 32), (1, 72, 60, 64)])
+def test_dw8x8_lds_tile_forward(be, shape):
+    """GETB's 8x8 depthwise conv on the reflect-extended map (UNetFormer_GETB.py:201-204) with the patch in LDS, against
+    torch (F.pad reflect (0,1,0,1) + conv2d padding 3): output and per-channel statistics; ragged tiles"""
+    import torch.nn.functional as F
+    from led_net_amd import ops
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(N, C, H, W, generator=g).to(torch.bfloat16).float()
+    w = 0.1 * torch.randn(C, 1, 8, 8, generator=g)
+    want = F.conv2d(F.pad(x, (0, 1, 0, 1), mode='reflect'), w, padding=3, groups=C).permute(0, 2, 3, 1)
+    st = (torch.zeros(C, device=be.dev), torch.zeros(C, device=be.dev))
+    xh = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(be.dev)
+    wk = w[:, 0].permute(1, 2, 0).contiguous().to(be.dev)
+    y = ops.dwconv2d(xh, wk, stride=1, pad=3, dil=(1, 1, 1, 1), group_size=C, ext1=True, stats=st)
+    assert tuple(y.shape) == (N, H, W, C)
+    torch.testing.assert_close(y.float().cpu(), want, rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(st[0].cpu(), want.sum((0, 1, 2)), rtol=5e-3, atol=3e-2 * (N * H * W) ** 0.5)
+    torch.testing.assert_close(st[1].cpu(), (want * want).sum((0, 1, 2)), rtol=5e-3, atol=1e-1)
