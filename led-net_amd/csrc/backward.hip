@@ -536,10 +536,14 @@ static int dwbwd_validate(const ledn_dwbwd_desc& d) {
 
 int dw3x3_bwd_data_bf16(const ledn_dwbwd_desc& b, hipStream_t s);   // dwconv.hip; -1 = shape not covered
 
+int dw8x8_bwd_data_tile(const ledn_dwbwd_desc& b, hipStream_t s);   // dwconv.hip; -1 = shape not covered
+
 int dw_bwd_data_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
     int rc = dwbwd_validate(d);
     if (rc != LEDN_OK) return rc;
     LEDN_REQUIRE(d.w && d.dx);
+    rc = dw8x8_bwd_data_tile(d, s);
+    if (rc >= 0) return rc;
     if (d.Ho == d.H && d.Wo == d.W) {
         rc = dw3x3_bwd_data_bf16(d, s);
         if (rc >= 0) return rc;

@@ -507,6 +507,70 @@ static bool dw8x8_tile_ok(const ledn_dw_desc& d) {
     return (long)d.N * d.H * d.W >= 4096 && (long)d.N * d.H * d.W * d.C < (1L << 31);
 }
 
+// data gradient of the same convolution: the tiled kernel with flipped taps (padding 4) yields the gradient of the
+// reflect-EXTENDED (H+1) x (W+1) map in workspace scratch; this pass folds the reflected row H / column W back
+// into row H-2 / column W-2 (the adjoint of F.pad(.., (0,1,0,1), 'reflect')) and adds the fan-in addend
+__global__ void __launch_bounds__(256) dw8x8_fold_kernel(const bf16_t* t, const bf16_t* add, bf16_t* dx, int N, int H,
+                                                         int W, int C) {
+    const int cv = C / 8;
+    const long total = (long)N * H * W * cv;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * 8;
+    const long pix = idx / cv;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    const int We = W + 1;
+    const bf16_t* tn = t + (long)n * (H + 1) * We * C + c;
+    float acc[8], v[8];
+    ld8(tn + ((long)y * We + x) * C, acc);
+    if (y == H - 2) {
+        ld8(tn + ((long)H * We + x) * C, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
+    if (x == W - 2) {
+        ld8(tn + ((long)y * We + W) * C, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += v[i];
+        if (y == H - 2) {
+            ld8(tn + ((long)H * We + W) * C, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
+        }
+    }
+    if (add) {
+        ld8(add + pix * C + c, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
+    st8(dx + pix * C + c, acc);
+}
+
+int dw8x8_bwd_data_tile(const ledn_dwbwd_desc& b, hipStream_t s) {   // used by backward.hip; -1 = shape not covered
+    if (!(options().stream_fast & 2) || b.dtype != LEDN_BF16 || b.KH != 8 || b.KW != 8 || b.stride != 1 || b.pad != 3 ||
+        !b.ext1 || b.C % 32 || b.Ho != b.H || b.Wo != b.W || b.H < 2 || b.W < 2)
+        return -1;
+    for (int g = 0; g * b.group_size < b.C; ++g)
+        if (b.dil[g] != 1) return -1;
+    const long npix = (long)b.N * b.H * b.W;
+    const long ext = (long)b.N * (b.H + 1) * (b.W + 1) * b.C;
+    if (npix < 4096 || ext >= (1L << 31)) return -1;
+    float* scratch = ws_take(cdiv(ext, 2));
+    if (!scratch) return -1;
+    ledn_dw_desc d = {};
+    d.x = b.dz; d.w = b.w; d.y = scratch;
+    d.N = b.N; d.H = b.H; d.W = b.W; d.C = b.C; d.Ho = b.H + 1; d.Wo = b.W + 1;
+    d.KH = d.KW = 8; d.stride = 1; d.pad = 3; d.group_size = b.group_size; d.ext1 = 0;
+    for (int i = 0; i < 4; ++i) d.dil[i] = 1;
+    d.dtype_x = d.dtype_y = LEDN_BF16;
+    const long tiles = (long)d.N * cdiv(d.Ho, 8) * cdiv(d.Wo, 32);
+    LEDN_LAUNCH((dw8x8_tile_kernel<1>), dim3((unsigned)(tiles * (d.C / 32))), dim3(256), 0, s, d, (float*)nullptr, 4);
+    LEDN_LAUNCH(dw8x8_fold_kernel, dim3((unsigned)cdiv(npix * (b.C / 8), 256)), dim3(256), 0, s,
+                reinterpret_cast<const bf16_t*>(scratch), reinterpret_cast<const bf16_t*>(b.add),
+                reinterpret_cast<bf16_t*>(b.dx), b.N, b.H, b.W, b.C);
+    return check_launch();
+}
+
 // launches the tiled kernel when it applies (returns the number of partial rows through *rows), else -1
 static int dw3x3_tile_launch(const ledn_dw_desc& d, bool flip, const bf16_t* add, bool want_stats, float** part_out,
                              long* rows_out, hipStream_t s) {

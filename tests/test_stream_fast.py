@@ -214,3 +214,25 @@ def test_dw8x8_lds_tile_forward(be, shape):
     torch.testing.assert_close(y.float().cpu(), want, rtol=2e-2, atol=3e-2)
     torch.testing.assert_close(st[0].cpu(), want.sum((0, 1, 2)), rtol=5e-3, atol=3e-2 * (N * H * W) ** 0.5)
     torch.testing.assert_close(st[1].cpu(), (want * want).sum((0, 1, 2)), rtol=5e-3, atol=1e-1)
+
+
+@pytest.mark.parametrize('shape', [(1, 64, 64, 128), (2, 40, 70, 32)])
+def test_dw8x8_lds_tile_data_gradient(be, shape):
+    """data gradient of GETB's 8x8 depthwise conv: tiled kernel with flipped taps on the extended map + the fold of the
+    reflected row / column (adjoint of the reflect pad), with a fan-in addend, against torch autograd"""
+    import torch.nn.functional as F
+    from led_net_amd import ops_train as T
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(H + W + C)
+    x = torch.randn(N, C, H, W, generator=g).to(torch.bfloat16).float().requires_grad_(True)
+    w = 0.1 * torch.randn(C, 1, 8, 8, generator=g)
+    y = F.conv2d(F.pad(x, (0, 1, 0, 1), mode='reflect'), w, padding=3, groups=C)
+    dz = torch.randn(y.shape, generator=g).to(torch.bfloat16).float()
+    y.backward(dz)
+    add = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16)
+    to = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(be.dev)     # noqa: E731
+    wk = w[:, 0].permute(1, 2, 0).contiguous().to(be.dev)
+    dx, _ = T.dwconv2d_bwd(to(x), to(dz), wk, stride=1, pad=3, dil=(1, 1, 1, 1), group_size=C, ext1=True,
+                           add=add.to(be.dev), need_dw=False)
+    want = x.grad.permute(0, 2, 3, 1) + add.float()
+    torch.testing.assert_close(dx.float().cpu(), want, rtol=2e-2, atol=5e-2)
