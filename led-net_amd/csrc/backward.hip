@@ -537,6 +537,7 @@ static int dwbwd_validate(const ledn_dwbwd_desc& d) {
 int dw3x3_bwd_data_bf16(const ledn_dwbwd_desc& b, hipStream_t s);   // dwconv.hip; -1 = shape not covered
 
 int dw8x8_bwd_data_tile(const ledn_dwbwd_desc& b, hipStream_t s);   // dwconv.hip; -1 = shape not covered
+int dw8x8_bwd_weight_tile(const ledn_dwbwd_desc& b, hipStream_t s);
 
 int dw_bwd_data_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
     int rc = dwbwd_validate(d);
@@ -574,6 +575,8 @@ int dw_bwd_weight_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
     if (rc != LEDN_OK) return rc;
     LEDN_REQUIRE(d.x && d.dw);
     rc = dw3x3_bwd_weight_bf16(d, s);
+    if (rc >= 0) return rc;
+    rc = dw8x8_bwd_weight_tile(d, s);
     if (rc >= 0) return rc;
     const bool v4 = d.C % 4 == 0 && d.group_size % 4 == 0;
     LEDN_REQUIRE((v4 ? d.C / 4 : d.C) <= 256);

@@ -571,6 +571,112 @@ int dw8x8_bwd_data_tile(const ledn_dwbwd_desc& b, hipStream_t s) {   // used by 
     return check_launch();
 }
 
+// weight gradient of the same convolution: dw[kh][kw][c] = sum_px xe[px + (kh, kw) - 3][c] * dz[px][c].  Workgroup =
+// 8 x 32 outputs x 32 channels (the forward tile): the (8+7) x (32+7) window of the reflect-extended input and the
+// dz tile sit in LDS; lane = (output row, 8-channel group, filter row kh): it walks the 32 pixels of its row and keeps
+// the 8 x 8 sums of its filter row in registers; the eight output rows are adjacent lanes (three shuffle steps), one
+// partial row [64 taps][C] per tile, finish_partials.  (The row-per-workgroup kernel: 132 us at 16 x 64 x 64 x 128.)
+__global__ void __launch_bounds__(256) dw8x8_wgrad_tile_kernel(ledn_dwbwd_desc d, float* part) {
+    constexpr int TH = 8, TW = 32, K = 8, PH = TH + K - 1, PW = TW + K - 1, CW = 32, PXB = 80;
+    constexpr int NL = (PH * PW * 4 + 255) / 256, NZ = (TH * TW * 4) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char s_patch[PH * PW * PXB];
+    __shared__ __attribute__((aligned(16))) unsigned char s_dz[TH * TW * 64];
+    const int tid = threadIdx.x;
+    const int tx = (d.Wo + TW - 1) / TW, ty = (d.Ho + TH - 1) / TH, nch = d.C / CW;
+    const unsigned bid = xcd_block(blockIdx.x, gridDim.x);
+    const int ch = (int)(bid % (unsigned)nch);
+    const unsigned tile = bid / (unsigned)nch;
+    const int txi = (int)(tile % (unsigned)tx), tyi = (int)((tile / (unsigned)tx) % (unsigned)ty);
+    const int n = (int)(tile / (unsigned)(tx * ty));
+    const int y0 = tyi * TH - 3, x0 = txi * TW - 3;
+    const int Hx = d.H + 1, Wx = d.W + 1;
+    const bf16_t* xin = reinterpret_cast<const bf16_t*>(d.x) + (long)n * d.H * d.W * d.C + ch * CW;
+    const bf16_t* zin = reinterpret_cast<const bf16_t*>(d.dz) + (long)n * d.Ho * d.Wo * d.C + ch * CW;
+    {
+        uint4 stage[NL], zs[NZ];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256, px = e >> 2, q = e & 3;
+            int gy = y0 + px / PW, gx = x0 + px % PW;
+            const bool ok = e < PH * PW * 4 && gy >= 0 && gy < Hx && gx >= 0 && gx < Wx;
+            if (gy == d.H) gy = d.H - 2;
+            if (gx == d.W) gx = d.W - 2;
+            stage[i] = ok ? *reinterpret_cast<const uint4*>(xin + ((long)gy * d.W + gx) * d.C + q * 8)
+                          : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const int e = tid + i * 256, px = e >> 2, q = e & 3;
+            const int gy = tyi * TH + px / TW, gx = txi * TW + px % TW;
+            const bool ok = gy < d.Ho && gx < d.Wo;
+            zs[i] = ok ? *reinterpret_cast<const uint4*>(zin + ((long)gy * d.Wo + gx) * d.C + q * 8) : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256;
+            if (e < PH * PW * 4) *reinterpret_cast<uint4*>(s_patch + (long)(e >> 2) * PXB + (e & 3) * 16) = stage[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) *reinterpret_cast<uint4*>(s_dz + (long)(tid + i * 256) * 16) = zs[i];
+    }
+    __syncthreads();
+    const int r = tid & 7, cg = (tid >> 3) & 3, kh = tid >> 5;
+    f32x2_t acc[K][4];
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[kw][i] = f32x2_t{0.f, 0.f};
+    const unsigned char* xrow = s_patch + ((r + kh) * PW) * PXB + cg * 16;
+    const unsigned char* zrow = s_dz + (r * TW) * 64 + cg * 16;
+#pragma unroll 2
+    for (int x = 0; x < TW; ++x) {
+        f32x2_t g[4];
+        bf16x8_unpack(*reinterpret_cast<const uint4*>(zrow + x * 64), g);
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            f32x2_t xv[4];
+            bf16x8_unpack(*reinterpret_cast<const uint4*>(xrow + (x + kw) * PXB), xv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[kw][i] = pk_fma(xv[i], g[i], acc[kw][i]);
+        }
+    }
+    // the eight output rows are lanes l, l^1, l^2, l^4
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float a = acc[kw][i].x, b = acc[kw][i].y;
+            a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
+            a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+            a += __shfl_xor(a, 4); b += __shfl_xor(b, 4);
+            acc[kw][i].x = a; acc[kw][i].y = b;
+        }
+    if (r == 0) {
+        float* row = part + (long)tile * (K * K) * d.C + ch * CW + cg * 8;
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            float* dst = row + (long)(kh * K + kw) * d.C;
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[kw][0].x, acc[kw][0].y, acc[kw][1].x, acc[kw][1].y);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[kw][2].x, acc[kw][2].y, acc[kw][3].x, acc[kw][3].y);
+        }
+    }
+}
+
+int dw8x8_bwd_weight_tile(const ledn_dwbwd_desc& b, hipStream_t s) {   // used by backward.hip; -1 = shape not covered
+    if (!(options().stream_fast & 2) || b.dtype != LEDN_BF16 || b.KH != 8 || b.KW != 8 || b.stride != 1 || b.pad != 3 ||
+        !b.ext1 || b.C % 32 || b.Ho != b.H || b.Wo != b.W || b.H < 2 || b.W < 2)
+        return -1;
+    for (int g = 0; g * b.group_size < b.C; ++g)
+        if (b.dil[g] != 1) return -1;
+    const long npix = (long)b.N * b.H * b.W;
+    if (npix < 4096 || npix * b.C >= (1L << 31)) return -1;
+    const long tiles = (long)b.N * cdiv(b.Ho, 8) * cdiv(b.Wo, 32);
+    float* part = ws_take(tiles * 64 * b.C);
+    if (!part) return -1;
+    LEDN_LAUNCH(dw8x8_wgrad_tile_kernel, dim3((unsigned)(tiles * (b.C / 32))), dim3(256), 0, s, b, part);
+    return finish_partials(part, (int)tiles, 64 * b.C, 1, b.dw, nullptr, nullptr, s);
+}
+
 // launches the tiled kernel when it applies (returns the number of partial rows through *rows), else -1
 static int dw3x3_tile_launch(const ledn_dw_desc& d, bool flip, const bf16_t* add, bool want_stats, float** part_out,
                              long* rows_out, hipStream_t s) {

@@ -236,3 +236,25 @@ def test_dw8x8_lds_tile_data_gradient(be, shape):
                            add=add.to(be.dev), need_dw=False)
     want = x.grad.permute(0, 2, 3, 1) + add.float()
     torch.testing.assert_close(dx.float().cpu(), want, rtol=2e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize('shape', [(1, 64, 64, 128), (2, 40, 70, 32)])
+def test_dw8x8_lds_tile_weight_gradient(be, shape):
+    """weight gradient of GETB's 8x8 depthwise conv (reflect-extended input, zero padding 3) from LDS tiles, against torch
+    autograd; accumulates into a pre-filled buffer (gradient-sink semantics)"""
+    import torch.nn.functional as F
+    from led_net_amd import ops_train as T
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(H * 3 + W + C)
+    x = torch.randn(N, C, H, W, generator=g).to(torch.bfloat16).float()
+    w = (0.1 * torch.randn(C, 1, 8, 8, generator=g)).requires_grad_(True)
+    y = F.conv2d(F.pad(x, (0, 1, 0, 1), mode='reflect'), w, padding=3, groups=C)
+    dz = torch.randn(y.shape, generator=g).to(torch.bfloat16).float()
+    y.backward(dz)
+    to = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(be.dev)     # noqa: E731
+    wk = w.detach()[:, 0].permute(1, 2, 0).contiguous().to(be.dev)
+    pre = torch.full((8, 8, C), 0.5, device=be.dev)
+    _, dw = T.dwconv2d_bwd(to(x), to(dz), wk, stride=1, pad=3, dil=(1, 1, 1, 1), group_size=C, ext1=True,
+                           need_dx=False, dw_out=pre)
+    want = w.grad[:, 0].permute(1, 2, 0) + 0.5
+    torch.testing.assert_close(dw.cpu(), want, rtol=2e-2, atol=2e-2 * float(want.abs().max()))
