@@ -299,25 +299,24 @@ __global__ void __launch_bounds__(256) relpos_bias_kernel(const float* table, co
     out[idx] = (r >= 0 && r < R) ? table[r * heads + h] : 0.f;
 }
 
+// scatter-add adjoint of the gather: one workgroup per head accumulates its T x T gradient values into an LDS copy of
+// the table column (LDS atomics: a few hundred distinct addresses) and adds the column to dtable -- one writer per
+// (entry, head), no global atomics.  (The first version ran one workgroup per table entry, each scanning the whole
+// index map once per head with a tree reduction: 61 us for 2 x 32 K values on the context branch's exposed tail.)
 __global__ void __launch_bounds__(256) relpos_bias_bwd_kernel(const float* dbias, const long long* index, float* dtable,
                                                               int R, int heads, int T) {
-    __shared__ float s_red[256];
-    const int r = blockIdx.x;
-    for (int h = 0; h < heads; ++h) {
-        float acc = 0.f;
-        for (int e = threadIdx.x; e < T * T; e += 256) {
-            const int i = e / T, j = e % T;
-            if (index[e] == r) acc += dbias[((long)h * T + j) * T + i];
-        }
-        s_red[threadIdx.x] = acc;
-        __syncthreads();
-        for (int st = 128; st >= 1; st >>= 1) {
-            if ((int)threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) dtable[(long)r * heads + h] += s_red[0];
-        __syncthreads();
+    constexpr int RMAX = 1024;
+    __shared__ float s_t[RMAX];
+    const int h = blockIdx.x;
+    for (int i = threadIdx.x; i < R; i += 256) s_t[i] = 0.f;
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * T; e += 256) {
+        const int i = e / T, j = e % T;
+        const long long r = index[e];
+        if (r >= 0 && r < R) atomicAdd(&s_t[r], dbias[((long)h * T + j) * T + i]);
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R; i += 256) dtable[(long)i * heads + h] += s_t[i];
 }
 
 int relpos_bias_impl(const float* table, const long long* index, float* out, int R, int heads, int T, hipStream_t s) {
@@ -329,8 +328,8 @@ int relpos_bias_impl(const float* table, const long long* index, float* out, int
 
 int relpos_bias_bwd_impl(const float* dbias, const long long* index, float* dtable, int R, int heads, int T,
                          hipStream_t s) {
-    LEDN_REQUIRE(dbias && index && dtable && R > 0 && heads > 0 && T > 0);
-    LEDN_LAUNCH(relpos_bias_bwd_kernel, dim3((unsigned)R), dim3(256), 0, s, dbias, index, dtable, R, heads, T);
+    LEDN_REQUIRE(dbias && index && dtable && R > 0 && R <= 1024 && heads > 0 && T > 0);
+    LEDN_LAUNCH(relpos_bias_bwd_kernel, dim3((unsigned)heads), dim3(256), 0, s, dbias, index, dtable, R, heads, T);
     return check_launch();
 }
 
