@@ -575,6 +575,58 @@ int ledn_ohem_ce_up_bwd(const float* src, int N, int Hs, int Ws, int H, int W, c
                         float* dsrc, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * The four pooled-context MLPs of Muti_AFF (classification/model_utils.py:377-400: AdaptiveAvgPool2d(S) ->
+ * Conv1x1(C->Ci)+bias -> BatchNorm -> ReLU -> Conv1x1(Ci->C)+bias -> [BatchNorm: in the gate kernel], S = 4, 8, 16, 1)
+ * as ONE launch sequence for all four scales: they are chains of tiny launch-bound kernels (~50 launches per
+ * Muti_AFF and train step through the per-layer entry points).  All tensors f32; pooled[k] / z2[k] / dz2[k] /
+ * dpooled[k] are [P_k][C], z1[k] / g[k] are [P_k][Ci], P_k = N*S_k*S_k; weights in PyTorch's OIHW order
+ * (w1 [Ci][C], w2 [C][Ci]).
+ *   ledn_mfaf_ctx_fwd: z1 = W1 pooled + b1 (saved); BatchNorm on batch statistics (training != 0: running
+ *     statistics updated, bn1[k] = [scale | shift | mean | invstd][Ci] saved) or on the running statistics;
+ *     z2 = W2 relu(bn(z1)) + b2.  stats1: [4][2][Ci] zeroed scratch.
+ *   ledn_mfaf_ctx_bwd: given dz2: dw2 / db2 / dgamma / dbeta / dw1 / db1 are ACCUMULATED (+=), dpooled written.
+ *     sums: [4][2][Ci] zeroed scratch; g: scratch. */
+typedef struct {
+    const float* pooled[4];
+    float* z1[4];
+    float* z2[4];
+    const float* w1[4];
+    const float* b1[4];        /* may be NULL */
+    const float* gamma[4];
+    const float* beta[4];
+    float* running_mean[4];    /* training: updated; inference: read */
+    float* running_var[4];
+    const float* w2[4];
+    const float* b2[4];        /* may be NULL */
+    float* bn1[4];             /* [4][Ci] */
+    float* stats1;
+    int P[4];
+    int C, Ci;
+    float momentum, eps;
+} ledn_mfafctx_desc;
+int ledn_mfaf_ctx_fwd(const ledn_mfafctx_desc* d, int training, void* stream);
+typedef struct {
+    const float* pooled[4];
+    const float* z1[4];
+    const float* dz2[4];
+    const float* w1[4];
+    const float* w2[4];
+    const float* bn1[4];
+    float* g[4];
+    float* dpooled[4];
+    float* dw1[4];
+    float* db1[4];             /* may be NULL */
+    float* dgamma[4];
+    float* dbeta[4];
+    float* dw2[4];
+    float* db2[4];             /* may be NULL */
+    float* sums;
+    int P[4];
+    int C, Ci;
+} ledn_mfafctx_bwd_desc;
+int ledn_mfaf_ctx_bwd(const ledn_mfafctx_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * SGD with momentum and weight decay over a table of tensors (torch.optim.SGD
  * semantics; config optimizer = dict(type='SGD', lr, momentum, weight_decay)):
  *   g' = grad_scale*g + wd*p;  m = momentum*m + g';  p -= lr*m;  g = 0.

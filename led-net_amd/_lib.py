@@ -59,6 +59,18 @@ class DwPackEntry(C.Structure):
     _fields_ = [('d', DwPackDesc), ('packed', fp), ('dpacked', fp)]
 
 
+class MfafCtxDesc(C.Structure):          # mirrors ledn_mfafctx_desc
+    _fields_ = [(n, vp * 4) for n in ('pooled', 'z1', 'z2', 'w1', 'b1', 'gamma', 'beta', 'running_mean', 'running_var',
+                                      'w2', 'b2', 'bn1')] + \
+               [('stats1', vp), ('P', i32 * 4), ('C', i32), ('Ci', i32), ('momentum', C.c_float), ('eps', C.c_float)]
+
+
+class MfafCtxBwdDesc(C.Structure):       # mirrors ledn_mfafctx_bwd_desc
+    _fields_ = [(n, vp * 4) for n in ('pooled', 'z1', 'dz2', 'w1', 'w2', 'bn1', 'g', 'dpooled', 'dw1', 'db1', 'dgamma',
+                                      'dbeta', 'dw2', 'db2')] + \
+               [('sums', vp), ('P', i32 * 4), ('C', i32), ('Ci', i32)]
+
+
 class AugEntry(C.Structure):          # mirrors ledn_aug_entry field for field
     _fields_ = [('img', vp), ('seg', vp), ('H', i32), ('W', i32), ('RH', i32), ('RW', i32),
                 ('sx', C.c_double), ('sy', C.c_double), ('oy', i32), ('ox', i32), ('ch', i32), ('cw', i32),
@@ -164,6 +176,8 @@ _PROTOS = {
     'ledn_iou_hist': ([vp, vp, i64, i32, i32, fp, vp], i32),
     'ledn_dw_pack': ([C.POINTER(DwPackDesc), fp, vp], i32),
     'ledn_dw_repack_multi': ([vp, i32, i32, i32, vp], i32),
+    'ledn_mfaf_ctx_fwd': ([C.POINTER(MfafCtxDesc), i32, vp], i32),
+    'ledn_mfaf_ctx_bwd': ([C.POINTER(MfafCtxBwdDesc), vp], i32),
     'ledn_augment_batch': ([vp, i32, vp, vp, i32, i32, i32, i32, vp], i32),
     'ledn_aug_crop_hist': ([vp, i32, i32, vp, vp], i32),
     'ledn_dw_unpack_grad': ([C.POINTER(DwPackDesc), fp, vp], i32),

@@ -31,6 +31,8 @@ int stem_conv_impl(const void* x, int dtype_x, const void* wp, void* y, int N, i
                    int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
                    float pad_val, const float* out_scale, const float* out_shift, int act_out, float* stat_sum,
                    float* stat_sqsum, hipStream_t s);
+int mfaf_ctx_fwd_impl(const ledn_mfafctx_desc& d, int training, hipStream_t s);
+int mfaf_ctx_bwd_impl(const ledn_mfafctx_bwd_desc& d, hipStream_t s);
 int dw_pack_impl(const ledn_dwpack_desc& d, float* packed, hipStream_t s);
 int dw_unpack_grad_impl(const ledn_dwpack_desc& d, const float* dpacked, hipStream_t s);
 int dw_repack_multi_impl(const ledn_dwpack_entry* table_dev, int n, int max_elems, int dir, hipStream_t s);
@@ -277,6 +279,12 @@ int ledn_stem_conv(const void* x, int dtype_x, const void* wp, void* y, int N, i
                    float* stat_sqsum, void* stream) {
     return stem_conv_impl(x, dtype_x, wp, y, N, H, W, C, Ho, Wo, Cout, in_scale, in_shift, map, valid_hw, pad_val,
                           out_scale, out_shift, act_out, stat_sum, stat_sqsum, S(stream));
+}
+int ledn_mfaf_ctx_fwd(const ledn_mfafctx_desc* d, int training, void* stream) {
+    return d ? mfaf_ctx_fwd_impl(*d, training, S(stream)) : LEDN_EINVAL;
+}
+int ledn_mfaf_ctx_bwd(const ledn_mfafctx_bwd_desc* d, void* stream) {
+    return d ? mfaf_ctx_bwd_impl(*d, S(stream)) : LEDN_EINVAL;
 }
 int ledn_dw_repack_multi(const ledn_dwpack_entry* table_dev, int n, int max_elems, int dir, void* stream) {
     return dw_repack_multi_impl(table_dev, n, max_elems, dir, S(stream));

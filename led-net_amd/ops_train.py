@@ -368,6 +368,81 @@ def ohem_ce_up_bwd(src, target, work, out, dloss, loss_weight, ignore_label=255)
     return dsrc
 
 
+def mfaf_ctx_fwd(pooled, seqs, training, stats1=None, momentum=0.1):
+    """The four pooled-context MLPs of Muti_AFF in one launch sequence (ledn_mfaf_ctx_fwd).
+    pooled: 4 f32 [N,S,S,C] maps; seqs: 4 x (conv1, bn1, conv2) modules.  -> (z2 list [N,S,S,C] f32, saved dict)"""
+    lib = _lib.get_lib()
+    d = _lib.MfafCtxDesc()
+    Cc = pooled[0].shape[-1]
+    Ci = seqs[0][0].out_channels
+    z1s, z2s, bn1s, keep = [], [], [], []
+    for k, (pz, (c1, bn, c2)) in enumerate(zip(pooled, seqs)):
+        if pz.dtype != torch.float32 or not pz.is_contiguous() or pz.shape[-1] != Cc:
+            raise LednError('mfaf_ctx: contiguous f32 [N,S,S,C] pooled maps required')
+        P = pz.numel() // Cc
+        z1 = torch.empty((P, Ci), dtype=torch.float32, device=pz.device)
+        z2 = torch.empty(pz.shape, dtype=torch.float32, device=pz.device)
+        bn1 = torch.empty((4, Ci), dtype=torch.float32, device=pz.device)
+        w1, w2 = _f32(c1.weight.detach()), _f32(c2.weight.detach())
+        b1 = _f32(c1.bias.detach()) if c1.bias is not None else None
+        b2 = _f32(c2.bias.detach()) if c2.bias is not None else None
+        _check(lib, pz, z1, z2, bn1, w1, w2, b1, b2, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        d.pooled[k], d.z1[k], d.z2[k], d.bn1[k] = _p(pz), _p(z1), _p(z2), _p(bn1)
+        d.w1[k], d.b1[k], d.w2[k], d.b2[k] = _p(w1), _p(b1), _p(w2), _p(b2)
+        d.gamma[k], d.beta[k] = _p(_f32(bn.weight.detach())), _p(_f32(bn.bias.detach()))
+        d.running_mean[k], d.running_var[k] = _p(bn.running_mean), _p(bn.running_var)
+        d.P[k] = P
+        z1s.append(z1); z2s.append(z2); bn1s.append(bn1); keep += [w1, w2, b1, b2]
+        eps, mom = bn.eps, (bn.momentum if bn.momentum is not None else momentum)
+    d.C, d.Ci, d.momentum, d.eps = Cc, Ci, float(mom), float(eps)
+    if training:
+        if stats1 is None:
+            stats1 = _ops.zeros_f32((4, 2, Ci), pooled[0].device)
+        d.stats1 = _p(stats1)
+    _run(lib, 'ledn_mfaf_ctx_fwd', pooled[0], C.byref(d), int(bool(training)),
+         work=_ops._TIMING is not None and ('mfaf_ctx_fwd', 0, 0, 'mfaf_ctx_fwd2_kernel'))
+    return z2s, dict(z1=z1s, bn1=bn1s)
+
+
+def mfaf_ctx_bwd(pooled, saved, dz2, seqs, sinks):
+    """-> (dpooled list, grads list of 4 x [dw1, db1, dgamma, dbeta, dw2, db2] -- None where a sink took it).
+    sinks: 4 x 6 f32 buffers (or None) the parameter gradients are accumulated into."""
+    lib = _lib.get_lib()
+    d = _lib.MfafCtxBwdDesc()
+    dev = pooled[0].device
+    Cc = pooled[0].shape[-1]
+    Ci = seqs[0][0].out_channels
+    sums = _ops.zeros_f32((4, 2, Ci), dev)
+    dps, grads, keep = [], [], []
+    for k, (pz, (c1, bn, c2)) in enumerate(zip(pooled, seqs)):
+        P = pz.numel() // Cc
+        g = torch.empty((P, Ci), dtype=torch.float32, device=dev)
+        dp = torch.empty_like(pz)
+        dz = dz2[k]
+        if dz.dtype != torch.float32 or not dz.is_contiguous() or dz.numel() != pz.numel():
+            raise LednError('mfaf_ctx_bwd: contiguous f32 dz2 of the pooled shape required')
+        outs = []
+        for j, prm in enumerate((c1.weight, c1.bias, bn.weight, bn.bias, c2.weight, c2.bias)):
+            if prm is None:
+                outs.append(None)
+                continue
+            sk = sinks[k][j] if sinks is not None else None
+            outs.append(sk if sk is not None else _ops.zeros_f32(tuple(prm.shape), dev))
+        w1, w2 = _f32(c1.weight.detach()), _f32(c2.weight.detach())
+        _check(lib, pz, dz, g, dp, w1, w2, saved['z1'][k], saved['bn1'][k], *[t for t in outs if t is not None])
+        d.pooled[k], d.z1[k], d.dz2[k], d.w1[k], d.w2[k] = _p(pz), _p(saved['z1'][k]), _p(dz), _p(w1), _p(w2)
+        d.bn1[k], d.g[k], d.dpooled[k] = _p(saved['bn1'][k]), _p(g), _p(dp)
+        d.dw1[k], d.db1[k], d.dgamma[k], d.dbeta[k], d.dw2[k], d.db2[k] = (_p(t) for t in outs)
+        d.P[k] = P
+        dps.append(dp)
+        grads.append([None if (sinks is not None and sinks[k][j] is not None) else outs[j] for j in range(6)])
+        keep += [g, w1, w2]
+    d.sums, d.C, d.Ci = _p(sums), Cc, Ci
+    _run(lib, 'ledn_mfaf_ctx_bwd', pooled[0], C.byref(d),
+         work=_ops._TIMING is not None and ('mfaf_ctx_bwd', 0, 0, 'mfaf_ctx_bwd1_kernel'))
+    return dps, grads
+
+
 class SgdTable:
     """Device table of (param, grad, momentum) pointers for ledn_sgd_step."""
 

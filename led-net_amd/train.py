@@ -961,6 +961,33 @@ SEAM_SLOT = int(_os.environ.get('LEDN_SEAM_SLOT', '0'))     # stream of the SEAM
 MFAF_FORK = int(_os.environ.get('LEDN_MFAF_FORK', '0'))   # measured: 785 vs 876 img/s with the forks in TRAINING (inference gains 4 %: blocks.MFAF)
 
 
+class MfafCtxFn(Function):
+    """The four pooled-context MLPs of Muti_AFF (conv1x1 + bias -> BatchNorm on batch statistics -> ReLU -> conv1x1 +
+    bias; the trailing BatchNorm belongs to the gate kernel) as one forward and one backward launch sequence
+    (ledn_mfaf_ctx_fwd / _bwd) instead of ~13 tiny launches per scale and step."""
+
+    @staticmethod
+    def forward(ctx, seqs, *args):
+        pooled, params = args[:4], args[4:]
+        z2s, saved = T.mfaf_ctx_fwd([_c(p) for p in pooled], seqs, True)
+        ctx.seqs, ctx.saved, ctx.pooled = seqs, saved, [_c(p) for p in pooled]
+        ctx.sinks = [[_Sinks.get(p) for p in (c1.weight, c1.bias, bn.weight, bn.bias, c2.weight, c2.bias)]
+                     for (c1, bn, c2) in seqs]
+        ctx.has = [p is not None for p in params]
+        return tuple(z2s)
+
+    @staticmethod
+    def backward(ctx, *dz2):
+        dps, grads = T.mfaf_ctx_bwd(ctx.pooled, ctx.saved, [_c(d) for d in dz2], ctx.seqs, ctx.sinks)
+        flat = []
+        for gk in grads:
+            flat += gk
+        return (None, *dps, *[g if h else None for g, h in zip(flat, ctx.has)])
+
+
+FUSE_MFAF_CTX = int(_os.environ.get('LEDN_FUSE_MFAF_CTX', '1'))
+
+
 def mfaf(m, x, r, out_relu=False, pre=None):
     """pre=(x alias for the gate, x alias for xa, acc): the caller already fanned x out (further consumers)"""
     if pre is not None:
@@ -995,7 +1022,17 @@ def mfaf(m, x, r, out_relu=False, pre=None):
         # the local branch: each runs on its own auxiliary stream while the local branch (full-resolution convs)
         # runs on the main one (forward here, backward through autograd's stream affinity)
         forks, ctx, bns_ctx = [], [], []
-        for idx, ((name, _), pz) in enumerate(zip(m.POOLS, pooled)):
+        seqs = [getattr(m, name) for name, _ in m.POOLS]
+        fused = (FUSE_MFAF_CTX and all(pz.dtype == torch.float32 and pz.shape[-1] == 64 for pz in pooled)
+                 and all(sq[1].out_channels == 16 and sq[4].out_channels == 64 for sq in seqs))
+        if fused:
+            triples = [(sq[1], sq[2], sq[4]) for sq in seqs]
+            params = []
+            for c1, bn, c2 in triples:
+                params += [c1.weight, c1.bias, bn.weight, bn.bias, c2.weight, c2.bias]
+            ctx = list(MfafCtxFn.apply(triples, *pooled, *params))
+            bns_ctx = [sq[5] for sq in seqs]
+        for idx, ((name, _), pz) in enumerate(zip(m.POOLS, pooled) if not fused else ()):
             f = ops.Fork(pz, 3 + idx if MFAF_FORK else 0)
             with f:
                 c, bn = mlp(getattr(m, name), 1, pz)

@@ -399,3 +399,53 @@ def test_conv_wgrad_single_input_channel(be, dt_x, dt_z, k):
     tol = 1e-4 if dt_z == torch.float32 and dt_x == torch.float32 else 2e-3
     close(dw, w.grad, tol, tol * float(w.grad.abs().max()))
     close(db, b.grad, tol, tol * float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_mfaf_context_mlps_fused(be, training):
+    """ledn_mfaf_ctx_fwd / _bwd: the four pooled-context MLPs of Muti_AFF (conv1x1 + bias -> BatchNorm -> ReLU ->
+    conv1x1 + bias at 4x4, 8x8, 16x16, 1x1) against torch modules: outputs, running statistics, every parameter
+    gradient and the gradient of the pooled maps; gradient sinks are accumulated into."""
+    from led_net_amd import ops_train as T
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(5)
+    N, Cc, Ci = 3, 64, 16
+    sizes = (4, 8, 16, 1)
+    seqs, ref = [], []
+    for S in sizes:
+        c1, bn, c2 = nn.Conv2d(Cc, Ci, 1), nn.BatchNorm2d(Ci), nn.Conv2d(Ci, Cc, 1)
+        with torch.no_grad():
+            bn.weight.copy_(0.5 + torch.rand(Ci, generator=g)); bn.bias.copy_(0.1 * torch.randn(Ci, generator=g))
+            bn.running_mean.copy_(0.1 * torch.randn(Ci, generator=g)); bn.running_var.copy_(0.5 + torch.rand(Ci, generator=g))
+        ref.append((c1, bn, c2))
+        import copy
+        seqs.append(tuple(copy.deepcopy(m).to(be.dev) for m in (c1, bn, c2)))
+    pooled = [torch.randn(N, S, S, Cc, generator=g) for S in sizes]
+    dz2 = [torch.randn(N, S, S, Cc, generator=g) for S in sizes]
+    for (c1, bn, c2) in ref:
+        for m in (c1, bn, c2):
+            m.train(training)
+    z2s, saved = T.mfaf_ctx_fwd([p.to(be.dev) for p in pooled], seqs, training)
+    want_z2, ins = [], []
+    for k, (c1, bn, c2) in enumerate(ref):
+        x = pooled[k].permute(0, 3, 1, 2).clone().requires_grad_(True)
+        y = c2(torch.relu(bn(c1(x))))
+        want_z2.append(y)
+        ins.append(x)
+        close(nchw(z2s[k]), y.detach(), 1e-4, 1e-4)
+        if training:
+            close(seqs[k][1].running_mean, bn.running_mean, 1e-5, 1e-6)
+            close(seqs[k][1].running_var, bn.running_var, 1e-5, 1e-6)
+    if not training:
+        return
+    sinks = [[torch.full(tuple(p.shape), 0.25, device=be.dev) if (j == 0 and p is not None) else None
+              for j, p in enumerate((c1.weight, c1.bias, bn.weight, bn.bias, c2.weight, c2.bias))] for (c1, bn, c2) in seqs]
+    dps, grads = T.mfaf_ctx_bwd([p.to(be.dev) for p in pooled], saved, [d.to(be.dev) for d in dz2], seqs, sinks)
+    for k, (c1, bn, c2) in enumerate(ref):
+        want_z2[k].backward(dz2[k].permute(0, 3, 1, 2))
+        close(nchw(dps[k]), ins[k].grad, 2e-4, 2e-5)
+        want = [c1.weight.grad, c1.bias.grad, bn.weight.grad, bn.bias.grad, c2.weight.grad, c2.bias.grad]
+        assert grads[k][0] is None                          # taken by the sink (pre-filled with 0.25)
+        close(sinks[k][0], want[0] + 0.25, 2e-4, 2e-4)
+        for j in range(1, 6):
+            close(grads[k][j], want[j], 2e-4, 2e-4 * max(1.0, float(want[j].abs().max())))
