@@ -371,6 +371,10 @@ def _aff_seq(c, inter, pool=None):
     return nn.Sequential(*layers)
 
 
+import os as _os
+FUSE_MFAF_CTX = int(_os.environ.get('LEDN_FUSE_MFAF_CTX', '1'))
+
+
 class MFAF(Block):
     """Muti_AFF, classification/model_utils.py:356-429."""
 
@@ -400,17 +404,29 @@ class MFAF(Block):
         # pooled-context chains (pool + two tiny convs each) on auxiliary streams, the local branch on the
         # main one (see train.mfaf)
         forks, ctx, affs_ctx = [], [], []
-        for idx, (name, S) in enumerate(self.POOLS):
-            f = ops.Fork(x, 3 + idx, r)
+        seqs = [getattr(self, name) for name, _ in self.POOLS]
+        if (FUSE_MFAF_CTX and x.shape[-1] == 64 and all(sq[1].out_channels == 16 and sq[4].out_channels == 64 for sq in seqs)):
+            # the four pooled-context MLPs (two tiny convs each, BatchNorm on the running statistics) in one launch
+            # sequence on ONE auxiliary stream (ledn_mfaf_ctx_fwd) instead of 8 launches on four streams
+            from . import ops_train as T
+            f = ops.Fork(x, 3, r)
             with f:
-                pooled = ops.adaptive_avgpool(x, S, xadd=r)
-                c, aff = self._mlp(getattr(self, name), 1, pooled)
-            forks.append((f, c))
-            ctx.append(c)
-            affs_ctx.append(aff)
+                pooled = [ops.adaptive_avgpool(x, S, xadd=r) for _, S in self.POOLS]
+                ctx, _ = T.mfaf_ctx_fwd(pooled, [(sq[1], sq[2], sq[4]) for sq in seqs], False)
+            affs_ctx = [self.cached(f'{id(sq)}b', lambda sq=sq: fold_bn(sq[5])) for sq in seqs]
+            forks = [(f, tuple(ctx))]
+        else:
+            for idx, (name, S) in enumerate(self.POOLS):
+                f = ops.Fork(x, 3 + idx, r)
+                with f:
+                    pooled = ops.adaptive_avgpool(x, S, xadd=r)
+                    c, aff = self._mlp(getattr(self, name), 1, pooled)
+                forks.append((f, c))
+                ctx.append(c)
+                affs_ctx.append(aff)
         xl, aff_l = self._mlp(self.local_att, 0, x, xadd=r)
         for f, c in forks:
-            f.join(c)
+            f.join(*(c if isinstance(c, tuple) else (c,)))
         affs = [aff_l] + affs_ctx
         return ops.mfaf_gate(x, r, xl, ctx, affs, act=ACT_RELU if out_relu else ACT_NONE)
 
