@@ -603,6 +603,14 @@ typedef struct {
     int P[4];
     int C, Ci;
     float momentum, eps;
+    /* optional (training, all or none): the TRAILING BatchNorm of each scale on batch statistics -- sums of z2 in
+     * stats2 ([4][2][C], zeroed), bn2[k] = [scale | shift | mean | invstd][C] written, running statistics updated */
+    const float* gamma2[4];
+    const float* beta2[4];
+    float* running_mean2[4];
+    float* running_var2[4];
+    float* bn2[4];
+    float* stats2;
 } ledn_mfafctx_desc;
 int ledn_mfaf_ctx_fwd(const ledn_mfafctx_desc* d, int training, void* stream);
 typedef struct {
@@ -623,6 +631,15 @@ typedef struct {
     float* sums;
     int P[4];
     int C, Ci;
+    /* optional (all or none): dz2[k] is then the gradient with respect to the trailing BatchNorm's OUTPUT; its
+     * backward runs first (z2, bn2 from the forward; sums2 [4][2][C] zeroed; dz2s[k]: scratch that receives the
+     * gradient with respect to z2; dgamma2 / dbeta2 accumulated) */
+    const float* z2[4];
+    const float* bn2[4];
+    float* dz2s[4];
+    float* dgamma2[4];
+    float* dbeta2[4];
+    float* sums2;
 } ledn_mfafctx_bwd_desc;
 int ledn_mfaf_ctx_bwd(const ledn_mfafctx_bwd_desc* d, void* stream);
 

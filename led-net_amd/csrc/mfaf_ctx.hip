@@ -95,10 +95,13 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd1_kernel(ledn_mfafctx_desc 
 __global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd2_kernel(ledn_mfafctx_desc d, int training) {
     __shared__ float s_w[MC_C * MC_CI];
     __shared__ float s_bn[2 * MC_CI];
+    __shared__ float s_st[2 * MC_C];
     const McBlock blk = mc_block(d.P);
     if (blk.s < 0) return;
     const int s = blk.s, tid = threadIdx.x;
+    const bool tail = training && d.stats2 != nullptr;
     for (int i = tid; i < MC_C * MC_CI; i += MC_PX) s_w[i] = d.w2[s][i];
+    if (tid < 2 * MC_C) s_st[tid] = 0.f;
     if (tid < MC_CI) {
         float mean, var;
         if (training) {
@@ -130,9 +133,10 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd2_kernel(ledn_mfafctx_desc 
     }
     __syncthreads();
     const int p = blk.p0 + tid;
-    if (p >= d.P[s]) return;
+    const bool ok = p < d.P[s];
+    if (!ok && !tail) return;
     float mid[MC_CI];
-    const float4* z4 = reinterpret_cast<const float4*>(d.z1[s] + (long)p * MC_CI);
+    const float4* z4 = reinterpret_cast<const float4*>(d.z1[s] + (long)(ok ? p : 0) * MC_CI);
 #pragma unroll
     for (int q = 0; q < MC_CI / 4; ++q) {
         const float4 v = z4[q];
@@ -153,8 +157,76 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd2_kernel(ledn_mfafctx_desc 
             for (int ci = 0; ci < MC_CI; ++ci) a = fmaf(mid[ci], s_w[co * MC_CI + ci], a);
             o[j] = a;
         }
-        o4[q] = make_float4(o[0], o[1], o[2], o[3]);
+        if (ok) o4[q] = make_float4(o[0], o[1], o[2], o[3]);
+        if (tail) {                       // sums of z2 for the trailing BatchNorm (whole waves take part)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = ok ? o[j] : 0.f;
+                const float a = mc_wave_sum(v), b = mc_wave_sum(v * v);
+                if ((tid & 63) == 0) {
+                    atomicAdd(&s_st[4 * q + j], a);
+                    atomicAdd(&s_st[MC_C + 4 * q + j], b);
+                }
+            }
+        }
     }
+    if (!tail) return;
+    __syncthreads();
+    if (tid < 2 * MC_C) atomicAdd(d.stats2 + s * 2 * MC_C + tid, s_st[tid]);
+}
+
+// ---- finalize of the trailing BatchNorms: one workgroup per scale, thread = channel ----------------------
+__global__ void __launch_bounds__(MC_C) mfaf_ctx_fin2_kernel(ledn_mfafctx_desc d) {
+    const int s = blockIdx.x, c = threadIdx.x;
+    const double cnt = (double)d.P[s];
+    const double m = (double)d.stats2[s * 2 * MC_C + c] / cnt;
+    double v = (double)d.stats2[s * 2 * MC_C + MC_C + c] / cnt - m * m;
+    if (v < 0.0) v = 0.0;
+    const float invstd = (float)(1.0 / sqrt(v + (double)d.eps));
+    const float sc = d.gamma2[s][c] * invstd;
+    d.bn2[s][c] = sc;
+    d.bn2[s][MC_C + c] = d.beta2[s][c] - (float)m * sc;
+    d.bn2[s][2 * MC_C + c] = (float)m;
+    d.bn2[s][3 * MC_C + c] = invstd;
+    const double unbiased = cnt > 1.0 ? v * cnt / (cnt - 1.0) : v;
+    d.running_mean2[s][c] = (1.f - d.momentum) * d.running_mean2[s][c] + d.momentum * (float)m;
+    d.running_var2[s][c] = (1.f - d.momentum) * d.running_var2[s][c] + d.momentum * (float)unbiased;
+}
+
+// ---- backward of the trailing BatchNorms, reduce half: sums of dy and dy * xhat2 per scale ---------------
+__global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwdT_kernel(ledn_mfafctx_bwd_desc d) {
+    __shared__ float s_bn[2 * MC_C];
+    __shared__ float s_st[2 * MC_C];
+    const McBlock blk = mc_block(d.P);
+    if (blk.s < 0) return;
+    const int s = blk.s, tid = threadIdx.x;
+    if (tid < 2 * MC_C) {
+        s_bn[tid] = d.bn2[s][2 * MC_C + tid];        // mean | invstd
+        s_st[tid] = 0.f;
+    }
+    __syncthreads();
+    const int p = blk.p0 + tid;
+    const bool ok = p < d.P[s];
+    const float4* dy4 = reinterpret_cast<const float4*>(d.dz2[s] + (long)(ok ? p : 0) * MC_C);
+    const float4* z4 = reinterpret_cast<const float4*>(d.z2[s] + (long)(ok ? p : 0) * MC_C);
+#pragma unroll 2
+    for (int q = 0; q < MC_C / 4; ++q) {
+        const float4 gv = dy4[q], zv = z4[q];
+        const float ga[4] = {gv.x, gv.y, gv.z, gv.w}, za[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * q + j;
+            const float g = ok ? ga[j] : 0.f;
+            const float xh = (za[j] - s_bn[c]) * s_bn[MC_C + c];
+            const float a = mc_wave_sum(g), b = mc_wave_sum(g * xh);
+            if ((tid & 63) == 0) {
+                atomicAdd(&s_st[c], a);
+                atomicAdd(&s_st[MC_C + c], b);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * MC_C) atomicAdd(d.sums2 + s * 2 * MC_C + tid, s_st[tid]);
 }
 
 // ---- backward 2: dmid = W2^T dz2, g = dmid * relu'(bn(z1)) (stored), per-scale sums of g and g * xhat ------
@@ -162,11 +234,26 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwd2_kernel(ledn_mfafctx_bwd_d
     __shared__ float s_w[MC_C * MC_CI];
     __shared__ float s_bn[4 * MC_CI];
     __shared__ float s_red[4][2 * MC_CI];
+    __shared__ float s_t[5 * MC_C];        // trailing BatchNorm: scale, mean, invstd, sum dy / n, sum dy xhat / n
     const McBlock blk = mc_block(d.P);
     if (blk.s < 0) return;
     const int s = blk.s, tid = threadIdx.x;
+    const bool tail = d.sums2 != nullptr;
     for (int i = tid; i < MC_C * MC_CI; i += MC_PX) s_w[i] = d.w2[s][i];
     if (tid < 4 * MC_CI) s_bn[tid] = d.bn1[s][tid];
+    if (tail && tid < MC_C) {
+        const float inv_n = 1.f / (float)d.P[s];
+        const float s1 = d.sums2[s * 2 * MC_C + tid], s2 = d.sums2[s * 2 * MC_C + MC_C + tid];
+        s_t[tid] = d.bn2[s][tid];
+        s_t[MC_C + tid] = d.bn2[s][2 * MC_C + tid];
+        s_t[2 * MC_C + tid] = d.bn2[s][3 * MC_C + tid];
+        s_t[3 * MC_C + tid] = s1 * inv_n;
+        s_t[4 * MC_C + tid] = s2 * inv_n;
+        if (blk.p0 == 0) {
+            atomicAdd(d.dbeta2[s] + tid, s1);
+            atomicAdd(d.dgamma2[s] + tid, s2);
+        }
+    }
     __syncthreads();
     const int p = blk.p0 + tid;
     const bool ok = p < d.P[s];
@@ -177,7 +264,20 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwd2_kernel(ledn_mfafctx_bwd_d
         const float4* dz4 = reinterpret_cast<const float4*>(d.dz2[s] + (long)p * MC_C);
 #pragma unroll 2
         for (int q = 0; q < MC_C / 4; ++q) {
-            const float4 v = dz4[q];
+            float4 v = dz4[q];
+            if (tail) {       // dz2 = scale2 * (dy - mean(dy) - xhat2 * mean(dy xhat2)), kept for the weight gradient
+                const float4 zv = reinterpret_cast<const float4*>(d.z2[s] + (long)p * MC_C)[q];
+                const float za[4] = {zv.x, zv.y, zv.z, zv.w};
+                float dv2[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * q + j;
+                    const float xh2 = (za[j] - s_t[MC_C + c]) * s_t[2 * MC_C + c];
+                    dv2[j] = s_t[c] * (dv2[j] - s_t[3 * MC_C + c] - xh2 * s_t[4 * MC_C + c]);
+                }
+                v = make_float4(dv2[0], dv2[1], dv2[2], dv2[3]);
+                reinterpret_cast<float4*>(d.dz2s[s] + (long)p * MC_C)[q] = v;
+            }
             const float dv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -278,7 +378,7 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_wgrad_kernel(ledn_mfafctx_bwd_
     if (blk.s < 0) return;
     const int s = blk.s, tid = threadIdx.x;
     if (MODE == 0 && tid < 2 * MC_CI) s_bn[tid] = d.bn1[s][tid];
-    const float* A = MODE == 0 ? d.dz2[s] : d.g[s];
+    const float* A = MODE == 0 ? (d.sums2 ? d.dz2s[s] : d.dz2[s]) : d.g[s];
     const float* B = MODE == 0 ? d.z1[s] : d.pooled[s];
     const int a = (tid * 4) / CB, b0 = (tid * 4) % CB;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb = 0.f;
@@ -328,9 +428,15 @@ int mfaf_ctx_fwd_impl(const ledn_mfafctx_desc& d, int training, hipStream_t s) {
         LEDN_REQUIRE(!training || d.bn1[k]);
     }
     LEDN_REQUIRE(!training || d.stats1);
+    if (d.stats2) {
+        LEDN_REQUIRE(training);
+        for (int k = 0; k < 4; ++k)
+            LEDN_REQUIRE(d.gamma2[k] && d.beta2[k] && d.running_mean2[k] && d.running_var2[k] && d.bn2[k]);
+    }
     const dim3 grid((unsigned)mc_blocks(d.P));
     LEDN_LAUNCH(mfaf_ctx_fwd1_kernel, grid, dim3(MC_PX), 0, s, d, training);
     LEDN_LAUNCH(mfaf_ctx_fwd2_kernel, grid, dim3(MC_PX), 0, s, d, training);
+    if (d.stats2) LEDN_LAUNCH(mfaf_ctx_fin2_kernel, dim3(4), dim3(MC_C), 0, s, d);
     return check_launch();
 }
 
@@ -343,6 +449,10 @@ int mfaf_ctx_bwd_impl(const ledn_mfafctx_bwd_desc& d, hipStream_t s) {
     }
     LEDN_REQUIRE(d.sums);
     const dim3 grid((unsigned)mc_blocks(d.P));
+    if (d.sums2) {
+        for (int k = 0; k < 4; ++k) LEDN_REQUIRE(d.z2[k] && d.bn2[k] && d.dz2s[k] && d.dgamma2[k] && d.dbeta2[k]);
+        LEDN_LAUNCH(mfaf_ctx_bwdT_kernel, grid, dim3(MC_PX), 0, s, d);
+    }
     LEDN_LAUNCH(mfaf_ctx_bwd2_kernel, grid, dim3(MC_PX), 0, s, d);
     LEDN_LAUNCH(mfaf_ctx_wgrad_kernel<0>, grid, dim3(MC_PX), 0, s, d);
     LEDN_LAUNCH(mfaf_ctx_bwd1_kernel, grid, dim3(MC_PX), 0, s, d);

@@ -368,9 +368,11 @@ def ohem_ce_up_bwd(src, target, work, out, dloss, loss_weight, ignore_label=255)
     return dsrc
 
 
-def mfaf_ctx_fwd(pooled, seqs, training, stats1=None, momentum=0.1):
+def mfaf_ctx_fwd(pooled, seqs, training, stats1=None, momentum=0.1, tails=None):
     """The four pooled-context MLPs of Muti_AFF in one launch sequence (ledn_mfaf_ctx_fwd).
-    pooled: 4 f32 [N,S,S,C] maps; seqs: 4 x (conv1, bn1, conv2) modules.  -> (z2 list [N,S,S,C] f32, saved dict)"""
+    pooled: 4 f32 [N,S,S,C] maps; seqs: 4 x (conv1, bn1, conv2) modules.  -> (z2 list [N,S,S,C] f32, saved dict)
+    tails (training): the 4 trailing BatchNorm modules -- their batch statistics are then formed here too:
+    saved['bn2'][k] = [scale | shift | mean | invstd][C], running statistics updated."""
     lib = _lib.get_lib()
     d = _lib.MfafCtxDesc()
     Cc = pooled[0].shape[-1]
@@ -395,18 +397,32 @@ def mfaf_ctx_fwd(pooled, seqs, training, stats1=None, momentum=0.1):
         z1s.append(z1); z2s.append(z2); bn1s.append(bn1); keep += [w1, w2, b1, b2]
         eps, mom = bn.eps, (bn.momentum if bn.momentum is not None else momentum)
     d.C, d.Ci, d.momentum, d.eps = Cc, Ci, float(mom), float(eps)
+    bn2s = None
     if training:
         if stats1 is None:
             stats1 = _ops.zeros_f32((4, 2, Ci), pooled[0].device)
         d.stats1 = _p(stats1)
+        if tails is not None:
+            bn2s = []
+            stats2 = _ops.zeros_f32((4, 2, Cc), pooled[0].device)
+            for k, bn in enumerate(tails):
+                bn2 = torch.empty((4, Cc), dtype=torch.float32, device=pooled[0].device)
+                _check(lib, bn2, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+                d.gamma2[k], d.beta2[k] = _p(_f32(bn.weight.detach())), _p(_f32(bn.bias.detach()))
+                d.running_mean2[k], d.running_var2[k], d.bn2[k] = _p(bn.running_mean), _p(bn.running_var), _p(bn2)
+                bn2s.append(bn2)
+            d.stats2 = _p(stats2)
+            keep.append(stats2)
     _run(lib, 'ledn_mfaf_ctx_fwd', pooled[0], C.byref(d), int(bool(training)),
          work=_ops._TIMING is not None and ('mfaf_ctx_fwd', 0, 0, 'mfaf_ctx_fwd2_kernel'))
-    return z2s, dict(z1=z1s, bn1=bn1s)
+    return z2s, dict(z1=z1s, bn1=bn1s, bn2=bn2s)
 
 
-def mfaf_ctx_bwd(pooled, saved, dz2, seqs, sinks):
-    """-> (dpooled list, grads list of 4 x [dw1, db1, dgamma, dbeta, dw2, db2] -- None where a sink took it).
-    sinks: 4 x 6 f32 buffers (or None) the parameter gradients are accumulated into."""
+def mfaf_ctx_bwd(pooled, saved, dz2, seqs, sinks, tails=None, sinks2=None):
+    """-> (dpooled list, grads list of 4 x [dw1, db1, dgamma, dbeta, dw2, db2 (, dgamma2, dbeta2)] -- None where a
+    sink took it).  sinks: 4 x 6 f32 buffers (or None) the parameter gradients are accumulated into.
+    tails: the forward ran the trailing BatchNorms too (saved['z2'] = its outputs, saved['bn2']) -- dz2 is then the
+    gradient with respect to THEIR output; sinks2: 4 x (dgamma2, dbeta2) sinks."""
     lib = _lib.get_lib()
     d = _lib.MfafCtxBwdDesc()
     dev = pooled[0].device
@@ -438,6 +454,21 @@ def mfaf_ctx_bwd(pooled, saved, dz2, seqs, sinks):
         grads.append([None if (sinks is not None and sinks[k][j] is not None) else outs[j] for j in range(6)])
         keep += [g, w1, w2]
     d.sums, d.C, d.Ci = _p(sums), Cc, Ci
+    if tails is not None:
+        sums2 = _ops.zeros_f32((4, 2, Cc), dev)
+        for k, bn in enumerate(tails):
+            scr = torch.empty_like(pooled[k])
+            outs2 = []
+            for j, prm in enumerate((bn.weight, bn.bias)):
+                sk = sinks2[k][j] if sinks2 is not None else None
+                outs2.append(sk if sk is not None else _ops.zeros_f32(tuple(prm.shape), dev))
+            _check(lib, saved['z2'][k], saved['bn2'][k], scr, *outs2)
+            d.z2[k], d.bn2[k], d.dz2s[k] = _p(saved['z2'][k]), _p(saved['bn2'][k]), _p(scr)
+            d.dgamma2[k], d.dbeta2[k] = _p(outs2[0]), _p(outs2[1])
+            grads[k] += [None if (sinks2 is not None and sinks2[k][j] is not None) else outs2[j] for j in range(2)]
+            keep += [scr]
+        d.sums2 = _p(sums2)
+        keep.append(sums2)
     _run(lib, 'ledn_mfaf_ctx_bwd', pooled[0], C.byref(d),
          work=_ops._TIMING is not None and ('mfaf_ctx_bwd', 0, 0, 'mfaf_ctx_bwd1_kernel'))
     return dps, grads

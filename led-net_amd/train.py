@@ -28,6 +28,7 @@ class _Env:
     world = 1
     head_acc = {}       # gradient fan-in accumulators (_Acc) of the stem tensors LEDHead reads: {'x1': .., 'x2': ..}
     grad_ready = None   # callable(tag) fired from the backward by GradReadyFn, or None
+    ctx_fin = {}        # z2.data_ptr() -> (scale, shift, mean, invstd) of its trailing BatchNorm (MfafCtxFn -> MfafTailFn)
 
 
 class _Collective:
@@ -706,6 +707,11 @@ class MfafTailFn(Function):
             for k, raw in enumerate(raws):
                 Cc = raw.shape[-1]
                 count = raw.numel() // Cc
+                given = _Env.ctx_fin.pop(raw.data_ptr(), None) if k else None
+                if given is not None:           # statistics + finalize already done by MfafCtxFn
+                    fin.append(given)
+                    counts.append(-count)       # (negative: the BatchNorm backward is MfafCtxFn's too)
+                    continue
                 stats = ops.zeros_f32((2, Cc), raw.device)
                 ops.channel_stats(raw, stats=(stats[0], stats[1]), defer_stats=True)
                 bn = bns[k]
@@ -730,12 +736,16 @@ class MfafTailFn(Function):
         affs = [(sv[4 * k], sv[4 * k + 1]) for k in range(5)]
         dx, dr, ds, dctx = T.mfaf_gate_bwd(x, r, xl, [c1, c2, c3, xg], affs, _c(dout), act=ctx.act)
         gys = [ds] + dctx
+        own = [k for k in range(5) if ctx.counts[k] > 0]
         outs = _bn_bwd_group([dict(z=raws[k], dy=gys[k], scale=sv[4 * k], shift=sv[4 * k + 1], mean=sv[4 * k + 2],
-                                   invstd=sv[4 * k + 3], count=ctx.counts[k], sinks=ctx.sinks[k]) for k in range(5)])
-        draws, dgb = [], []
-        for o in outs:
-            draws.append(o[0])
-            dgb += [o[2], o[3]]
+                                   invstd=sv[4 * k + 3], count=ctx.counts[k], sinks=ctx.sinks[k]) for k in own])
+        draws, dgb = [None] * 5, [None] * 10
+        for k, o in zip(own, outs):
+            draws[k] = o[0]
+            dgb[2 * k], dgb[2 * k + 1] = o[2], o[3]
+        for k in range(5):
+            if ctx.counts[k] < 0:               # MfafCtxFn runs this BatchNorm's backward: pass dy through
+                draws[k] = gys[k]
         for acc, g in zip(ctx.accs, (dx, dr)):       # first partial gradient of x / r (MfafFrontFn adds d xa onto it)
             if acc is not None:
                 acc.put(g, False)
@@ -963,29 +973,48 @@ MFAF_FORK = int(_os.environ.get('LEDN_MFAF_FORK', '0'))   # measured: 785 vs 876
 
 class MfafCtxFn(Function):
     """The four pooled-context MLPs of Muti_AFF (conv1x1 + bias -> BatchNorm on batch statistics -> ReLU -> conv1x1 +
-    bias; the trailing BatchNorm belongs to the gate kernel) as one forward and one backward launch sequence
-    (ledn_mfaf_ctx_fwd / _bwd) instead of ~13 tiny launches per scale and step."""
+    bias) AND the batch statistics / backward of their trailing BatchNorms as one forward and one backward launch
+    sequence (ledn_mfaf_ctx_fwd / _bwd) instead of ~18 tiny launches per scale and step.  The trailing BatchNorm's
+    affine pair travels to the gate kernel through _Env.ctx_fin; MfafTailFn hands back the gradient with respect to
+    the BatchNorm OUTPUT.  (Every tensor the backward needs goes through save_for_backward: holding the outputs on
+    ctx as attributes is a reference cycle, and its collection inside a graph capture crashed the capture.)"""
 
     @staticmethod
-    def forward(ctx, seqs, *args):
-        pooled, params = args[:4], args[4:]
-        z2s, saved = T.mfaf_ctx_fwd([_c(p) for p in pooled], seqs, True)
-        ctx.seqs, ctx.saved, ctx.pooled = seqs, saved, [_c(p) for p in pooled]
+    def forward(ctx, seqs, tails, *args):
+        pooled, params = [_c(p) for p in args[:4]], args[4:]
+        if not FUSE_MFAF_TAIL:
+            tails = None
+        z2s, saved = T.mfaf_ctx_fwd(pooled, seqs, True, tails=tails)
+        ctx.seqs, ctx.tails = seqs, tails
+        ctx.save_for_backward(*pooled, *saved['z1'], *saved['bn1'], *(saved['bn2'] or ()), *z2s)
         ctx.sinks = [[_Sinks.get(p) for p in (c1.weight, c1.bias, bn.weight, bn.bias, c2.weight, c2.bias)]
                      for (c1, bn, c2) in seqs]
+        ctx.sinks2 = [[_Sinks.get(bn.weight), _Sinks.get(bn.bias)] for bn in tails] if tails is not None else None
         ctx.has = [p is not None for p in params]
+        for z2, bn2 in zip(z2s, saved['bn2'] or ()):
+            _Env.ctx_fin[z2.data_ptr()] = (bn2[0], bn2[1], bn2[2], bn2[3])
         return tuple(z2s)
 
     @staticmethod
-    def backward(ctx, *dz2):
-        dps, grads = T.mfaf_ctx_bwd(ctx.pooled, ctx.saved, [_c(d) for d in dz2], ctx.seqs, ctx.sinks)
+    def backward(ctx, *dy):
+        sv = ctx.saved_tensors
+        pooled, z1, bn1 = list(sv[0:4]), list(sv[4:8]), list(sv[8:12])
+        if ctx.tails is not None:
+            saved = dict(z1=z1, bn1=bn1, bn2=list(sv[12:16]), z2=list(sv[16:20]))
+        else:
+            saved = dict(z1=z1, bn1=bn1)
+        dps, grads = T.mfaf_ctx_bwd(pooled, saved, [_c(d) for d in dy], ctx.seqs, ctx.sinks, tails=ctx.tails,
+                                    sinks2=ctx.sinks2)
         flat = []
         for gk in grads:
-            flat += gk
-        return (None, *dps, *[g if h else None for g, h in zip(flat, ctx.has)])
+            flat += gk[:6]
+        for gk in grads:
+            flat += gk[6:] if ctx.tails is not None else [None, None]
+        return (None, None, *dps, *[g if h else None for g, h in zip(flat, ctx.has)])
 
 
 FUSE_MFAF_CTX = int(_os.environ.get('LEDN_FUSE_MFAF_CTX', '1'))
+FUSE_MFAF_TAIL = int(_os.environ.get('LEDN_FUSE_MFAF_TAIL', '1'))   # ... and their trailing BatchNorms
 
 
 def mfaf(m, x, r, out_relu=False, pre=None):
@@ -1027,11 +1056,13 @@ def mfaf(m, x, r, out_relu=False, pre=None):
                  and all(sq[1].out_channels == 16 and sq[4].out_channels == 64 for sq in seqs))
         if fused:
             triples = [(sq[1], sq[2], sq[4]) for sq in seqs]
+            bns_ctx = [sq[5] for sq in seqs]
             params = []
             for c1, bn, c2 in triples:
                 params += [c1.weight, c1.bias, bn.weight, bn.bias, c2.weight, c2.bias]
-            ctx = list(MfafCtxFn.apply(triples, *pooled, *params))
-            bns_ctx = [sq[5] for sq in seqs]
+            for bn in bns_ctx:
+                params += [bn.weight, bn.bias]
+            ctx = list(MfafCtxFn.apply(triples, bns_ctx, *pooled, *params))
         for idx, ((name, _), pz) in enumerate(zip(m.POOLS, pooled) if not fused else ()):
             f = ops.Fork(pz, 3 + idx if MFAF_FORK else 0)
             with f:

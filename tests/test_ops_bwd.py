@@ -449,3 +449,47 @@ def test_mfaf_context_mlps_fused(be, training):
         close(sinks[k][0], want[0] + 0.25, 2e-4, 2e-4)
         for j in range(1, 6):
             close(grads[k][j], want[j], 2e-4, 2e-4 * max(1.0, float(want[j].abs().max())))
+
+
+def test_mfaf_context_mlps_fused_with_trailing_batchnorm(be):
+    """the same with the trailing BatchNorm of every scale folded in: its batch statistics (forward) and its
+    backward run inside the launch sequence; the caller hands in the gradient with respect to the BatchNorm OUTPUT"""
+    from led_net_amd import ops_train as T
+    import copy
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(8)
+    N, Cc, Ci = 2, 64, 16
+    sizes = (4, 8, 16, 1)
+    seqs, tails, ref = [], [], []
+    for S in sizes:
+        mods = [nn.Conv2d(Cc, Ci, 1), nn.BatchNorm2d(Ci), nn.Conv2d(Ci, Cc, 1), nn.BatchNorm2d(Cc)]
+        with torch.no_grad():
+            for bn in (mods[1], mods[3]):
+                bn.weight.copy_(0.5 + torch.rand(bn.num_features, generator=g))
+                bn.bias.copy_(0.1 * torch.randn(bn.num_features, generator=g))
+        ref.append(mods)
+        dev = [copy.deepcopy(m).to(be.dev) for m in mods]
+        seqs.append(tuple(dev[:3]))
+        tails.append(dev[3])
+    pooled = [torch.randn(N, S, S, Cc, generator=g) for S in sizes]
+    dy = [torch.randn(N, S, S, Cc, generator=g) for S in sizes]
+    z2s, saved = T.mfaf_ctx_fwd([p.to(be.dev) for p in pooled], seqs, True, tails=tails)
+    saved['z2'] = z2s
+    outs, ins = [], []
+    for k, (c1, bn, c2, bn2) in enumerate(ref):
+        x = pooled[k].permute(0, 3, 1, 2).clone().requires_grad_(True)
+        y = bn2(c2(torch.relu(bn(c1(x)))))
+        outs.append(y); ins.append(x)
+        sc, sh = saved['bn2'][k][0].cpu(), saved['bn2'][k][1].cpu()
+        # (the 1x1 scale normalises over N = 2 samples: 1 / std amplifies the f32 summation-order differences)
+        close(nchw(z2s[k].cpu() * sc + sh), y.detach(), *((2e-4, 2e-4) if sizes[k] > 1 else (2e-2, 2e-3)))
+        close(tails[k].running_var, bn2.running_var, 1e-5, 1e-6)
+    dps, grads = T.mfaf_ctx_bwd([p.to(be.dev) for p in pooled], saved, [d.to(be.dev) for d in dy], seqs, None, tails=tails)
+    for k, (c1, bn, c2, bn2) in enumerate(ref):
+        outs[k].backward(dy[k].permute(0, 3, 1, 2))
+        tol = 5e-4 if sizes[k] > 1 else 3e-2
+        close(nchw(dps[k]), ins[k].grad, tol, tol * max(0.1, float(ins[k].grad.abs().max())))
+        want = [c1.weight.grad, c1.bias.grad, bn.weight.grad, bn.bias.grad, c2.weight.grad, c2.bias.grad, bn2.weight.grad,
+                bn2.bias.grad]
+        for j in range(8):
+            close(grads[k][j], want[j], tol, tol * max(1.0, float(want[j].abs().max())))
