@@ -89,6 +89,8 @@ def main():
     if args.augment:
         import numpy as np
         from led_net_amd import transforms as T
+        if 'train_pipeline' not in cfg:
+            raise SystemExit(f'--augment: {args.config} defines no train_pipeline')
         pipe_cfg = [dict(c) for c in cfg['train_pipeline']]
         for c in pipe_cfg:                  # the CLI's crop size wins over the dataset config's
             if c['type'] == 'RandomCrop':
