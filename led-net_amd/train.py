@@ -966,6 +966,8 @@ def getb(m, x):
     return ActFn.apply(y, x1r, ACT_NONE, None, acc_x1)
 
 
+TEST_HOOKS = {}     # tests only: 'edge' -> a given SEAM edge map [N,h,w,1] f32 instead of the kernel's (freezes the
+                    # percentile binarisation for the deterministic whole-step gradient test)
 CTX_FORKS = int(_os.environ.get('LEDN_CTX_FORKS', '7'))    # bit s: context branch of stage 3+s on the aux stream
 SEAM_SLOT = int(_os.environ.get('LEDN_SEAM_SLOT', '0'))     # stream of the SEAM edge map: 0 = main (measured 895 vs 878 img/s on its own stream)
 MFAF_FORK = int(_os.environ.get('LEDN_MFAF_FORK', '0'))   # measured: 785 vs 876 img/s with the forks in TRAINING (inference gains 4 %: blocks.MFAF)
@@ -1112,6 +1114,8 @@ def lednet_forward_train(m, x, pre=None):
         # the binarised edge map is piecewise constant: no gradient (ddrnet_speed.py:290-338)
         seg = conv_module(m.seam.conv_1, y.detach(), out_dtype=torch.float32)
         edge = ops.seam_edge(seg, m.seam.percentile, m.seam.fixed_threshold, 0.1)
+        if TEST_HOOKS.get('edge') is not None:
+            edge = TEST_HOOKS['edge'].to(edge.device, edge.dtype).reshape(edge.shape)
     # stage 3
     with ops.Fork(y, 1 if CTX_FORKS & 1 else 0) as f3:
         x_c = cespb(m.layer3, y)
