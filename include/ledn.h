@@ -45,11 +45,13 @@ int ledn_set_workspace(void* ptr, long long nfloats);
 enum {
     LEDN_OPT_CONV_WORKGROUPS = 0,   /* persistent workgroups of the MFMA conv (default 512) */
     LEDN_OPT_WGRAD_WORKGROUPS = 1,  /* pixel-range workgroups of the MFMA weight gradient (default 512) */
-    LEDN_OPT_STREAM_FAST = 2        /* bit mask, default 11.  bit 0: 16-B-per-lane streaming kernels (csrc/stream_fast.hip) for
+    LEDN_OPT_STREAM_FAST = 2        /* bit mask, default 27.  bit 0: 16-B-per-lane streaming kernels (csrc/stream_fast.hip) for
                                        the bf16 elementwise / BatchNorm passes; bit 1: LDS-tiled depthwise 3x3
                                        (csrc/dwconv.hip); bit 2: MFMA conv tiles handed out round-robin instead of
                                        as contiguous ranges (off); bit 3: 8-row MFMA conv tiles when a launch has fewer
-                                       16-row tiles than workgroups; 0: the generic kernels (A/B measurements) */
+                                       16-row tiles than workgroups; bit 4: 1x1 stride-1 convolutions without input prologue /
+                                       output affine on the register-direct streaming kernel (csrc/conv1x1.hip);
+                                       0: the generic kernels (A/B measurements) */
 };
 int ledn_set_option(int option, long long value);
 
@@ -106,8 +108,9 @@ int ledn_conv2d_deferred_stats(const ledn_conv_desc* d, float** part, int* rows,
  * sum / sqsum outputs as usual). */
 int ledn_stats_defer_begin(void);
 int ledn_stats_defer_end(float** part, int* rows);
-/* Pure query, no launch: 1 if ledn_conv2d would run this descriptor on conv_mfma_kernel (matrix
- * cores), 0 if on conv_direct_kernel (VALU).  bench.py names the kernel in its roofline with it. */
+/* Pure query, no launch: 1 if ledn_conv2d would run this descriptor on conv_mfma_kernel, 2 if on
+ * conv1x1_mfma_kernel (both matrix cores), 0 if on conv_direct_kernel (VALU).  bench.py names the kernel in its
+ * roofline with it. */
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d);
 
 /* bf16 weight pack for the MFMA path, from the OIHW f32 master [Cout][Cin/groups][KH][KW]

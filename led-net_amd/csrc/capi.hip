@@ -7,6 +7,8 @@ int conv_validate(const ledn_conv_desc& d);
 int conv_direct(const ledn_conv_desc& d, hipStream_t s);
 bool conv_mfma_supported(const ledn_conv_desc& d);
 int conv_mfma(const ledn_conv_desc& d, hipStream_t s);
+bool conv1x1_reg_supported(const ledn_conv_desc& d);
+int conv1x1_reg(const ledn_conv_desc& d, hipStream_t s);
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d);
 bool conv_wgrad_cout2_supported(const ledn_wgrad_desc& d);
 int conv_wgrad_cout2(const ledn_wgrad_desc& d, hipStream_t s);
@@ -106,7 +108,7 @@ int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_
 namespace ledn {
 static Workspace g_ws = {nullptr, 0};
 Workspace& workspace() { return g_ws; }
-static Options g_opt = {512, 512, 11};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3, bit 2 round-robin conv tiles (off), bit 3 8-row conv tiles for under-filled grids
+static Options g_opt = {512, 512, 27};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3, bit 2 round-robin conv tiles (off), bit 3 8-row conv tiles for under-filled grids, bit 4 register-direct 1x1 conv (conv1x1.hip)
 Options& options() { return g_opt; }
 static DeferredStats g_defer = {false, nullptr, 0};
 DeferredStats& deferred_stats() { return g_defer; }
@@ -140,7 +142,10 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
     if (!d) return LEDN_EINVAL;
     const int rc = conv_validate(*d);
     if (rc != LEDN_OK) return rc;
-    if (conv_mfma_supported(*d)) return conv_mfma(*d, S(stream));
+    if (conv_mfma_supported(*d)) {
+        if (conv1x1_reg_supported(*d)) return conv1x1_reg(*d, S(stream));
+        return conv_mfma(*d, S(stream));
+    }
     return conv_direct(*d, S(stream));
 }
 
@@ -187,7 +192,10 @@ int ledn_bn_finalize_rows(const float* part, int rows, double count, const float
                                  shift, mean, invstd, sum, sqsum, C, S(stream));
 }
 
-int ledn_conv2d_uses_mfma(const ledn_conv_desc* d) { return d && conv_mfma_supported(*d) ? 1 : 0; }
+int ledn_conv2d_uses_mfma(const ledn_conv_desc* d) {
+    if (!d || !conv_mfma_supported(*d)) return 0;
+    return conv1x1_reg_supported(*d) ? 2 : 1;
+}
 int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d) {
     return d && !conv_wgrad_cout2_supported(*d) && wgrad_mfma_supported(*d) ? 1 : 0;
 }

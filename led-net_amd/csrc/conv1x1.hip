@@ -1,0 +1,355 @@
+// conv1x1.hip -- 1x1 stride-1 convolution (forward and data gradient) as a register-direct streaming GEMM on the
+// CDNA4 matrix cores (gfx950, v_mfma_f32_16x16x32_bf16).
+//
+// A 1x1 convolution over NHWC storage is a plain [pixels][Cin] x [Cin][Cout] product: no halo, every input row is
+// read once and every output row written once -- the kernel is bound by HBM, not by the matrix cores (64 -> 64:
+// 256 B per pixel against 8 KFLOP).  conv_mfma_kernel (conv_mfma.hip) runs such layers through its 3x3 machinery
+// (LDS patch, workgroup barriers, per-tile prologue chain of weights -> patch -> first product); here nothing goes
+// through LDS at all:
+//   * B operand = pixels.  Lane l of a wave owns pixel (l & 15) of a 16-pixel group and the 8 consecutive input
+//     channels 32 ks + 8 (l >> 4) .. + 7 of k-step ks: ONE 16-byte global load per fragment, straight into the MFMA
+//     register layout; a wave instruction covers 16 pixels x 64 contiguous bytes (whole rows when Cin = 32).
+//   * A operand = weights, resident in registers for the lifetime of the wave (64 x 64 bf16 = 32 VGPRs per lane;
+//     grouped convolutions keep only the 32 x 32 diagonal blocks that are not zero).
+//   * The output channels are PERMUTED inside the A fragments (a free row permutation of the weight matrix): row
+//     4q + i of M-tile mt is channel 32 (mt >> 1) + 8 q + 4 (mt & 1) + i, so that lane (pixel, q) ends up with the
+//     8 CONSECUTIVE channels 32 p + 8 q .. + 7 of its pixel in the accumulators of tiles 2p, 2p + 1: one 16-byte
+//     store per lane and pair, the four lanes of a pixel write its 64-byte row piece.  No LDS transposition.
+//   * Waves are autonomous: no barrier, no LDS in the main loop; each walks pixel-group pairs with a grid stride
+//     (neighbouring waves touch neighbouring memory) and fetches the fragments of its NEXT iteration before the matrix
+//     instructions of the current one, so ~3 waves per SIMD keep > 48 KB of loads in flight per CU.
+//   * Epilogue flavours: raw, raw + per-channel statistics (training forward: one partial row per workgroup, the
+//     deferred-rows protocol of finish_partials), raw + addend (gradient fan-in of the training backward); the bias is
+//     the accumulator's initial value.
+#include "ledn_rt.h"
+
+namespace ledn {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+#ifdef LEDN_CPU_EMU
+__device__ __forceinline__ f32x4_t mfma_16x16x32_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return emu::mfma_16x16x32_bf16(a, b, c);
+}
+#else
+// v_mfma_f32_16x16x32_bf16: lane l holds A[l&15][8(l>>4)+j], B[8(l>>4)+j][l&15]; D: col = l&15, row = 4(l>>4)+reg
+__device__ __forceinline__ f32x4_t mfma_16x16x32_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hw_bf16x8_t, a),
+                                                   __builtin_bit_cast(hw_bf16x8_t, b), c, 0, 0, 0);
+}
+#endif
+
+struct C11Args {
+    const bf16_t* x;       // [P][Cin]
+    const bf16_t* wp;      // [Cout][Cin] bf16 (ledn_pack_conv_weights, either mode: rows = this kernel's outputs)
+    bf16_t* y;             // [P][Cout]
+    const bf16_t* res;     // optional addend [P][Cout] (EPI_ACC)
+    const float* bias;     // optional [Cout]
+    float* part;           // statistics: per-workgroup rows [gridDim.x][2][Cout], or NULL -> atomics
+    float* stat_sum;
+    float* stat_sqsum;
+    long P;
+    long iters;            // ceil(P / (16 G))
+    int Cin, Cout;
+};
+
+constexpr int C11_RAW = 0, C11_STATS = 1, C11_ACC = 2;
+
+template <int V> struct c11_int { static constexpr int value = V; };
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void c11_for(F&& f) {
+    if constexpr (I < N) {
+        f(c11_int<I>{});
+        c11_for<N, I + 1>(f);
+    }
+}
+
+// channel of row 4q + i of M-tile mt (see the header): pairs of tiles interleave in blocks of four
+template <int NMT>
+__device__ __forceinline__ int c11_channel(int mt, int q, int i) {
+    if ((mt | 1) < NMT) return 32 * (mt >> 1) + 8 * q + 4 * (mt & 1) + i;
+    return 16 * mt + 4 * q + i;                    // unpaired last tile (Cout % 32 == 16): natural order
+}
+
+// sum over the 16 lanes that share (lane >> 4) of V per-lane values (V = 4, 8 or 16): every lane ends up with the
+// total of ONE value, index c11_red_index<V>(lane); V - 1 + (4 - log2 V) * ... shuffles instead of 4 V
+template <int V>
+__device__ __forceinline__ float c11_reduce16(const float* v, int lane) {
+    static_assert(V == 4 || V == 8 || V == 16, "");
+    float r8[8], r4[4], r2[2], r;
+    if constexpr (V == 16) {
+        const bool b = lane & 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r8[j] = (b ? v[8 + j] : v[j]) + __shfl_xor(b ? v[j] : v[8 + j], 8);
+    } else if constexpr (V == 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r8[j] = v[j] + __shfl_xor(v[j], 8);
+    }
+    if constexpr (V >= 8) {
+        const bool b = lane & 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r4[j] = (b ? r8[4 + j] : r8[j]) + __shfl_xor(b ? r8[j] : r8[4 + j], 4);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = v[j] + __shfl_xor(v[j], 8);
+            r4[j] = t + __shfl_xor(t, 4);
+        }
+    }
+    {
+        const bool b = lane & 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) r2[j] = (b ? r4[2 + j] : r4[j]) + __shfl_xor(b ? r4[j] : r4[2 + j], 2);
+    }
+    {
+        const bool b = lane & 1;
+        r = (b ? r2[1] : r2[0]) + __shfl_xor(b ? r2[0] : r2[1], 1);
+    }
+    return r;
+}
+template <int V>
+__device__ __forceinline__ int c11_red_index(int lane) {
+    int idx = ((lane >> 1) & 1) * 2 + (lane & 1);
+    if (V >= 8) idx += ((lane >> 2) & 1) * 4;
+    if (V == 16) idx += ((lane >> 3) & 1) * 8;
+    return idx;
+}
+
+// NKS: k-steps of 32 input channels; NMT: M-tiles of 16 output channels; DIAG: only the 32 x 32 diagonal blocks of
+// the weight matrix are non-zero (grouped convolution, Cin == Cout); G: 16-pixel groups per iteration
+template <int NKS, int NMT, bool DIAG, int G, int EPI, int OCC>
+__global__ void __launch_bounds__(256, OCC) conv1x1_mfma_kernel(C11Args a) {
+    constexpr int NP = (NMT + 1) / 2;                        // 32-channel pairs of M-tiles (the last may be half)
+    constexpr int NWF = DIAG ? NMT : NMT * NKS;              // resident weight fragments
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int pl = lane & 15, q = lane >> 4;
+    const int Cin = a.Cin, Cout = a.Cout;
+
+    // ---- weight fragments: A[row r = lane & 15][k = 8 (lane >> 4) + j] of (mt, ks) = W[channel(mt, r)][32 ks + 8 q + j]
+    bf16x8_t wf[NWF];
+#pragma unroll
+    for (int f = 0; f < NWF; ++f) {
+        const int mt = DIAG ? f : f / NKS, ks = DIAG ? (f >> 1) : f % NKS;
+        const int co = c11_channel<NMT>(mt, pl >> 2, pl & 3);
+        const int ci = 32 * ks + 8 * q;
+        const bool ok = ci < Cin && co < Cout;
+        uint4 v = *reinterpret_cast<const uint4*>(a.wp + (ok ? (long)co * Cin + ci : 0L));
+        if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+        wf[f] = __builtin_bit_cast(bf16x8_t, v);
+    }
+    // ---- bias = initial accumulator (rows 4q + i of tile mt)
+    float binit[NMT][4];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c11_channel<NMT>(mt, q, i);
+            binit[mt][i] = (a.bias && c < Cout) ? a.bias[c] : 0.f;
+        }
+    constexpr int NST = EPI == C11_STATS ? NMT * 4 : 1;
+    float st1[NST], st2[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
+
+    const long nwaves = (long)gridDim.x * 4;
+    long it = (long)blockIdx.x * 4 + wid;
+    const bool kok[2] = {true, true};
+    (void)kok;
+
+    // fragments of one iteration: G groups x NKS k-steps (one 16-byte load each; out-of-range pieces read the tensor
+    // base and are zeroed)
+    auto fetch = [&](long iter, bf16x8_t (&bf)[G][NKS]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const long pix = (iter * G + g) * 16 + pl;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int ci = 32 * ks + 8 * q;
+                const bool ok = pix < a.P && ci < Cin;
+                uint4 v = *reinterpret_cast<const uint4*>(a.x + (ok ? pix * Cin + ci : 0L));
+                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                bf[g][ks] = __builtin_bit_cast(bf16x8_t, v);
+            }
+        }
+    };
+
+    bf16x8_t bcur[G][NKS], bnext[G][NKS];
+    if (it < a.iters) fetch(it, bcur);
+    while (it < a.iters) {
+        const long nit = it + nwaves;
+        if (nit < a.iters) fetch(nit, bnext);
+        // addend pieces of this iteration (EPI_ACC): in flight during the matrix instructions
+        uint4 radd[G][NP];
+        if constexpr (EPI == C11_ACC) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const long pix = (it * G + g) * 16 + pl;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const bool ok = pix < a.P && 32 * p + 8 * q < Cout;
+                    radd[g][p] = *reinterpret_cast<const uint4*>(a.res + (ok ? pix * Cout + 32 * p + 8 * q : 0L));
+                }
+            }
+        }
+        sched_fence();
+        f32x4_t acc[G][NMT];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[g][mt][i] = binit[mt][i];
+#pragma unroll
+        for (int f = 0; f < NWF; ++f) {
+            const int mt = DIAG ? f : f / NKS, ks = DIAG ? (f >> 1) : f % NKS;
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g][mt] = mfma_16x16x32_bf16(wf[f], bcur[g][ks], acc[g][mt]);
+        }
+        // ---- epilogue: lane (pixel pl, q) holds channels 32 p + 8 q .. + 7 in acc[2p], acc[2p + 1]
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const long pix = (it * G + g) * 16 + pl;
+            const bool pok = pix < a.P;
+            if constexpr (EPI == C11_STATS) {
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = pok ? acc[g][mt][i] : 0.f;
+                        st1[mt * 4 + i] += v;
+                        st2[mt * 4 + i] = fmaf(v, v, st2[mt * 4 + i]);
+                    }
+            }
+            c11_for<NP>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                if constexpr (2 * p + 1 < NMT) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = acc[g][2 * p][i];
+                        v[4 + i] = acc[g][2 * p + 1][i];
+                    }
+                    if constexpr (EPI == C11_ACC) {
+                        float r[8];
+                        ld8(reinterpret_cast<const bf16_t*>(&radd[g][p]), r);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = bf16_to_f32(f32_to_bf16(v[i])) + r[i];   // as conv_mfma: bf16(z) + addend
+                    }
+                    if (pok && 32 * p + 8 * q < Cout) st8(a.y + pix * Cout + 32 * p + 8 * q, v);
+                } else {                                     // unpaired tile: channels 16 mt + 4 q .. + 3, 8-byte store
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[g][2 * p][i];
+                    const int c = 32 * p + 4 * q;
+                    if constexpr (EPI == C11_ACC) {
+                        float r[4];
+                        if (pok) {
+                            ld4(a.res + pix * Cout + c, r);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = bf16_to_f32(f32_to_bf16(v[i])) + r[i];
+                        }
+                    }
+                    if (pok) st4(a.y + pix * Cout + c, v);
+                }
+            });
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) bcur[g][ks] = bnext[g][ks];
+        it = nit;
+    }
+
+    if constexpr (EPI == C11_STATS) {
+        // per-wave totals -> LDS -> one row per workgroup.  16 values per reduction call (4 M-tiles); lanes with equal
+        // (lane >> 4) hold the same channels of different pixels.
+        __shared__ float s_st[4][2][NMT * 16];
+        constexpr int CH = NMT >= 4 ? 16 : NMT * 4;          // values per reduction call
+#pragma unroll
+        for (int c0 = 0; c0 < NMT * 4; c0 += CH) {
+            const float t1 = c11_reduce16<CH>(st1 + c0, lane), t2 = c11_reduce16<CH>(st2 + c0, lane);
+            const int vi = c0 + c11_red_index<CH>(lane);     // value index = mt * 4 + i
+            const int ch = c11_channel<NMT>(vi >> 2, q, vi & 3);
+            if ((lane & 15) < CH) {                          // (with CH < 16 the other lanes hold copies of the same totals)
+                s_st[wid][0][ch] = t1;
+                s_st[wid][1][ch] = t2;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * Cout; i += 256) {
+            const int j = i / Cout, c = i % Cout;
+            const float t = s_st[0][j][c] + s_st[1][j][c] + s_st[2][j][c] + s_st[3][j][c];
+            if (a.part) a.part[(long)blockIdx.x * 2 * Cout + (long)j * Cout + c] = t;
+            else atomicAdd((j ? a.stat_sqsum : a.stat_sum) + c, t);
+        }
+    }
+}
+
+template <int NKS, int NMT, bool DIAG, int EPI>
+static int c11_launch(C11Args a, hipStream_t s) {
+    constexpr int G = NMT >= 8 ? 1 : 2;
+    constexpr int OCC = (EPI == C11_STATS || NMT * NKS > 8) ? 2 : 3;       // waves per SIMD the register budget allows
+    a.iters = cdiv(a.P, 16 * G);
+    long nb = cdiv(a.iters, 4);
+    const long cap = (long)options().conv_workgroups * OCC;                  // default 512 x OCC: two rounds of resident workgroups
+    if (nb > cap) nb = cap;
+    a.part = (EPI == C11_STATS && a.stat_sum && nb > 16) ? ws_take(nb * 2 * a.Cout) : nullptr;
+    LEDN_LAUNCH((conv1x1_mfma_kernel<NKS, NMT, DIAG, G, EPI, OCC>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    if (a.part) return finish_partials(a.part, (int)nb, a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
+    return check_launch();
+}
+
+template <int NKS, int NMT, bool DIAG>
+static int c11_epi(const C11Args& a, int epi, hipStream_t s) {
+    switch (epi) {
+        case C11_STATS: return c11_launch<NKS, NMT, DIAG, C11_STATS>(a, s);
+        case C11_ACC: return c11_launch<NKS, NMT, DIAG, C11_ACC>(a, s);
+        default: return c11_launch<NKS, NMT, DIAG, C11_RAW>(a, s);
+    }
+}
+
+static bool c11_diag(const ledn_conv_desc& d) {
+    if (d.groups <= 1 || d.Cin != d.Cout) return false;
+    const int cg = d.Cin / d.groups;
+    return cg <= 32 && 32 % cg == 0 && d.Cin % 32 == 0;    // every group lies inside one 32 x 32 diagonal block
+}
+
+// shapes the register-resident weight fragments fit (<= 16 fragments = 64 VGPRs)
+bool conv1x1_reg_supported(const ledn_conv_desc& d) {
+    if (!(options().stream_fast & 16)) return false;
+    if (!d.w_bf16 || d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16) return false;
+    if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.pad != 0 || d.dil != 1 || d.xadd) return false;
+    if (d.in_scale || d.in_shift || d.in_act != LEDN_ACT_NONE) return false;
+    if (d.out_scale || d.act_out != LEDN_ACT_NONE) return false;
+    if (d.res_mode != LEDN_RES_NONE && !(d.res_mode == LEDN_RES_ADD && d.res && !d.stat_sum && !d.out_shift)) return false;
+    if (d.Cin % 16 || d.Cout % 16 || d.Cin > 128 || d.Cout > 128) return false;
+    const int nks = (d.Cin + 31) / 32, nmt = d.Cout / 16;
+    if (!(nks == 1 || nks == 2 || nks == 4) || !(nmt == 1 || nmt == 2 || nmt == 4 || nmt == 8)) return false;
+    const int nwf = c11_diag(d) ? nmt : nmt * nks;
+    return nwf <= 16;
+}
+
+int conv1x1_reg(const ledn_conv_desc& d, hipStream_t s) {
+    C11Args a;
+    a.x = (const bf16_t*)d.x; a.wp = (const bf16_t*)d.w_bf16; a.y = (bf16_t*)d.y;
+    a.res = d.res_mode == LEDN_RES_ADD ? (const bf16_t*)d.res : nullptr;
+    a.bias = d.out_shift; a.part = nullptr; a.stat_sum = d.stat_sum; a.stat_sqsum = d.stat_sqsum;
+    a.P = (long)d.N * d.H * d.W; a.iters = 0; a.Cin = d.Cin; a.Cout = d.Cout;
+    const int epi = a.res ? C11_ACC : (d.stat_sum ? C11_STATS : C11_RAW);
+    const int nks = (d.Cin + 31) / 32, nmt = d.Cout / 16;
+    const bool diag = c11_diag(d);
+#define LEDN_C11(NKS_, NMT_)                                                     \
+    if (nks == NKS_ && nmt == NMT_) {                                            \
+        if constexpr (NKS_ * 2 == NMT_) {                                        \
+            if (diag) return c11_epi<NKS_, NMT_, true>(a, epi, s);               \
+        }                                                                        \
+        if constexpr (NKS_ * NMT_ <= 16) return c11_epi<NKS_, NMT_, false>(a, epi, s); \
+    }
+    LEDN_C11(1, 1) LEDN_C11(1, 2) LEDN_C11(1, 4) LEDN_C11(1, 8)
+    LEDN_C11(2, 1) LEDN_C11(2, 2) LEDN_C11(2, 4) LEDN_C11(2, 8)
+    LEDN_C11(4, 1) LEDN_C11(4, 2) LEDN_C11(4, 4) LEDN_C11(4, 8)
+#undef LEDN_C11
+    return LEDN_EINVAL;
+}
+
+}  // namespace ledn

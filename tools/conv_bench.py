@@ -36,6 +36,12 @@ SHAPES = [
     ('dgrad', 64, 64, 1, 1, 4, 16, 128, 128),
     ('wgrad', 64, 64, 1, 1, 4, 16, 128, 128),
     ('fwd', 64, 16, 1, 1, 4, 16, 128, 128),
+    ('dgrad', 64, 16, 1, 1, 4, 16, 128, 128),
+    ('fwd', 16, 64, 1, 1, 1, 16, 128, 128),
+    ('fwd', 128, 128, 1, 1, 4, 16, 128, 128),
+    ('dgrad', 128, 128, 1, 1, 4, 16, 128, 128),
+    ('fwd', 128, 64, 1, 1, 1, 16, 64, 64),
+    ('fwd', 128, 32, 1, 1, 1, 16, 64, 64),
     ('fwd', 128, 64, 3, 1, 1, 16, 128, 128),
     ('fwd', 128, 512, 1, 1, 1, 16, 64, 64),
     ('fwd', 512, 128, 1, 1, 1, 16, 64, 64),
@@ -51,6 +57,8 @@ def main():
     ap.add_argument('--conv-wgs', type=int, default=0, help='LEDN_OPT_CONV_WORKGROUPS (0 = default)')
     ap.add_argument('--wgrad-wgs', type=int, default=0, help='LEDN_OPT_WGRAD_WORKGROUPS (0 = default)')
     ap.add_argument('--only', default='', help='substring filter on the kind (fwd/dgrad/wgrad)')
+    ap.add_argument('--k', type=int, default=0, help='only this kernel size')
+    ap.add_argument('--ab', default='', help='comma list of LEDN_OPT_STREAM_FAST values to time each shape under')
     args = ap.parse_args()
     from led_net_amd import _lib
     _lib.get_lib().set_option(0, args.conv_wgs)
@@ -58,7 +66,7 @@ def main():
     dev = torch.device('cuda:0')
     g = torch.Generator(device='cpu').manual_seed(1)
     for kind, ci, co, k, s, grp, N, H, W in SHAPES:
-        if args.only and args.only not in kind:
+        if (args.only and args.only not in kind) or (args.k and args.k != k):
             continue
         pad = k // 2
         Ho, Wo = ops.conv_out_size(H, k, s, pad, 1), ops.conv_out_size(W, k, s, pad, 1)
@@ -77,19 +85,24 @@ def main():
         else:
             fn = lambda: ops.conv2d_wgrad(x, dz, tuple(w.shape), stride=s, pad=pad, groups=grp)
             nbytes = x.numel() * 2 + dz.numel() * 2
-        for _ in range(3):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(args.iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / args.iters
         flops = 2.0 * N * Ho * Wo * co * (ci // grp) * k * k
-        print(f'{kind:5s} {k}x{k} {ci:3d}->{co:3d} g{grp} s{s} {N}x{H}x{W}: {us:8.1f} us  '
-              f'{nbytes / us * 1e-3:7.0f} GB/s  {flops / us * 1e-6:6.1f} TFLOP/s', flush=True)
+        line = f'{kind:5s} {k}x{k} {ci:3d}->{co:3d} g{grp} s{s} {N}x{H}x{W}:'
+        for opt in ([int(v) for v in args.ab.split(',')] if args.ab else [None]):
+            if opt is not None:
+                _lib.get_lib().set_option(2, opt)
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            line += (f' [{opt}]' if opt is not None else '') + (f'{us:8.1f} us  {nbytes / us * 1e-3:7.0f} GB/s  '
+                                                                  f'{flops / us * 1e-6:6.1f} TFLOP/s')
+        print(line, flush=True)
 
 
 if __name__ == '__main__':
