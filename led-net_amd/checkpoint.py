@@ -38,15 +38,24 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False):
 
 
 def save_checkpoint(model, filename, meta=None, trainer=None):
-    """mmengine layout: {'meta': ..., 'state_dict': cpu tensors} and, with a Trainer, what mmengine's
-    CheckpointHook adds for --resume: 'optimizer' (torch.optim.SGD.state_dict(): the momentum buffers, indexed
-    by position in model.parameters()) and 'param_schedulers' (the PolyLR position)."""
+    """mmengine layout: {'meta': ..., 'state_dict': cpu tensors} and, with a Trainer, the keys mmengine's
+    CheckpointHook adds and Runner.resume reads: 'optimizer' (torch.optim.SGD.state_dict(): the momentum buffers,
+    indexed by position in model.parameters()), 'param_schedulers' (the PolyLR position), 'message_hub'
+    (runtime_info iter / epoch / max_iters) and meta['epoch' | 'iter' | 'seed' | 'experiment_name'].  The layout is
+    restated from mmengine's documented checkpoint format (mmengine is not installed here: no file written by
+    the reference stack pins it)."""
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ckpt = {'meta': dict(meta or {}), 'state_dict': sd}
+    ckpt['meta'].setdefault('epoch', 0)
     if trainer is not None:
         ckpt['optimizer'] = trainer.optimizer_state_dict()
         ckpt['param_schedulers'] = [trainer.scheduler_state_dict()]
         ckpt['meta'].setdefault('iter', trainer.iter)
+        ckpt['meta'].setdefault('seed', 304)
+        ckpt['meta'].setdefault('experiment_name', 'led_net_amd')
+        ckpt['message_hub'] = {'log_scalars': {}, 'resumed_keys': {'epoch': True, 'iter': True, 'max_iters': True},
+                               'runtime_info': {'epoch': 0, 'iter': int(ckpt['meta']['iter']),
+                                                'max_iters': int(trainer.max_iters), 'max_epochs': 1}}
     torch.save(ckpt, filename)
 
 

@@ -136,6 +136,11 @@ class EncoderDecoder(nn.Module):
         dp.pop('type', None)
         self.data_preprocessor = SegDataPreProcessor(**dp)
         self.bgr_to_rgb = self.data_preprocessor.channel_conversion
+        # Trainer.capture(): a resident int32 [N, 2] buffer of the per-image valid extents.  While set, _pre hands THIS
+        # buffer to the stem kernel (and never builds one on the fly): the captured hipGraph reads the extents of the
+        # batch being replayed, which Trainer.replay() writes here -- not the frozen extents of the capture batch.
+        self._valid_static = None
+        self._valid_for_ptr = None          # address of the Trainer's static input batch the buffer belongs to
 
     # the normalisation constants handed to the stem's input kernel (kept under their first-round names)
     @property
@@ -164,6 +169,10 @@ class EncoderDecoder(nn.Module):
 
     def _pre(self, inputs, data_samples=None):
         """RAW uint8 batches (and padded RAW float batches) are normalised by the stem's input kernel."""
+        if (self._valid_static is not None and inputs.data_ptr() == self._valid_for_ptr
+                and self.pre_scale is not None and inputs.dtype == torch.uint8):
+            assert self._valid_static.shape[0] == inputs.shape[0]
+            return (self.pre_scale, self.pre_shift, self.pre_map, self._valid_static, float(self.data_preprocessor.pad_val))
         padded = data_samples is not None and any(any(self._padding(ds)) for ds in data_samples)
         if inputs.dtype != torch.uint8 and not padded:
             return None                  # already normalised float input (the first-round / test contract)
@@ -171,15 +180,21 @@ class EncoderDecoder(nn.Module):
             raise ValueError('uint8 input needs data_preprocessor mean/std')
         if not padded:
             return (self.pre_scale, self.pre_shift, self.pre_map)
-        H, W = inputs.shape[2:]
+        valid = self.valid_extents(inputs.shape[2:], data_samples).to(inputs.device)
+        return (self.pre_scale, self.pre_shift, self.pre_map, valid, float(self.data_preprocessor.pad_val))
+
+    def valid_extents(self, hw, data_samples, n=None):
+        """int32 [N, 2] (host): rows / columns of each image that hold data (the rest is batch padding)"""
+        H, W = hw
         valid = []
-        for ds in data_samples:
+        for ds in (data_samples or []):
             left, right, top, bottom = self._padding(ds)
             if left or top:
                 raise NotImplementedError('stack_batch pads right/bottom only (misc.py:83,87)')
             valid.append((H - bottom, W - right))
-        valid = torch.tensor(valid, dtype=torch.int32).to(inputs.device)
-        return (self.pre_scale, self.pre_shift, self.pre_map, valid, float(self.data_preprocessor.pad_val))
+        if not valid:
+            valid = [(H, W)] * int(n)
+        return torch.tensor(valid, dtype=torch.int32)
 
     def extract_feat(self, inputs, data_samples=None):
         return self.backbone(inputs, self._pre(inputs, data_samples))

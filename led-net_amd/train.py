@@ -1553,11 +1553,13 @@ class Trainer:
     # per step are submitted as ONE graph, the host only refreshes the input buffers and the
     # device-resident learning rate.  With N > 1 ranks the collectives must be stream operations
     # (rccl.Comm): torch.distributed's cannot be captured.
-    def capture(self, inputs, data_samples, warmup=3):
+    def capture(self, inputs, data_samples, warmup=3, restore=False):
         """Capture one whole step on (inputs, data_samples).  The `warmup` eager steps before the capture are
         REAL optimizer steps on that batch (allocator / workspace / sink warm-up needs them); self.iter counts
-        them.  Afterwards: replay(), or train_step() (eager) -- both keep the device-resident learning rate
-        current."""
+        them.  restore=True makes the capture free of side effects instead: parameters, momentum buffers, module
+        buffers (BatchNorm running statistics) and the iteration counter are put back after the warm-up, so the
+        first replay() is step `self.iter` of an uninterrupted schedule (tools/train.py: --resume continues exactly).
+        Afterwards: replay(), or train_step() (eager) -- both keep the device-resident learning rate current."""
         assert self.dist is None or self.comm is not None, 'graph capture with N > 1 needs the direct RCCL communicator'
         dev = inputs.device
         self._static_in = inputs.clone()
@@ -1568,12 +1570,28 @@ class Trainer:
         self._static_samples = [SegDataSample(gt=self._static_lab[i], metainfo=dict(getattr(ds, 'metainfo', {}) or {}))
                                 for i, ds in enumerate(data_samples)]
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        if inputs.dtype == torch.uint8 and getattr(self.model, 'pre_scale', None) is not None:
+            # per-image valid extents (batch padding) live in a resident buffer the graph reads: replay() refreshes it
+            self.model._valid_static = self.model.valid_extents(inputs.shape[2:], data_samples, inputs.shape[0]).to(dev)
+            self.model._valid_for_ptr = self._static_in.data_ptr()
+        snap = None
+        if restore:
+            snap = ([p.detach().clone() for p in self.params], self.flat_mom.clone(),
+                    [b.detach().clone() for b in self.model.buffers()], self.iter)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            for _ in range(max(warmup, 2 if self.table is None else 0)):     # (the sinks attach in the second step)
                 self._lr_dev.fill_(self.lr())
                 self.train_step(self._static_in, self._static_samples)
+            if snap is not None:
+                with torch.no_grad():
+                    for p, v in zip(self.params, snap[0]):
+                        p.copy_(v)
+                    self.flat_mom.copy_(snap[1])
+                    for b, v in zip(self.model.buffers(), snap[2]):
+                        b.copy_(v)
+                self.iter = snap[3]
         torch.cuda.current_stream(dev).wait_stream(side)
         self._lr_dev.fill_(self.lr())
         self._graph = torch.cuda.CUDAGraph()
@@ -1586,11 +1604,27 @@ class Trainer:
         return self
 
     def replay(self, inputs=None, data_samples=None):
-        """one captured step; new inputs are copied into the static buffers first."""
+        """one captured step; new inputs (same shapes as the captured batch) are copied into the static buffers
+        first: pixels, labels and the per-image padding extents.  Stream-ordered: the copies and the graph launch go
+        to the current stream, so a batch produced on another stream needs the usual event / wait_stream first."""
         if inputs is not None and inputs is not self._static_in:
-            self._static_in.copy_(inputs)
-            for i, ds in enumerate(data_samples):
-                self._static_lab[i].copy_(ds.gt_sem_seg.data)
+            if inputs.shape != self._static_in.shape or inputs.dtype != self._static_in.dtype:
+                raise ValueError(f'replay: batch {tuple(inputs.shape)} {inputs.dtype} != captured '
+                                 f'{tuple(self._static_in.shape)} {self._static_in.dtype}')
+            self._static_in.copy_(inputs, non_blocking=True)
+            labs = [ds.gt_sem_seg.data for ds in data_samples]
+            base = labs[0]._base
+            if (base is not None and base.shape == self._static_lab.shape and base.is_contiguous()
+                    and all(lb._base is base and lb.data_ptr() == base[i].data_ptr() for i, lb in enumerate(labs))):
+                self._static_lab.copy_(base, non_blocking=True)       # views of one N x 1 x H x W batch: one copy
+            else:
+                for i, lb in enumerate(labs):
+                    self._static_lab[i].copy_(lb, non_blocking=True)
+            if self.model._valid_static is not None:
+                ext = self.model.valid_extents(inputs.shape[2:], data_samples, inputs.shape[0])
+                if getattr(self, '_valid_host', None) is None or not torch.equal(ext, self._valid_host):
+                    self._valid_host = ext
+                    self.model._valid_static.copy_(ext.to(self.model._valid_static.device))
         self._lr_dev.fill_(self.lr())
         self._graph.replay()
         self.iter += 1

@@ -296,7 +296,8 @@ class Compose:
     def batch(self, samples, out_hw=None):
         """samples: list of dict(img=uint8 H x W x 3 device tensor, gt_seg_map=uint8 H x W device tensor or None, ...)
         -> dict(inputs=[3 x h x w uint8 views], data_samples=[SegDataSample]); the views share one batch tensor
-        (``out['batch']``, N x 3 x OH x OW, padded with pad_val / seg_pad_val)."""
+        (``out['batch']``, N x 3 x OH x OW, padded with pad_val / seg_pad_val); ``padded_samples`` = the samples as
+        the data preprocessor would return them for ``batch`` (padded labels, img_shape / pad_shape / padding_size)."""
         lib = _lib.get_lib()
         dev = samples[0]['img'].device
         for r in samples:
@@ -327,11 +328,17 @@ class Compose:
         tab = _table([_entry(r) for r in samples], dev)
         _run(lib, 'ledn_augment_batch', batch, tab.data_ptr(), n, batch.data_ptr(),
              labels.data_ptr() if has_seg else None, OH, OW, int(self.pad_val), int(self.seg_pad_val))
-        inputs, data_samples = [], []
+        inputs, data_samples, padded = [], [], []
         for i, r in enumerate(samples):
             p = r['_aug']
             inputs.append(batch[i, :, :p.ch, :p.cw])
-            ds = SegDataSample(gt=labels[i, :, :p.ch, :p.cw] if has_seg else None,
-                               metainfo={k: r[k] for k in self.pack.meta_keys if k in r})
-            data_samples.append(ds)
-        return dict(inputs=inputs, data_samples=data_samples, batch=batch, labels=labels)
+            meta = {k: r[k] for k in self.pack.meta_keys if k in r}
+            data_samples.append(SegDataSample(gt=labels[i, :, :p.ch, :p.cw] if has_seg else None, metainfo=meta))
+            # the same sample as SegDataPreProcessor.forward(training=True) would hand it on (stack_batch's metainfo,
+            # mmseg/utils/misc.py:77-117): the padded label and the padding extents, so that `batch` can go straight
+            # into the model -- EncoderDecoder then makes the stem emit pad_val in the NORMALISED domain over the
+            # padded area (normalise-then-pad, data_preprocessor.py:121-133) instead of normalising the raw fill
+            padded.append(SegDataSample(gt=labels[i] if has_seg else None,
+                                        metainfo=dict(meta, img_shape=(p.ch, p.cw), pad_shape=(OH, OW),
+                                                      padding_size=(0, OW - p.cw, 0, OH - p.ch))))
+        return dict(inputs=inputs, data_samples=data_samples, batch=batch, labels=labels, padded_samples=padded)

@@ -37,6 +37,9 @@ def parse_args():
     p.add_argument('--width', type=int, default=1024)
     p.add_argument('--save-interval', type=int, default=0)
     p.add_argument('--f32', action='store_true')
+    p.add_argument('--eager', action='store_true', help='per-kernel launches instead of the captured hipGraph of the step')
+    p.add_argument('--capture-warmup', type=int, default=3,
+                   help='eager warm-up steps before the graph capture (rolled back: they do not count as iterations)')
     p.add_argument('--augment', action='store_true',
                    help="run the config's train_pipeline (RandomResize / RandomCrop / RandomFlip / PhotoMetricDistortion) on the "
                         'GPU over synthetic decoded images (H x 2W uint8 BGR) instead of feeding ready-made crops')
@@ -83,7 +86,6 @@ def main():
         L.resume(trainer, ckpt)           # momentum buffers + PolyLR position (mmengine 'optimizer' / 'param_schedulers')
     trainer.iter = start
     max_iters = args.max_iters or trainer.max_iters
-    g = torch.Generator().manual_seed(304 + rank)
     bs = args.batch_size
     pipe = None
     if args.augment:
@@ -99,33 +101,75 @@ def main():
                 c['scale'] = (2 * args.width, args.height)
         pre = cfg['model'].get('data_preprocessor') or {}
         pipe = T.Compose(pipe_cfg, pad_val=pre.get('pad_val', 0), seg_pad_val=pre.get('seg_pad_val', 255))
-        np.random.seed(304 + rank)
-    t0, tlog = time.perf_counter(), time.perf_counter()
-    for it in range(start, max_iters):
+    # Batches are made ON THE DEVICE (torch's device generator / the augmentation kernel), on a side stream, one
+    # iteration ahead of the step that consumes them; each is a function of (seed, rank, iteration) only, so a resumed
+    # run sees the batches the uninterrupted run would have seen.  The step itself is ONE hipGraph replay
+    # (Trainer.capture / replay: what bench.py times); --eager keeps the per-kernel launches.
+    gdev = torch.Generator(device=dev)
+    side = torch.cuda.Stream(device=dev)
+    H, W = args.height, args.width
+
+    def make_batch(it):
+        gdev.manual_seed(304 + 7919 * rank + 1000003 * it)
         if pipe is not None:                # "decoded" H x 2W images + label maps -> augmented crops, one launch
-            raw = torch.randint(0, 256, (bs, args.height, 2 * args.width, 3), dtype=torch.uint8, generator=g).to(dev)
-            seg = torch.randint(0, 2, (bs, args.height // 8, args.width // 4), dtype=torch.uint8, generator=g).to(dev)
+            np.random.seed((304 + 7919 * rank + 1000003 * it) % (2 ** 32))
+            raw = torch.randint(0, 256, (bs, H, 2 * W, 3), dtype=torch.uint8, device=dev, generator=gdev)
+            seg = torch.randint(0, 2, (bs, H // 8, W // 4), dtype=torch.uint8, device=dev, generator=gdev)
             seg = seg.repeat_interleave(8, 1).repeat_interleave(8, 2).contiguous()
-            aug = pipe.batch([dict(img=raw[i], gt_seg_map=seg[i]) for i in range(bs)], out_hw=(args.height, args.width))
-            img, lab = aug['batch'], aug['labels']
-        else:
-            img = torch.randint(0, 256, (bs, 3, args.height, args.width), dtype=torch.uint8, generator=g).to(dev)
-            lab = torch.randint(0, 2, (bs, 1, args.height, args.width), dtype=torch.int64, generator=g)
-            lab[:, :, :16], lab[:, :, -16:], lab[..., :16], lab[..., -16:] = 255, 255, 255, 255
-            lab = lab.to(dev)
-        out = trainer.train_step(img, [L.SegDataSample(gt=lab[i]) for i in range(bs)])
+            aug = pipe.batch([dict(img=raw[i], gt_seg_map=seg[i]) for i in range(bs)], out_hw=(H, W))
+            # padded_samples carry img_shape / pad_shape / padding_size: the stem then writes pad_val in the
+            # NORMALISED domain over the padded area, as SegDataPreProcessor.forward(training=True) + stack_batch do
+            return aug['batch'], aug['padded_samples']
+        img = torch.randint(0, 256, (bs, 3, H, W), dtype=torch.uint8, device=dev, generator=gdev)
+        lab = torch.randint(0, 2, (bs, 1, H, W), dtype=torch.int64, device=dev, generator=gdev)
+        lab[:, :, :16], lab[:, :, -16:], lab[..., :16], lab[..., -16:] = 255, 255, 255, 255
+        return img, [L.SegDataSample(gt=lab[i]) for i in range(bs)]
+
+    def prefetch(it):
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            b = make_batch(it)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        return b, ev
+
+    def save(it):
+        L.save_checkpoint(model, osp.join(work_dir, f'iter_{it}.pth'), trainer=trainer,
+                          meta=dict(iter=it, dataset_meta=dict(classes=('background', 'foreground'), palette=None)))
+
+    use_graph = not args.eager
+    if start < max_iters and use_graph:
+        # capture on the first batch, free of side effects (restore=True: weights, momentum, running statistics and
+        # the iteration counter are put back after the warm-up steps): the loop below replays every iteration of
+        # the schedule exactly once, and a resumed run continues as the uninterrupted one would have
+        (img, samples), ev = prefetch(start)
+        ev.wait()
+        trainer.capture(img, samples, warmup=args.capture_warmup, restore=True)
+    t0, tlog = time.perf_counter(), time.perf_counter()
+    first = trainer.iter
+    nxt = prefetch(first) if first < max_iters else None
+    for it in range(first, max_iters):
+        (img, samples), ev = nxt
+        ev.wait()                           # the launch stream waits for the batch (device-side dependency)
+        nxt = prefetch(it + 1) if it + 1 < max_iters else None
+        out = trainer.replay(img, samples) if use_graph else trainer.train_step(img, samples)
         if rank == 0 and ((it + 1) % 50 == 0 or it + 1 == max_iters):
             vals = {k: float(v.float().reshape(-1)[0]) for k, v in out.items()}
-            dt = (time.perf_counter() - tlog) / min(50, it + 1 - start)
+            dt = (time.perf_counter() - tlog) / max(1, min(50, it + 1 - first))
             tlog = time.perf_counter()
             print(f'Iter(train) [{it + 1:6d}/{max_iters}]  lr: {trainer.lr():.4e}  time: {dt:.4f}  '
-                  + '  '.join(f'{k}: {v:.4f}' for k, v in vals.items()), flush=True)
-        if rank == 0 and ((args.save_interval and (it + 1) % args.save_interval == 0) or it + 1 == max_iters):
-            L.save_checkpoint(model, osp.join(work_dir, f'iter_{it + 1}.pth'), trainer=trainer,
-                              meta=dict(iter=it + 1, dataset_meta=dict(classes=('background', 'foreground'), palette=None)))
+                  + '  '.join(f'{k}: {v:.4f}' for k, v in vals.items())
+                  + f'  data: {int(img.sum(dtype=torch.int64))}', flush=True)     # fingerprint of this iteration's batch
+        if rank == 0 and args.save_interval and (it + 1) % args.save_interval == 0 and it + 1 < max_iters:
+            save(it + 1)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0           # (the final checkpoint below is not part of the training throughput)
+    if rank == 0 and max_iters > first:
+        save(max_iters)
     if rank == 0:
-        n = max_iters - start
-        print(f'{n} iterations, {bs * world * n / (time.perf_counter() - t0):.1f} images/s (incl. synthetic data generation)')
+        n = max_iters - first
+        print(f'{n} iterations, {bs * world * n / max(el, 1e-9):.1f} images/s '
+              f'({"hipGraph replay" if use_graph else "eager launches"}, incl. on-device batch generation)', flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
