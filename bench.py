@@ -173,6 +173,20 @@ def launch_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def _coll_launches(log):
+    """launches the logged collectives amount to: an ncclGroup is one launch, every other all-reduce one"""
+    n, depth = 0, 0
+    for _slot, op, _numel in log:
+        if op == 'group_begin':
+            depth += 1
+            n += 1
+        elif op == 'group_end':
+            depth -= 1
+        elif depth == 0:
+            n += 1
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=None, help='ranks (one per GPU); default: WORLD_SIZE when launched by torch.distributed.run, else 1')
@@ -324,9 +338,17 @@ def main():
         eager_step()
         barrier()
         ops.start_timing()
-        for _ in range(k_steps):
-            eager_step()
-        barrier()
+        coll_log = None
+        if mode == 'train':
+            from led_net_amd import train as _TR
+            coll_log = _TR._Collective.log = []
+        try:
+            for _ in range(k_steps):
+                eager_step()
+            barrier()
+        finally:
+            if mode == 'train':
+                _TR._Collective.log = None
         launches = ops.stop_timing()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -386,9 +408,19 @@ def main():
                        'batchnorm': ('SyncBN (config): one RCCL all-reduce of [2,C] per BN (or group of BNs ready together) and direction' if mode == 'train' and not args.local_bn and trainer._all_reduce is not None
                                      else 'per-rank statistics'),
                        'collectives': (None if mode != 'train' or trainer._all_reduce is None else
-                                       ('ncclAllReduce on the launch streams, one communicator per stream (in the graph); '
-                                        'non-stem gradients exchanged during the stem backward' if trainer.comm is not None
+                                       (('ncclAllReduce on the launch stream (in the graph)' if trainer._single_stream else
+                                         'ncclAllReduce on the launch streams, one communicator per stream (in the graph); '
+                                         'non-stem gradients exchanged during the stem backward') if trainer.comm is not None
                                         else 'torch.distributed (eager)')),
+                       'rccl_nranks_all': (trainer.comm.nranks_all if mode == 'train' and trainer.comm is not None else None),
+                       'collective_path': (None if mode != 'train' or trainer._all_reduce is None else
+                                           ('one launch stream, one ordered collective sequence per rank (default for N > 1)'
+                                            if trainer._single_stream else 'LEDN_MULTI_COMM=1: one communicator per branch stream')),
+                       'collectives_per_step': (None if not coll_log else
+                                                sum(1 for c in coll_log if c[1] == 'all_reduce') // k_steps),
+                       'collective_launches_per_step': (None if not coll_log else _coll_launches(coll_log) // k_steps),
+                       'collective_bytes_per_step': (None if not coll_log else
+                                                     4 * sum(c[2] for c in coll_log if c[1] == 'all_reduce') // k_steps),
                        'kernel_launches_per_step': len(launches) // k_steps,
                        'submission': 'hipGraph replay' if graphed else 'eager launches',
                        'kernel_timing': 'HIP events on the launch streams, instrumented eager pass of the same step right after the timed region',

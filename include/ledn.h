@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LEDN_ABI_VERSION 1
+#define LEDN_ABI_VERSION 2
 
 enum { LEDN_OK = 0, LEDN_EINVAL = 1, LEDN_ELAUNCH = 2 };
 enum { LEDN_F32 = 0, LEDN_BF16 = 1, LEDN_U8 = 2 };
@@ -39,6 +39,12 @@ int ledn_abi_version(void);
  * partials there and finish with a second tiny kernel instead of same-address atomics.
  * ptr = NULL, nfloats = 0 detaches it (kernels then fall back to atomics). */
 int ledn_set_workspace(void* ptr, long long nfloats);
+/* The same scratch bound to ONE stream: launches issued with `stream` use this buffer, launches on other streams
+ * their own binding (or the process default above).  The library keeps no other per-call state: the workspace
+ * binding by stream and the deferred-statistics hand-off (ledn_stats_defer_begin/end: per calling host thread) are
+ * re-entrant across streams and threads; the launch-shape options below are process-wide tuning knobs that never
+ * change results.  ptr = NULL, nfloats = 0 removes the binding. */
+int ledn_bind_workspace(void* stream, void* ptr, long long nfloats);
 
 /* Launch-shape knobs (process-wide; defaults are tuned for a 256-CU MI355X).  value <= 0 restores
  * the default.  Results never depend on them beyond f32 summation order. */

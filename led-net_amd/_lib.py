@@ -160,6 +160,7 @@ _PROTOS = {
     'ledn_sgd_step': ([vp, i32, i64, C.c_float, fp, C.c_float, C.c_float, C.c_float, vp], i32),
     'ledn_abi_version': ([], i32),
     'ledn_set_workspace': ([vp, i64], i32),
+    'ledn_bind_workspace': ([vp, vp, i64], i32),
     'ledn_set_option': ([i32, i64], i32),
     'ledn_conv2d': ([C.POINTER(ConvDesc), vp], i32),
     'ledn_conv2d_uses_mfma': ([C.POINTER(ConvDesc)], i32),
@@ -203,6 +204,9 @@ _PROTOS = {
 EXPORTS = tuple(_PROTOS)
 
 
+ABI_VERSION = 2      # include/ledn.h LEDN_ABI_VERSION: bumped with every struct / signature change
+
+
 class LednError(RuntimeError):
     pass
 
@@ -223,23 +227,24 @@ class Library:
             fn.argtypes = argtypes
             fn.restype = restype
         v = self.cdll.ledn_abi_version()
-        if v != 1:
-            raise LednError(f'{path}: ABI version {v}, expected 1')
+        if v != ABI_VERSION:
+            raise LednError(f'{path}: ABI version {v}, expected {ABI_VERSION} (stale build? run __graft_entry__.build())')
         self._workspaces = {}
-        self._bound = None
+        self._bound = set()
 
-    def ensure_workspace(self, device, slot=0, nfloats=32 << 20):
-        """bind the reusable scratch buffer (128 MiB) of two-stage reductions.  The scratch is
-        reused launch after launch in stream order, so every HIP stream that runs ledn kernels
-        concurrently (ops.Fork) has its own buffer: slot 0 = the main stream."""
-        key = (device, slot)
-        if self._bound != key:
-            ws = self._workspaces.get(key)
+    def ensure_workspace(self, device, slot=0, nfloats=32 << 20, stream=None):
+        """the reusable scratch buffer (128 MiB) of two-stage reductions, BOUND TO THE LAUNCH STREAM
+        (ledn_bind_workspace): the scratch is reused launch after launch in stream order, so every HIP stream that
+        runs ledn kernels (ops.Fork's branch streams, a capture's side stream) has its own buffer and the library
+        finds it by the stream argument of the call -- no process-wide "current workspace" to keep in step."""
+        key = (device, slot, stream)
+        if key not in self._bound:
+            ws = self._workspaces.get((device, slot))
             if ws is None:
                 import torch
-                ws = self._workspaces[key] = torch.empty(nfloats, dtype=torch.float32, device=device)
-            self.call('ledn_set_workspace', ws.data_ptr(), ws.numel())
-            self._bound = key
+                ws = self._workspaces[(device, slot)] = torch.empty(nfloats, dtype=torch.float32, device=device)
+            self.call('ledn_bind_workspace', stream, ws.data_ptr(), ws.numel())
+            self._bound.add(key)
 
     def set_option(self, option, value):
         """launch-shape knob (include/ledn.h LEDN_OPT_*); value <= 0 restores the default"""

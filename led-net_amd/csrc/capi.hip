@@ -105,17 +105,35 @@ int sgd_step_impl(const ledn_sgd_entry* table_dev, int n_tensors, long long max_
                   const float* lr_dev, float momentum, float weight_decay, float grad_scale, hipStream_t s);
 }  // namespace ledn
 
+#include <mutex>
+#include <unordered_map>
+
 namespace ledn {
+// Scratch state is keyed by the HIP stream an entry point is called with (every entry takes one): a workspace bound
+// to a stream (ledn_bind_workspace) serves the launches on that stream only, so two models / host threads / streams
+// in one process do not depend on each other's call order.  ledn_set_workspace keeps the process default (used by
+// streams without a binding).  The deferred-statistics hand-off lives in the calling host thread.
 static Workspace g_ws = {nullptr, 0};
-Workspace& workspace() { return g_ws; }
+static std::mutex g_ws_mutex;
+static std::unordered_map<void*, Workspace> g_ws_by_stream;
+static thread_local void* tls_stream = nullptr;
+static thread_local Workspace tls_ws = {nullptr, 0};
+static hipStream_t enter_stream(void* stream) {         // every extern "C" entry passes its stream through here
+    tls_stream = stream;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    auto it = g_ws_by_stream.find(stream);
+    tls_ws = it != g_ws_by_stream.end() ? it->second : g_ws;
+    return (hipStream_t)stream;
+}
+Workspace& workspace() { return tls_ws; }
 static Options g_opt = {512, 512, 27};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3, bit 2 round-robin conv tiles (off), bit 3 8-row conv tiles for under-filled grids, bit 4 register-direct 1x1 conv (conv1x1.hip)
 Options& options() { return g_opt; }
-static DeferredStats g_defer = {false, nullptr, 0};
+static thread_local DeferredStats g_defer = {false, nullptr, 0};
 DeferredStats& deferred_stats() { return g_defer; }
 }  // namespace ledn
 
 using namespace ledn;
-#define S(stream) ((hipStream_t)(stream))
+#define S(stream) (ledn::enter_stream(stream))
 
 extern "C" {
 
@@ -125,6 +143,14 @@ int ledn_set_workspace(void* ptr, long long nfloats) {
     if (nfloats < 0 || (ptr == nullptr) != (nfloats == 0)) return LEDN_EINVAL;
     workspace().ptr = (float*)ptr;
     workspace().nfloats = (long)nfloats;
+    return LEDN_OK;
+}
+
+int ledn_bind_workspace(void* stream, void* ptr, long long nfloats) {
+    if (nfloats < 0 || (ptr == nullptr) != (nfloats == 0)) return LEDN_EINVAL;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    if (ptr) g_ws_by_stream[stream] = Workspace{(float*)ptr, (long)nfloats};
+    else g_ws_by_stream.erase(stream);
     return LEDN_OK;
 }
 

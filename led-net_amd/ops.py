@@ -185,8 +185,8 @@ class Fork:
 
 
 def _run(lib, name, ref, *args, work=None):
-    lib.ensure_workspace(ref.device, _slot(ref) if lib.is_hip else 0)
     stream = _stream(lib, ref)
+    lib.ensure_workspace(ref.device, _slot(ref) if lib.is_hip else 0, stream=stream)
     if _TIMING is not None and lib.is_hip:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -6,7 +6,10 @@ and direction, as ``torch.nn.SyncBatchNorm`` does in the reference's DDP run) pl
 all-reduce.  ``ncclAllReduce`` on the caller's HIP stream is a plain stream operation: it is captured
 into the step's hipGraph with the kernels around it and replayed by every rank in the same order.
 
-One communicator PER LAUNCH STREAM (``CommSet``): the step runs on several HIP streams (main, the
+DEFAULT for N > 1 (train.Trainer): ONE launch stream, so one ordered sequence of collectives per rank
+(communicator 0 for the SyncBN statistics, 'grad' for the gradient exchange issued after the backward behind a stream
+wait -- never concurrent).  Opt-in (LEDN_MULTI_COMM=1), validated on one rank only:
+one communicator PER LAUNCH STREAM (``CommSet``): the step runs on several HIP streams (main, the
 context-branch stream, the gradient-exchange stream).  Operations of one communicator must be issued
 in the same order on every rank and are serialised by RCCL; a communicator per stream keeps the
 streams independent -- each stream's collectives are issued in (deterministic) program order, and the
@@ -128,6 +131,8 @@ class CommSet:
         self.rank, self.world, self.device = rank, world, device
         self.comms = {s: Comm(rank, world, device) for s in slots}
         self.nranks = self.comms[slots[0]].nranks
+        # what RCCL itself reports (ncclCommCount) for EVERY communicator of the step, not only slot 0
+        self.nranks_all = {str(s): c.nranks for s, c in self.comms.items()}
 
     def get(self, slot):
         c = self.comms.get(slot)

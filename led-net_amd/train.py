@@ -37,15 +37,25 @@ class _Collective:
     step's hipGraph); else torch.distributed (`dist`: RCCL through ProcessGroupNCCL on the GPU, gloo in the
     CPU tests)."""
 
+    log = None      # tests / bench: a list that receives (slot, 'all_reduce' | 'group_begin' | 'group_end', numel)
+                    # for every collective issued, in issue order (the per-communicator operation sequence that
+                    # must be identical on every rank)
+
     def __init__(self, commset=None, dist=None):
         assert (commset is None) != (dist is None)
         self.commset, self.dist = commset, dist
+
+    @staticmethod
+    def _slot_of(ref, slot):
+        return slot if slot is not None else (ops._slot(ref) if ref.is_cuda else 0)
 
     def _comm(self, ref, slot=None):
         return self.commset.get(ops._slot(ref) if slot is None else slot)
 
     def all_reduce(self, src, dst, slot=None):
         """dst = sum over ranks of src (dst may be src)."""
+        if _Collective.log is not None:
+            _Collective.log.append((self._slot_of(src, slot), 'all_reduce', int(src.numel())))
         if self.commset is not None:
             return self._comm(src, slot).all_reduce(src, dst)
         if dst is not src:
@@ -56,10 +66,19 @@ class _Collective:
     def group(self, ref, slot=None):
         """context manager: the all-reduces inside are ONE launch (ncclGroupStart/End); BatchNorms whose
         statistics are ready together (MFAF's five context BNs) share it."""
-        if self.commset is not None:
-            return self._comm(ref, slot).group()
         import contextlib
-        return contextlib.nullcontext()
+        inner = self._comm(ref, slot).group() if self.commset is not None else contextlib.nullcontext()
+        if _Collective.log is None:
+            return inner
+        key = self._slot_of(ref, slot)
+
+        @contextlib.contextmanager
+        def logged():
+            _Collective.log.append((key, 'group_begin', 0))
+            with inner:
+                yield
+            _Collective.log.append((key, 'group_end', 0))
+        return logged()
 
 
 def _c(t):
@@ -1311,6 +1330,15 @@ class Trainer:
         # hipGraph), 'torch' = torch.distributed (eager only), default 'auto' = rccl on the GPU when it
         # initialises, else torch.  'rccl' with world_size 1 is the single-GPU self-test of that path.
         mode = collectives or _os.environ.get('LEDN_COLLECTIVES', 'auto')
+        # N > 1 default = ONE launch stream: every collective of the step (SyncBN statistics, then the gradient
+        # exchange) is issued from a single stream in program order, so the order is identical on all ranks under
+        # eager launches AND under hipGraph replay, whatever the runtime does with independent graph branches.  The
+        # multi-communicator form (one communicator per branch stream, gradient exchange overlapped with the stem's
+        # backward; validated on ONE rank only) deadlocks if two ranks ever start two communicators' kernels from a
+        # shared hardware queue in opposite orders -- opt in with LEDN_MULTI_COMM=1 once an 8-GPU run has shown it.
+        self.multi_comm = bool(int(_os.environ.get('LEDN_MULTI_COMM', '0')))
+        self._single_stream = (world_size > 1 or mode == 'rccl') and not self.multi_comm   # ('rccl' at N = 1: the self-test
+        # of the N > 1 path on one GPU runs what N > 1 would run)
         self.comm = None
         self.dist = None
         if world_size > 1:
@@ -1324,8 +1352,9 @@ class Trainer:
         if mode in ('auto', 'rccl') and dev.type == 'cuda' and (world_size > 1 or mode == 'rccl'):
             try:
                 from . import rccl
-                slots = sorted({0} | ({1} if CTX_FORKS else set()) | ({SEAM_SLOT} if SEAM_SLOT else set())
-                               | (set(range(3, 7)) if MFAF_FORK else set()))
+                slots = [0] if self._single_stream else sorted(
+                    {0} | ({1} if CTX_FORKS else set()) | ({SEAM_SLOT} if SEAM_SLOT else set())
+                    | (set(range(3, 7)) if MFAF_FORK else set()))
                 self.comm = rccl.CommSet(self.dist.get_rank() if self.dist is not None else 0, world_size, dev,
                                          slots=tuple(slots) + ('grad',))
             except Exception as e:   # noqa: BLE001 -- 'auto': fall back to torch.distributed
@@ -1341,10 +1370,11 @@ class Trainer:
         else:
             self.coll = None
         self._sync_bn = self.coll if sync else None
-        self._gstream = torch.cuda.Stream(device=dev) if (self.coll is not None and dev.type == 'cuda') else None
+        self._gstream = (torch.cuda.Stream(device=dev)
+                         if (self.coll is not None and dev.type == 'cuda' and not self._single_stream) else None)
         self._ready = {}
         self._early_done = False
-        self.overlap_exchange = bool(int(_os.environ.get('LEDN_OVERLAP_EXCHANGE', '1')))
+        self.overlap_exchange = bool(int(_os.environ.get('LEDN_OVERLAP_EXCHANGE', '1'))) and not self._single_stream
 
     @property
     def _all_reduce(self):      # (bench.py / older callers: "does this trainer exchange gradients")
@@ -1397,6 +1427,9 @@ class Trainer:
             p.grad = v
 
     def _enter(self):
+        self._saved_multi_stream = ops.MULTI_STREAM
+        if self._single_stream:
+            ops.MULTI_STREAM = False         # no branch streams: one ordered sequence of collectives per rank
         ops.PendingRows.entry = None
         self._arena.reset()                  # one fill for every small zeroed scratch of the step
         ops.set_zero_arena(self._arena)
@@ -1409,6 +1442,7 @@ class Trainer:
                                                   and self._sink_map) else None
 
     def _leave(self):
+        ops.MULTI_STREAM = self._saved_multi_stream
         ops.set_zero_arena(None)
         _Sinks.map = {}
         _Env.sync_bn = None

@@ -96,6 +96,7 @@ def _cmp_worker(rank, world, port, out_dir):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    os.environ['LEDN_MULTI_COMM'] = '1'      # the opt-in form: exchange of the non-stem gradients from inside the backward
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import led_net_amd as L
@@ -165,14 +166,75 @@ def test_ddp_world2_equals_world1_on_concatenated_batch(tmp_path):
     assert rels[len(rels) // 2][0] < 3e-2 and rels[0][0] < 0.25, (rels[len(rels) // 2], rels[:5])
 
 
+def _order_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.pop('LEDN_MULTI_COMM', None)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import led_net_amd as L
+    from led_net_amd import train as TR
+    from conftest import bind_emu
+    torch.manual_seed(100 + rank)
+    cfg = L.load_config(os.path.join(ROOT, 'tests', 'data', 'lednet_test_config.py'))
+    for c in cfg['model']['decode_head']['loss_decode']:
+        c['min_kept'] = 3000
+    logs = []
+    with bind_emu():
+        model = L.MODELS.build(cfg['model'])
+        tr = L.Trainer(model, cfg, world_size=world)
+        assert tr._single_stream and not tr.overlap_exchange          # the default for N > 1
+        g = torch.Generator().manual_seed(7 + rank)
+        img = torch.randint(0, 256, (1, 3, 320, 320), dtype=torch.uint8, generator=g)
+        lab = torch.randint(0, 2, (1, 1, 320, 320), dtype=torch.int64, generator=g)
+        for _ in range(2):        # step 1: gradients through autograd; step 2: gradient sinks + table launches
+            TR._Collective.log = []
+            tr.train_step(img, [L.SegDataSample(gt=lab[0])])
+            logs.append(TR._Collective.log)
+            TR._Collective.log = None
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.save({'logs': logs, 'sd': sd}, os.path.join(out_dir, f'order{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+def test_collective_order_identical_on_four_ranks(tmp_path):
+    """The deadlock condition of the data-parallel step, checked without hardware: every rank must issue the SAME
+    ordered list of (communicator slot, operation, element count) -- per slot and overall -- in every step; a rank
+    that issues one all-reduce more, fewer, or in another order than its peers hangs the job.  World 4 over gloo
+    (one image per rank), the default N > 1 path (one launch stream); also: four identical replicas afterwards."""
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_order_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    res = [torch.load(tmp_path / f'order{r}.pt') for r in range(4)]
+    ref = res[0]['logs']
+    assert len(ref[0]) > 100, len(ref[0])                       # ~170 SyncBN all-reduces + the gradient buckets
+    for r in range(1, 4):
+        for step in range(2):
+            assert res[r]['logs'][step] == ref[step], (r, step)
+        for k in res[0]['sd']:
+            assert torch.equal(res[r]['sd'][k], res[0]['sd'][k]), (r, k)
+    # same sequence with and without the gradient sinks (step 1 vs step 2): what a captured replay re-issues
+    assert ref[0] == ref[1]
+    slots = {c[0] for c in ref[0]}
+    assert slots == {0, 'grad'}, slots                           # one stream: SyncBN on slot 0, then the exchange
+    first_grad = next(i for i, c in enumerate(ref[0]) if c[0] == 'grad')
+    assert all(c[0] == 'grad' for c in ref[0][first_grad:])      # the exchange comes after the last SyncBN collective
+    nbytes = 4 * sum(c[2] for c in ref[0] if c[0] == 'grad' and c[1] == 'all_reduce')
+    assert 5.5e6 < nbytes < 7e6, nbytes                          # the flat f32 gradient buffer, once
+
+
 @pytest.mark.gpu
-def test_rccl_in_graph_single_rank():
+@pytest.mark.parametrize('multi', ['0', '1'])
+def test_rccl_in_graph_single_rank(multi, monkeypatch):
     """The N > 1 step keeps its collectives inside the hipGraph by issuing ncclAllReduce on the launch
     stream (led_net_amd/rccl.py).  One GPU can check everything but the wire: a one-rank communicator,
     SyncBN statistics and the flat gradient all-reduced through it (identity), the whole step captured
     and replayed -- same parameters as the plain single-GPU trainer after three steps."""
     import copy
     sys.path.insert(0, ROOT)
+    monkeypatch.setenv('LEDN_MULTI_COMM', multi)     # '0': the default N > 1 path (one launch stream); '1': opt-in
     import led_net_amd as L
     assert torch.cuda.is_available()
     dev = torch.device('cuda:0')
@@ -194,7 +256,9 @@ def test_rccl_in_graph_single_rank():
         tr = L.Trainer(model, cfg, max_iters=100, collectives=mode)
         assert (tr.comm is not None) == (mode == 'rccl')
         if mode == 'rccl':
-            assert tr.comm.nranks == 1 and set(tr.comm.comms) >= {0, 1, 'grad'}
+            assert tr.comm.nranks == 1 and set(tr.comm.nranks_all.values()) == {1}
+            assert set(tr.comm.comms) == ({0, 'grad'} if multi == '0' else {0, 1, 'grad'})
+            assert tr._single_stream == (multi == '0')
         out = tr.train_step(img, samples)           # one eager step from identical weights
         torch.cuda.synchronize()
         res.append(({k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()},
