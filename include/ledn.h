@@ -582,6 +582,21 @@ int ledn_ohem_ce_up_fwd(const float* src, int N, int Hs, int Ws, int H, int W, c
 int ledn_ohem_ce_up_bwd(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target,
                         int ignore_label, const float* work, const float* out, const float* dloss, float loss_weight,
                         float* dsrc, void* stream);
+/* BOTH losses of LEDHead.loss_by_feat (led_head.py:132-146: loss_context = Ohem_0(resize(ctx)), loss_spatial =
+ * Ohem_1(resize(spa)), same labels) in one launch set: src0 / src1 [N,Hs,Ws,2] f32 are the two fused outputs at half
+ * the label size, target [N,H,W] int64 (W % 4 == 0, class ids and ignore_label < 256).  The int64 labels are read
+ * once (a uint8 copy inside `work` serves the later passes and the backward), no per-pixel loss array is kept, both
+ * radix selects / masked means run per launch.  work: ledn_ohem2_work_floats(N*H*W) floats; out[2][4] = per loss
+ * {loss, accuracy of output 0, threshold, #selected} as ledn_ohem_ce_fwd.  Selection semantics per loss exactly
+ * ohem_cross_entropy_loss.py:62-90.  ledn_ohem2_up_bwd (H = 2 Hs, W = 2 Ws): dsrc_k = resize^T(dloss_k * loss_weight_k
+ * / #selected_k * (softmax - onehot)) over the selected pixels of loss k; target is not needed again. */
+int ledn_ohem2_up_fwd(const float* src0, const float* src1, int N, int Hs, int Ws, int H, int W,
+                      const long long* target, float thres0, long long min_kept0, float loss_weight0, float thres1,
+                      long long min_kept1, float loss_weight1, int ignore_label, float* work, float* out, void* stream);
+int ledn_ohem2_up_bwd(const float* src0, const float* src1, int N, int Hs, int Ws, int H, int W, int ignore_label,
+                      const float* work, const float* out, const float* dloss0, const float* dloss1,
+                      float loss_weight0, float loss_weight1, float* dsrc0, float* dsrc1, void* stream);
+long long ledn_ohem2_work_floats(long long P);
 
 /* ------------------------------------------------------------------------- *
  * The four pooled-context MLPs of Muti_AFF (classification/model_utils.py:377-400: AdaptiveAvgPool2d(S) ->

@@ -157,6 +157,10 @@ _PROTOS = {
     'ledn_ohem_ce_bwd': ([fp, vp, i64, i32, i32, fp, fp, fp, C.c_float, fp, vp], i32),
     'ledn_ohem_ce_up_fwd': ([fp, i32, i32, i32, i32, i32, vp, C.c_float, i64, C.c_float, i32, fp, fp, vp], i32),
     'ledn_ohem_ce_up_bwd': ([fp, i32, i32, i32, i32, i32, vp, i32, fp, fp, fp, C.c_float, fp, vp], i32),
+    'ledn_ohem2_up_fwd': ([fp, fp, i32, i32, i32, i32, i32, vp, C.c_float, i64, C.c_float, C.c_float, i64, C.c_float, i32,
+                           fp, fp, vp], i32),
+    'ledn_ohem2_up_bwd': ([fp, fp, i32, i32, i32, i32, i32, i32, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, vp], i32),
+    'ledn_ohem2_work_floats': ([i64], i64),
     'ledn_sgd_step': ([vp, i32, i64, C.c_float, fp, C.c_float, C.c_float, C.c_float, vp], i32),
     'ledn_abi_version': ([], i32),
     'ledn_set_workspace': ([vp, i64], i32),

@@ -95,6 +95,13 @@ int ohem_ce_fwd_impl(const float* logits, const long long* target, long long P, 
 int ohem_ce_up_fwd_impl(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target, float thres,
                         long long min_kept, float loss_weight, int ignore_label, float* work, float* out,
                         hipStream_t s);
+int ohem2_up_fwd_impl(const float* src0, const float* src1, int N, int Hs, int Ws, int H, int W,
+                      const long long* target, float thres0, long long min_kept0, float lw0, float thres1,
+                      long long min_kept1, float lw1, int ignore_label, float* work, float* out, hipStream_t s);
+int ohem2_up_bwd_impl(const float* src0, const float* src1, int N, int Hs, int Ws, int H, int W, int ignore_label,
+                      const float* work, const float* out, const float* dloss0, const float* dloss1, float lw0,
+                      float lw1, float* dsrc0, float* dsrc1, hipStream_t s);
+long long ohem2_work_floats(long long P);
 int ohem_ce_up_bwd_impl(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target,
                         int ignore_label, const float* work, const float* out, const float* dloss, float loss_weight,
                         float* dsrc, hipStream_t s);
@@ -405,6 +412,19 @@ int ledn_ohem_ce_up_fwd(const float* src, int N, int Hs, int Ws, int H, int W, c
                         long long min_kept, float loss_weight, int ignore_label, float* work, float* out, void* stream) {
     return ohem_ce_up_fwd_impl(src, N, Hs, Ws, H, W, target, thres, min_kept, loss_weight, ignore_label, work, out, S(stream));
 }
+int ledn_ohem2_up_fwd(const float* src0, const float* src1, int N, int Hs, int Ws, int H, int W,
+                      const long long* target, float thres0, long long min_kept0, float loss_weight0, float thres1,
+                      long long min_kept1, float loss_weight1, int ignore_label, float* work, float* out, void* stream) {
+    return ohem2_up_fwd_impl(src0, src1, N, Hs, Ws, H, W, target, thres0, min_kept0, loss_weight0, thres1, min_kept1,
+                             loss_weight1, ignore_label, work, out, S(stream));
+}
+int ledn_ohem2_up_bwd(const float* src0, const float* src1, int N, int Hs, int Ws, int H, int W, int ignore_label,
+                      const float* work, const float* out, const float* dloss0, const float* dloss1,
+                      float loss_weight0, float loss_weight1, float* dsrc0, float* dsrc1, void* stream) {
+    return ohem2_up_bwd_impl(src0, src1, N, Hs, Ws, H, W, ignore_label, work, out, dloss0, dloss1, loss_weight0,
+                             loss_weight1, dsrc0, dsrc1, S(stream));
+}
+long long ledn_ohem2_work_floats(long long P) { return ohem2_work_floats(P); }
 int ledn_ohem_ce_up_bwd(const float* src, int N, int Hs, int Ws, int H, int W, const long long* target,
                         int ignore_label, const float* work, const float* out, const float* dloss, float loss_weight,
                         float* dsrc, void* stream) {

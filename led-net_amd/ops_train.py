@@ -368,6 +368,48 @@ def ohem_ce_up_bwd(src, target, work, out, dloss, loss_weight, ignore_label=255)
     return dsrc
 
 
+def ohem2_up_fwd(src0, src1, target, cfg0, cfg1, ignore_label=255):
+    """Both OHEM-CE losses of LEDHead.loss_by_feat in one launch set (ledn_ohem2_up_fwd).  src0 / src1 [N,Hs,Ws,2]
+    f32, target [N,H,W] int64, cfg_k = (thres, min_kept, loss_weight) -> (out [2,4], work)."""
+    lib = _lib.get_lib()
+    for src in (src0, src1):
+        if src.dtype != torch.float32 or src.dim() != 4 or src.shape[-1] != 2 or src.shape != src0.shape:
+            raise LednError('ohem2_up: two f32 [N,Hs,Ws,2] sources of one shape required')
+    N, Hs, Ws, _ = src0.shape
+    if target.dtype != torch.int64 or target.dim() != 3 or target.shape[0] != N:
+        raise LednError('ohem2_up: int64 target [N,H,W] required')
+    H, W = int(target.shape[1]), int(target.shape[2])
+    if W % 4 or not 0 <= ignore_label <= 255:
+        raise LednError('ohem2_up: W % 4 == 0 and ignore_label in [0, 255] required')
+    P = N * H * W
+    work = torch.empty(lib.cdll.ledn_ohem2_work_floats(P), dtype=torch.float32, device=src0.device)
+    out = torch.empty((2, 4), dtype=torch.float32, device=src0.device)
+    _check(lib, src0, src1, target, work, out)
+    _run(lib, 'ledn_ohem2_up_fwd', src0, _p(src0), _p(src1), N, Hs, Ws, H, W, _p(target), cfg0[0], int(cfg0[1]), cfg0[2],
+         cfg1[0], int(cfg1[1]), cfg1[2], ignore_label, _p(work), _p(out),
+         work=_ops._TIMING is not None and (f'ohem2_up_fwd P{P}', _nb(src0, src1, target) + (1 + 5 * 8) * P, 80 * P,
+                                            'ohem2_prob_kernel'))
+    return out, work
+
+
+def ohem2_up_bwd(src0, src1, hw, work, out, dloss0, dloss1, lw0, lw1, ignore_label=255):
+    """-> (dsrc0, dsrc1): the adjoint of the exact 2x resize applied to both loss gradients (never materialised)."""
+    lib = _lib.get_lib()
+    N, Hs, Ws, _ = src0.shape
+    H, W = hw
+    if H != 2 * Hs or W != 2 * Ws:
+        raise LednError('ohem2_up_bwd: exact 2x resize only')
+    d0, d1 = torch.empty_like(src0), torch.empty_like(src1)
+    g0 = dloss0.reshape(1).to(torch.float32).contiguous()
+    g1 = dloss1.reshape(1).to(torch.float32).contiguous()
+    _check(lib, src0, src1, work, out, g0, g1, d0, d1)
+    _run(lib, 'ledn_ohem2_up_bwd', src0, _p(src0), _p(src1), N, Hs, Ws, H, W, ignore_label, _p(work), _p(out), _p(g0), _p(g1),
+         lw0, lw1, _p(d0), _p(d1),
+         work=_ops._TIMING is not None and (f'ohem2_up_bwd P{N * H * W}', _nb(src0, src1, d0, d1) + 9 * N * H * W,
+                                            60 * N * H * W, 'ohem2_bwd_up2_kernel'))
+    return d0, d1
+
+
 def mfaf_ctx_fwd(pooled, seqs, training, stats1=None, momentum=0.1, tails=None):
     """The four pooled-context MLPs of Muti_AFF in one launch sequence (ledn_mfaf_ctx_fwd).
     pooled: 4 f32 [N,S,S,C] maps; seqs: 4 x (conv1, bn1, conv2) modules.  -> (z2 list [N,S,S,C] f32, saved dict)

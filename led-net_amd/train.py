@@ -1239,7 +1239,33 @@ class OhemUpFn(Function):
         return T.ohem_ce_up_bwd(src, target, work, out, dloss, ctx.cfg[0], ctx.cfg[1]), None, None, None, None, None
 
 
+class OhemUp2Fn(Function):
+    """Both OhemCrossEntropy losses of LEDHead.loss_by_feat on resize(src_k -> label size) in one launch set
+    (ledn_ohem2_up_fwd / _bwd): shared label reads (uint8 copy), no per-pixel loss array."""
+
+    @staticmethod
+    def forward(ctx, src0, src1, target, cfg0, cfg1, ignore_label):
+        out, work = T.ohem2_up_fwd(src0, src1, target, cfg0, cfg1, ignore_label)
+        ctx.save_for_backward(src0, src1, work, out)
+        ctx.cfg = (cfg0[2], cfg1[2], ignore_label, (int(target.shape[1]), int(target.shape[2])))
+        ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
+        return out[0, 0].clone(), out[1, 0].clone(), out
+
+    @staticmethod
+    def backward(ctx, dl0, dl1, _dout):
+        src0, src1, work, out = ctx.saved_tensors
+        lw0, lw1, ign, hw = ctx.cfg
+        zero = None
+        if dl0 is None or dl1 is None:          # (one of the losses not part of the objective: its gradient is zero)
+            zero = torch.zeros(1, dtype=torch.float32, device=src0.device)
+        d0, d1 = T.ohem2_up_bwd(src0, src1, hw, work, out, dl0 if dl0 is not None else zero,
+                                dl1 if dl1 is not None else zero, lw0, lw1, ign)
+        return d0, d1, None, None, None, None
+
+
 FUSE_LOSS_RESIZE = int(_os.environ.get('LEDN_FUSE_LOSS_RESIZE', '1'))
+FUSE_LOSS_PAIR = int(_os.environ.get('LEDN_FUSE_LOSS_PAIR', '1'))     # both losses in one launch set (ohem_fused.hip)
 
 
 def led_head_loss_by_feat(h, seg_logits, batch_data_samples):
@@ -1261,6 +1287,10 @@ def led_head_loss_by_feat(h, seg_logits, batch_data_samples):
         # the last (exact 2x) resize of each fused output runs inside the loss kernels: the full-resolution logits
         # and their gradient are never written
         ctx2, spa2 = fuse_loss_half(xc, h1, h2, hw), fuse_loss_half(xs, h1, h2, hw)
+        if (FUSE_LOSS_PAIR and W % 4 == 0 and c0.ignore_label == c1.ignore_label and 0 <= c0.ignore_label <= 255):
+            l0, l1, out = OhemUp2Fn.apply(ctx2, spa2, y, (c0.thresh, c0.min_kept, c0.loss_weight),
+                                          (c1.thresh, c1.min_kept, c1.loss_weight), c0.ignore_label)
+            return {'loss_context': l0, 'loss_spatial': l1, 'acc_seg': out[0, 1:2]}
         l0, out0 = OhemUpFn.apply(ctx2, y, c0.thresh, c0.min_kept, c0.loss_weight, c0.ignore_label)
         l1, _ = OhemUpFn.apply(spa2, y, c1.thresh, c1.min_kept, c1.loss_weight, c1.ignore_label)
         return {'loss_context': l0, 'loss_spatial': l1, 'acc_seg': out0[1:2]}
