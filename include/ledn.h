@@ -180,6 +180,24 @@ typedef struct {
 } ledn_wgrad_desc;
 int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream);
 int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d);   /* same query for the weight gradient */
+/* Deferred reduction of the weight gradient.  ledn_conv2d_wgrad runs the MFMA kernel (per-workgroup partial tiles into the
+ * stream's workspace) and then a small summing launch -- ~55 of them per training step, each on the critical path of the
+ * stream although nothing reads dW before the optimizer.  ledn_conv2d_wgrad_partial instead writes the partial tiles into a
+ * CALLER-OWNED buffer (`part`, at least ledn_conv2d_wgrad_partial_floats(d) floats, private to this convolution until the
+ * finish) and fills `entry`; ledn_conv2d_wgrad_finish_multi then sums every recorded convolution into its dW in ONE launch
+ * (table_dev: the entries in device memory with chunk0 = running sum of pairs * KK * 16 over the entries before,
+ * total_chunks = that sum over all).  Bias gradients (d->db) are formed at once as in ledn_conv2d_wgrad.
+ * ledn_conv2d_wgrad_partial_floats returns 0 when the descriptor does not take the MFMA path (use ledn_conv2d_wgrad). */
+typedef struct {
+    const float* part;
+    float* dw;
+    long long ws_co, ws_ci, ws_tap;
+    int nbx, pairs, KK, ci_tiles, Cin, Cout, groups, chunk0;
+} ledn_wgrad_finish_entry;
+long long ledn_conv2d_wgrad_partial_floats(const ledn_wgrad_desc* d);
+int ledn_conv2d_wgrad_partial(const ledn_wgrad_desc* d, float* part, long long part_floats,
+                              ledn_wgrad_finish_entry* entry, void* stream);
+int ledn_conv2d_wgrad_finish_multi(const ledn_wgrad_finish_entry* table_dev, int n, int total_chunks, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Depthwise convolution (KxK, per-channel-group dilation, pad = dil*(K-1)/2

@@ -42,6 +42,12 @@ class WgradDesc(C.Structure):
                 ('in_act', i32), ('dtype_x', i32), ('dtype_dz', i32), ('in_slope', fp)]
 
 
+class WgradFinishEntry(C.Structure):
+    _fields_ = [('part', fp), ('dw', fp), ('ws_co', i64), ('ws_ci', i64), ('ws_tap', i64),
+                ('nbx', i32), ('pairs', i32), ('KK', i32), ('ci_tiles', i32), ('Cin', i32), ('Cout', i32),
+                ('groups', i32), ('chunk0', i32)]
+
+
 class DwDesc(C.Structure):
     _fields_ = [('x', vp), ('w', fp), ('y', vp), ('out_scale', fp), ('out_shift', fp), ('slope', fp),
                 ('stat_sum', fp), ('stat_sqsum', fp),
@@ -173,6 +179,9 @@ _PROTOS = {
     'ledn_conv2d_deferred_stats': ([C.POINTER(ConvDesc), C.POINTER(C.c_void_p), C.POINTER(i32), vp], i32),
     'ledn_bn_finalize_rows': ([fp, i32, C.c_double, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, fp, fp, fp, fp, i32, vp], i32),
     'ledn_conv2d_wgrad_uses_mfma': ([C.POINTER(WgradDesc)], i32),
+    'ledn_conv2d_wgrad_partial_floats': ([C.POINTER(WgradDesc)], i64),
+    'ledn_conv2d_wgrad_partial': ([C.POINTER(WgradDesc), fp, i64, C.POINTER(WgradFinishEntry), vp], i32),
+    'ledn_conv2d_wgrad_finish_multi': ([vp, i32, i32, vp], i32),
     'ledn_pack_conv_weights_multi': ([vp, i32, i64, vp], i32),
     'ledn_im2col_stem': ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_im2col_stem_planar': ([vp, i32, vp, i32, i32, i32, i32, i32, i32, fp, fp, vp, vp, C.c_float, vp], i32),

@@ -7,6 +7,9 @@ int conv_validate(const ledn_conv_desc& d);
 int conv_direct(const ledn_conv_desc& d, hipStream_t s);
 bool conv_mfma_supported(const ledn_conv_desc& d);
 int conv_mfma(const ledn_conv_desc& d, hipStream_t s);
+int conv_wgrad_mfma_partial(const ledn_wgrad_desc& d, float* part, long long part_floats, ledn_wgrad_finish_entry* entry,
+                            bool query, hipStream_t s);
+int conv_wgrad_finish_multi_impl(const ledn_wgrad_finish_entry* table_dev, int n, int total_chunks, hipStream_t s);
 bool conv1x1_reg_supported(const ledn_conv_desc& d);
 int conv1x1_reg(const ledn_conv_desc& d, hipStream_t s);
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d);
@@ -263,6 +266,25 @@ int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream) {
                                   nullptr, S(stream));
     }
     return conv_wgrad_direct(*d, S(stream));
+}
+
+long long ledn_conv2d_wgrad_partial_floats(const ledn_wgrad_desc* d) {
+    if (!d || wgrad_validate(*d) != LEDN_OK || conv_wgrad_cout2_supported(*d) || !wgrad_mfma_supported(*d)) return 0;
+    ledn_wgrad_finish_entry e;
+    if (conv_wgrad_mfma_partial(*d, nullptr, 0, &e, true, nullptr) != LEDN_OK || e.nbx <= 4) return 0;
+    return (long long)e.nbx * e.pairs * e.KK * 1024;
+}
+int ledn_conv2d_wgrad_partial(const ledn_wgrad_desc* d, float* part, long long part_floats,
+                              ledn_wgrad_finish_entry* entry, void* stream) {
+    if (!d || !part || !entry) return LEDN_EINVAL;
+    if (ledn_conv2d_wgrad_partial_floats(d) <= 0) return LEDN_EINVAL;
+    const int rc = conv_wgrad_mfma_partial(*d, part, part_floats, entry, false, S(stream));
+    if (rc != LEDN_OK || !d->db) return rc;
+    return channel_stats_impl(d->dz, nullptr, (long long)d->N * d->Ho * d->Wo, d->Cout, d->dtype_dz, d->db, nullptr,
+                              S(stream));
+}
+int ledn_conv2d_wgrad_finish_multi(const ledn_wgrad_finish_entry* table_dev, int n, int total_chunks, void* stream) {
+    return conv_wgrad_finish_multi_impl(table_dev, n, total_chunks, S(stream));
 }
 
 int ledn_iou_hist(const unsigned char* pred, const long long* label, long long P, int num_classes,

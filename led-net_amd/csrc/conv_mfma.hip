@@ -1352,8 +1352,17 @@ bool wgrad_mfma_supported(const ledn_wgrad_desc& d) {
     return d.stride == 1 || d.stride == 2;
 }
 
+// deferred reduction (ledn_conv2d_wgrad_partial): the partial tiles go to a caller-owned buffer and the summing launch is
+// left to ledn_conv2d_wgrad_finish_multi (one launch for every convolution of the backward pass)
+struct WgradDefer {
+    float* part;                     // caller's buffer (nullptr: classic path)
+    long long part_floats;
+    ledn_wgrad_finish_entry* entry;  // filled on success
+    bool query;                      // only report the buffer size in entry->nbx/pairs/KK
+};
+
 template <int K, int S>
-static int launch_wgrad(MfmaWgradArgs a, hipStream_t s) {
+static int launch_wgrad(MfmaWgradArgs a, hipStream_t s, WgradDefer* df = nullptr) {
     a.tiles_h = (int)cdiv(a.Ho, S == 2 ? 4 : 8);
     a.tiles_w = (int)cdiv(a.Wo, 32);
     a.ci_tiles = (int)cdiv(a.Cin, 32);
@@ -1366,6 +1375,18 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s) {
     a.tiles_per_block = (int)cdiv(ntiles, blocks_x);
     const int nbx = (int)cdiv(ntiles, a.tiles_per_block);
     const dim3 grid((unsigned)nbx, (unsigned)pairs);
+    if (df) {
+        ledn_wgrad_finish_entry& e = *df->entry;
+        e.nbx = nbx; e.pairs = pairs; e.KK = K * K; e.ci_tiles = a.ci_tiles; e.Cin = a.Cin; e.Cout = a.Cout;
+        e.groups = a.groups; e.chunk0 = 0;
+        e.ws_co = a.ws_co; e.ws_ci = a.ws_ci; e.ws_tap = a.ws_tap;
+        e.dw = a.dw; e.part = df->part;
+        if (df->query) return LEDN_OK;
+        if (!df->part || df->part_floats < (long long)nbx * pairs * K * K * 1024) return LEDN_EINVAL;
+        a.part = df->part;
+        LEDN_LAUNCH((conv_wgrad_mfma_kernel<K, S>), grid, dim3(256), 0, s, a);
+        return check_launch();
+    }
     a.part = nbx > 4 ? ws_take((long)nbx * pairs * K * K * 1024) : nullptr;
     LEDN_LAUNCH((conv_wgrad_mfma_kernel<K, S>), grid, dim3(256), 0, s, a);
     if (a.part)
@@ -1374,7 +1395,16 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s) {
     return check_launch();
 }
 
-int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s) {
+static int conv_wgrad_mfma_x(const ledn_wgrad_desc& d, hipStream_t s, WgradDefer* df);
+int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s) { return conv_wgrad_mfma_x(d, s, nullptr); }
+// -> entry filled; query: no launch
+int conv_wgrad_mfma_partial(const ledn_wgrad_desc& d, float* part, long long part_floats, ledn_wgrad_finish_entry* entry,
+                            bool query, hipStream_t s) {
+    WgradDefer df = {part, part_floats, entry, query};
+    return conv_wgrad_mfma_x(d, s, &df);
+}
+
+static int conv_wgrad_mfma_x(const ledn_wgrad_desc& d, hipStream_t s, WgradDefer* df) {
     MfmaWgradArgs a;
     a.x = (const bf16_t*)d.x; a.dz = (const bf16_t*)d.dz; a.dw = d.dw;
     a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_slope = d.in_slope;
@@ -1383,8 +1413,65 @@ int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s) {
     a.pad = d.pad; a.in_act = d.in_act; a.groups = d.groups;
     a.tiles_h = a.tiles_w = a.tiles_per_block = a.ci_tiles = 0;
     a.part = nullptr;
-    if (d.KH == 3) return d.stride == 1 ? launch_wgrad<3, 1>(a, s) : launch_wgrad<3, 2>(a, s);
-    return d.stride == 1 ? launch_wgrad<1, 1>(a, s) : launch_wgrad<1, 2>(a, s);
+    if (d.KH == 3) return d.stride == 1 ? launch_wgrad<3, 1>(a, s, df) : launch_wgrad<3, 2>(a, s, df);
+    return d.stride == 1 ? launch_wgrad<1, 1>(a, s, df) : launch_wgrad<1, 2>(a, s, df);
+}
+
+// One launch for the deferred reductions of a whole backward pass.  Workgroup (1024 lanes) = 64 consecutive elements of
+// one (co, ci) tile pair of one table entry x 16 row groups, exactly as conv_wgrad_finish_kernel; the entry is found from
+// the chunk prefix (chunk0) of the table.
+__global__ void __launch_bounds__(1024) conv_wgrad_finish_multi_kernel(const ledn_wgrad_finish_entry* tab, int n) {
+    __shared__ float s_red[16][64];
+    __shared__ int s_e;
+    if (threadIdx.x < 64) {
+        int cnt = 0;
+        for (int i = threadIdx.x; i < n; i += 64) cnt += tab[i].chunk0 <= (int)blockIdx.x ? 1 : 0;
+        cnt = (int)wave_sum((float)cnt);
+        if (threadIdx.x == 0) s_e = cnt - 1;
+    }
+    __syncthreads();
+    const ledn_wgrad_finish_entry e = tab[s_e];
+    const int KK = e.KK, per_pair = KK * 16;                  // 64-element chunks per tile pair
+    const int local = (int)blockIdx.x - e.chunk0;
+    const int pair = local / per_pair, cx = local % per_pair;
+    const int ci_tile = pair % e.ci_tiles, co_tile = pair / e.ci_tiles;
+    const int ci0 = ci_tile * 32, co0 = co_tile * 32;
+    const int cig = e.Cin / e.groups, cog = e.Cout / e.groups;
+    if (e.groups > 1) {
+        const int g_lo = co0 / cog, g_hi = min(co0 + 31, e.Cout - 1) / cog;
+        if (ci0 + 31 < g_lo * cig || ci0 >= (g_hi + 1) * cig) return;
+    }
+    const int el = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int el_idx = cx * 64 + el;
+    const long stride = (long)e.pairs * (KK * 1024);
+    const float* src = e.part + (long)pair * (KK * 1024) + el_idx;
+    float acc = 0.f;
+    int b = rg;
+    for (; b + 112 < e.nbx; b += 128) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(long)(b + 16 * u) * stride];
+        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; b < e.nbx; b += 16) acc += src[(long)b * stride];
+    s_red[rg][el] = acc;
+    __syncthreads();
+    if (rg != 0) return;
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += s_red[r][el];
+    const int tap = el_idx / 1024, co = co0 + (el_idx / 32) % 32, ci = ci0 + el_idx % 32;
+    if (co >= e.Cout || ci >= e.Cin) return;
+    const int g = co / cog;
+    if (ci / cig != g) return;
+    float* dst = e.dw + (long)co * e.ws_co + (long)(ci - g * cig) * e.ws_ci + (long)tap * e.ws_tap;
+    *dst += t;
+}
+
+int conv_wgrad_finish_multi_impl(const ledn_wgrad_finish_entry* table_dev, int n, int total_chunks, hipStream_t s) {
+    LEDN_REQUIRE(table_dev && n > 0 && total_chunks > 0);
+    LEDN_LAUNCH(conv_wgrad_finish_multi_kernel, dim3((unsigned)total_chunks), dim3(1024), 0, s, table_dev, n);
+    return check_launch();
 }
 
 }  // namespace ledn

@@ -29,7 +29,7 @@ namespace ledn {
 
 constexpr int O2_BINS = 2048;
 constexpr int O2_REP = 16;          // replicas of the histograms / counters (workgroup b uses replica b % O2_REP)
-constexpr int O2_GRID = 1024;       // persistent workgroups of the per-pixel passes (4 per CU)
+constexpr int O2_GRID = 1024;       // persistent workgroups of the per-pixel passes (4 per CU; 2048 measured slower)
 
 struct Ohem2Work {
     float* prob[2];
@@ -54,8 +54,14 @@ __host__ __device__ inline Ohem2Work o2_work(float* work, long long P) {
 constexpr long long O2_CLEAR_WORDS = 2LL * 3 * O2_REP * O2_BINS + O2_REP * 2;     // histograms + counters (zeroed per call)
 long long ohem2_work_floats(long long P) { return 2 * P + o2_lab_floats(P) + O2_CLEAR_WORDS + O2_GRID * 4 + 32; }
 
+// radix digits of the probability's f32 bit pattern, most significant first: 11 + 11 + 8 bits starting at bit 29.  A
+// probability is <= 1.0 = 0x3F800000 < 2^30, so bits 31..30 carry nothing; starting the first digit there (as the
+// single-loss kernels do: 11 + 11 + 10 from bit 31) leaves it two mantissa bits -- four bins per octave, and at random
+// initialisation (p ~ 0.5) a wave's 64 LDS atomics land on ~5 addresses.  From bit 29 it has four mantissa bits.
+constexpr int O2_SH0 = 19, O2_SH1 = 8;
+constexpr unsigned O2_MASK1 = 0xfff80000u, O2_MASK2 = 0xffffff00u;     // prefix bits known after level 0 / level 1
 __device__ __forceinline__ int o2_bin(unsigned u, int pass) {
-    return pass == 0 ? (int)(u >> 21) : (pass == 1 ? (int)((u >> 10) & 2047u) : (int)(u & 1023u));
+    return pass == 0 ? (int)(u >> O2_SH0) : (pass == 1 ? (int)((u >> O2_SH1) & 2047u) : (int)(u & 255u));
 }
 
 // lerp_coord (ledn_rt.h) with the scale in / out formed once by the caller: the same expressions, bit-identical
@@ -71,15 +77,19 @@ __device__ __forceinline__ Lerp o2_lerp(int dst, int in, float scale) {
     return l;
 }
 
+__device__ __forceinline__ float2 o2_mix(float wy0, float wy1, float wx0, float wx1, float2 v00, float2 v01, float2 v10,
+                                          float2 v11) {
+    float2 r;
+    r.x = wy0 * (wx0 * v00.x + wx1 * v01.x) + wy1 * (wx0 * v10.x + wx1 * v11.x);
+    r.y = wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
+    return r;
+}
 __device__ __forceinline__ float2 o2_up(const float* src, int Ws, const Lerp& ly, const Lerp& lx) {
     const float2 v00 = *reinterpret_cast<const float2*>(src + ((long)ly.i0 * Ws + lx.i0) * 2);
     const float2 v01 = *reinterpret_cast<const float2*>(src + ((long)ly.i0 * Ws + lx.i1) * 2);
     const float2 v10 = *reinterpret_cast<const float2*>(src + ((long)ly.i1 * Ws + lx.i0) * 2);
     const float2 v11 = *reinterpret_cast<const float2*>(src + ((long)ly.i1 * Ws + lx.i1) * 2);
-    float2 r;
-    r.x = ly.w0 * (lx.w0 * v00.x + lx.w1 * v01.x) + ly.w1 * (lx.w0 * v10.x + lx.w1 * v11.x);
-    r.y = ly.w0 * (lx.w0 * v00.y + lx.w1 * v01.y) + ly.w1 * (lx.w0 * v10.y + lx.w1 * v11.y);
-    return r;
+    return o2_mix(ly.w0, ly.w1, lx.w0, lx.w1, v00, v01, v10, v11);
 }
 
 // pass over the pixels, four per thread (W % 4 == 0: a quad never crosses a row): probabilities of the target class for
@@ -98,6 +108,7 @@ __global__ void __launch_bounds__(256) ohem2_prob_kernel(const float* src0, cons
     unsigned nvalid = 0u, ncorr = 0u;
     const int rows = N * H, qpr = W / 4;
     const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;
+    const bool exact2x = H == 2 * Hs && W == 2 * Ws;
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
         const int n = r / H, y = r - n * H;
         const Lerp ly = o2_lerp(y, Hs, sy);
@@ -117,15 +128,39 @@ __global__ void __launch_bounds__(256) ohem2_prob_kernel(const float* src0, cons
             }
             float pr[2][4];
             unsigned lab = 0u;
+            // exact 2x resize, quad away from the left / right border: pixels 4q .. 4q+3 interpolate source columns
+            // 2q-1 .. 2q+2 with the weights (.25 .75) (.75 .25) (.25 .75) (.75 .25) -- what o2_lerp returns there
+            // (scale 0.5: every coordinate is an exact multiple of 0.25), so the eight source values of a row pair are
+            // loaded once per quad instead of four gathers per pixel and no coordinate arithmetic is left
+            const bool fast = exact2x && qx >= 1 && qx < qpr - 1;
+            float2 c[2][2][4];           // [source][row][column 2q-1+i]
+            if (fast) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const float* rowp2 = (j ? s1 : s0) + ((long)(rr ? ly.i1 : ly.i0) * Ws + 2 * qx - 1) * 2;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) c[j][rr][i] = *reinterpret_cast<const float2*>(rowp2 + 2 * i);
+                    }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const bool ok = tg[k] != ignore_label;
                 lab |= ((unsigned)tg[k] & 0xffu) << (8 * k);
-                const Lerp lx = o2_lerp(4 * qx + k, Ws, sx);
+                Lerp lx;
+                if (!fast) lx = o2_lerp(4 * qx + k, Ws, sx);
                 const int t = ok ? (int)tg[k] : 0;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float2 lg = o2_up(j ? s1 : s0, Ws, ly, lx);
+                    float2 lg;
+                    if (fast) {
+                        constexpr int ci[4] = {0, 1, 1, 2};
+                        const float wx1 = (k & 1) ? 0.25f : 0.75f, wx0 = 1.f - wx1;
+                        lg = o2_mix(ly.w0, ly.w1, wx0, wx1, c[j][0][ci[k]], c[j][0][ci[k] + 1], c[j][1][ci[k]], c[j][1][ci[k] + 1]);
+                    } else {
+                        lg = o2_up(j ? s1 : s0, Ws, ly, lx);
+                    }
                     const int am = lg.y > lg.x ? 1 : 0;
                     const float mx = am ? lg.y : lg.x;
                     const float se = __expf(lg.x - mx) + __expf(lg.y - mx);
@@ -195,15 +230,35 @@ __global__ void __launch_bounds__(256) ohem2_scan_kernel(float* work, long P, in
     }
     const unsigned prefix_bits = pass == 0 ? 0u : st[3];
     const unsigned* h = wk.hist + (long)(L * 3 + pass) * O2_REP * O2_BINS;
-    const int nb = pass == 2 ? 1024 : 2048;
+    const int nb = pass == 2 ? 256 : 2048;
     const int per = nb / 256;
     unsigned hb[8], mine = 0u;
+    if (pass == 2) {                     // one bin per thread
+        unsigned v[O2_REP];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        hb[i] = 0u;
-        if (i < per)
-            for (int r = 0; r < O2_REP; ++r) hb[i] += h[r * O2_BINS + threadIdx.x * per + i];
-        mine += hb[i];
+        for (int r = 0; r < O2_REP; ++r) v[r] = h[r * O2_BINS + threadIdx.x];
+        hb[0] = 0u;
+#pragma unroll
+        for (int r = 0; r < O2_REP; ++r) hb[0] += v[r];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) hb[i] = 0u;
+        mine = hb[0];
+    } else {                             // eight consecutive bins per thread: two 16-byte loads per replica, all in flight
+        uint4 v[O2_REP][2];
+#pragma unroll
+        for (int r = 0; r < O2_REP; ++r) {
+            v[r][0] = *reinterpret_cast<const uint4*>(h + r * O2_BINS + threadIdx.x * 8);
+            v[r][1] = *reinterpret_cast<const uint4*>(h + r * O2_BINS + threadIdx.x * 8 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hb[i] = 0u;
+#pragma unroll
+        for (int r = 0; r < O2_REP; ++r) {
+            hb[0] += v[r][0].x; hb[1] += v[r][0].y; hb[2] += v[r][0].z; hb[3] += v[r][0].w;
+            hb[4] += v[r][1].x; hb[5] += v[r][1].y; hb[6] += v[r][1].z; hb[7] += v[r][1].w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mine += hb[i];
     }
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     unsigned incl = mine;
@@ -235,7 +290,7 @@ __global__ void __launch_bounds__(256) ohem2_scan_kernel(float* work, long P, in
         b = nb - 1;
     }
     if (b >= 0) {
-        const unsigned bits = pass == 0 ? ((unsigned)b << 21) : (pass == 1 ? ((unsigned)b << 10) : (unsigned)b);
+        const unsigned bits = pass == 0 ? ((unsigned)b << O2_SH0) : (pass == 1 ? ((unsigned)b << O2_SH1) : (unsigned)b);
         const unsigned full = prefix_bits | bits;
         st[3] = full;
         st[2] = r;
@@ -253,7 +308,7 @@ __global__ void __launch_bounds__(256) ohem2_hist_kernel(float* work, long P, in
     for (int i = threadIdx.x; i < 2 * O2_BINS; i += blockDim.x) (&s_hist[0][0])[i] = 0u;
     __syncthreads();
     const unsigned prefix[2] = {w.state[3], w.state[16 + 3]};
-    const unsigned mask = pass == 1 ? 0xffe00000u : 0xfffffc00u;
+    const unsigned mask = pass == 1 ? O2_MASK1 : O2_MASK2;
     const long nq = P / 4, stride = (long)gridDim.x * blockDim.x;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
 #pragma unroll
@@ -376,55 +431,53 @@ int ohem2_up_fwd_impl(const float* src0, const float* src1, int N, int Hs, int W
 
 // Backward (exact 2x): a workgroup owns a 16 x 16 tile of the half-resolution maps; the softmax gradients of its
 // 34 x 34 children are formed once in LDS for BOTH losses (labels: the uint8 plane; selection: stored probability
-// < threshold), then every source pixel gathers its 4 x 4 children with the interpolation weights.
-__global__ void __launch_bounds__(256) ohem2_bwd_up2_kernel(const float* src0, const float* src1, int N, int Hs, int Ws,
+// < threshold; the gradient itself from the stored probability), then every source pixel gathers its 4 x 4 children
+// with the interpolation weights.  src0 / src1 are not read.
+__global__ void __launch_bounds__(512) ohem2_bwd_up2_kernel(const float* src0, const float* src1, int N, int Hs, int Ws,
                                                             int ignore_label, const float* work, const float* out,
                                                             const float* dloss0, const float* dloss1, float lw0,
                                                             float lw1, float* dsrc0, float* dsrc1) {
-    constexpr int T = 16, CH = 2 * T + 2;
-    __shared__ float4 s_g[CH * CH];                           // (g0.x, g0.y, g1.x, g1.y) of one child
+    // 8 x 64 source pixels per workgroup: the 18 x 130 children are read as 520-byte row segments (the first version's
+    // 16 x 16 tile read 136-byte segments at a 4 KB stride: two cache lines for 34 floats, 99 us at 2.2 TB/s)
+    constexpr int TH = 8, TW = 64, CHH = 2 * TH + 2, CHW = 2 * TW + 2;
+    __shared__ float4 s_g[CHH * CHW];                         // (g0.x, g0.y, g1.x, g1.y) of one child
     const int H = 2 * Hs, W = 2 * Ws;
     const long P = (long)N * H * W;
     const Ohem2Work w = o2_work(const_cast<float*>(work), P);
-    const int tw = (Ws + T - 1) / T, th = (Hs + T - 1) / T;
+    const int tw = (Ws + TW - 1) / TW, th = (Hs + TH - 1) / TH;
     const int bj = blockIdx.x % tw, bi = (blockIdx.x / tw) % th, n = blockIdx.x / (tw * th);
-    const int i0 = bi * T, j0 = bj * T;
+    const int i0 = bi * TH, j0 = bj * TW;
     const float thr0 = out[2], thr1 = out[4 + 2];
     const float coef0 = dloss0[0] * lw0 / out[3], coef1 = dloss1[0] * lw1 / out[4 + 3];
-    const float* sn0 = src0 + (long)n * Hs * Ws * 2;
-    const float* sn1 = src1 + (long)n * Hs * Ws * 2;
+    (void)src0; (void)src1;
     const float sy = (float)Hs / (float)H, sx = (float)Ws / (float)W;
-    for (int k = threadIdx.x; k < CH * CH; k += 256) {
-        const int y = 2 * i0 - 1 + k / CH, x = 2 * j0 - 1 + k % CH;
+    for (int k = threadIdx.x; k < CHH * CHW; k += 512) {
+        const int y = 2 * i0 - 1 + k / CHW, x = 2 * j0 - 1 + k % CHW;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (y >= 0 && y < H && x >= 0 && x < W) {
             const long p = ((long)n * H + y) * W + x;
             const int tg = w.lab8[p];
             if (tg != ignore_label) {
-                const bool sel0 = w.prob[0][p] < thr0, sel1 = w.prob[1][p] < thr1;
-                if (sel0 || sel1) {
-                    const Lerp ly = o2_lerp(y, Hs, sy), lx = o2_lerp(x, Ws, sx);
-                    if (sel0) {
-                        const float2 l = o2_up(sn0, Ws, ly, lx);
-                        const float mx = fmaxf(l.x, l.y);
-                        const float e0 = __expf(l.x - mx), e1 = __expf(l.y - mx), inv = 1.f / (e0 + e1);
-                        g.x = coef0 * (e0 * inv - (tg == 0 ? 1.f : 0.f));
-                        g.y = coef0 * (e1 * inv - (tg == 1 ? 1.f : 0.f));
-                    }
-                    if (sel1) {
-                        const float2 l = o2_up(sn1, Ws, ly, lx);
-                        const float mx = fmaxf(l.x, l.y);
-                        const float e0 = __expf(l.x - mx), e1 = __expf(l.y - mx), inv = 1.f / (e0 + e1);
-                        g.z = coef1 * (e0 * inv - (tg == 0 ? 1.f : 0.f));
-                        g.w = coef1 * (e1 * inv - (tg == 1 ? 1.f : 0.f));
-                    }
+                // two classes: softmax = (p_t, 1 - p_t) with p_t the STORED probability of the target class, so
+                // softmax - onehot = -(1 - p_t) at the target class and +(1 - p_t) at the other: no logits, no
+                // interpolation, no exponentials in the backward (the first version re-formed them: 143 us, VALU-bound)
+                const float p0 = w.prob[0][p], p1 = w.prob[1][p];
+                if (p0 < thr0) {
+                    const float d = coef0 * (1.f - p0);
+                    g.x = tg == 0 ? -d : d;
+                    g.y = tg == 1 ? -d : d;
+                }
+                if (p1 < thr1) {
+                    const float d = coef1 * (1.f - p1);
+                    g.z = tg == 0 ? -d : d;
+                    g.w = tg == 1 ? -d : d;
                 }
             }
         }
         s_g[k] = g;
     }
     __syncthreads();
-    const int a = threadIdx.x / T, b = threadIdx.x % T, i = i0 + a, j = j0 + b;
+    const int a = threadIdx.x / TW, b = threadIdx.x % TW, i = i0 + a, j = j0 + b;
     if (i >= Hs || j >= Ws) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float wys[4], wxs[4];         // the interpolation weight of child (dy, dx) onto this source pixel = wys[dy] * wxs[dx]
@@ -446,7 +499,7 @@ __global__ void __launch_bounds__(256) ohem2_bwd_up2_kernel(const float* src0, c
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx) {
             const float wgt = wys[dy] * wxs[dx];
-            const float4 g = s_g[(2 * a + dy) * CH + 2 * b + dx];
+            const float4 g = s_g[(2 * a + dy) * CHW + 2 * b + dx];
             acc.x += wgt * g.x;
             acc.y += wgt * g.y;
             acc.z += wgt * g.z;
@@ -463,9 +516,9 @@ int ohem2_up_bwd_impl(const float* src0, const float* src1, int N, int Hs, int W
                       float lw1, float* dsrc0, float* dsrc1, hipStream_t s) {
     LEDN_REQUIRE(src0 && src1 && work && out && dloss0 && dloss1 && dsrc0 && dsrc1 && N > 0 && Hs > 0 && Ws > 0);
     LEDN_REQUIRE(H == 2 * Hs && W == 2 * Ws);               // the fused adjoint is written for the exact 2x resize
-    const long nb = (long)N * cdiv(Hs, 16) * cdiv(Ws, 16);
+    const long nb = (long)N * cdiv(Hs, 8) * cdiv(Ws, 64);
     LEDN_REQUIRE(nb < (1L << 31));
-    LEDN_LAUNCH(ohem2_bwd_up2_kernel, dim3((unsigned)nb), dim3(256), 0, s, src0, src1, N, Hs, Ws, ignore_label, work,
+    LEDN_LAUNCH(ohem2_bwd_up2_kernel, dim3((unsigned)nb), dim3(512), 0, s, src0, src1, N, Hs, Ws, ignore_label, work,
                 out, dloss0, dloss1, lw0, lw1, dsrc0, dsrc1);
     return check_launch();
 }

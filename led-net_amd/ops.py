@@ -379,6 +379,46 @@ def pack_conv_weights(w, mode=0, groups=1):
     return out
 
 
+class WgradDefer:
+    """Deferred reduction of the convolution weight gradients (ledn_conv2d_wgrad_partial / _finish_multi).  While
+    `active`, conv2d_wgrad calls whose gradient goes into a persistent sink (`dw_out`: the Trainer's flat gradient
+    buffer) only run the main MFMA kernel -- partial tiles into a buffer owned by that convolution -- and record a
+    table entry; finish() sums all of them into their sinks with ONE launch (instead of one small launch per
+    convolution on the critical stream: ~55 per step).  The buffers and the device table persist from step to step
+    (the same convolutions arrive in the same order), so a captured hipGraph replays them unchanged."""
+    active = False
+    bufs = {}          # (dw.data_ptr(), floats) -> partial-tile buffer
+    pending = []       # [(key, WgradFinishEntry)] of the current step
+    table = None       # (keys, device table tensor, host keep-alive, n, total_chunks)
+
+    @staticmethod
+    def reset():
+        WgradDefer.active, WgradDefer.bufs, WgradDefer.pending, WgradDefer.table = False, {}, [], None
+
+    @staticmethod
+    def finish():
+        """sum every recorded convolution's partial tiles into its gradient sink: one launch"""
+        pend = WgradDefer.pending
+        if not pend:
+            return
+        WgradDefer.pending = []
+        lib = _lib.get_lib()
+        keys = tuple(p[0] for p in pend)
+        tab = WgradDefer.table
+        if tab is None or tab[0] != keys:
+            arr = (_lib.WgradFinishEntry * len(pend))()
+            chunk = 0
+            for i, (_, e, _buf) in enumerate(pend):
+                arr[i] = e
+                arr[i].chunk0 = chunk
+                chunk += e.pairs * e.KK * 16
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            tab = WgradDefer.table = (keys, host.to(pend[0][2].device), len(pend), chunk, pend[0][2])
+        ref = tab[4]
+        _run(lib, 'ledn_conv2d_wgrad_finish_multi', ref, tab[1].data_ptr(), tab[2], tab[3],
+             work=_TIMING is not None and (f'wgrad_finish_multi x{tab[2]}', 0, 0, 'conv_wgrad_finish_multi_kernel'))
+
+
 def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None,
                  in_shift=None, in_act=ACT_NONE, in_slope=None, bias=False, dw_out=None, db_out=None):
     """Returns (dw [OIHW f32], db or None) of conv2d(pre(x), w).  dw_out / db_out: contiguous f32
@@ -407,6 +447,19 @@ def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None,
     d.KH, d.KW, d.stride, d.pad, d.dil, d.groups = KH, KW, stride, pad, dil, groups
     d.in_act, d.dtype_x, d.dtype_dz = in_act, _dt(x), _dt(dz)
     flops = 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW
+    if WgradDefer.active and dw_out is not None:
+        nfl = int(lib.cdll.ledn_conv2d_wgrad_partial_floats(d))
+        if nfl > 0:
+            key = (dw.data_ptr(), nfl)
+            buf = WgradDefer.bufs.get(key)
+            if buf is None:
+                buf = WgradDefer.bufs[key] = torch.empty(nfl, dtype=torch.float32, device=x.device)
+            e = _lib.WgradFinishEntry()
+            _run(lib, 'ledn_conv2d_wgrad_partial', x, d, buf.data_ptr(), nfl, C.byref(e),
+                 work=_TIMING is not None and (f'wgrad{KH}x{KW} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W}',
+                                               _nb(x, xadd, dz, dw), flops, 'conv_wgrad_mfma_kernel'))
+            WgradDefer.pending.append((key, e, buf))
+            return dw, db
     _run(lib, 'ledn_conv2d_wgrad', x, d,
          work=_TIMING is not None and (f'wgrad{KH}x{KW} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W}', _nb(x, xadd, dz, dw), flops,
                                        'conv_wgrad_mfma_kernel' if lib.cdll.ledn_conv2d_wgrad_uses_mfma(d) else 'conv_wgrad_direct'))

@@ -313,6 +313,7 @@ class BNActFn(Function):
         return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None, None, None
 
 
+WGRAD_DEFER = int(_os.environ.get('LEDN_WGRAD_DEFER', '1'))   # one summing launch for all weight gradients of a step (ops.WgradDefer)
 WGRAD_SLOT = int(_os.environ.get('LEDN_WGRAD_SLOT', '0'))   # auxiliary stream of the weight gradients, 0 = launch stream (measured r02n: 782 img/s on its own stream vs 892 on the launch stream)
 
 
@@ -1464,6 +1465,8 @@ class Trainer:
         self._arena.reset()                  # one fill for every small zeroed scratch of the step
         ops.set_zero_arena(self._arena)
         _Sinks.map = self._sink_map
+        ops.WgradDefer.active = bool(WGRAD_DEFER and self._sink_map)
+        ops.WgradDefer.pending = []
         _Env.world = self.world
         _Env.sync_bn = self._sync_bn
         self._ready, self._early_done = {}, False
@@ -1474,6 +1477,7 @@ class Trainer:
     def _leave(self):
         ops.MULTI_STREAM = self._saved_multi_stream
         ops.set_zero_arena(None)
+        ops.WgradDefer.active = False
         _Sinks.map = {}
         _Env.sync_bn = None
         _Env.grad_ready = None
@@ -1542,12 +1546,14 @@ class Trainer:
         if tag == 'post_stem' and self._ready[tag] == 3 and not self._early_done:
             self._early_done = True
             _DwBanks.flush()            # (every depthwise filter lives outside the stem: their gradients are complete)
+            ops.WgradDefer.finish()     # (and the non-stem convolution weight gradients: summed into the buffer now)
             self._exchange(self.n_late, self.flat_grad.numel())
 
     def _forward_backward(self, inputs, data_samples, first):
         if first:
             _Packs.reset()
             _DwBanks.reset()
+            ops.WgradDefer.reset()
             for p in self.params:
                 p.grad = None
         else:
@@ -1563,6 +1569,7 @@ class Trainer:
                 total = v if total is None else total + v
         total.backward()
         _DwBanks.flush()                    # all depthwise bank gradients -> the filters' gradient views, one launch
+        ops.WgradDefer.finish()             # all convolution weight gradients: partial tiles -> gradient views, one launch
         self._join_side_streams()
         if first:
             # Parameters that never receive a gradient (SEAM conv_1: the binarised edge
