@@ -148,6 +148,47 @@ def cpu_baseline(mode, h, w, budget_s=20.0):
                       f'at batch {bs}, {h}x{w}, fp32, torch CPU ops, {cores} threads'}
 
 
+def bf16_parity(h, w, dev):
+    """The north_star's "argmax masks bit-exact" holds for f32 activations (tests/test_parity_argmax.py); for the
+    benched dtype the flip rate is MEASURED here, at the bench image size: one synthetic h x w image cut into its four
+    (h/2) x (w/2) quadrants (the oracle needs ~3 s per quadrant on the host cores), the product's bf16 predict pass
+    against the f32 CPU oracle on the same quadrants.  Checker side only: the oracle never computes a benched value."""
+    from oracle import spec
+    import led_net_amd as L
+    torch.manual_seed(304)
+    cfg = L.load_config(os.path.join(ROOT, 'tests', 'data', 'lednet_test_config.py'))
+    model = L.MODELS.build(cfg['model']).eval()
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():            # non-trivial running statistics / affine parameters, as a trained network has
+        for n, b in model.named_buffers():
+            if n.endswith('running_mean'):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+            elif n.endswith('running_var'):
+                b.copy_(0.6 + 0.8 * torch.rand(b.shape, generator=g))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.set_act_dtype(torch.bfloat16)
+    model.to(dev)
+    img, _ = synthetic_batch(1, h, w, 'cpu')
+    hh, hw = h // 2, w // 2
+    crops = torch.cat([img[:, :, i:i + hh, j:j + hw] for i in (0, hh) for j in (0, hw)]).contiguous()
+    with torch.no_grad():
+        want, want_mask = spec.predict(spec.preprocess(crops), sd)
+        out = model(crops.to(dev), mode='predict')
+    logits = torch.stack([o.seg_logits.data for o in out]).float().cpu()
+    mask = torch.cat([o.pred_sem_seg.data for o in out]).long().cpu()
+    err = (logits - want).abs()
+    scale = want.abs().max().item()
+    margin = (want[:, 0] - want[:, 1]).abs()
+    flips = mask != want_mask
+    return {'what': f'bf16 predict vs f32 CPU oracle, argmax over the four {hh}x{hw} quadrants of one {h}x{w} image',
+            'pixels': int(mask.numel()), 'flips': int(flips.sum()), 'bf16_flip_frac': float(flips.float().mean()),
+            'flip_frac_margin_gt_1pct_of_scale': float((flips & (margin > 0.01 * scale)).float().mean()),
+            'flip_frac_margin_gt_5pct_of_scale': float((flips & (margin > 0.05 * scale)).float().mean()),
+            'max_logit_err_over_scale': round(err.max().item() / scale, 5),
+            'mean_logit_err_over_scale': round(err.mean().item() / scale, 6),
+            'f32_flip_frac': 0.0, 'f32_source': 'tests/test_parity_argmax.py (asserted per run on the GPU)'}
+
+
 def launch_ranks(n):
     """python bench.py --gpus N without a launcher: start `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 bench.py <same arguments>` as a child process, pass its output
@@ -431,6 +472,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(mode, H, W, args.cpu_baseline_seconds)
+            try:
+                out['parity'] = bf16_parity(H, W, dev)
+            except Exception as e:   # noqa: BLE001 -- the parity note must never cost the bench line
+                out['parity'] = {'error': repr(e)}
         if os.environ.get('LEDN_BENCH_VERBOSE'):
             for e, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms']):
                 print(f"{v['ms'] / k_steps:9.3f} ms/step  x{v['n'] // k_steps:4d}  {v['bytes'] / max(1e-9, v['ms']) / 1e6:8.1f} GB/s "

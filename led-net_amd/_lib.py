@@ -281,6 +281,9 @@ def get_lib():
         return _override
     if _hip is None:
         _hip = Library(HIP_LIB_PATH, is_hip=True)
+        for env, opt in (('LEDN_CONV_WGS', 0), ('LEDN_WGRAD_WGS', 1)):      # A/B measurements of the launch-shape knobs
+            if os.environ.get(env) is not None:
+                _hip.set_option(opt, int(os.environ[env]))
         if os.environ.get('LEDN_STREAM_FAST') is not None:      # A/B measurements: bit 0 = BatchNorm / affine streaming
             _hip.set_option(OPT_STREAM_FAST, int(os.environ['LEDN_STREAM_FAST']))   # kernels, bit 1 = LDS-tiled depthwise 3x3
     return _hip
