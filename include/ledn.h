@@ -484,7 +484,14 @@ typedef struct {
      * the separate elementwise add of autograd's gradient fan-in. */
     const void* dz_add;
     const void* dres_add;
+    /* optional, both passes: ZEROED f32 scratch [LEDN_BNBWD_ROWS][3][C].  When given (and the streaming bf16 kernels
+     * take the call) the reduce pass adds its per-workgroup sums into row (workgroup % LEDN_BNBWD_ROWS) with float
+     * atomics and launches NO summing kernel; the apply pass adds the rows up itself (sum_g / sum_gx / dslope then
+     * receive the totals from its first workgroup).  One launch less per BatchNorm backward on the critical stream;
+     * the summation order over rows is fixed, within a row it is the atomics' arrival order. */
+    float* rows;
 } ledn_bnbwd_desc;
+enum { LEDN_BNBWD_ROWS = 32 };
 int ledn_bn_act_bwd_reduce(const ledn_bnbwd_desc* d, void* stream);
 int ledn_bn_act_bwd_apply(const ledn_bnbwd_desc* d, void* stream);
 

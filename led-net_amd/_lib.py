@@ -115,7 +115,10 @@ class BnBwdDesc(C.Structure):
                 ('mean', fp), ('invstd', fp), ('sum_g', fp), ('sum_gx', fp), ('dslope', fp),
                 ('dz', vp), ('dres', vp), ('count', C.c_double), ('P', i64),
                 ('C', i32), ('act', i32), ('res_mode', i32), ('bn_mode', i32),
-                ('dtype_z', i32), ('dtype_y', i32), ('dz_add', vp), ('dres_add', vp)]
+                ('dtype_z', i32), ('dtype_y', i32), ('dz_add', vp), ('dres_add', vp), ('rows', fp)]
+
+
+BNBWD_ROWS = 32     # include/ledn.h LEDN_BNBWD_ROWS
 
 
 class DwBwdDesc(C.Structure):

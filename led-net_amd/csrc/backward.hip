@@ -216,7 +216,20 @@ static long bn_rows(const ledn_bnbwd_desc& d) {
     return 256 / (d.C / V);
 }
 
-int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
+// d.rows (see ledn.h) is honoured only when BOTH passes run on the streaming kernels: the same pure function of the
+// descriptor decides it in the reduce and in the apply call, so the two always agree
+static bool bn_rows_mode(const ledn_bnbwd_desc& d) {
+    if (!d.rows || !(options().stream_fast & 1) || d.act == LEDN_ACT_SIGMOID) return false;
+    if (d.dtype_z != LEDN_BF16 || d.dtype_y != LEDN_BF16) return false;
+    if (d.C < 8 || d.C > 512 || (d.C & (d.C - 1))) return false;
+    if (d.P * d.C / 8 < 4096) return false;
+    if (d.dres != nullptr && d.res_mode == LEDN_RES_NONE) return false;
+    return true;
+}
+
+int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d0, hipStream_t s) {
+    ledn_bnbwd_desc d = d0;
+    if (!bn_rows_mode(d)) d.rows = nullptr;
     const int rc = bnbwd_validate(d, false);
     if (rc != LEDN_OK) return rc;
     if ((options().stream_fast & 1) && d.act != LEDN_ACT_SIGMOID) {
@@ -234,7 +247,9 @@ int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
     return check_launch();
 }
 
-int bn_act_bwd_apply_impl(const ledn_bnbwd_desc& d, hipStream_t s) {
+int bn_act_bwd_apply_impl(const ledn_bnbwd_desc& d0, hipStream_t s) {
+    ledn_bnbwd_desc d = d0;
+    if (!bn_rows_mode(d)) d.rows = nullptr;
     const int rc = bnbwd_validate(d, true);
     if (rc != LEDN_OK) return rc;
     if ((options().stream_fast & 1) && d.act != LEDN_ACT_SIGMOID) {

@@ -164,7 +164,24 @@ __global__ void __launch_bounds__(256) bn_apply_fast_kernel(ledn_bnbwd_desc d, l
         s_par[1][c] = d.shift ? d.shift[c] : 0.f;
         s_par[2][c] = d.slope ? d.slope[c] : 0.f;
         float A = 0.f, B = 0.f;
-        if (d.bn_mode) {
+        if (d.rows) {                        // per-row sums left by the reduce pass: add them up (fixed order)
+            float tg = 0.f, tgx = 0.f, tsl = 0.f;
+            for (int r = 0; r < LEDN_BNBWD_ROWS; ++r) {
+                const float* row = d.rows + (long)r * 3 * d.C;
+                tg += row[c];
+                tgx += row[d.C + c];
+                tsl += row[2 * d.C + c];
+            }
+            if (d.bn_mode) {
+                A = -sc * (tgx * invn) * d.invstd[c];
+                B = -sc * (tg * invn) - A * d.mean[c];
+            }
+            if (blockIdx.x == 0) {           // the totals ARE d_beta, d_gamma, d_slope: accumulated into the sinks once
+                if (d.sum_g) d.sum_g[c] += tg;
+                if (d.sum_gx) d.sum_gx[c] += tgx;
+                if (d.dslope) d.dslope[c] += tsl;
+            }
+        } else if (d.bn_mode) {
             const float mg = d.sum_g[c] * invn, mgx = d.sum_gx[c] * invn;
             A = -sc * mgx * d.invstd[c];
             B = -sc * mg - A * d.mean[c];
@@ -337,7 +354,8 @@ __global__ void __launch_bounds__(256) bn_reduce_fast_kernel(ledn_bnbwd_desc d, 
         if (rr2 < rows) t0 += src[rr2 * cvn * 8];
         float t = t0 + t1;
         if (j == 1) t *= s_par[4][c];
-        part[(long)blockIdx.x * 3 * d.C + o] = t;
+        if (d.rows) atomicAdd(d.rows + (long)(blockIdx.x % LEDN_BNBWD_ROWS) * 3 * d.C + o, t);
+        else part[(long)blockIdx.x * 3 * d.C + o] = t;
     }
 }
 
@@ -349,11 +367,12 @@ int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
     long nb = cdiv(d.P, (long)rows * UNR);           // one trip per lane up to 2048 workgroups
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
-    float* part = ws_take(nb * 3 * d.C);
-    if (!part) return -1;
+    float* part = d.rows ? nullptr : ws_take(nb * 3 * d.C);
+    if (!part && !d.rows) return -1;
     const dim3 grid((unsigned)nb);
     SF_ACT_SWITCH(d.act, SF_RES_SWITCH(d.res_mode,
         LEDN_LAUNCH((bn_reduce_fast_kernel<A_, R_, UNR>), grid, dim3(256), 0, s, d, part)));
+    if (d.rows) return check_launch();       // the apply pass adds the rows up (no summing launch)
     return finish_partials(part, (int)nb, d.C, 3, d.sum_g, d.sum_gx, d.dslope, s);
 }
 

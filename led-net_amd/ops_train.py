@@ -15,6 +15,9 @@ class _BnBwd:
     __slots__ = ('lib', 'd', 'z', 'bn', 'Cc', 'P', 'local', 'sunk', 'dz', 'dres', 'dslope', 'slope_sunk', 'keep')
 
 
+BN_ROWS = int(__import__('os').environ.get('LEDN_BN_ROWS', '0'))   # measured r3k: 13.85 vs 13.85 ms -- the 69 summing launches it removes were not on the critical path; off: keeps the reduction order fixed
+
+
 def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
                       res=None, res_mode=RES_NONE, count=None, want_dres=False, sinks=None, sync=False,
                       dz_add=None, dres_add=None):
@@ -62,11 +65,17 @@ def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, 
     d.P, d.C, d.act = P, Cc, act
     d.res_mode = res_mode if res is not None else RES_NONE
     d.bn_mode, d.dtype_z, d.dtype_y = int(bn), _dt(z), _dt(dy)
+    rows = None
+    if BN_ROWS and not sync and (bn or slope is not None) and z.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16:
+        # the reduce pass leaves per-row sums (float atomics into 32 zeroed rows), the apply pass adds them up: no
+        # summing launch between the two (ledn.h: ledn_bnbwd_desc.rows).  Not under SyncBN: the all-reduce needs totals.
+        rows = _ops.zeros_f32((_lib.BNBWD_ROWS, 3, Cc), z.device)
+        d.rows = _p(rows)
     if bn or slope is not None:
         _run(lib, 'ledn_bn_act_bwd_reduce', z, d, work=_ops._TIMING is not None and (f'bnbwd_reduce C{Cc} P{P}', _nb(z, dy, res), 6 * z.numel()))
     st.lib, st.d, st.z, st.bn, st.Cc, st.P, st.local, st.sunk = lib, d, z, bn, Cc, P, local, sunk
     st.dz, st.dres, st.dslope, st.slope_sunk = dz, dres, dslope, slope_sunk
-    st.keep = (dy, res, scale, shift, slope, mean, invstd, sum_g, sum_gx, sk_g, sk_b, dz_add, dres_add)
+    st.keep = (dy, res, scale, shift, slope, mean, invstd, sum_g, sum_gx, sk_g, sk_b, dz_add, dres_add, rows)
     return st
 
 
