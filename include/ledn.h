@@ -56,8 +56,9 @@ enum {
                                        (csrc/dwconv.hip); bit 2: MFMA conv tiles handed out round-robin instead of
                                        as contiguous ranges (off); bit 3: 8-row MFMA conv tiles when a launch has fewer
                                        16-row tiles than workgroups; bit 4: 1x1 stride-1 convolutions without input prologue /
-                                       output affine on the register-direct streaming kernel (csrc/conv1x1.hip);
-                                       0: the generic kernels (A/B measurements) */
+                                       output affine on the register-direct streaming kernel (csrc/conv1x1.hip); bit 5: 3x3 convolutions with
+                                       32 < Cin <= 64 and 64-channel output tiles keep both K-chunks' weights resident in LDS (off by default: measured 13.49 vs 13.42 ms per step);
+                                       0: the generic kernels (A/B measurements); < 0: the default mask */
 };
 int ledn_set_option(int option, long long value);
 

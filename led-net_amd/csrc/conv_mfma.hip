@@ -324,7 +324,10 @@ constexpr bool epi_stats(int e) { return e == EPI_RAW_STATS || e == EPI_FULL; }
 // step i and fly during its MFMA phase and epilogue.  Because vmcnt retires in order, nothing in
 // the MFMA phase or the RAW epilogues waits on vector memory: the weight fragments of the current
 // K-chunk sit in LDS ([tap][cout][32 ci + 8 pad], zero-filled tails; loaded once when Cin <= 32).
-template <int WM, int WN, int MT, int K, int S, int UP, int EPI, bool VEC>
+// RW: K-chunks whose weight slices stay RESIDENT in LDS for the lifetime of the workgroup (1: only the Cin <= 32 case;
+// 2: Cin <= 64 too -- the 64-output-channel configuration already owns its CU, and re-staging 46 KB of weights per
+// K-chunk and tile moved more L2 -> LDS bytes than the activations it multiplies them with)
+template <int WM, int WN, int MT, int K, int S, int UP, int EPI, bool VEC, int RW = 1>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     constexpr int TR = WM * MT;
     constexpr int PR = (TR - 1) * S + K, PC = 31 * S + K;
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     constexpr int WROWS = KK * NCO;                         // weight rows of one K-chunk
     constexpr int NLW = (WROWS * 4 + 255) / 256;
     __shared__ __attribute__((aligned(16))) unsigned char s_patch[PR * PC * PIXB];
-    __shared__ __attribute__((aligned(16))) unsigned char s_w[WROWS * PIXB];
+    __shared__ __attribute__((aligned(16))) unsigned char s_w[RW * WROWS * PIXB];
     __shared__ float s_par[3 * NCO];                        // EPI_FULL: out_scale, out_shift, slope
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -355,11 +358,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     const long tb = a.tile_stride > 0 ? (long)blockIdx.x : (long)blockIdx.x * a.tiles_per_block;
     const long te = a.tile_stride > 0 ? ntiles : min(ntiles, tb + a.tiles_per_block);
     if (tb >= te) return;                                   // workgroup-uniform
-    const bool one_chunk = a.Cin <= CK;
+    const bool one_chunk = a.Cin <= RW * CK;            // every K-chunk's weights resident: loaded once
 
     // weights of K-chunk c0 -> LDS (16-byte pieces; rows beyond Cout / channels beyond Cin are zero)
-#define LEDN_CONV_WEIGHTS(c0_)                                                                        \
+#define LEDN_CONV_WEIGHTS(c0_, slot_)                                                                 \
     do {                                                                                              \
+        unsigned char* s_wd_ = s_w + (slot_) * (WROWS * PIXB);                                        \
         uint4 wv_[NLW];                                                                               \
         _Pragma("unroll") for (int j = 0; j < NLW; ++j) {                                             \
             const int e_ = tid + j * 256, row_ = e_ >> 2, part_ = e_ & 3;                             \
@@ -371,7 +375,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
         }                                                                                             \
         _Pragma("unroll") for (int j = 0; j < NLW; ++j) {                                             \
             const int e_ = tid + j * 256;                                                             \
-            if (e_ < WROWS * 4) *reinterpret_cast<uint4*>(s_w + (e_ >> 2) * PIXB + (e_ & 3) * 16) = wv_[j]; \
+            if (e_ < WROWS * 4) *reinterpret_cast<uint4*>(s_wd_ + (e_ >> 2) * PIXB + (e_ & 3) * 16) = wv_[j]; \
         }                                                                                             \
     } while (0)
     // DEEP: two register staging sets, the loads of step i+2 issued while step i computes and step i+1's are still
@@ -388,7 +392,11 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
         st_.fetch(a.x, (int)(b_ / a.tiles_h), a.H, a.W, a.Cin, th_ * TR * S - a.pad,                  \
                   tw_ * 32 * S - a.pad, (c0_), tid);                                                  \
     } while (0)
-    if (one_chunk) LEDN_CONV_WEIGHTS(0);
+    if (one_chunk) {
+#pragma unroll
+        for (int ch = 0; ch < RW; ++ch)
+            if (ch * CK < a.Cin) LEDN_CONV_WEIGHTS(ch * CK, ch);
+    }
     if (epi_full(EPI)) {
         for (int i = tid; i < NCO; i += 256) {
             const int c = cbw + i;
@@ -412,7 +420,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     // one (tile, K-chunk) step: `stg` holds its patch; afterwards stg is refilled with the step `look` ahead
     auto do_step = [&](auto& stg, const long tile, const int c0, const int look) {
         stg.commit(s_patch, a.in_scale, a.in_shift, a.in_slope, a.in_act, c0, tid);
-        if (!one_chunk) LEDN_CONV_WEIGHTS(c0);
+        if (!one_chunk) LEDN_CONV_WEIGHTS(c0, 0);
         __syncthreads();
         long ntile = tile;
         int nc0 = c0 + CK;
@@ -435,7 +443,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
         // right in front of their first use.  Measured r03h: 3x3 32->32 forward + statistics 43.6 -> 37.4 us,
         // 64->64 37.8 -> 33.3 us, no scratch in any flavour.
         constexpr int NSTEP = KK * (CK / 16);
-        const unsigned char* wbase = s_w + (wn * 32 + lr) * PIXB + lh * 16;
+        const unsigned char* wbase = s_w + (one_chunk && RW > 1 ? (c0 / CK) * (WROWS * PIXB) : 0) + (wn * 32 + lr) * PIXB + lh * 16;
         const unsigned char* xbase = s_patch + (long)((wm * MT * S) * PC + lr * S) * PIXB + lh * 16;
         bf16x8_t wf_n, xf_n[MT];
 #define LEDN_FRAGS(i_, wf_, xf_)                                                                          \
@@ -657,6 +665,13 @@ static int launch_epi(MfmaConvArgs a, hipStream_t s) {
     a.tile_stride = (options().stream_fast & 4) ? (int)nbx : 0;
     const dim3 grid((unsigned)nbx, (unsigned)gy);
     a.part = (epi_stats(EPI) && a.stat_sum && nbx > 16) ? ws_take(nbx * 2 * a.Cout) : nullptr;
+    if constexpr (WN == 2 && K == 3 && S == 1) {     // 64 output channels per workgroup, 3x3: one workgroup per CU anyway
+        if (a.Cin > CK && a.Cin <= 2 * CK && (a.Cout & 7) == 0 && (options().stream_fast & 32)) {
+            LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI, true, 2>), grid, dim3(256), 0, s, a);
+            if (a.part) return finish_partials(a.part, (int)nbx, a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
+            return check_launch();
+        }
+    }
     if ((a.Cout & 7) == 0) LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI, true>), grid, dim3(256), 0, s, a);
     else LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI, false>), grid, dim3(256), 0, s, a);
     if (a.part) return finish_partials(a.part, (int)nbx, a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
