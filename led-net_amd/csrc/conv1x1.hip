@@ -45,6 +45,10 @@ struct C11Args {
     bf16_t* y;             // [P][Cout]
     const bf16_t* res;     // optional addend [P][Cout] (EPI_ACC)
     const float* bias;     // optional [Cout]
+    const float* in_scale; // optional input prologue pre(x) = act_in(x * in_scale + in_shift) (the producer's BatchNorm +
+    const float* in_shift; // activation folded into this convolution), applied to the fragments in registers
+    const float* in_slope;
+    int in_act;
     float* part;           // statistics: per-workgroup rows [gridDim.x][2][Cout], or NULL -> atomics
     float* stat_sum;
     float* stat_sqsum;
@@ -117,7 +121,24 @@ __device__ __forceinline__ int c11_red_index(int lane) {
 
 // NKS: k-steps of 32 input channels; NMT: M-tiles of 16 output channels; DIAG: only the 32 x 32 diagonal blocks of
 // the weight matrix are non-zero (grouped convolution, Cin == Cout); G: 16-pixel groups per iteration
-template <int NKS, int NMT, bool DIAG, int G, int EPI, int OCC>
+// pre(x) on one fragment: 8 consecutive input channels of one pixel, per-channel coefficients in registers
+__device__ __forceinline__ bf16x8_t c11_prologue(bf16x8_t f, const float* sc, const float* sh, const float* ng) {
+    const uint4 v = __builtin_bit_cast(uint4, f);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+        lo = lo * sc[2 * i] + sh[2 * i];
+        hi = hi * sc[2 * i + 1] + sh[2 * i + 1];
+        lo = fmaxf(lo, 0.f) + ng[2 * i] * fminf(lo, 0.f);          // none: ng = 1, relu: 0, prelu: slope
+        hi = fmaxf(hi, 0.f) + ng[2 * i + 1] * fminf(hi, 0.f);
+        o[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+    }
+    return __builtin_bit_cast(bf16x8_t, make_uint4(o[0], o[1], o[2], o[3]));
+}
+
+template <int NKS, int NMT, bool DIAG, int G, int EPI, int OCC, bool PRO = false>
 __global__ void __launch_bounds__(256, OCC) conv1x1_mfma_kernel(C11Args a) {
     constexpr int NP = (NMT + 1) / 2;                        // 32-channel pairs of M-tiles (the last may be half)
     constexpr int NWF = DIAG ? NMT : NMT * NKS;              // resident weight fragments
@@ -146,6 +167,21 @@ __global__ void __launch_bounds__(256, OCC) conv1x1_mfma_kernel(C11Args a) {
             const int c = c11_channel<NMT>(mt, q, i);
             binit[mt][i] = (a.bias && c < Cout) ? a.bias[c] : 0.f;
         }
+    // input prologue coefficients of this lane's 8 channels per k-step
+    constexpr int NPR = PRO ? NKS : 1;
+    float psc[NPR][8], psh[NPR][8], png[NPR][8];
+    if constexpr (PRO) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = 32 * ks + 8 * q + i;
+                const bool ok = c < Cin;
+                psc[ks][i] = (ok && a.in_scale) ? a.in_scale[c] : 1.f;
+                psh[ks][i] = (ok && a.in_shift) ? a.in_shift[c] : 0.f;
+                png[ks][i] = a.in_act == LEDN_ACT_PRELU ? (ok ? a.in_slope[c] : 0.f) : (a.in_act == LEDN_ACT_NONE ? 1.f : 0.f);
+            }
+    }
     constexpr int NST = EPI == C11_STATS ? NMT * 4 : 1;
     float st1[NST], st2[NST];
 #pragma unroll
@@ -188,6 +224,18 @@ __global__ void __launch_bounds__(256, OCC) conv1x1_mfma_kernel(C11Args a) {
                 for (int p = 0; p < NP; ++p) {
                     const bool ok = pix < a.P && 32 * p + 8 * q < Cout;
                     radd[g][p] = *reinterpret_cast<const uint4*>(a.res + (ok ? pix * Cout + 32 * p + 8 * q : 0L));
+                }
+            }
+        }
+        if constexpr (PRO) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bool pok = (it * G + g) * 16 + pl < a.P;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const bool ok = pok && 32 * ks + 8 * q < Cin;
+                    const bf16x8_t t = c11_prologue(bcur[g][ks], psc[ks], psh[ks], png[ks]);
+                    bcur[g][ks] = ok ? t : __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u));
                 }
             }
         }
@@ -294,7 +342,14 @@ static int c11_launch(C11Args a, hipStream_t s) {
     const long cap = (long)options().conv_workgroups * OCC;                  // default 512 x OCC: two rounds of resident workgroups
     if (nb > cap) nb = cap;
     a.part = (EPI == C11_STATS && a.stat_sum && nb > 16) ? ws_take(nb * 2 * a.Cout) : nullptr;
-    LEDN_LAUNCH((conv1x1_mfma_kernel<NKS, NMT, DIAG, G, EPI, OCC>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    const bool pro = a.in_scale || a.in_act != LEDN_ACT_NONE;
+    if constexpr (NKS <= 2) {        // (prologue coefficients: 24 VGPRs per k-step -- offered for Cin <= 64)
+        if (pro) LEDN_LAUNCH((conv1x1_mfma_kernel<NKS, NMT, DIAG, G, EPI, 2, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+        else LEDN_LAUNCH((conv1x1_mfma_kernel<NKS, NMT, DIAG, G, EPI, OCC>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    } else {
+        if (pro) return LEDN_EINVAL;
+        LEDN_LAUNCH((conv1x1_mfma_kernel<NKS, NMT, DIAG, G, EPI, OCC>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    }
     if (a.part) return finish_partials(a.part, (int)nb, a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
     return check_launch();
 }
@@ -319,7 +374,10 @@ bool conv1x1_reg_supported(const ledn_conv_desc& d) {
     if (!(options().stream_fast & 16)) return false;
     if (!d.w_bf16 || d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16) return false;
     if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.pad != 0 || d.dil != 1 || d.xadd) return false;
-    if (d.in_scale || d.in_shift || d.in_act != LEDN_ACT_NONE) return false;
+    if (d.in_scale || d.in_shift || d.in_act != LEDN_ACT_NONE) {       // input prologue: Cin <= 64, none / ReLU / PReLU
+        if (d.Cin > 64 || (d.in_scale == nullptr) != (d.in_shift == nullptr)) return false;
+        if (d.in_act != LEDN_ACT_NONE && d.in_act != LEDN_ACT_RELU && !(d.in_act == LEDN_ACT_PRELU && d.in_slope)) return false;
+    }
     if (d.out_scale || d.act_out != LEDN_ACT_NONE) return false;
     if (d.res_mode != LEDN_RES_NONE && !(d.res_mode == LEDN_RES_ADD && d.res && !d.stat_sum && !d.out_shift)) return false;
     if (d.Cin % 16 || d.Cout % 16 || d.Cin > 128 || d.Cout > 128) return false;
@@ -333,6 +391,7 @@ int conv1x1_reg(const ledn_conv_desc& d, hipStream_t s) {
     C11Args a;
     a.x = (const bf16_t*)d.x; a.wp = (const bf16_t*)d.w_bf16; a.y = (bf16_t*)d.y;
     a.res = d.res_mode == LEDN_RES_ADD ? (const bf16_t*)d.res : nullptr;
+    a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_slope = d.in_slope; a.in_act = d.in_act;
     a.bias = d.out_shift; a.part = nullptr; a.stat_sum = d.stat_sum; a.stat_sqsum = d.stat_sqsum;
     a.P = (long)d.N * d.H * d.W; a.iters = 0; a.Cin = d.Cin; a.Cout = d.Cout;
     const int epi = a.res ? C11_ACC : (d.stat_sum ? C11_STATS : C11_RAW);

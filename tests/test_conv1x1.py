@@ -132,3 +132,29 @@ def _many_iterations(ops):
     torch.testing.assert_close(nchw(got), want, rtol=1e-2, atol=2e-2)
     torch.testing.assert_close(stats[0].cpu(), want.sum((0, 2, 3)), rtol=1e-3, atol=0.5)
     torch.testing.assert_close(stats[1].cpu(), (want * want).sum((0, 2, 3)), rtol=2e-3, atol=2.0)
+
+
+@pytest.mark.parametrize('cin,cout,g,act', [(64, 64, 4, 'prelu'), (64, 64, 1, 'relu'), (32, 32, 1, 'none'), (64, 16, 4, 'prelu'),
+                                           (16, 64, 1, 'relu')])
+def test_conv1x1_input_prologue(be, cin, cout, g, act):
+    """the producer's BatchNorm (+ ReLU / PReLU) folded into the convolution's input (training fusion level 2: SESP
+    cat -> expansion, eesp.py:99-104): pre(x) = act(x * scale + shift) applied to the fragments in registers, with
+    channel statistics of the output; ragged pixel count (the tail must stay zero AFTER the prologue)"""
+    from led_net_amd import ops
+    N, H, W = 2, 9, 21
+    x = r16(torch.randn(N, cin, H, W))
+    w = torch.randn(cout, cin // g, 1, 1) / (cin // g) ** 0.5
+    sc, sh, sl = torch.rand(cin) + 0.5, torch.randn(cin) * 0.3, torch.rand(cin) * 0.4
+    pre = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    pre = {'prelu': lambda t: F.prelu(t, sl), 'relu': F.relu, 'none': lambda t: t}[act](pre)
+    want = F.conv2d(r16(pre), r16(w), groups=g)
+    wp = ops.pack_conv_weights(D(w), 0, g)
+    kw = dict(groups=g, in_scale=D(sc), in_shift=D(sh), w_bf16=wp,
+              in_act={'prelu': ops.ACT_PRELU, 'relu': ops.ACT_RELU, 'none': ops.ACT_NONE}[act],
+              in_slope=D(sl) if act == 'prelu' else None)
+    xb = nhwc(x).bfloat16()
+    assert ops.conv2d_kernel_id(xb, D(w), **kw) == 2
+    stats = (D(torch.zeros(cout)), D(torch.zeros(cout)))
+    got = ops.conv2d(xb, D(w), stats=stats, **kw)
+    torch.testing.assert_close(nchw(got), want, rtol=1e-2, atol=3e-2)
+    torch.testing.assert_close(stats[0].cpu(), want.sum((0, 2, 3)), rtol=2e-3, atol=2e-3 * N * H * W)
