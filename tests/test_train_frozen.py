@@ -7,7 +7,7 @@ gradient must agree per parameter (relative L2), instead of the distribution bou
 Stated tolerance (measured x ~2, profiles/r03_frozen_step_gradients.txt; parameters holding > 1e-3 of the gradient norm):
   f32 activations (VALU kernels): per-parameter rel-L2 <= 5e-2 on the emulator (batch 3: measured worst 2.3e-2, median
       1.2e-2; the head's parameters 1e-5, the rise to 1e-2 happens in the backward through Muti_AFF, whose global
-      branch normalises N = 3 values per channel) and <= 1e-2 on the MI355X (batch 8).  What is left is not
+      branch normalises N = 3 values per channel) and <= 2.5e-2 on the MI355X (batch 8: 5.0e-3 and 1.0e-2 in two runs).  What is left is not
       arithmetic error: every block reproduces its golden gradients to 1e-6 (tests/test_train.py); a ReLU / PReLU
       pre-activation within 1e-6 of zero picks the other branch under another f32 summation order, and a fraction f of
       flipped derivative masks is a relative L2 error of sqrt(f) -- the ORACLE moves by as much against itself under
@@ -192,7 +192,7 @@ def test_frozen_step_gradients_f32(be):
         assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, (k, a, b)
     rows = _per_param(leaves, grads)
     print(f'frozen step f32: {len(rows)} parameters, median rel-L2 {rows[len(rows) // 2][0]:.2e}, worst {rows[-1]}')
-    assert rows[-1][0] <= (5e-2 if _DEV[0].type == 'cpu' else 1e-2), rows[-5:]      # MI355X, batch 8: measured 5.0e-3
+    assert rows[-1][0] <= (5e-2 if _DEV[0].type == 'cpu' else 2.5e-2), rows[-5:]    # MI355X, batch 8: measured 5.0e-3 and 1.0e-2 in two runs (f32 atomics order), median 1.6e-3 / 5.4e-3
 
 
 def test_frozen_step_gradients_bf16(be):

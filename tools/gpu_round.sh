@@ -24,3 +24,8 @@ bash tools/gpu_trace.sh $TAG train > /dev/null 2>&1; head -3 $OUT/timeline_train
 bash tools/gpu_trace.sh $TAG infer > /dev/null 2>&1; head -3 $OUT/timeline_infer.txt
 timeout -k 10 900 python tools/pmc_traffic.py --mode train --dtype bf16 --out $OUT/pmc_traffic_train_bf16.json || { echo "pmc train failed"; exit 1; }
 timeout -k 10 600 python tools/pmc_traffic.py --mode infer --dtype bf16 --out $OUT/pmc_traffic_infer_bf16.json || { echo "pmc infer failed"; exit 1; }
+# round 3 additions: the published-size variant next to the default, conv micro-benchmark, frozen-decision gradient numbers
+timeout -k 10 600 python bench.py --backbone "cespb_depth=(2,3)" --no-cpu-baseline > $OUT/bench_train_bf16_cespb23.json 2> $OUT/bench_cespb23.err || { echo "bench cespb(2,3) failed"; tail -5 $OUT/bench_cespb23.err; exit 1; }
+cat $OUT/bench_train_bf16_cespb23.json
+timeout -k 10 300 python tools/conv_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/conv_bench.txt || { echo "conv_bench failed"; exit 1; }
+timeout -k 10 600 python -m pytest tests/test_train_frozen.py tests/test_bf16_blocks.py tests/test_tools.py -m gpu -q -s 2>&1 | grep -E "frozen step|head parameters|worst rel-L2|resume:|replay\(new|tools/train.py [0-9]|passed|failed" > $OUT/parity_numbers.txt; cat $OUT/parity_numbers.txt
