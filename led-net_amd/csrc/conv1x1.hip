@@ -45,6 +45,9 @@ struct C11Args {
     bf16_t* y;             // [P][Cout]
     const bf16_t* res;     // optional addend [P][Cout] (EPI_ACC)
     const float* bias;     // optional [Cout]
+    const float* out_scale;// C11_FULL: y = act(res_mode(z * out_scale + bias, res)); NULL = 1
+    const float* slope;    // [Cout] when act_out == PRELU
+    int act_out, res_mode;
     const float* in_scale; // optional input prologue pre(x) = act_in(x * in_scale + in_shift) (the producer's BatchNorm +
     const float* in_shift; // activation folded into this convolution), applied to the fragments in registers
     const float* in_slope;
@@ -57,7 +60,7 @@ struct C11Args {
     int Cin, Cout;
 };
 
-constexpr int C11_RAW = 0, C11_STATS = 1, C11_ACC = 2;
+constexpr int C11_RAW = 0, C11_STATS = 1, C11_ACC = 2, C11_FULL = 3;   // FULL: scale / shift, residual, activation (inference)
 
 template <int V> struct c11_int { static constexpr int value = V; };
 template <int N, int I = 0, typename F>
@@ -187,6 +190,24 @@ __global__ void __launch_bounds__(256, OCC) conv1x1_mfma_kernel(C11Args a) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
 
+    // C11_FULL: per-channel (scale, negative slope) in LDS, read per use (the bias is already the accumulator's start
+    // value -- scaled below: y = z * scale + shift = (z + shift / scale) * scale would round differently, so the shift is
+    // added after the scale instead and binit stays zero)
+    __shared__ float s_par[EPI == C11_FULL ? 3 * NMT * 16 : 1];
+    if constexpr (EPI == C11_FULL) {
+        for (int i = tid; i < NMT * 16; i += 256) {
+            const bool ok = i < Cout;
+            s_par[i] = (ok && a.out_scale) ? a.out_scale[i] : 1.f;
+            s_par[NMT * 16 + i] = (ok && a.bias) ? a.bias[i] : 0.f;
+            s_par[2 * NMT * 16 + i] = a.act_out == LEDN_ACT_PRELU ? (ok ? a.slope[i] : 0.f) : (a.act_out == LEDN_ACT_NONE ? 1.f : 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) binit[mt][i] = 0.f;
+    }
+    const float act_hi = a.act_out == LEDN_ACT_RELU6 ? 6.f : 3.0e38f;
     const long nwaves = (long)gridDim.x * 4;
     long it = (long)blockIdx.x * 4 + wid;
     const bool kok[2] = {true, true};
@@ -216,7 +237,7 @@ __global__ void __launch_bounds__(256, OCC) conv1x1_mfma_kernel(C11Args a) {
         if (nit < a.iters) fetch(nit, bnext);
         // addend pieces of this iteration (EPI_ACC): in flight during the matrix instructions
         uint4 radd[G][NP];
-        if constexpr (EPI == C11_ACC) {
+        if (EPI == C11_ACC || (EPI == C11_FULL && a.res_mode != LEDN_RES_NONE)) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const long pix = (it * G + g) * 16 + pl;
@@ -283,6 +304,23 @@ __global__ void __launch_bounds__(256, OCC) conv1x1_mfma_kernel(C11Args a) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) v[i] = bf16_to_f32(f32_to_bf16(v[i])) + r[i];   // as conv_mfma: bf16(z) + addend
                     }
+                    if constexpr (EPI == C11_FULL) {
+                        const int c0 = 32 * p + 8 * q;
+                        float sc[8], sh[8], ng[8];
+                        ld8(s_par + c0, sc);
+                        ld8(s_par + NMT * 16 + c0, sh);
+                        ld8(s_par + 2 * NMT * 16 + c0, ng);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sh[i];
+                        if (a.res_mode != LEDN_RES_NONE) {
+                            float r[8];
+                            ld8(reinterpret_cast<const bf16_t*>(&radd[g][p]), r);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = a.res_mode == LEDN_RES_ADD ? v[i] + r[i] : v[i] * r[i] + r[i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(v[i], 0.f) + ng[i] * fminf(v[i], 0.f), act_hi);
+                    }
                     if (pok && 32 * p + 8 * q < Cout) st8(a.y + pix * Cout + 32 * p + 8 * q, v);
                 } else {                                     // unpaired tile: channels 16 mt + 4 q .. + 3, 8-byte store
                     float v[4];
@@ -296,6 +334,22 @@ __global__ void __launch_bounds__(256, OCC) conv1x1_mfma_kernel(C11Args a) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v[i] = bf16_to_f32(f32_to_bf16(v[i])) + r[i];
                         }
+                    }
+                    if constexpr (EPI == C11_FULL) {
+                        float sc[4], sh[4], ng[4];
+                        ld4(s_par + c, sc);
+                        ld4(s_par + NMT * 16 + c, sh);
+                        ld4(s_par + 2 * NMT * 16 + c, ng);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = v[i] * sc[i] + sh[i];
+                        if (a.res_mode != LEDN_RES_NONE && pok) {
+                            float r[4];
+                            ld4(a.res + pix * Cout + c, r);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = a.res_mode == LEDN_RES_ADD ? v[i] + r[i] : v[i] * r[i] + r[i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fminf(fmaxf(v[i], 0.f) + ng[i] * fminf(v[i], 0.f), act_hi);
                     }
                     if (pok) st4(a.y + pix * Cout + c, v);
                 }
@@ -359,6 +413,7 @@ static int c11_epi(const C11Args& a, int epi, hipStream_t s) {
     switch (epi) {
         case C11_STATS: return c11_launch<NKS, NMT, DIAG, C11_STATS>(a, s);
         case C11_ACC: return c11_launch<NKS, NMT, DIAG, C11_ACC>(a, s);
+        case C11_FULL: return c11_launch<NKS, NMT, DIAG, C11_FULL>(a, s);
         default: return c11_launch<NKS, NMT, DIAG, C11_RAW>(a, s);
     }
 }
@@ -378,8 +433,14 @@ bool conv1x1_reg_supported(const ledn_conv_desc& d) {
         if (d.Cin > 64 || (d.in_scale == nullptr) != (d.in_shift == nullptr)) return false;
         if (d.in_act != LEDN_ACT_NONE && d.in_act != LEDN_ACT_RELU && !(d.in_act == LEDN_ACT_PRELU && d.in_slope)) return false;
     }
-    if (d.out_scale || d.act_out != LEDN_ACT_NONE) return false;
-    if (d.res_mode != LEDN_RES_NONE && !(d.res_mode == LEDN_RES_ADD && d.res && !d.stat_sum && !d.out_shift)) return false;
+    const bool full = d.out_scale || d.act_out != LEDN_ACT_NONE || d.res_mode == LEDN_RES_GATE ||
+                      (d.res_mode == LEDN_RES_ADD && d.out_shift);
+    if (full) {        // inference epilogue: scale / shift, residual, activation; no statistics
+        if (d.stat_sum || d.act_out == LEDN_ACT_SIGMOID || (d.act_out == LEDN_ACT_PRELU && !d.slope)) return false;
+        if (d.res_mode != LEDN_RES_NONE && !d.res) return false;
+    } else if (d.res_mode != LEDN_RES_NONE && !(d.res_mode == LEDN_RES_ADD && d.res && !d.stat_sum)) {
+        return false;
+    }
     if (d.Cin % 16 || d.Cout % 16 || d.Cin > 128 || d.Cout > 128) return false;
     const int nks = (d.Cin + 31) / 32, nmt = d.Cout / 16;
     if (!(nks == 1 || nks == 2 || nks == 4) || !(nmt == 1 || nmt == 2 || nmt == 4 || nmt == 8)) return false;
@@ -393,8 +454,12 @@ int conv1x1_reg(const ledn_conv_desc& d, hipStream_t s) {
     a.res = d.res_mode == LEDN_RES_ADD ? (const bf16_t*)d.res : nullptr;
     a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_slope = d.in_slope; a.in_act = d.in_act;
     a.bias = d.out_shift; a.part = nullptr; a.stat_sum = d.stat_sum; a.stat_sqsum = d.stat_sqsum;
+    a.out_scale = d.out_scale; a.slope = d.slope; a.act_out = d.act_out; a.res_mode = d.res_mode;
     a.P = (long)d.N * d.H * d.W; a.iters = 0; a.Cin = d.Cin; a.Cout = d.Cout;
-    const int epi = a.res ? C11_ACC : (d.stat_sum ? C11_STATS : C11_RAW);
+    const bool full = d.out_scale || d.act_out != LEDN_ACT_NONE || d.res_mode == LEDN_RES_GATE ||
+                      (d.res_mode == LEDN_RES_ADD && d.out_shift);
+    if (full) a.res = (const bf16_t*)d.res;
+    const int epi = full ? C11_FULL : (a.res ? C11_ACC : (d.stat_sum ? C11_STATS : C11_RAW));
     const int nks = (d.Cin + 31) / 32, nmt = d.Cout / 16;
     const bool diag = c11_diag(d);
 #define LEDN_C11(NKS_, NMT_)                                                     \

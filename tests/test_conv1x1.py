@@ -158,3 +158,39 @@ def test_conv1x1_input_prologue(be, cin, cout, g, act):
     got = ops.conv2d(xb, D(w), stats=stats, **kw)
     torch.testing.assert_close(nchw(got), want, rtol=1e-2, atol=3e-2)
     torch.testing.assert_close(stats[0].cpu(), want.sum((0, 2, 3)), rtol=2e-3, atol=2e-3 * N * H * W)
+
+
+@pytest.mark.parametrize('cin,cout,g,act,res', [(64, 64, 4, 'prelu', 'add'), (64, 64, 1, 'relu6', None), (32, 32, 1, 'none', 'gate'),
+                                               (64, 16, 4, 'relu', None), (128, 128, 4, 'prelu', 'add'), (16, 64, 1, 'relu', 'add')])
+def test_conv1x1_inference_epilogue(be, cin, cout, g, act, res):
+    """folded BatchNorm (scale / shift), residual (add | gate) and activation in the epilogue: the inference form of the
+    1x1 ConvModules (y = act(res_mode(z * scale + shift, res)), ledn.h) against torch and against the general kernel"""
+    from led_net_amd import ops, _lib
+    N, H, W = 2, 7, 23
+    x = r16(torch.randn(N, cin, H, W))
+    w = torch.randn(cout, cin // g, 1, 1) / (cin // g) ** 0.5
+    sc, sh, sl = torch.rand(cout) + 0.5, torch.randn(cout) * 0.3, torch.rand(cout) * 0.4
+    v = F.conv2d(x, r16(w), groups=g) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    r = r16(torch.randn_like(v))
+    if res == 'add':
+        v = v + r
+    elif res == 'gate':
+        v = v * r + r
+    want = {'prelu': lambda t: F.prelu(t, sl), 'relu': F.relu, 'relu6': F.relu6, 'none': lambda t: t}[act](v)
+    wp = ops.pack_conv_weights(D(w), 0, g)
+    kw = dict(groups=g, out_scale=D(sc), out_shift=D(sh), w_bf16=wp,
+              act={'prelu': ops.ACT_PRELU, 'relu': ops.ACT_RELU, 'relu6': ops.ACT_RELU6, 'none': ops.ACT_NONE}[act],
+              slope=D(sl) if act == 'prelu' else None,
+              res=nhwc(r).bfloat16() if res else None,
+              res_mode={'add': ops.RES_ADD, 'gate': ops.RES_GATE, None: ops.RES_NONE}[res])
+    xb = nhwc(x).bfloat16()
+    assert ops.conv2d_kernel_id(xb, D(w), **kw) == 2
+    got = ops.conv2d(xb, D(w), **kw)
+    torch.testing.assert_close(nchw(got), want, rtol=1.5e-2, atol=3e-2)
+    lib = _lib.get_lib()
+    lib.set_option(2, 11)
+    try:
+        ref = ops.conv2d(xb, D(w), **kw)
+    finally:
+        lib.set_option(2, -1)
+    torch.testing.assert_close(got.float().cpu(), ref.float().cpu(), rtol=8e-3, atol=2e-3)
