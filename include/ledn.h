@@ -661,6 +661,13 @@ typedef struct {
     float* running_var2[4];
     float* bn2[4];
     float* stats2;
+    /* SyncBN (data-parallel): the launch sequence in PHASES with the caller's all-reduce of the statistics in between.
+     * phase = bit mask of the launches to run (0 = all): 1 = conv1 + sums of z1 (-> stats1), 2 = BatchNorm + ReLU +
+     * conv2 + sums of z2 (-> stats2), 4 = finalize of the trailing BatchNorms.  The caller all-reduces stats1 between
+     * 1 and 2 and stats2 between 2 and 4 (in place: they are used for nothing else); count_scale = number of ranks
+     * (the statistics are then over P_k * count_scale samples); 0 means 1. */
+    int phase;
+    float count_scale;
 } ledn_mfafctx_desc;
 int ledn_mfaf_ctx_fwd(const ledn_mfafctx_desc* d, int training, void* stream);
 typedef struct {
@@ -690,6 +697,15 @@ typedef struct {
     float* dgamma2[4];
     float* dbeta2[4];
     float* sums2;
+    /* SyncBN: phase = bit mask (0 = all): 1 = sums of the trailing BatchNorms' backward (-> sums2), 2 = backward through
+     * conv2 / ReLU + sums of the first BatchNorm's backward (-> sums) + dW2, 4 = BatchNorm backward + dpooled + dW1.
+     * The caller all-reduces sums2 between 1 and 2 and sums between 2 and 4 OUT OF PLACE: sums2 / sums then hold the
+     * global sums (used for dz), sums2_local / sums_local this rank's own (= its d gamma / d beta, as
+     * torch.nn.SyncBatchNorm keeps them; NULL: the same buffers).  count_scale as in the forward. */
+    int phase;
+    float count_scale;
+    const float* sums_local;
+    const float* sums2_local;
 } ledn_mfafctx_bwd_desc;
 int ledn_mfaf_ctx_bwd(const ledn_mfafctx_bwd_desc* d, void* stream);
 

@@ -69,14 +69,16 @@ class MfafCtxDesc(C.Structure):          # mirrors ledn_mfafctx_desc
     _fields_ = [(n, vp * 4) for n in ('pooled', 'z1', 'z2', 'w1', 'b1', 'gamma', 'beta', 'running_mean', 'running_var',
                                       'w2', 'b2', 'bn1')] + \
                [('stats1', vp), ('P', i32 * 4), ('C', i32), ('Ci', i32), ('momentum', C.c_float), ('eps', C.c_float)] + \
-               [(n, vp * 4) for n in ('gamma2', 'beta2', 'running_mean2', 'running_var2', 'bn2')] + [('stats2', vp)]
+               [(n, vp * 4) for n in ('gamma2', 'beta2', 'running_mean2', 'running_var2', 'bn2')] + [('stats2', vp)] + \
+               [('phase', i32), ('count_scale', C.c_float)]
 
 
 class MfafCtxBwdDesc(C.Structure):       # mirrors ledn_mfafctx_bwd_desc
     _fields_ = [(n, vp * 4) for n in ('pooled', 'z1', 'dz2', 'w1', 'w2', 'bn1', 'g', 'dpooled', 'dw1', 'db1', 'dgamma',
                                       'dbeta', 'dw2', 'db2')] + \
                [('sums', vp), ('P', i32 * 4), ('C', i32), ('Ci', i32)] + \
-               [(n, vp * 4) for n in ('z2', 'bn2', 'dz2s', 'dgamma2', 'dbeta2')] + [('sums2', vp)]
+               [(n, vp * 4) for n in ('z2', 'bn2', 'dz2s', 'dgamma2', 'dbeta2')] + [('sums2', vp)] + \
+               [('phase', i32), ('count_scale', C.c_float), ('sums_local', vp), ('sums2_local', vp)]
 
 
 class AugEntry(C.Structure):          # mirrors ledn_aug_entry field for field

@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd2_kernel(ledn_mfafctx_desc 
     if (tid < MC_CI) {
         float mean, var;
         if (training) {
-            const double cnt = (double)d.P[s];
+            const double cnt = (double)d.P[s] * (d.count_scale > 0.f ? (double)d.count_scale : 1.0);
             const double m = (double)d.stats1[s * 2 * MC_CI + tid] / cnt;
             double v = (double)d.stats1[s * 2 * MC_CI + MC_CI + tid] / cnt - m * m;
             if (v < 0.0) v = 0.0;
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd2_kernel(ledn_mfafctx_desc 
 // ---- finalize of the trailing BatchNorms: one workgroup per scale, thread = channel ----------------------
 __global__ void __launch_bounds__(MC_C) mfaf_ctx_fin2_kernel(ledn_mfafctx_desc d) {
     const int s = blockIdx.x, c = threadIdx.x;
-    const double cnt = (double)d.P[s];
+    const double cnt = (double)d.P[s] * (d.count_scale > 0.f ? (double)d.count_scale : 1.0);
     const double m = (double)d.stats2[s * 2 * MC_C + c] / cnt;
     double v = (double)d.stats2[s * 2 * MC_C + MC_C + c] / cnt - m * m;
     if (v < 0.0) v = 0.0;
@@ -242,16 +242,17 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwd2_kernel(ledn_mfafctx_bwd_d
     for (int i = tid; i < MC_C * MC_CI; i += MC_PX) s_w[i] = d.w2[s][i];
     if (tid < 4 * MC_CI) s_bn[tid] = d.bn1[s][tid];
     if (tail && tid < MC_C) {
-        const float inv_n = 1.f / (float)d.P[s];
+        const float inv_n = 1.f / ((float)d.P[s] * (d.count_scale > 0.f ? d.count_scale : 1.f));
         const float s1 = d.sums2[s * 2 * MC_C + tid], s2 = d.sums2[s * 2 * MC_C + MC_C + tid];
+        const float* loc = d.sums2_local ? d.sums2_local : d.sums2;     // this rank's own sums = its d beta / d gamma
         s_t[tid] = d.bn2[s][tid];
         s_t[MC_C + tid] = d.bn2[s][2 * MC_C + tid];
         s_t[2 * MC_C + tid] = d.bn2[s][3 * MC_C + tid];
         s_t[3 * MC_C + tid] = s1 * inv_n;
         s_t[4 * MC_C + tid] = s2 * inv_n;
         if (blk.p0 == 0) {
-            atomicAdd(d.dbeta2[s] + tid, s1);
-            atomicAdd(d.dgamma2[s] + tid, s2);
+            atomicAdd(d.dbeta2[s] + tid, loc[s * 2 * MC_C + tid]);
+            atomicAdd(d.dgamma2[s] + tid, loc[s * 2 * MC_C + MC_C + tid]);
         }
     }
     __syncthreads();
@@ -327,13 +328,14 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwd1_kernel(ledn_mfafctx_bwd_d
     if (tid < 4 * MC_CI) s_bn[tid] = d.bn1[s][tid];
     if (tid < 2 * MC_CI) s_sum[tid] = d.sums[s * 2 * MC_CI + tid];
     __syncthreads();
-    if (blk.p0 == 0 && tid < MC_CI) {      // parameter gradients of the BatchNorm: the sums themselves
-        atomicAdd(d.dbeta[s] + tid, s_sum[tid]);
-        atomicAdd(d.dgamma[s] + tid, s_sum[MC_CI + tid]);
+    if (blk.p0 == 0 && tid < MC_CI) {      // parameter gradients of the BatchNorm: this rank's own sums
+        const float* loc = d.sums_local ? d.sums_local : d.sums;
+        atomicAdd(d.dbeta[s] + tid, loc[s * 2 * MC_CI + tid]);
+        atomicAdd(d.dgamma[s] + tid, loc[s * 2 * MC_CI + MC_CI + tid]);
     }
     const int p = blk.p0 + tid;
     if (p >= d.P[s]) return;
-    const float inv_n = 1.f / (float)d.P[s];
+    const float inv_n = 1.f / ((float)d.P[s] * (d.count_scale > 0.f ? d.count_scale : 1.f));
     float dz[MC_CI];
     float4* g4 = reinterpret_cast<float4*>(d.g[s] + (long)p * MC_CI);
     const float4* z4 = reinterpret_cast<const float4*>(d.z1[s] + (long)p * MC_CI);
@@ -434,9 +436,10 @@ int mfaf_ctx_fwd_impl(const ledn_mfafctx_desc& d, int training, hipStream_t s) {
             LEDN_REQUIRE(d.gamma2[k] && d.beta2[k] && d.running_mean2[k] && d.running_var2[k] && d.bn2[k]);
     }
     const dim3 grid((unsigned)mc_blocks(d.P));
-    LEDN_LAUNCH(mfaf_ctx_fwd1_kernel, grid, dim3(MC_PX), 0, s, d, training);
-    LEDN_LAUNCH(mfaf_ctx_fwd2_kernel, grid, dim3(MC_PX), 0, s, d, training);
-    if (d.stats2) LEDN_LAUNCH(mfaf_ctx_fin2_kernel, dim3(4), dim3(MC_C), 0, s, d);
+    const int ph = d.phase ? d.phase : 7;
+    if (ph & 1) LEDN_LAUNCH(mfaf_ctx_fwd1_kernel, grid, dim3(MC_PX), 0, s, d, training);
+    if (ph & 2) LEDN_LAUNCH(mfaf_ctx_fwd2_kernel, grid, dim3(MC_PX), 0, s, d, training);
+    if ((ph & 4) && d.stats2) LEDN_LAUNCH(mfaf_ctx_fin2_kernel, dim3(4), dim3(MC_C), 0, s, d);
     return check_launch();
 }
 
@@ -449,14 +452,25 @@ int mfaf_ctx_bwd_impl(const ledn_mfafctx_bwd_desc& d, hipStream_t s) {
     }
     LEDN_REQUIRE(d.sums);
     const dim3 grid((unsigned)mc_blocks(d.P));
+    const int ph = d.phase ? d.phase : 7;
     if (d.sums2) {
         for (int k = 0; k < 4; ++k) LEDN_REQUIRE(d.z2[k] && d.bn2[k] && d.dz2s[k] && d.dgamma2[k] && d.dbeta2[k]);
-        LEDN_LAUNCH(mfaf_ctx_bwdT_kernel, grid, dim3(MC_PX), 0, s, d);
+        if (ph & 1) {
+            ledn_mfafctx_bwd_desc dl = d;            // this launch accumulates the LOCAL sums
+            if (d.sums2_local) dl.sums2 = const_cast<float*>(d.sums2_local);
+            LEDN_LAUNCH(mfaf_ctx_bwdT_kernel, grid, dim3(MC_PX), 0, s, dl);
+        }
     }
-    LEDN_LAUNCH(mfaf_ctx_bwd2_kernel, grid, dim3(MC_PX), 0, s, d);
-    LEDN_LAUNCH(mfaf_ctx_wgrad_kernel<0>, grid, dim3(MC_PX), 0, s, d);
-    LEDN_LAUNCH(mfaf_ctx_bwd1_kernel, grid, dim3(MC_PX), 0, s, d);
-    LEDN_LAUNCH(mfaf_ctx_wgrad_kernel<1>, grid, dim3(MC_PX), 0, s, d);
+    if (ph & 2) {
+        ledn_mfafctx_bwd_desc dl = d;                // reads the global sums2, accumulates the LOCAL sums
+        if (d.sums_local) dl.sums = const_cast<float*>(d.sums_local);
+        LEDN_LAUNCH(mfaf_ctx_bwd2_kernel, grid, dim3(MC_PX), 0, s, dl);
+        LEDN_LAUNCH(mfaf_ctx_wgrad_kernel<0>, grid, dim3(MC_PX), 0, s, d);
+    }
+    if (ph & 4) {
+        LEDN_LAUNCH(mfaf_ctx_bwd1_kernel, grid, dim3(MC_PX), 0, s, d);
+        LEDN_LAUNCH(mfaf_ctx_wgrad_kernel<1>, grid, dim3(MC_PX), 0, s, d);
+    }
     return check_launch();
 }
 

@@ -419,11 +419,13 @@ def ohem2_up_bwd(src0, src1, hw, work, out, dloss0, dloss1, lw0, lw1, ignore_lab
     return d0, d1
 
 
-def mfaf_ctx_fwd(pooled, seqs, training, stats1=None, momentum=0.1, tails=None):
+def mfaf_ctx_fwd(pooled, seqs, training, stats1=None, momentum=0.1, tails=None, sync=None, world=1):
     """The four pooled-context MLPs of Muti_AFF in one launch sequence (ledn_mfaf_ctx_fwd).
     pooled: 4 f32 [N,S,S,C] maps; seqs: 4 x (conv1, bn1, conv2) modules.  -> (z2 list [N,S,S,C] f32, saved dict)
     tails (training): the 4 trailing BatchNorm modules -- their batch statistics are then formed here too:
-    saved['bn2'][k] = [scale | shift | mean | invstd][C], running statistics updated."""
+    saved['bn2'][k] = [scale | shift | mean | invstd][C], running statistics updated.
+    sync (training, data-parallel): object with all_reduce(src, dst); the sequence then runs in its phases with ONE
+    all-reduce of the [4,2,Ci] (and [4,2,C]) statistics between them -- SyncBN over `world` ranks."""
     lib = _lib.get_lib()
     d = _lib.MfafCtxDesc()
     Cc = pooled[0].shape[-1]
@@ -464,13 +466,25 @@ def mfaf_ctx_fwd(pooled, seqs, training, stats1=None, momentum=0.1, tails=None):
                 bn2s.append(bn2)
             d.stats2 = _p(stats2)
             keep.append(stats2)
-    _run(lib, 'ledn_mfaf_ctx_fwd', pooled[0], C.byref(d), int(bool(training)),
-         work=_ops._TIMING is not None and ('mfaf_ctx_fwd', 0, 0, 'mfaf_ctx_fwd2_kernel'))
+    work = _ops._TIMING is not None and ('mfaf_ctx_fwd', 0, 0, 'mfaf_ctx_fwd2_kernel')
+    if sync is None or not training:
+        _run(lib, 'ledn_mfaf_ctx_fwd', pooled[0], C.byref(d), int(bool(training)), work=work)
+    else:
+        d.count_scale = float(world)
+        for phase, st in ((1, stats1), (2, stats2 if tails is not None else None), (4, None)):
+            if phase == 4 and tails is None:
+                break
+            d.phase = phase
+            _run(lib, 'ledn_mfaf_ctx_fwd', pooled[0], C.byref(d), 1, work=work if phase == 2 else False)
+            if st is not None:
+                sync.all_reduce(st, st)
     return z2s, dict(z1=z1s, bn1=bn1s, bn2=bn2s)
 
 
-def mfaf_ctx_bwd(pooled, saved, dz2, seqs, sinks, tails=None, sinks2=None):
-    """-> (dpooled list, grads list of 4 x [dw1, db1, dgamma, dbeta, dw2, db2 (, dgamma2, dbeta2)] -- None where a
+def mfaf_ctx_bwd(pooled, saved, dz2, seqs, sinks, tails=None, sinks2=None, sync=None, world=1):
+    """(sync / world: as mfaf_ctx_fwd -- the BatchNorm backward sums are all-reduced between the phases, the
+    parameter gradients stay this rank's own, as torch.nn.SyncBatchNorm's)
+    -> (dpooled list, grads list of 4 x [dw1, db1, dgamma, dbeta, dw2, db2 (, dgamma2, dbeta2)] -- None where a
     sink took it).  sinks: 4 x 6 f32 buffers (or None) the parameter gradients are accumulated into.
     tails: the forward ran the trailing BatchNorms too (saved['z2'] = its outputs, saved['bn2']) -- dz2 is then the
     gradient with respect to THEIR output; sinks2: 4 x (dgamma2, dbeta2) sinks."""
@@ -520,8 +534,24 @@ def mfaf_ctx_bwd(pooled, saved, dz2, seqs, sinks, tails=None, sinks2=None):
             keep += [scr]
         d.sums2 = _p(sums2)
         keep.append(sums2)
-    _run(lib, 'ledn_mfaf_ctx_bwd', pooled[0], C.byref(d),
-         work=_ops._TIMING is not None and ('mfaf_ctx_bwd', 0, 0, 'mfaf_ctx_bwd1_kernel'))
+    work = _ops._TIMING is not None and ('mfaf_ctx_bwd', 0, 0, 'mfaf_ctx_bwd1_kernel')
+    if sync is None:
+        _run(lib, 'ledn_mfaf_ctx_bwd', pooled[0], C.byref(d), work=work)
+    else:
+        d.count_scale = float(world)
+        sums_l = _ops.zeros_f32((4, 2, Ci), dev)
+        d.sums_local = _p(sums_l)
+        sums2_l = None
+        if tails is not None:
+            sums2_l = _ops.zeros_f32((4, 2, Cc), dev)
+            d.sums2_local = _p(sums2_l)
+        for phase, (src, dst) in ((1, (sums2_l, sums2 if tails is not None else None)), (2, (sums_l, sums)), (4, (None, None))):
+            if phase == 1 and tails is None:
+                continue
+            d.phase = phase
+            _run(lib, 'ledn_mfaf_ctx_bwd', pooled[0], C.byref(d), work=work if phase == 4 else False)
+            if src is not None:
+                sync.all_reduce(src, dst)
     return dps, grads
 
 

@@ -720,14 +720,21 @@ class MfafTailFn(Function):
         raws = [xl, c1, c2, c3, xg]
         ctx.accs = accs or (None, None)
         affs, saved = [], []
+        givens = [_Env.ctx_fin.pop(raw.data_ptr(), None) if k else None for k, raw in enumerate(raws)]
         if _Env.sync_bn is not None:
-            fin, counts = _bn_stats_group(raws, bns, gb[0::2], gb[1::2])
+            own = [k for k in range(5) if givens[k] is None]
+            f_own, c_own = _bn_stats_group([raws[k] for k in own], [bns[k] for k in own], [gb[2 * k] for k in own],
+                                           [gb[2 * k + 1] for k in own])
+            fin = list(givens)
+            counts = [-(raw.numel() // raw.shape[-1]) for raw in raws]
+            for k, f, c in zip(own, f_own, c_own):
+                fin[k], counts[k] = f, c
         else:
             fin, counts = [], []
             for k, raw in enumerate(raws):
                 Cc = raw.shape[-1]
                 count = raw.numel() // Cc
-                given = _Env.ctx_fin.pop(raw.data_ptr(), None) if k else None
+                given = givens[k]
                 if given is not None:           # statistics + finalize already done by MfafCtxFn
                     fin.append(given)
                     counts.append(-count)       # (negative: the BatchNorm backward is MfafCtxFn's too)
@@ -1006,7 +1013,8 @@ class MfafCtxFn(Function):
         pooled, params = [_c(p) for p in args[:4]], args[4:]
         if not FUSE_MFAF_TAIL:
             tails = None
-        z2s, saved = T.mfaf_ctx_fwd(pooled, seqs, True, tails=tails)
+        ctx.sync, ctx.world = _Env.sync_bn, _Env.world
+        z2s, saved = T.mfaf_ctx_fwd(pooled, seqs, True, tails=tails, sync=ctx.sync, world=ctx.world)
         ctx.seqs, ctx.tails = seqs, tails
         ctx.save_for_backward(*pooled, *saved['z1'], *saved['bn1'], *(saved['bn2'] or ()), *z2s)
         ctx.sinks = [[_Sinks.get(p) for p in (c1.weight, c1.bias, bn.weight, bn.bias, c2.weight, c2.bias)]
@@ -1026,7 +1034,7 @@ class MfafCtxFn(Function):
         else:
             saved = dict(z1=z1, bn1=bn1)
         dps, grads = T.mfaf_ctx_bwd(pooled, saved, [_c(d) for d in dy], ctx.seqs, ctx.sinks, tails=ctx.tails,
-                                    sinks2=ctx.sinks2)
+                                    sinks2=ctx.sinks2, sync=ctx.sync, world=ctx.world)
         flat = []
         for gk in grads:
             flat += gk[:6]
@@ -1037,6 +1045,7 @@ class MfafCtxFn(Function):
 
 FUSE_MFAF_CTX = int(_os.environ.get('LEDN_FUSE_MFAF_CTX', '1'))
 FUSE_MFAF_TAIL = int(_os.environ.get('LEDN_FUSE_MFAF_TAIL', '1'))   # ... and their trailing BatchNorms
+FUSE_MFAF_SYNC = int(_os.environ.get('LEDN_FUSE_MFAF_SYNC', '1'))   # ... under SyncBN too (phases + all-reduces in between)
 
 
 def mfaf(m, x, r, out_relu=False, pre=None):
@@ -1053,7 +1062,10 @@ def mfaf(m, x, r, out_relu=False, pre=None):
         mid = conv_bn_act(inp, seq[off], seq[off + 1], ACT_RELU)
         c1 = seq[off + 3]
         return ConvFn.apply(mid, c1.weight, c1.bias, None, 1, 0, 1, None, out_dtype), seq[off + 4]
-    if _Env.sync_bn is not None:
+    ctx_seqs = [getattr(m, name) for name, _ in m.POOLS]
+    fused = (FUSE_MFAF_CTX and all(pz.dtype == torch.float32 and pz.shape[-1] == 64 for pz in pooled)
+             and all(sq[1].out_channels == 16 and sq[4].out_channels == 64 for sq in ctx_seqs))
+    if _Env.sync_bn is not None and not (fused and FUSE_MFAF_SYNC):
         # data-parallel: the five first-level BatchNorms (local + four pooled contexts) see their inputs
         # together -> one grouped SyncBN all-reduce per direction instead of five
         seqs = [(m.local_att, 0, xa)] + [(getattr(m, name), 1, pz) for (name, _), pz in zip(m.POOLS, pooled)]
@@ -1072,10 +1084,9 @@ def mfaf(m, x, r, out_relu=False, pre=None):
         # the four pooled-context MLPs are chains of tiny launch-bound kernels, independent of each other and of
         # the local branch: each runs on its own auxiliary stream while the local branch (full-resolution convs)
         # runs on the main one (forward here, backward through autograd's stream affinity)
+        # (data-parallel: the fused sequence runs in phases with one all-reduce of the [4,2,C] statistics between them)
         forks, ctx, bns_ctx = [], [], []
-        seqs = [getattr(m, name) for name, _ in m.POOLS]
-        fused = (FUSE_MFAF_CTX and all(pz.dtype == torch.float32 and pz.shape[-1] == 64 for pz in pooled)
-                 and all(sq[1].out_channels == 16 and sq[4].out_channels == 64 for sq in seqs))
+        seqs = ctx_seqs
         if fused:
             triples = [(sq[1], sq[2], sq[4]) for sq in seqs]
             bns_ctx = [sq[5] for sq in seqs]

@@ -493,3 +493,89 @@ def test_mfaf_context_mlps_fused_with_trailing_batchnorm(be):
                 bn2.bias.grad]
         for j in range(8):
             close(grads[k][j], want[j], tol, tol * max(1.0, float(want[j].abs().max())))
+
+
+def test_mfaf_context_mlps_fused_syncbn_two_ranks(be):
+    """the launch sequence in its PHASES with the statistics all-reduced in between (SyncBN, data-parallel): two
+    "ranks" (threads, a barrier-backed sum as the all-reduce) with two samples each against the torch modules on the
+    four samples: outputs and running statistics of the GLOBAL batch, the gradient of every rank's pooled maps, and
+    parameter gradients whose SUM over the ranks is the big-batch gradient (the BatchNorm gamma / beta gradients
+    are each rank's own sums, as torch.nn.SyncBatchNorm's -- the all-reduced ones would count world x)."""
+    import copy
+    import threading
+    import torch.nn as nn
+    from led_net_amd import ops_train as T
+    g = torch.Generator().manual_seed(9)
+    N, Cc, Ci, world = 4, 64, 16, 2
+    sizes = (4, 8, 16, 1)
+    ref = []
+    for S in sizes:
+        mods = [nn.Conv2d(Cc, Ci, 1), nn.BatchNorm2d(Ci), nn.Conv2d(Ci, Cc, 1), nn.BatchNorm2d(Cc)]
+        with torch.no_grad():
+            for bn in (mods[1], mods[3]):
+                bn.weight.copy_(0.5 + torch.rand(bn.num_features, generator=g))
+                bn.bias.copy_(0.1 * torch.randn(bn.num_features, generator=g))
+        ref.append(mods)
+    pooled = [torch.randn(N, S, S, Cc, generator=g) for S in sizes]
+    dy = [torch.randn(N, S, S, Cc, generator=g) for S in sizes]
+
+    class PairSync:
+        def __init__(self):
+            self.barrier, self.slots, self.tl, self.calls = threading.Barrier(world), [None] * world, threading.local(), 0
+            self.turn = threading.Lock()        # one rank launches at a time (the emulator's kernel state is global)
+
+        def all_reduce(self, src, dst):
+            self.slots[self.tl.rank] = src.detach().clone()
+            self.turn.release()
+            self.barrier.wait()
+            total = self.slots[0] + self.slots[1]
+            self.barrier.wait()
+            self.turn.acquire()
+            dst.copy_(total)
+            if self.tl.rank == 0:
+                self.calls += 1
+            return dst
+    sync = PairSync()
+    res, errs = [None] * world, []
+
+    def rank_fn(r):
+        try:
+            sync.tl.rank = r
+            with sync.turn:
+                dev = [[copy.deepcopy(m).to(be.dev) for m in mods] for mods in ref]
+                seqs, tails = [tuple(d[:3]) for d in dev], [d[3] for d in dev]
+                mine = [p[2 * r:2 * r + 2].contiguous().to(be.dev) for p in pooled]
+                z2s, saved = T.mfaf_ctx_fwd(mine, seqs, True, tails=tails, sync=sync, world=world)
+                saved['z2'] = z2s
+                dps, grads = T.mfaf_ctx_bwd(mine, saved, [d[2 * r:2 * r + 2].contiguous().to(be.dev) for d in dy], seqs, None,
+                                            tails=tails, sync=sync, world=world)
+                res[r] = dict(z2=[z.cpu() for z in z2s], bn2=[b.cpu() for b in saved['bn2']], dps=[d.cpu() for d in dps],
+                              grads=[[t.cpu() for t in gk] for gk in grads],
+                              rv=[t.running_var.cpu() for t in tails], rm1=[s[1].running_mean.cpu() for s in seqs])
+        except Exception as e:       # noqa: BLE001 -- re-raised in the main thread
+            errs.append(e)
+            sync.barrier.abort()
+    ths = [threading.Thread(target=rank_fn, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+    assert sync.calls == 4          # stats1, stats2 forward; sums2, sums backward: one all-reduce each
+    for k, (c1, bn, c2, bn2) in enumerate(ref):
+        x = pooled[k].permute(0, 3, 1, 2).clone().requires_grad_(True)
+        y = bn2(c2(torch.relu(bn(c1(x)))))
+        y.backward(dy[k].permute(0, 3, 1, 2))
+        tol = 5e-4 if sizes[k] > 1 else 3e-2
+        for r in range(world):
+            sc, sh = res[r]['bn2'][k][0], res[r]['bn2'][k][1]
+            close(nchw(res[r]['z2'][k] * sc + sh), y.detach()[2 * r:2 * r + 2], *((2e-4, 2e-4) if sizes[k] > 1 else (2e-2, 2e-3)))
+            close(res[r]['rv'][k], bn2.running_var, 1e-5, 1e-6)
+            close(res[r]['rm1'][k], bn.running_mean, 1e-5, 1e-6)
+            close(nchw(res[r]['dps'][k]), x.grad[2 * r:2 * r + 2], tol, tol * max(0.1, float(x.grad.abs().max())))
+        want = [c1.weight.grad, c1.bias.grad, bn.weight.grad, bn.bias.grad, c2.weight.grad, c2.bias.grad, bn2.weight.grad,
+                bn2.bias.grad]
+        for j in range(8):
+            got = res[0]['grads'][k][j] + res[1]['grads'][k][j]
+            close(got, want[j], tol, tol * max(1.0, float(want[j].abs().max())))
