@@ -145,6 +145,37 @@ class BasicBlock(Block):
         return self.conv2(out, res=res, res_mode=RES_ADD, act_override=act)
 
 
+class Bottleneck(Block):
+    """mmseg/models/utils/basic_block.py:156-221: 1x1 -> 3x3 (stride) -> 1x1 to channels * 2, shortcut (identity or a
+    1x1 stride-s conv + BatchNorm, as ddrnet.py:186-206 builds it), optional output activation (default: none)."""
+    expansion = 2
+
+    def __init__(self, cin, channels, stride=1, downsample=False, act_out=False):
+        super().__init__()
+        self.conv1 = ConvModule(cin, channels, 1, 1, 0, act='relu')
+        self.conv2 = ConvModule(channels, channels, 3, stride, 1, act='relu')
+        self.conv3 = ConvModule(channels, channels * self.expansion, 1, 1, 0, act=None)
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, channels * self.expansion, 1, stride, bias=False),
+                                            nn.BatchNorm2d(channels * self.expansion))
+        else:
+            self.downsample = None
+        self.act_out = act_out
+        self.stride = stride
+
+    def forward(self, x, final_relu=False):
+        assert not self.training
+        out = self.conv2(self.conv1(x))
+        if self.downsample is not None:
+            s, b = self.cached('ds', lambda: fold_bn(self.downsample[1]))
+            wd = self.downsample[0].weight
+            res = ops.conv2d(x, wd, stride=self.stride, out_scale=s, out_shift=b, w_bf16=packed(self, wd, x))
+        else:
+            res = x
+        act = ACT_RELU if (self.act_out or final_relu) else ACT_NONE
+        return self.conv3(out, res=res, res_mode=RES_ADD, act_override=act)
+
+
 # --------------------------------------------------------------------------- #
 class _CBR(nn.Module):
     def __init__(self, cin, cout, groups, act=True):

@@ -889,6 +889,18 @@ def basic_block(m, x, final_relu=False, pre=None):
     return conv_module(c2, out, act_override=act, res=res, res_mode=RES_ADD, acc_res=acc_res)
 
 
+def bottleneck(m, x, final_relu=False):
+    """blocks.Bottleneck in training mode (basic_block.py:207-221)."""
+    (x, xr), acc = fanout(x, 2)           # consumers: conv1, the shortcut
+    if m.downsample is not None:
+        res, acc_res = conv_bn_act(xr, m.downsample[0], m.downsample[1], acc=acc), None
+    else:
+        res, acc_res = xr, acc
+    act = ACT_RELU if (m.act_out or final_relu) else ACT_NONE
+    out = conv_module(m.conv2, conv_module(m.conv1, x, acc=acc))
+    return conv_module(m.conv3, out, act_override=act, res=res, res_mode=RES_ADD, acc_res=acc_res)
+
+
 def sesp(m, x):
     residual = (m.stride == 2 and not m.spatial) or (m.stride == 1 and m.nIn == m.nOut)
     xr, acc = x, None

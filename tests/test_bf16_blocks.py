@@ -170,6 +170,16 @@ def test_basic_block_train_bf16(be, name):
     _check_block_bf16(fx, _basic(fx), TR.basic_block)
 
 
+@pytest.mark.parametrize('name', train_names('g16_'))
+def test_bottleneck_train_bf16(be, name):
+    from led_net_amd import train as TR
+    from led_net_amd.blocks import Bottleneck
+    fx = Fixture(name)
+    kw = fx.meta['kwargs']
+    m = Bottleneck(kw['in_channels'], kw['channels'], kw['stride'], kw.get('downsample', False), kw.get('act_out', False))
+    _check_block_bf16(fx, m, TR.bottleneck)
+
+
 @pytest.mark.parametrize('name', train_names('g14_'))
 def test_ppm_train_bf16(be, name):
     from led_net_amd import train as TR

@@ -83,6 +83,18 @@ def test_basic_block_eval_golden(be, name):
     close(nchw(m(nhwc(fx.ins['x']))), fx.outs['y'])
 
 
+@pytest.mark.parametrize('name', eval_names('g16_'))
+def test_bottleneck_eval_golden(be, name):
+    from led_net_amd.blocks import Bottleneck
+    fx = Fixture(name)
+    kw = fx.meta['kwargs']
+    m = Bottleneck(kw['in_channels'], kw['channels'], kw['stride'], kw.get('downsample', False),
+                   kw.get('act_out', False)).eval()
+    m.load_state_dict(fx.sd, strict=True)
+    m.to(_DEV[0])
+    close(nchw(m(nhwc(fx.ins['x']))), fx.outs['y'])
+
+
 def test_led_head_eval_golden(be):
     from led_net_amd import LEDHead
     fx = Fixture('g10_ledhead_eval')

@@ -122,6 +122,16 @@ def test_mfaf_train_golden(be, name):
     _check_block(fx, MFAF(64, 4), TR.mfaf)
 
 
+@pytest.mark.parametrize('name', train_names('g16_'))
+def test_bottleneck_train_golden(be, name):
+    from led_net_amd.blocks import Bottleneck
+    from led_net_amd import train as TR
+    fx = Fixture(name)
+    kw = fx.meta['kwargs']
+    m = Bottleneck(kw['in_channels'], kw['channels'], kw['stride'], kw.get('downsample', False), kw.get('act_out', False))
+    _check_block(fx, m, TR.bottleneck)
+
+
 @pytest.mark.parametrize('name', train_names('g11_'))
 def test_basic_block_train_golden(be, name):
     from led_net_amd.blocks import BasicBlock
