@@ -327,6 +327,9 @@ constexpr bool epi_stats(int e) { return e == EPI_RAW_STATS || e == EPI_FULL; }
 // RW: K-chunks whose weight slices stay RESIDENT in LDS for the lifetime of the workgroup (1: only the Cin <= 32 case;
 // 2: Cin <= 64 too -- the 64-output-channel configuration already owns its CU, and re-staging 46 KB of weights per
 // K-chunk and tile moved more L2 -> LDS bytes than the activations it multiplies them with)
+#ifndef LEDN_EXP
+#define LEDN_EXP 0      // phase-cost experiments (tools/gpu_exp.sh): 1 no stores, 2 no matrix phase, 3 no fetch, 4 no fetch / commit
+#endif
 template <int WM, int WN, int MT, int K, int S, int UP, int EPI, bool VEC, int RW = 1>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     constexpr int TR = WM * MT;
@@ -346,12 +349,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
     // VEC: Cout % 8 == 0, 16-byte NHWC stores through LDS; else the narrow heads (Cout < 8), scalar stores.
     // Compile-time: as a run-time flag it put a branch around every accumulator quad of the epilogue.
     constexpr bool vec = VEC;
-    // per-wave store transposition (after the MFMA phase): EG output rows at a time, so that one pair of wave
-    // synchronisations (each a full LDS drain) serves EG rows instead of one -- the epilogue was the longest phase
-    // of a RAW step (cycle counters r03s: 3900 of 10500 cycles, 8 drains per step)
-    constexpr int EG = MT >= 2 ? 2 : 1;
-    static_assert(PR * PC * PIXB >= 4 * EG * 32 * PIXB, "store-transposition buffers alias the patch");
-    unsigned char* s_ow = s_patch + wid * (EG * 32 * PIXB);
+    constexpr int EG = 1;
 
     const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
     const long tstep = a.tile_stride > 0 ? a.tile_stride : 1;
@@ -419,7 +417,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
 
     // one (tile, K-chunk) step: `stg` holds its patch; afterwards stg is refilled with the step `look` ahead
     auto do_step = [&](auto& stg, const long tile, const int c0, const int look) {
-        stg.commit(s_patch, a.in_scale, a.in_shift, a.in_slope, a.in_act, c0, tid);
+        if (LEDN_EXP != 4 || a.N < 0) stg.commit(s_patch, a.in_scale, a.in_shift, a.in_slope, a.in_act, c0, tid);
         if (!one_chunk) LEDN_CONV_WEIGHTS(c0, 0);
         __syncthreads();
         long ntile = tile;
@@ -432,7 +430,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                 fc += CK;
                 if (fc >= a.Cin) { fc = 0; ft += tstep; }
             }
-            if (ft < te) LEDN_CONV_FETCH(stg, ft, fc);
+            if (ft < te && ((LEDN_EXP != 3 && LEDN_EXP != 4) || a.N < 0)) LEDN_CONV_FETCH(stg, ft, fc);
         }
         // ---- taps x k-steps, all operands from LDS.  A = weights (M = cout), B = pixels (N = 32
         // pixels of a row): the accumulator lane owns ONE pixel and 4 x 4 consecutive channels.
@@ -454,6 +452,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                 xf_[m] = *reinterpret_cast<const bf16x8_t*>(xbase + (long)((m * S + kh_) * PC + kw_) * PIXB + kk_ * 32); \
         } while (0)
         LEDN_FRAGS(0, wf_n, xf_n);
+        if (LEDN_EXP != 2 || a.N < 0)
         static_for<NSTEP>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const bf16x8_t wf = wf_n;
@@ -479,17 +478,18 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
             const int ho0 = th * TR + wm * MT, wo0 = tw * 32;
             const int wo = wo0 + lr;
             const float hi = a.act_out == LEDN_ACT_RELU6 ? 6.f : 3.0e38f;
-            // the two 16-byte pieces this lane moves per output row: pixel px_h = (lane >> 2) + 16 h, channels
-            // cb0 + 8 (lane & 3) ...; element offset of row ho0 (rows advance by Wo * Cout)
-            const int piece = lane & 3;
-            const bool pc_ok = cb0 + piece * 8 < a.Cout;
+            // the two 16-byte pieces this lane stores per output row, straight from registers: after the
+            // v_permlane32_swap of the channel quads of lanes l / l + 32 (below) the lane holds channels
+            // cb0 + 8 lh + 0..7 and cb0 + 16 + 8 lh + 0..7 of ITS pixel -- no LDS transposition, no wave
+            // synchronisation (each was a full LDS drain: the epilogue was the longest phase of a RAW step, cycle
+            // counters r03s), and no workgroup barrier after the epilogue.  Element offset of row ho0 (rows advance
+            // by Wo * Cout).
             bool px_ok[2];
             long yoff[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int px = (lane >> 2) + 16 * h;
-                px_ok[h] = pc_ok && wo0 + px < a.Wo;
-                yoff[h] = (((long)n * a.Ho + ho0) * a.Wo + wo0 + px) * a.Cout + cb0 + piece * 8;
+                px_ok[h] = cb0 + 16 * h + 8 * lh < a.Cout && wo < a.Wo;
+                yoff[h] = (((long)n * a.Ho + ho0) * a.Wo + wo) * a.Cout + cb0 + 16 * h + 8 * lh;
             }
             const long row_elems = (long)a.Wo * a.Cout;
 #pragma unroll
@@ -499,7 +499,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                 const int ho = ho0 + m;
                 const bool pix_ok = ho < a.Ho && wo < a.Wo;
                 const long pix = (((long)n * a.Ho + ho) * a.Wo + wo) * a.Cout;
-                unsigned char* s_om = s_ow + (m - mg) * (32 * PIXB);
+                unsigned pk[4][2];
+                uint4 radd[2];
+                if (vec && EPI == EPI_RAW_ACC) {    // the addend's pieces, in flight during the conversion
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        radd[h] = *reinterpret_cast<const uint4*>(a.res + ((px_ok[h] && ho < a.Ho) ? yoff[h] + m * row_elems : 0L));
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int cl = wn * 32 + 8 * q + 4 * lh;         // channel inside the workgroup's slice
@@ -546,7 +552,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                         for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], 0.f) + ng[j] * fminf(v[j], 0.f), hi);
                     }
                     if constexpr (vec) {
-                        st4(reinterpret_cast<bf16_t*>(s_om + lr * PIXB) + 8 * q + 4 * lh, v);
+                        pk[q][0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                        pk[q][1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
                     } else if (q == 0) {   // narrow heads (Cout < 8): channels 4*lh + j, scalar stores
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -556,42 +563,29 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                             }
                     }
                 }
-            }
                 if constexpr (vec) {
-                    // bf16 rows through the per-wave LDS buffer: every global store is 16 B per lane,
-                    // 4 lanes per pixel (whole 64-byte channel rows)
-                    uint4 radd[EG][2];
-                    if (EPI == EPI_RAW_ACC) {    // the addend's pieces, in flight during the transposition
+                    // lanes l / l + 32 hold channels {0-3, 8-11, 16-19, 24-27} (+4): after the swaps l has 0-7 and
+                    // 16-23, l + 32 has 8-15 and 24-31
+                    permlane32_swap(pk[0][0], pk[1][0]);
+                    permlane32_swap(pk[0][1], pk[1][1]);
+                    permlane32_swap(pk[2][0], pk[3][0]);
+                    permlane32_swap(pk[2][1], pk[3][1]);
 #pragma unroll
-                        for (int e = 0; e < EG; ++e)
+                    for (int h = 0; h < 2; ++h) {
+                        uint4 o = make_uint4(pk[2 * h][0], pk[2 * h][1], pk[2 * h + 1][0], pk[2 * h + 1][1]);
+                        if (EPI == EPI_RAW_ACC) {
+                            float fo[8], fr[8];
+                            ld8(reinterpret_cast<const bf16_t*>(&o), fo);
+                            ld8(reinterpret_cast<const bf16_t*>(&radd[h]), fr);
 #pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const bool okp = px_ok[h] && ho0 + mg + e < a.Ho;
-                                radd[e][h] = *reinterpret_cast<const uint4*>(a.res + (okp ? yoff[h] + (mg + e) * row_elems : 0L));
-                            }
-                    }
-                    wave_sync();
-#pragma unroll
-                    for (int e = 0; e < EG; ++e)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int px = (lane >> 2) + 16 * h;
-                            uint4 o = *reinterpret_cast<const uint4*>(s_ow + e * (32 * PIXB) + px * PIXB + piece * 16);
-                            if (EPI == EPI_RAW_ACC) {
-                                float fo[8], fr[8];
-                                ld8(reinterpret_cast<const bf16_t*>(&o), fo);
-                                ld8(reinterpret_cast<const bf16_t*>(&radd[e][h]), fr);
-#pragma unroll
-                                for (int k2 = 0; k2 < 8; ++k2) fo[k2] += fr[k2];
-                                st8(reinterpret_cast<bf16_t*>(&o), fo);
-                            }
-                            if (px_ok[h] && ho0 + mg + e < a.Ho)
-                                *reinterpret_cast<uint4*>(a.y + yoff[h] + (mg + e) * row_elems) = o;
+                            for (int k2 = 0; k2 < 8; ++k2) fo[k2] += fr[k2];
+                            st8(reinterpret_cast<bf16_t*>(&o), fo);
                         }
-                    wave_sync();
+                        if (px_ok[h] && ho < a.Ho && (LEDN_EXP != 1 || a.N < 0)) *reinterpret_cast<uint4*>(a.y + yoff[h] + m * row_elems) = o;
+                    }
                 }
             }
-            if constexpr (vec) __syncthreads();   // the transposition buffers alias the patch of the next step
+            }
         }
     };
     {
@@ -697,7 +691,10 @@ static int launch_shape(const MfmaConvArgs& a, hipStream_t s) {
     if constexpr (S == 2) {
         return launch_cfg<4, 1, 1, K, S, UP>(a, s);
     } else {
-        if (a.Cout % 64 == 0) return launch_cfg<2, 2, 4, K, S, UP>(a, s);
+        // 64 output channels per workgroup (one read of the patch for both 32-channel halves) pays for 1x1 only: the
+        // 3x3 slices of 32 channels at 2 workgroups per CU measured 6-8 % faster (r03 exp7: 64->64 39.7 -> 37.3 us,
+        // data gradient 33.5 -> 31.0, 128->64 65.1 -> 59.9) -- the second read of the patch comes from L2
+        if (a.Cout % 64 == 0 && K == 1) return launch_cfg<2, 2, 4, K, S, UP>(a, s);
         // fewer 16-row tiles than workgroups wanted (1/8-resolution maps, small batches): 8-row tiles double the
         // parallelism of these latency-bound launches
         if ((options().stream_fast & 8) &&

@@ -229,6 +229,7 @@ inline unsigned long long __ballot(int pred) {
     return r;
 }
 
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }

@@ -87,9 +87,9 @@ __global__ void __launch_bounds__(SEAM_T) seam_edge_kernel(const float* seg_all,
                                                            float* scratch, int h, int w, int kth,
                                                            float thr, float final_thr) {
     __shared__ float s_red[2][SEAM_T / 64];
-    __shared__ unsigned s_hist[256];
-    __shared__ unsigned s_wave[4];
-    __shared__ unsigned s_sel[2];  // prefix, remaining rank
+    __shared__ unsigned s_hist[3][256];
+    __shared__ unsigned s_wave[3][4];
+    __shared__ unsigned s_sel[3][2];  // per level: prefix, remaining rank
     __shared__ float s_thr[3];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int hw = h * w;
@@ -136,58 +136,71 @@ __global__ void __launch_bounds__(SEAM_T) seam_edge_kernel(const float* seg_all,
     }
     __syncthreads();
 
-    // phase 3: k-th smallest response per level (4 x 8-bit radix select)
+    // phase 3: k-th smallest response of the THREE levels together (4 x 8-bit radix select, one histogram per
+    // level).  The clamped Laplacian is exactly 0 on about half of the pixels: those would all hit bin 0 of every
+    // pass (same-address LDS atomics serialise), so a wavefront counts its zeros with one ballot per level.
     if (kth > 0) {
         const int kk = kth > hw ? hw : kth;
-        for (int sidx = 0; sidx < 3; ++sidx) {
-            const float* r = resp + sidx * hw;
-            if (tid == 0) {
-                s_sel[0] = 0u;
-                s_sel[1] = (unsigned)(kk - 1);  // 0-based rank still to locate
-            }
-            for (int pass = 0; pass < 4; ++pass) {
-                const int shift = 24 - 8 * pass;
-                if (tid < 256) s_hist[tid] = 0u;
-                __syncthreads();
-                const unsigned prefix = s_sel[0];
-                const unsigned rank0 = s_sel[1];
-                const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-                for (int i = tid; i < hw; i += SEAM_T) {
-                    const unsigned u = __float_as_uint(r[i]);
-                    if ((u & himask) == prefix) atomicAdd(&s_hist[(u >> shift) & 255u], 1u);
-                }
-                __syncthreads();
-                // bucket holding the rank: prefix sum over the 256 bins by the first four wavefronts
-                unsigned mine = 0u, incl = 0u;
-                if (tid < 256) {
-                    mine = s_hist[tid];
-                    incl = mine;
-                    const int lane = tid & 63;
+        if (tid < 3) {
+            s_sel[tid][0] = 0u;
+            s_sel[tid][1] = (unsigned)(kk - 1);     // 0-based rank still to locate
+        }
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 768) s_hist[tid >> 8][tid & 255] = 0u;
+            __syncthreads();
+            const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+            unsigned prefix[3], rank[3];
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const unsigned nbr = __shfl(incl, lane >= o ? lane - o : lane);
-                        if (lane >= o) incl += nbr;
-                    }
-                    if (lane == 63) s_wave[tid >> 6] = incl;
-                }
-                __syncthreads();
-                if (tid < 256) {
-                    for (int i = 0; i < (tid >> 6); ++i) incl += s_wave[i];
-                    const unsigned excl = incl - mine;
-                    const unsigned total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-                    if (rank0 >= excl && rank0 < incl) {            // exactly one thread when rank0 < total
-                        s_sel[0] = prefix | ((unsigned)tid << shift);
-                        s_sel[1] = rank0 - excl;
-                    } else if (rank0 >= total && tid == 255) {      // (cannot happen: rank < count; kept as the
-                        s_sel[0] = prefix | (256u << shift);        //  serial scan's fall-through: b = 256)
-                        s_sel[1] = rank0 - total;
-                    }
-                }
-                __syncthreads();
+            for (int l = 0; l < 3; ++l) {
+                prefix[l] = s_sel[l][0];
+                rank[l] = s_sel[l][1];
             }
-            if (tid == 0) s_thr[sidx] = __uint_as_float(s_sel[0]);
+            for (int i0 = 0; i0 < hw; i0 += SEAM_T) {
+                const int i = i0 + tid;
+#pragma unroll
+                for (int l = 0; l < 3; ++l) {
+                    const unsigned u = i < hw ? __float_as_uint(resp[l * hw + i]) : 0xffffffffu;
+                    const bool zero = u == 0u && prefix[l] == 0u;
+                    const unsigned long long zm = __ballot(zero);
+                    if (zm != 0ull && (tid & 63) == 0) atomicAdd(&s_hist[l][0], (unsigned)__popcll(zm));
+                    if (i < hw && !zero && (u & himask) == prefix[l]) atomicAdd(&s_hist[l][(u >> shift) & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            // bucket holding the rank: prefix sum over the 256 bins of level l by wavefronts 4l .. 4l+3
+            unsigned mine = 0u, incl = 0u;
+            const int l = tid >> 8, b = tid & 255;
+            if (tid < 768) {
+                mine = s_hist[l][b];
+                incl = mine;
+                const int lane = tid & 63;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned nbr = __shfl(incl, lane >= o ? lane - o : lane);
+                    if (lane >= o) incl += nbr;
+                }
+                if (lane == 63) s_wave[l][b >> 6] = incl;
+            }
+            __syncthreads();
+            if (tid < 768) {
+                const unsigned rank0 = l == 0 ? rank[0] : l == 1 ? rank[1] : rank[2];
+                const unsigned pre = l == 0 ? prefix[0] : l == 1 ? prefix[1] : prefix[2];
+                for (int i = 0; i < (b >> 6); ++i) incl += s_wave[l][i];
+                const unsigned excl = incl - mine;
+                const unsigned total = s_wave[l][0] + s_wave[l][1] + s_wave[l][2] + s_wave[l][3];
+                if (rank0 >= excl && rank0 < incl) {                // exactly one thread when rank0 < total
+                    s_sel[l][0] = pre | ((unsigned)b << shift);
+                    s_sel[l][1] = rank0 - excl;
+                } else if (rank0 >= total && b == 255) {            // (cannot happen: rank < count; kept as the
+                    s_sel[l][0] = pre | (256u << shift);            //  serial scan's fall-through: b = 256)
+                    s_sel[l][1] = rank0 - total;
+                }
+            }
             __syncthreads();
         }
+        if (tid < 3) s_thr[tid] = __uint_as_float(s_sel[tid][0]);
+        __syncthreads();
     } else {
         if (tid < 3) s_thr[tid] = thr;
         __syncthreads();
@@ -202,12 +215,188 @@ __global__ void __launch_bounds__(SEAM_T) seam_edge_kernel(const float* seg_all,
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same map for h * w <= 16 K pixels (every size the network produces up to 1024 x 1024 inputs) with the image
+// RESIDENT: the min-max normalised map lives in LDS (64 KB), each lane keeps its 16 pixels x 3 responses in
+// registers.  The generic kernel above reads the map from global memory inside the Laplacian's border branches (27
+// dependent L2 round trips per pixel and lane: 88 of its 133 us at 16 x 128 x 128) and the responses back from a
+// global scratch in every radix pass.  Arithmetic, summation order and the radix select are the generic kernel's
+// (bit-identical responses and thresholds).  Histogram: 4 interleaved copies per level (lane & 3) -- most responses
+// share their top byte, and same-address LDS atomics of a wavefront serialise.
+// ---------------------------------------------------------------------------
+constexpr int SEAM_RPT = 16, SEAM_HC = 4;
+__device__ __forceinline__ float seam_lap_lds(const float* s, int h, int w, int cy, int cx) {
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = cy + dy, xx = cx + dx;
+            const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
+            const float v = s[min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
+            const float term = (dy == 0 && dx == 0) ? 8.f * v : -v;
+            if (in) acc += term;
+        }
+    return acc > 0.f ? acc : 0.f;
+}
+
+__global__ void __launch_bounds__(SEAM_T) seam_edge_lds_kernel(const float* seg_all, float* edge_all, int h, int w,
+                                                               int kth, float thr, float final_thr) {
+    __shared__ float s_seg[SEAM_T * SEAM_RPT];
+    __shared__ float s_red[2][SEAM_T / 64];
+    __shared__ unsigned s_hist[3][SEAM_HC][256];
+    __shared__ unsigned s_wave[3][4];
+    __shared__ unsigned s_sel[3][2];  // per level: prefix, remaining rank
+    __shared__ float s_thr[3];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int hw = h * w;
+    const float* seg = seg_all + (long)n * hw;
+    float* edge = edge_all + (long)n * hw;
+
+    // phase 1: min / max, then the normalised map -> LDS
+    float raw[SEAM_RPT];
+    float mn = 3.0e38f, mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < SEAM_RPT; ++r) {
+        const int i = tid + r * SEAM_T;
+        raw[r] = i < hw ? seg[i] : 0.f;
+        if (i < hw) {
+            mn = fminf(mn, raw[r]);
+            mx = fmaxf(mx, raw[r]);
+        }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) {
+        s_red[0][tid >> 6] = mn;
+        s_red[1][tid >> 6] = mx;
+    }
+    __syncthreads();
+    mn = s_red[0][0];
+    mx = s_red[1][0];
+    for (int i = 1; i < SEAM_T / 64; ++i) {
+        mn = fminf(mn, s_red[0][i]);
+        mx = fmaxf(mx, s_red[1][i]);
+    }
+    const float den = mx - mn;
+#pragma unroll
+    for (int r = 0; r < SEAM_RPT; ++r) {
+        const int i = tid + r * SEAM_T;
+        if (i < hw) s_seg[i] = (raw[r] - mn) / den;
+    }
+    __syncthreads();
+
+    // phase 2: the three Laplacian responses (strides 1 / 2 / 4, nearest-upsampled) of this lane's pixels
+    float resp[3][SEAM_RPT];
+#pragma unroll
+    for (int r = 0; r < SEAM_RPT; ++r) {
+        const int i = tid + r * SEAM_T;
+        const int ic = min(i, hw - 1);
+        const int y = ic / w, x = ic % w;
+        resp[0][r] = seam_lap_lds(s_seg, h, w, y, x);
+#pragma unroll
+        for (int sidx = 1; sidx < 3; ++sidx) {
+            const int st = sidx == 1 ? 2 : 4;
+            const int hs = (h - 1) / st + 1, wss = (w - 1) / st + 1;  // conv2d(stride, pad 1) size
+            int sy = (int)((float)y * ((float)hs / (float)h));
+            int sx = (int)((float)x * ((float)wss / (float)w));
+            if (sy > hs - 1) sy = hs - 1;
+            if (sx > wss - 1) sx = wss - 1;
+            resp[sidx][r] = seam_lap_lds(s_seg, h, w, sy * st, sx * st);
+        }
+    }
+
+    // phase 3: k-th smallest response of the three levels together (4 x 8-bit radix select)
+    if (kth > 0) {
+        const int kk = kth > hw ? hw : kth;
+        if (tid < 3) {
+            s_sel[tid][0] = 0u;
+            s_sel[tid][1] = (unsigned)(kk - 1);     // 0-based rank still to locate
+        }
+        const int hc = tid & (SEAM_HC - 1);
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            for (int i = tid; i < 3 * SEAM_HC * 256; i += SEAM_T) (&s_hist[0][0][0])[i] = 0u;
+            __syncthreads();
+            const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+            unsigned prefix[3], rank[3];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                prefix[l] = s_sel[l][0];
+                rank[l] = s_sel[l][1];
+            }
+#pragma unroll
+            for (int r = 0; r < SEAM_RPT; ++r) {
+                const bool live = tid + r * SEAM_T < hw;
+#pragma unroll
+                for (int l = 0; l < 3; ++l) {
+                    const unsigned u = __float_as_uint(resp[l][r]);
+                    const bool zero = live && u == 0u && prefix[l] == 0u;     // (exact zeros: about half of the map)
+                    const unsigned long long zm = __ballot(zero);
+                    if (zm != 0ull && (tid & 63) == 0) atomicAdd(&s_hist[l][0][0], (unsigned)__popcll(zm));
+                    if (live && !zero && (u & himask) == prefix[l]) atomicAdd(&s_hist[l][hc][(u >> shift) & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            // bucket holding the rank: prefix sum over the 256 bins of level l by wavefronts 4l .. 4l+3
+            unsigned mine = 0u, incl = 0u;
+            const int l = tid >> 8, b = tid & 255;
+            if (tid < 768) {
+#pragma unroll
+                for (int c = 0; c < SEAM_HC; ++c) mine += s_hist[l][c][b];
+                incl = mine;
+                const int lane = tid & 63;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned nbr = __shfl(incl, lane >= o ? lane - o : lane);
+                    if (lane >= o) incl += nbr;
+                }
+                if (lane == 63) s_wave[l][b >> 6] = incl;
+            }
+            __syncthreads();
+            if (tid < 768) {
+                const unsigned rank0 = l == 0 ? rank[0] : l == 1 ? rank[1] : rank[2];
+                const unsigned pre = l == 0 ? prefix[0] : l == 1 ? prefix[1] : prefix[2];
+                for (int i = 0; i < (b >> 6); ++i) incl += s_wave[l][i];
+                const unsigned excl = incl - mine;
+                const unsigned total = s_wave[l][0] + s_wave[l][1] + s_wave[l][2] + s_wave[l][3];
+                if (rank0 >= excl && rank0 < incl) {                // exactly one thread when rank0 < total
+                    s_sel[l][0] = pre | ((unsigned)b << shift);
+                    s_sel[l][1] = rank0 - excl;
+                } else if (rank0 >= total && b == 255) {            // (cannot happen: rank < count)
+                    s_sel[l][0] = pre | (256u << shift);
+                    s_sel[l][1] = rank0 - total;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid < 3) s_thr[tid] = __uint_as_float(s_sel[tid][0]);
+        __syncthreads();
+    } else {
+        if (tid < 3) s_thr[tid] = thr;
+        __syncthreads();
+    }
+
+    // phase 4: binarise, fuse, binarise
+    const float t0 = s_thr[0], t1 = s_thr[1], t2 = s_thr[2];
+#pragma unroll
+    for (int r = 0; r < SEAM_RPT; ++r) {
+        const int i = tid + r * SEAM_T;
+        const float f = 0.6f * (resp[0][r] > t0 ? 1.f : 0.f) + 0.3f * (resp[1][r] > t1 ? 1.f : 0.f) +
+                        0.1f * (resp[2][r] > t2 ? 1.f : 0.f);
+        if (i < hw) edge[i] = f > final_thr ? 1.f : 0.f;
+    }
+}
+
 int seam_edge_impl(const float* seg, float* edge, float* scratch, int N, int h, int w, int kth, float thr,
                    float final_thr, hipStream_t s) {
     LEDN_REQUIRE(seg && edge && scratch && N > 0 && h > 0 && w > 0);
     LEDN_REQUIRE(kth >= 0);
-    LEDN_LAUNCH(seam_edge_kernel, dim3((unsigned)N), dim3(SEAM_T), 0, s, seg, edge, scratch, h, w, kth, thr,
-                final_thr);
+    if ((long)h * w <= SEAM_T * SEAM_RPT)
+        LEDN_LAUNCH(seam_edge_lds_kernel, dim3((unsigned)N), dim3(SEAM_T), 0, s, seg, edge, h, w, kth, thr, final_thr);
+    else
+        LEDN_LAUNCH(seam_edge_kernel, dim3((unsigned)N), dim3(SEAM_T), 0, s, seg, edge, scratch, h, w, kth, thr,
+                    final_thr);
     return check_launch();
 }
 
