@@ -51,13 +51,15 @@ int ledn_bind_workspace(void* stream, void* ptr, long long nfloats);
 enum {
     LEDN_OPT_CONV_WORKGROUPS = 0,   /* persistent workgroups of the MFMA conv (default 512) */
     LEDN_OPT_WGRAD_WORKGROUPS = 1,  /* pixel-range workgroups of the MFMA weight gradient (default 512) */
-    LEDN_OPT_STREAM_FAST = 2        /* bit mask, default 27.  bit 0: 16-B-per-lane streaming kernels (csrc/stream_fast.hip) for
+    LEDN_OPT_STREAM_FAST = 2        /* bit mask, default 91.  bit 0: 16-B-per-lane streaming kernels (csrc/stream_fast.hip) for
                                        the bf16 elementwise / BatchNorm passes; bit 1: LDS-tiled depthwise 3x3
                                        (csrc/dwconv.hip); bit 2: MFMA conv tiles handed out round-robin instead of
                                        as contiguous ranges (off); bit 3: 8-row MFMA conv tiles when a launch has fewer
                                        16-row tiles than workgroups; bit 4: 1x1 stride-1 convolutions without input prologue /
                                        output affine on the register-direct streaming kernel (csrc/conv1x1.hip); bit 5: 3x3 convolutions with
                                        32 < Cin <= 64 and 64-channel output tiles keep both K-chunks' weights resident in LDS (off by default: measured 13.49 vs 13.42 ms per step);
+                                       bit 6: 3x3 stride-1 convolutions with 32 input channels on the register-direct wave-autonomous kernel
+                                       (csrc/conv3x3.hip);
                                        0: the generic kernels (A/B measurements); < 0: the default mask */
 };
 int ledn_set_option(int option, long long value);
@@ -116,7 +118,7 @@ int ledn_conv2d_deferred_stats(const ledn_conv_desc* d, float** part, int* rows,
 int ledn_stats_defer_begin(void);
 int ledn_stats_defer_end(float** part, int* rows);
 /* Pure query, no launch: 1 if ledn_conv2d would run this descriptor on conv_mfma_kernel, 2 if on
- * conv1x1_mfma_kernel (both matrix cores), 0 if on conv_direct_kernel (VALU).  bench.py names the kernel in its
+ * conv1x1_mfma_kernel, 3 if on conv3x3_reg_kernel (all matrix cores), 0 if on conv_direct_kernel (VALU).  bench.py names the kernel in its
  * roofline with it. */
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d);
 

@@ -12,6 +12,8 @@ int conv_wgrad_mfma_partial(const ledn_wgrad_desc& d, float* part, long long par
 int conv_wgrad_finish_multi_impl(const ledn_wgrad_finish_entry* table_dev, int n, int total_chunks, hipStream_t s);
 bool conv1x1_reg_supported(const ledn_conv_desc& d);
 int conv1x1_reg(const ledn_conv_desc& d, hipStream_t s);
+bool conv3x3_reg_supported(const ledn_conv_desc& d);
+int conv3x3_reg(const ledn_conv_desc& d, hipStream_t s);
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d);
 bool conv_wgrad_cout2_supported(const ledn_wgrad_desc& d);
 int conv_wgrad_cout2(const ledn_wgrad_desc& d, hipStream_t s);
@@ -136,7 +138,7 @@ static hipStream_t enter_stream(void* stream) {         // every extern "C" entr
     return (hipStream_t)stream;
 }
 Workspace& workspace() { return tls_ws; }
-static Options g_opt = {512, 512, 27};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3, bit 2 round-robin conv tiles (off), bit 3 8-row conv tiles for under-filled grids, bit 4 register-direct 1x1 conv (conv1x1.hip), bit 5 resident 3x3 weights for 32 < Cin <= 64 (off: measured slower, r3l)
+static Options g_opt = {512, 512, 91};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3, bit 2 round-robin conv tiles (off), bit 3 8-row conv tiles for under-filled grids, bit 4 register-direct 1x1 conv (conv1x1.hip), bit 5 resident 3x3 weights for 32 < Cin <= 64 (off: measured slower, r3l), bit 6 register-direct 3x3 conv for 32 input channels (conv3x3.hip)
 Options& options() { return g_opt; }
 static thread_local DeferredStats g_defer = {false, nullptr, 0};
 DeferredStats& deferred_stats() { return g_defer; }
@@ -169,7 +171,7 @@ int ledn_set_option(int option, long long value) {
     switch (option) {
         case LEDN_OPT_CONV_WORKGROUPS: options().conv_workgroups = value > 0 ? (int)value : 512; return LEDN_OK;
         case LEDN_OPT_WGRAD_WORKGROUPS: options().wgrad_workgroups = value > 0 ? (int)value : 512; return LEDN_OK;
-        case LEDN_OPT_STREAM_FAST: options().stream_fast = value < 0 ? 27 : (int)value; return LEDN_OK;   // (< 0: the default mask)
+        case LEDN_OPT_STREAM_FAST: options().stream_fast = value < 0 ? 91 : (int)value; return LEDN_OK;   // (< 0: the default mask)
         default: return LEDN_EINVAL;
     }
 }
@@ -180,6 +182,7 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
     if (rc != LEDN_OK) return rc;
     if (conv_mfma_supported(*d)) {
         if (conv1x1_reg_supported(*d)) return conv1x1_reg(*d, S(stream));
+        if (conv3x3_reg_supported(*d)) return conv3x3_reg(*d, S(stream));
         return conv_mfma(*d, S(stream));
     }
     return conv_direct(*d, S(stream));
@@ -230,7 +233,7 @@ int ledn_bn_finalize_rows(const float* part, int rows, double count, const float
 
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d) {
     if (!d || !conv_mfma_supported(*d)) return 0;
-    return conv1x1_reg_supported(*d) ? 2 : 1;
+    return conv1x1_reg_supported(*d) ? 2 : (conv3x3_reg_supported(*d) ? 3 : 1);
 }
 int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d) {
     return d && !conv_wgrad_cout2_supported(*d) && wgrad_mfma_supported(*d) ? 1 : 0;

@@ -1,0 +1,395 @@
+// conv3x3.hip -- 3x3 stride-1 pad-1 convolution (forward and data gradient) for 32 input channels as a
+// register-direct, wave-autonomous implicit GEMM on the CDNA4 matrix cores (gfx950, v_mfma_f32_16x16x32_bf16).
+//
+// conv_mfma_kernel (conv_mfma.hip) stages a patch in LDS for four waves: fetch -> commit -> barrier -> fragments +
+// matrix instructions -> barrier -> stores is ONE serial chain per workgroup (profiles/r03_conv_phase_costs.txt: no
+// phase owns the time, none overlaps another, the matrix pipe is busy 9-18 % of a launch).  Here a wave owns a column
+// strip of 16 G output pixels and walks DOWN the rows of its segment; nothing goes through LDS and there is no
+// barrier in the main loop:
+//   * B operand = pixels, K = 32 input channels per matrix instruction: lane l owns pixel (l & 15) of a 16-pixel group
+//     and channels 8 (l >> 4) .. + 7 -- one 16-byte global load per (input row, group, 32-channel chunk) is the whole
+//     fragment, four lanes read a pixel's 64 contiguous bytes, a wave instruction 16 pixels x 64 B.
+//   * The kw = 0 / 2 taps are the SAME fragment shifted by one pixel: DPP row_shr:1 / row_shl:1 move it by one lane inside
+//     the 16-lane rows (= pixels of equal channel octet); the lane that has no source keeps `old` = the halo pixel, which
+//     a second load instruction puts into lanes 0 (pixel x0 - 1) and 15 (pixel x0 + 16).  8 v_mov_dpp per fragment
+//     instead of two more loads.
+//   * One input row feeds the three output rows r - 1, r, r + 1 (kh = 2, 1, 0): three rolling accumulator sets; after
+//     input row r the set of output row r - 1 is complete and goes through the epilogue.  The row loop is unrolled by
+//     three so that every register index is static.
+//   * A operand = weights, resident in registers for the lifetime of the wave: 9 taps x 2 M-tiles (32 output channels per
+//     workgroup slice, blockIdx.y) x Cin / 32 chunks = 18 (36) fragments of 4 VGPRs.  Output channels permuted inside the
+//     fragments as in conv1x1.hip: lane (pixel, q) ends up with channels 8 q .. + 7 -> one 16-byte store.
+//   * The loads of input row r + 3 are issued when row r is consumed (three rows = 6 KB per wave in flight); the first
+//     three rows of a wave's first task are requested before its weights.
+//   * Segments of RS output rows re-read 2 halo rows (L2 hits of the neighbouring segment's rows).
+// Epilogue flavours as conv1x1.hip: raw, raw + per-channel statistics, raw + addend (gradient fan-in), full (scale /
+// shift, residual add | gate, activation: inference).
+#include "regconv.h"
+
+namespace ledn {
+
+struct C33Args {
+    const bf16_t* x;       // [N][H][W][Cin]
+    const bf16_t* wp;      // [9][Cout][Cin] bf16 (ledn_pack_conv_weights, either mode: rows = this kernel's outputs)
+    bf16_t* y;             // [N][H][W][Cout]
+    const bf16_t* res;     // addend (C33_ACC) / residual (C33_FULL)
+    const float* bias;
+    const float* out_scale;
+    const float* slope;
+    int act_out, res_mode;
+    float* part;           // statistics: per-workgroup rows [gridDim.y][gridDim.x][2][32] -> see c33_launch
+    float* stat_sum;
+    float* stat_sqsum;
+    int N, H, W, Cin, Cout;
+    int strips, segs, RS;  // column strips of 16 G pixels, row segments of RS rows per image
+    long tasks;            // N * segs * strips
+};
+
+constexpr int C33_RAW = 0, C33_STATS = 1, C33_ACC = 2, C33_FULL = 3;
+
+// v_mov_b32_dpp row_shr:1 / row_shl:1 with bound_ctrl off: lane i of a 16-lane row takes src of lane i -/+ 1; the lane
+// without a source keeps `old`
+__device__ __forceinline__ unsigned c33_row_shift(unsigned old, unsigned src, bool right) {
+#ifdef LEDN_CPU_EMU
+    const int lane = lane_id(), pl = lane & 15;
+    const bool has = right ? pl > 0 : pl < 15;
+    const unsigned got = __shfl(src, has ? (right ? lane - 1 : lane + 1) : lane);
+    return has ? got : old;
+#else
+    return right ? (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111, 0xf, 0xf, false)
+                 : (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x101, 0xf, 0xf, false);
+#endif
+}
+// row_ror:1 (right: lane i takes lane i - 1, lane 0 takes lane 15) / row_ror:15 (left: lane 15 takes lane 0)
+__device__ __forceinline__ unsigned c33_row_rot(unsigned src, bool right) {
+#ifdef LEDN_CPU_EMU
+    const int lane = lane_id(), pl = lane & 15;
+    return __shfl(src, (lane & ~15) | ((pl + (right ? 15 : 1)) & 15));
+#else
+    return right ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)src, 0x121, 0xf, 0xf, false)
+                 : (unsigned)__builtin_amdgcn_update_dpp(0, (int)src, 0x12f, 0xf, 0xf, false);
+#endif
+}
+__device__ __forceinline__ uint4 c33_rotate(uint4 v, bool right) {
+    return make_uint4(c33_row_rot(v.x, right), c33_row_rot(v.y, right), c33_row_rot(v.z, right), c33_row_rot(v.w, right));
+}
+__device__ __forceinline__ bf16x8_t c33_shift(uint4 halo, uint4 main, bool right) {
+    return __builtin_bit_cast(bf16x8_t, make_uint4(c33_row_shift(halo.x, main.x, right), c33_row_shift(halo.y, main.y, right),
+                                                   c33_row_shift(halo.z, main.z, right), c33_row_shift(halo.w, main.w, right)));
+}
+
+// NKC: 32-channel chunks of the input; G: 16-pixel groups side by side
+template <int NKC, int G, int EPI, int OCC>
+__global__ void __launch_bounds__(256, OCC) conv3x3_reg_kernel(C33Args a) {
+    constexpr int NMT = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int pl = lane & 15, q = lane >> 4;
+    const int Cin = a.Cin, Cout = a.Cout, H = a.H, W = a.W;
+    const int co0 = blockIdx.y * 32;
+
+    // this lane's 8 output channels co0 + 8 q .. + 7: acc[0][i] = channel 8 q + i, acc[1][i] = 8 q + 4 + i
+    const int cl = 8 * q, cg = co0 + cl;
+    const bool c_ok = cg < Cout;
+    // C33_FULL: per-channel (scale, shift, negative slope) of the slice in LDS, read per use; the other flavours add the
+    // bias (rare in front of a BatchNorm) in the epilogue straight from memory -- no registers held across the row loop
+    __shared__ float s_par[EPI == C33_FULL ? 96 : 1];
+    if constexpr (EPI == C33_FULL) {
+        if (tid < 32) {
+            const bool ok = co0 + tid < Cout;
+            s_par[tid] = (a.out_scale && ok) ? a.out_scale[co0 + tid] : 1.f;
+            s_par[32 + tid] = (a.bias && ok) ? a.bias[co0 + tid] : 0.f;
+            s_par[64 + tid] = a.act_out == LEDN_ACT_PRELU ? (ok ? a.slope[co0 + tid] : 0.f) : (a.act_out == LEDN_ACT_NONE ? 1.f : 0.f);
+        }
+        __syncthreads();
+    }
+    const float act_hi = a.act_out == LEDN_ACT_RELU6 ? 6.f : 3.0e38f;
+    constexpr int NST = EPI == C33_STATS ? 8 : 1;
+    float st1[NST], st2[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
+
+    const long nwaves = (long)gridDim.x * 4;
+    struct Task { int n, x0, r0, r1; };
+    auto geom = [&](long task) {
+        Task t;
+        const int strip = (int)(task % a.strips);
+        const int seg = (int)((task / a.strips) % a.segs);
+        t.n = (int)(task / ((long)a.strips * a.segs));
+        t.x0 = strip * 16 * G;
+        t.r0 = seg * a.RS;
+        t.r1 = min(t.r0 + a.RS, H);
+        return t;
+    };
+    // raw loads of one input row: [g][kc] = this lane's pixel of group g; [G][kc] = the strip's outer halo (lane 0:
+    // pixel x0 - 1, lane 15: pixel x0 + 16 G); the halo between two groups comes from the neighbouring group's
+    // fragment (row rotation)
+    auto fetch = [&](const Task& t, int ir, uint4 (&rw)[G + 1][NKC]) {
+        const bf16_t* xn = a.x + (long)t.n * H * W * Cin;
+        const bool rok = ir >= 0 && ir < H;
+        const int hx = pl == 0 ? t.x0 - 1 : t.x0 + 16 * G;                // (lanes 1..14: never used)
+        const bool hok = rok && (pl == 0 || pl == 15) && hx >= 0 && hx < W;
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int ci = 32 * kc + 8 * q;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int px = t.x0 + 16 * g + pl;
+                const bool mok = rok && px < W;
+                uint4 m = *reinterpret_cast<const uint4*>(xn + (mok ? ((long)ir * W + px) * Cin + ci : 0L));
+                if (!mok) m = make_uint4(0u, 0u, 0u, 0u);
+                rw[g][kc] = m;
+            }
+            uint4 h = *reinterpret_cast<const uint4*>(xn + (hok ? ((long)ir * W + hx) * Cin + ci : 0L));
+            if (!hok) h = make_uint4(0u, 0u, 0u, 0u);
+            rw[G][kc] = h;
+        }
+    };
+
+    // the first three input rows of the first task are requested BEFORE the weights (18 / 36 fragments from L2): the
+    // HBM round trip of the activations and the L2 round trips of the weights overlap instead of adding up
+    const long first = (long)blockIdx.x * 4 + wid;
+    long task = first;
+    uint4 raw[3][G + 1][NKC];
+    if (task < a.tasks) {
+        const Task t = geom(task);
+        fetch(t, t.r0 - 1, raw[0]);
+        fetch(t, t.r0, raw[1]);
+        fetch(t, t.r0 + 1, raw[2]);
+    }
+    // ---- weight fragments: A[row r = lane & 15][k = 8 q + j] of (tap, kc, mt) = W[tap][co0 + channel(mt, r)][32 kc + 8 q + j]
+    bf16x8_t wf[9][NKC][NMT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                const int co = co0 + c11_channel<NMT>(mt, pl >> 2, pl & 3);
+                const int ci = 32 * kc + 8 * q;
+                const bool ok = co < Cout && ci < Cin;
+                uint4 v = *reinterpret_cast<const uint4*>(a.wp + (ok ? ((long)t * Cout + co) * Cin + ci : 0L));
+                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                wf[t][kc][mt] = __builtin_bit_cast(bf16x8_t, v);
+            }
+
+    for (; task < a.tasks; task += nwaves) {
+        const Task tk = geom(task);
+        const int n = tk.n, x0 = tk.x0, r0 = tk.r0, r1 = tk.r1;
+        if (task != first) {
+            fetch(tk, r0 - 1, raw[0]);
+            fetch(tk, r0, raw[1]);
+            fetch(tk, r0 + 1, raw[2]);
+        }
+        f32x4_t acc[3][G][NMT];
+
+        // epilogue of output row `o` (accumulator slot s)
+        auto finish = [&](int o, f32x4_t (&ac)[G][NMT]) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int px = x0 + 16 * g + pl;
+                const bool pok = px < W && c_ok;
+                const long off = (((long)n * H + o) * W + px) * Cout + cg;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = ac[g][0][i];
+                    v[4 + i] = ac[g][1][i];
+                }
+                if (EPI != C33_FULL && a.bias) {                    // (wave-uniform)
+                    float bb[8];
+                    ld8(a.bias + (c_ok ? cg : 0), bb);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += bb[i];
+                }
+                if constexpr (EPI == C33_STATS) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float vm = px < W ? v[i] : 0.f;
+                        st1[i] += vm;
+                        st2[i] = fmaf(vm, vm, st2[i]);
+                    }
+                }
+                if constexpr (EPI == C33_ACC) {
+                    float r[8];
+                    const uint4 rv = *reinterpret_cast<const uint4*>(a.res + (pok ? off : 0L));
+                    ld8(reinterpret_cast<const bf16_t*>(&rv), r);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = bf16_to_f32(f32_to_bf16(v[i])) + r[i];   // as conv_mfma: bf16(z) + addend
+                }
+                if constexpr (EPI == C33_FULL) {
+                    float fsc[8], fsh[8], fng[8];
+                    ld8(s_par + cl, fsc);
+                    ld8(s_par + 32 + cl, fsh);
+                    ld8(s_par + 64 + cl, fng);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = v[i] * fsc[i] + fsh[i];
+                    if (a.res_mode != LEDN_RES_NONE) {
+                        float r[8];
+                        const uint4 rv = *reinterpret_cast<const uint4*>(a.res + (pok ? off : 0L));
+                        ld8(reinterpret_cast<const bf16_t*>(&rv), r);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = a.res_mode == LEDN_RES_ADD ? v[i] + r[i] : v[i] * r[i] + r[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(v[i], 0.f) + fng[i] * fminf(v[i], 0.f), act_hi);
+                }
+                if (pok) st8(a.y + off, v);
+            }
+        };
+
+        // input row ir = r0 - 1 + 3 b + j feeds output rows ir + 1 (kh = 0, slot j: its FIRST contribution), ir (kh = 1,
+        // slot (j + 2) % 3) and ir - 1 (kh = 2, slot (j + 1) % 3: complete afterwards)
+        for (int base = r0 - 1; base <= r1; base += 3) {
+            c11_for<3>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int ir = base + j;
+                if (ir > r1) return;                                 // wave-uniform
+                bf16x8_t bf[3][G][NKC];                              // [kw]
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        const uint4 m = raw[j][g][kc];
+                        // left neighbour of pixel 0 / right neighbour of pixel 15: the outer halo, or lane 15 / lane 0 of
+                        // the neighbouring group's fragment (rotated into place)
+                        const uint4 hl = g == 0 ? raw[j][G][kc] : c33_rotate(raw[j][g > 0 ? g - 1 : 0][kc], true);
+                        const uint4 hr = g == G - 1 ? raw[j][G][kc] : c33_rotate(raw[j][g < G - 1 ? g + 1 : g][kc], false);
+                        bf[0][g][kc] = c33_shift(hl, m, true);
+                        bf[1][g][kc] = __builtin_bit_cast(bf16x8_t, m);
+                        bf[2][g][kc] = c33_shift(hr, m, false);
+                    }
+                if (ir + 3 <= r1) fetch(tk, ir + 3, raw[j]);
+                sched_fence();
+                constexpr int s0 = j, s1 = (j + 2) % 3, s2 = (j + 1) % 3;
+                if (ir + 1 < r1) {                                   // kh = 0 -> output row ir + 1 starts here
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc[s0][g][0][i] = 0.f;
+                            acc[s0][g][1][i] = 0.f;
+                        }
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+                            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                                for (int g = 0; g < G; ++g)
+                                    acc[s0][g][mt] = mfma_16x16x32_bf16(wf[kw][kc][mt], bf[kw][g][kc], acc[s0][g][mt]);
+                }
+                if (ir >= r0 && ir < r1) {                           // kh = 1 -> output row ir
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+                            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                                for (int g = 0; g < G; ++g)
+                                    acc[s1][g][mt] = mfma_16x16x32_bf16(wf[3 + kw][kc][mt], bf[kw][g][kc], acc[s1][g][mt]);
+                }
+                if (ir - 1 >= r0) {                                  // kh = 2 -> output row ir - 1, complete
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+                            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                                for (int g = 0; g < G; ++g)
+                                    acc[s2][g][mt] = mfma_16x16x32_bf16(wf[6 + kw][kc][mt], bf[kw][g][kc], acc[s2][g][mt]);
+                    finish(ir - 1, acc[s2]);
+                }
+            });
+        }
+    }
+
+    if constexpr (EPI == C33_STATS) {
+        // per-wave totals -> LDS -> one row of this slice's 32 channels per workgroup (lanes with equal q hold the same
+        // channels of different pixels)
+        __shared__ float s_st[4][2][32];
+        const float t1 = c11_reduce16<8>(st1, lane), t2 = c11_reduce16<8>(st2, lane);
+        const int vi = c11_red_index<8>(lane);
+        if ((lane & 15) < 8) {
+            s_st[wid][0][cl + vi] = t1;
+            s_st[wid][1][cl + vi] = t2;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int jj = tid >> 5, c = tid & 31;
+            const float t = (s_st[0][jj][c] + s_st[1][jj][c]) + (s_st[2][jj][c] + s_st[3][jj][c]);
+            if (co0 + c < Cout) {
+                if (a.part) a.part[(long)blockIdx.x * 2 * Cout + (long)jj * Cout + co0 + c] = t;
+                else atomicAdd((jj ? a.stat_sqsum : a.stat_sum) + co0 + c, t);
+            }
+        }
+    }
+}
+
+template <int NKC, int G, int EPI>
+static int c33_launch(C33Args a, hipStream_t s) {
+    constexpr int OCC = NKC == 1 ? 2 : 1;
+    a.strips = (int)cdiv(a.W, 16 * G);
+    const int slices = a.Cout / 32;
+    // segments of 16 rows (12.5 % halo rows); smaller maps: as many 8-row segments as fill the chip
+    a.RS = ((long)a.N * a.strips * cdiv(a.H, 16) * slices >= 1024) ? 16 : 8;
+    a.segs = (int)cdiv(a.H, a.RS);
+    a.tasks = (long)a.N * a.segs * a.strips;
+    long nb = cdiv(a.tasks, 4);
+    const long cap = cdiv((long)options().conv_workgroups * OCC, slices);
+    if (nb > cap) nb = cap;
+    a.part = (EPI == C33_STATS && a.stat_sum && nb > 16) ? ws_take(nb * 2 * a.Cout) : nullptr;
+    LEDN_LAUNCH((conv3x3_reg_kernel<NKC, G, EPI, OCC>), dim3((unsigned)nb, (unsigned)slices), dim3(256), 0, s, a);
+    if (a.part) return finish_partials(a.part, (int)nb, a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
+    return check_launch();
+}
+
+template <int NKC, int G>
+static int c33_epi(const C33Args& a, int epi, hipStream_t s) {
+    switch (epi) {
+        case C33_STATS: return c33_launch<NKC, G, C33_STATS>(a, s);
+        case C33_ACC: return c33_launch<NKC, G, C33_ACC>(a, s);
+        case C33_FULL: return c33_launch<NKC, G, C33_FULL>(a, s);
+        default: return c33_launch<NKC, G, C33_RAW>(a, s);
+    }
+}
+
+static bool c33_full(const ledn_conv_desc& d) {
+    return d.out_scale || d.act_out != LEDN_ACT_NONE || d.res_mode == LEDN_RES_GATE || (d.res_mode == LEDN_RES_ADD && d.out_shift);
+}
+
+// 3x3, stride 1, pad 1 (forward, or the data gradient of such a layer: the same correlation with the flipped /
+// transposed weight pack), 32 or 64 input channels, output channels a multiple of 32
+bool conv3x3_reg_supported(const ledn_conv_desc& d) {
+    if (!(options().stream_fast & 64)) return false;
+    if (!d.w_bf16 || d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16) return false;
+    if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.dil != 1 || d.groups != 1 || d.xadd) return false;
+    if (d.in_scale || d.in_shift || d.in_act != LEDN_ACT_NONE) return false;
+    // 64 input channels (36 weight fragments = 144 VGPRs: one wave per SIMD) measured 60 us against conv_mfma_kernel's
+    // 37 us at 16 x 128 x 128 (r03): not offered
+    if (d.Cin != 32 || d.Cout % 32 || d.Cout > 128) return false;
+    if (d.Ho != d.H || d.Wo != d.W) return false;
+    if (c33_full(d)) {
+        if (d.stat_sum || d.act_out == LEDN_ACT_SIGMOID || (d.act_out == LEDN_ACT_PRELU && !d.slope)) return false;
+        if (d.res_mode != LEDN_RES_NONE && !d.res) return false;
+    } else if (d.res_mode != LEDN_RES_NONE && !(d.res_mode == LEDN_RES_ADD && d.res && !d.stat_sum)) {
+        return false;
+    }
+    return true;
+}
+
+int conv3x3_reg(const ledn_conv_desc& d, hipStream_t s) {
+    C33Args a;
+    a.x = (const bf16_t*)d.x; a.wp = (const bf16_t*)d.w_bf16; a.y = (bf16_t*)d.y;
+    a.res = (const bf16_t*)d.res; a.bias = d.out_shift; a.out_scale = d.out_scale; a.slope = d.slope;
+    a.act_out = d.act_out; a.res_mode = d.res_mode;
+    a.part = nullptr; a.stat_sum = d.stat_sum; a.stat_sqsum = d.stat_sqsum;
+    a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Cout = d.Cout;
+    a.strips = a.segs = a.RS = 0; a.tasks = 0;
+    const int epi = c33_full(d) ? C33_FULL : (d.res_mode == LEDN_RES_ADD ? C33_ACC : (d.stat_sum ? C33_STATS : C33_RAW));
+    return c33_epi<1, 2>(a, epi, s);
+}
+
+}  // namespace ledn

@@ -11,8 +11,16 @@ _DEV = [torch.device('cpu')]
 
 @pytest.fixture(autouse=True)
 def _track_device(request):
+    """(LEDN_OPT_STREAM_FAST without bit 6: the 3x3 / 32-channel shapes of this file stay on conv_mfma_kernel, which
+    still runs them whenever the launch carries an input prologue; tests/test_conv3x3.py covers the register kernel)"""
     _DEV[0] = request.getfixturevalue('be').dev if 'be' in request.fixturenames else torch.device('cpu')
+    if 'be' in request.fixturenames:
+        from led_net_amd import _lib
+        _lib.get_lib().set_option(2, 27)
     yield
+    if 'be' in request.fixturenames:
+        from led_net_amd import _lib
+        _lib.get_lib().set_option(2, -1)
 
 
 def D(t):
