@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LEDN_ABI_VERSION 2
+#define LEDN_ABI_VERSION 3
 
 enum { LEDN_OK = 0, LEDN_EINVAL = 1, LEDN_ELAUNCH = 2 };
 enum { LEDN_F32 = 0, LEDN_BF16 = 1, LEDN_U8 = 2 };
@@ -59,7 +59,9 @@ enum {
                                        output affine on the register-direct streaming kernel (csrc/conv1x1.hip); bit 5: 3x3 convolutions with
                                        32 < Cin <= 64 and 64-channel output tiles keep both K-chunks' weights resident in LDS (off by default: measured 13.49 vs 13.42 ms per step);
                                        bit 6: 3x3 stride-1 convolutions with 32 input channels on the register-direct wave-autonomous kernel
-                                       (csrc/conv3x3.hip);
+                                       (csrc/conv3x3.hip), and 3x3 convolutions with <= 2 input channels and 32 k output channels (the data
+                                       gradient of the two-class heads) as one K = 32 fragment per pixel; bit 7 (off): the two-class heads'
+                                       forward convolution on that kernel too (measured slower than conv_mfma_kernel's narrow epilogue);
                                        0: the generic kernels (A/B measurements); < 0: the default mask */
 };
 int ledn_set_option(int option, long long value);
@@ -118,7 +120,8 @@ int ledn_conv2d_deferred_stats(const ledn_conv_desc* d, float** part, int* rows,
 int ledn_stats_defer_begin(void);
 int ledn_stats_defer_end(float** part, int* rows);
 /* Pure query, no launch: 1 if ledn_conv2d would run this descriptor on conv_mfma_kernel, 2 if on
- * conv1x1_mfma_kernel, 3 if on conv3x3_reg_kernel (all matrix cores), 0 if on conv_direct_kernel (VALU).  bench.py names the kernel in its
+ * conv1x1_mfma_kernel, 3 if on conv3x3_reg_kernel, 4 if on conv3x3_narrowin_mfma_kernel (all matrix cores), 0 if on
+ * conv_direct_kernel / conv_narrowin_kernel (VALU).  bench.py names the kernel in its
  * roofline with it. */
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d);
 

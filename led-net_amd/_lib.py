@@ -222,7 +222,7 @@ _PROTOS = {
 EXPORTS = tuple(_PROTOS)
 
 
-ABI_VERSION = 2      # include/ledn.h LEDN_ABI_VERSION: bumped with every struct / signature change
+ABI_VERSION = 3      # include/ledn.h LEDN_ABI_VERSION: bumped with every struct / signature change
 
 
 class LednError(RuntimeError):

@@ -14,6 +14,8 @@ bool conv1x1_reg_supported(const ledn_conv_desc& d);
 int conv1x1_reg(const ledn_conv_desc& d, hipStream_t s);
 bool conv3x3_reg_supported(const ledn_conv_desc& d);
 int conv3x3_reg(const ledn_conv_desc& d, hipStream_t s);
+bool conv3x3_narrowin_mfma_supported(const ledn_conv_desc& d);
+int conv3x3_narrowin_mfma(const ledn_conv_desc& d, hipStream_t s);
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d);
 bool conv_wgrad_cout2_supported(const ledn_wgrad_desc& d);
 int conv_wgrad_cout2(const ledn_wgrad_desc& d, hipStream_t s);
@@ -185,6 +187,7 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
         if (conv3x3_reg_supported(*d)) return conv3x3_reg(*d, S(stream));
         return conv_mfma(*d, S(stream));
     }
+    if (conv3x3_narrowin_mfma_supported(*d)) return conv3x3_narrowin_mfma(*d, S(stream));
     return conv_direct(*d, S(stream));
 }
 
@@ -232,6 +235,7 @@ int ledn_bn_finalize_rows(const float* part, int rows, double count, const float
 }
 
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d) {
+    if (d && !conv_mfma_supported(*d) && conv3x3_narrowin_mfma_supported(*d)) return 4;
     if (!d || !conv_mfma_supported(*d)) return 0;
     return conv1x1_reg_supported(*d) ? 2 : (conv3x3_reg_supported(*d) ? 3 : 1);
 }

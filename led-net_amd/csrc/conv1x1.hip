@@ -50,23 +50,6 @@ constexpr int C11_RAW = 0, C11_STATS = 1, C11_ACC = 2, C11_FULL = 3;   // FULL: 
 
 // NKS: k-steps of 32 input channels; NMT: M-tiles of 16 output channels; DIAG: only the 32 x 32 diagonal blocks of
 // the weight matrix are non-zero (grouped convolution, Cin == Cout); G: 16-pixel groups per iteration
-// pre(x) on one fragment: 8 consecutive input channels of one pixel, per-channel coefficients in registers
-__device__ __forceinline__ bf16x8_t c11_prologue(bf16x8_t f, const float* sc, const float* sh, const float* ng) {
-    const uint4 v = __builtin_bit_cast(uint4, f);
-    const unsigned w[4] = {v.x, v.y, v.z, v.w};
-    unsigned o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
-        lo = lo * sc[2 * i] + sh[2 * i];
-        hi = hi * sc[2 * i + 1] + sh[2 * i + 1];
-        lo = fmaxf(lo, 0.f) + ng[2 * i] * fminf(lo, 0.f);          // none: ng = 1, relu: 0, prelu: slope
-        hi = fmaxf(hi, 0.f) + ng[2 * i + 1] * fminf(hi, 0.f);
-        o[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
-    }
-    return __builtin_bit_cast(bf16x8_t, make_uint4(o[0], o[1], o[2], o[3]));
-}
-
 template <int NKS, int NMT, bool DIAG, int G, int EPI, int OCC, bool PRO = false>
 __global__ void __launch_bounds__(256, OCC) conv1x1_mfma_kernel(C11Args a) {
     constexpr int NP = (NMT + 1) / 2;                        // 32-channel pairs of M-tiles (the last may be half)

@@ -37,6 +37,10 @@ struct C33Args {
     const float* out_scale;
     const float* slope;
     int act_out, res_mode;
+    const float* in_scale; // C33_NARROW with PRO: input prologue pre(x) = act_in(x * in_scale + in_shift) (the producer's
+    const float* in_shift; // BatchNorm + activation folded into this convolution; the zero padding is applied AFTER it)
+    const float* in_slope;
+    int in_act, y_f32;
     float* part;           // statistics: per-workgroup rows [gridDim.y][gridDim.x][2][32] -> see c33_launch
     float* stat_sum;
     float* stat_sqsum;
@@ -46,6 +50,7 @@ struct C33Args {
 };
 
 constexpr int C33_RAW = 0, C33_STATS = 1, C33_ACC = 2, C33_FULL = 3;
+constexpr int C33_NARROW = 4;   // Cout <= 4 (the two-class heads): one M-tile, rows 0..3 of lane group q = 0, scalar stores, f32 | bf16
 
 // v_mov_b32_dpp row_shr:1 / row_shl:1 with bound_ctrl off: lane i of a 16-lane row takes src of lane i -/+ 1; the lane
 // without a source keeps `old`
@@ -79,9 +84,9 @@ __device__ __forceinline__ bf16x8_t c33_shift(uint4 halo, uint4 main, bool right
 }
 
 // NKC: 32-channel chunks of the input; G: 16-pixel groups side by side
-template <int NKC, int G, int EPI, int OCC>
+template <int NKC, int G, int EPI, int OCC, int NMT = 2, bool PRO = false>
 __global__ void __launch_bounds__(256, OCC) conv3x3_reg_kernel(C33Args a) {
-    constexpr int NMT = 2;
+    static_assert((EPI == C33_NARROW) == (NMT == 1), "one M-tile = the narrow heads");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int pl = lane & 15, q = lane >> 4;
     const int Cin = a.Cin, Cout = a.Cout, H = a.H, W = a.W;
@@ -108,6 +113,21 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_reg_kernel(C33Args a) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
 
+    // input prologue coefficients of this lane's 8 input channels per chunk
+    constexpr int NPR = PRO ? NKC : 1;
+    float psc[NPR][8], psh[NPR][8], png[NPR][8];
+    if constexpr (PRO) {
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = 32 * kc + 8 * q + i;
+                const bool ok = c < Cin;
+                psc[kc][i] = (ok && a.in_scale) ? a.in_scale[c] : 1.f;
+                psh[kc][i] = (ok && a.in_shift) ? a.in_shift[c] : 0.f;
+                png[kc][i] = a.in_act == LEDN_ACT_PRELU ? (ok ? a.in_slope[c] : 0.f) : (a.in_act == LEDN_ACT_NONE ? 1.f : 0.f);
+            }
+    }
     const long nwaves = (long)gridDim.x * 4;
     struct Task { int n, x0, r0, r1; };
     auto geom = [&](long task) {
@@ -187,13 +207,33 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_reg_kernel(C33Args a) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int px = x0 + 16 * g + pl;
+                if constexpr (EPI == C33_NARROW) {                  // lanes q = 0: channels 0 .. Cout - 1 of pixel px
+                    if (q == 0 && px < W) {
+                        const long o0 = (((long)n * H + o) * W + px) * Cout;
+                        float vv[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) vv[i] = ac[g][0][i] + ((a.bias && i < Cout) ? a.bias[i] : 0.f);
+                        if (Cout == 2) {       // the two-class heads: ONE store per pixel (sub-dword stores are partial writes)
+                            if (a.y_f32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(a.y) + o0) = make_float2(vv[0], vv[1]);
+                            else *reinterpret_cast<unsigned*>(a.y + o0) = (unsigned)f32_to_bf16(vv[0]) | ((unsigned)f32_to_bf16(vv[1]) << 16);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (i < Cout) {
+                                    if (a.y_f32) reinterpret_cast<float*>(a.y)[o0 + i] = vv[i];
+                                    else st(a.y + o0 + i, vv[i]);
+                                }
+                        }
+                    }
+                    continue;
+                }
                 const bool pok = px < W && c_ok;
                 const long off = (((long)n * H + o) * W + px) * Cout + cg;
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     v[i] = ac[g][0][i];
-                    v[4 + i] = ac[g][1][i];
+                    v[4 + i] = ac[g][NMT - 1][i];
                 }
                 if (EPI != C33_FULL && a.bias) {                    // (wave-uniform)
                     float bb[8];
@@ -245,15 +285,35 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_reg_kernel(C33Args a) {
                 const int ir = base + j;
                 if (ir > r1) return;                                 // wave-uniform
                 bf16x8_t bf[3][G][NKC];                              // [kw]
+                uint4 rm[G + 1][NKC];                                // this row's pixels (after the input prologue)
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+                    for (int g = 0; g <= G; ++g) rm[g][kc] = raw[j][g][kc];
+                if constexpr (PRO) {                                 // pre(x) on the loaded pixels; padding stays zero
+                    const bool rok = ir >= 0 && ir < H;
+                    const int hx = pl == 0 ? x0 - 1 : x0 + 16 * G;
+                    const bool hok = rok && (pl == 0 || pl == 15) && hx >= 0 && hx < W;
+                    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+                        for (int g = 0; g <= G; ++g) {
+                            const bool ok = g == G ? hok : (rok && x0 + 16 * g + pl < W);
+                            uint4 t = __builtin_bit_cast(uint4, c11_prologue(__builtin_bit_cast(bf16x8_t, rm[g][kc]), psc[kc], psh[kc], png[kc]));
+                            if (!ok) t = zero;
+                            rm[g][kc] = t;
+                        }
+                }
 #pragma unroll
                 for (int g = 0; g < G; ++g)
 #pragma unroll
                     for (int kc = 0; kc < NKC; ++kc) {
-                        const uint4 m = raw[j][g][kc];
+                        const uint4 m = rm[g][kc];
                         // left neighbour of pixel 0 / right neighbour of pixel 15: the outer halo, or lane 15 / lane 0 of
                         // the neighbouring group's fragment (rotated into place)
-                        const uint4 hl = g == 0 ? raw[j][G][kc] : c33_rotate(raw[j][g > 0 ? g - 1 : 0][kc], true);
-                        const uint4 hr = g == G - 1 ? raw[j][G][kc] : c33_rotate(raw[j][g < G - 1 ? g + 1 : g][kc], false);
+                        const uint4 hl = g == 0 ? rm[G][kc] : c33_rotate(rm[g > 0 ? g - 1 : 0][kc], true);
+                        const uint4 hr = g == G - 1 ? rm[G][kc] : c33_rotate(rm[g < G - 1 ? g + 1 : g][kc], false);
                         bf[0][g][kc] = c33_shift(hl, m, true);
                         bf[1][g][kc] = __builtin_bit_cast(bf16x8_t, m);
                         bf[2][g][kc] = c33_shift(hr, m, false);
@@ -267,7 +327,7 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_reg_kernel(C33Args a) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             acc[s0][g][0][i] = 0.f;
-                            acc[s0][g][1][i] = 0.f;
+                            acc[s0][g][NMT - 1][i] = 0.f;
                         }
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw)
@@ -328,13 +388,21 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_reg_kernel(C33Args a) {
     }
 }
 
+// rows per segment: the longest of 32 / 16 / 8 that still yields one task per resident wave (2 per SIMD); a task
+// re-reads 2 halo rows and starts with an exposed load round trip, so fewer, longer tasks win once the chip is full
+static int c33_rows(long columns, int H) {
+    if (columns * cdiv(H, 32) >= 2048) return 32;
+    if (columns * cdiv(H, 16) >= 1024) return 16;
+    return 8;
+}
+
 template <int NKC, int G, int EPI>
 static int c33_launch(C33Args a, hipStream_t s) {
     constexpr int OCC = NKC == 1 ? 2 : 1;
     a.strips = (int)cdiv(a.W, 16 * G);
     const int slices = a.Cout / 32;
     // segments of 16 rows (12.5 % halo rows); smaller maps: as many 8-row segments as fill the chip
-    a.RS = ((long)a.N * a.strips * cdiv(a.H, 16) * slices >= 1024) ? 16 : 8;
+    a.RS = c33_rows((long)a.N * a.strips * slices, a.H);
     a.segs = (int)cdiv(a.H, a.RS);
     a.tasks = (long)a.N * a.segs * a.strips;
     long nb = cdiv(a.tasks, 4);
@@ -360,12 +428,28 @@ static bool c33_full(const ledn_conv_desc& d) {
     return d.out_scale || d.act_out != LEDN_ACT_NONE || d.res_mode == LEDN_RES_GATE || (d.res_mode == LEDN_RES_ADD && d.out_shift);
 }
 
+// the two-class heads (led_head.py:44-51: norm -> act -> 3x3 conv 32 -> 2, f32 logits): Cout <= 4, optional input
+// prologue (the BatchNorm + ReLU in front), optional bias, no statistics / residual / activation behind
+static bool c33_narrow(const ledn_conv_desc& d) {
+    // opt-in (LEDN_OPT_STREAM_FAST bit 7): measured 145-155 us against conv_mfma_kernel's narrow epilogue at 123-132 us
+    // (16 x 512 x 512, prologue + bias, r03) -- correct and tested, not the default
+    if (!(options().stream_fast & 128)) return false;
+    if (d.Cout > 4 || d.Cin != 32 || d.transposed) return false;
+    if (d.dtype_y != LEDN_BF16 && d.dtype_y != LEDN_F32) return false;
+    if ((d.in_scale == nullptr) != (d.in_shift == nullptr)) return false;
+    if (d.in_act != LEDN_ACT_NONE && d.in_act != LEDN_ACT_RELU && !(d.in_act == LEDN_ACT_PRELU && d.in_slope)) return false;
+    return !d.out_scale && !d.stat_sum && d.res_mode == LEDN_RES_NONE && d.act_out == LEDN_ACT_NONE;
+}
+
 // 3x3, stride 1, pad 1 (forward, or the data gradient of such a layer: the same correlation with the flipped /
 // transposed weight pack), 32 or 64 input channels, output channels a multiple of 32
 bool conv3x3_reg_supported(const ledn_conv_desc& d) {
     if (!(options().stream_fast & 64)) return false;
-    if (!d.w_bf16 || d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16) return false;
+    if (!d.w_bf16 || d.dtype_x != LEDN_BF16) return false;
     if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.dil != 1 || d.groups != 1 || d.xadd) return false;
+    if (d.Ho != d.H || d.Wo != d.W) return false;
+    if (d.dtype_y != LEDN_BF16 && !c33_narrow(d)) return false;
+    if (c33_narrow(d)) return true;
     if (d.in_scale || d.in_shift || d.in_act != LEDN_ACT_NONE) return false;
     // 64 input channels (36 weight fragments = 144 VGPRs: one wave per SIMD) measured 60 us against conv_mfma_kernel's
     // 37 us at 16 x 128 x 128 (r03): not offered
@@ -388,8 +472,165 @@ int conv3x3_reg(const ledn_conv_desc& d, hipStream_t s) {
     a.part = nullptr; a.stat_sum = d.stat_sum; a.stat_sqsum = d.stat_sqsum;
     a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Cout = d.Cout;
     a.strips = a.segs = a.RS = 0; a.tasks = 0;
+    a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_slope = d.in_slope; a.in_act = d.in_act;
+    a.y_f32 = d.dtype_y == LEDN_F32;
+    if (c33_narrow(d)) {
+        constexpr int G = 2;
+        a.strips = (int)cdiv(a.W, 16 * G);
+        a.RS = c33_rows((long)a.N * a.strips, a.H);
+        a.segs = (int)cdiv(a.H, a.RS);
+        a.tasks = (long)a.N * a.segs * a.strips;
+        long nb = cdiv(a.tasks, 4);
+        const long cap = (long)options().conv_workgroups * 2;
+        if (nb > cap) nb = cap;
+        if (d.in_scale || d.in_act != LEDN_ACT_NONE)
+            LEDN_LAUNCH((conv3x3_reg_kernel<1, G, C33_NARROW, 2, 1, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+        else
+            LEDN_LAUNCH((conv3x3_reg_kernel<1, G, C33_NARROW, 2, 1, false>), dim3((unsigned)nb), dim3(256), 0, s, a);
+        return check_launch();
+    }
     const int epi = c33_full(d) ? C33_FULL : (d.res_mode == LEDN_RES_ADD ? C33_ACC : (d.stat_sum ? C33_STATS : C33_RAW));
     return c33_epi<1, 2>(a, epi, s);
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 convolution with TWO input channels and 32 k output channels (the data gradient of LEDHead's 32 -> 2 heads,
+// led_head.py:47-48: dz [., 2] -> dx [., 32], 268 MB written at 16 x 512 x 512): the whole 3 x 3 x 2 neighbourhood of a
+// pixel is ONE K = 32 fragment (k = 2 tap + ci, 18 used), so a 16-pixel group costs one matrix instruction per 16
+// output channels instead of 576 multiply-adds per pixel on the vector units (conv_narrowin_kernel: 145 us, VALU-bound).
+// Lane (pixel pl, q) gathers taps 4 q .. 4 q + 3 with four 4-byte loads (L1 / L2 hits: the input is 1 / 16 of the
+// output); weights (f32, any strides) become resident bf16 A fragments; stores as conv1x1.hip.  Iteration = one image
+// row x strip of 16 G pixels (row and strip are wave-uniform: no per-lane division), grid-stride, next iteration's
+// gathers in flight during the matrix instructions and stores.
+// ---------------------------------------------------------------------------
+struct NinArgs {
+    const bf16_t* x;
+    const float* w;
+    bf16_t* y;
+    long long ws_co, ws_ci, ws_tap;
+    int N, H, W, Cin, Cout, pad, transposed;
+    int strips;
+    long iters;            // N * H * strips
+};
+
+template <int NMT, int G>
+__global__ void __launch_bounds__(256, 3) conv3x3_narrowin_mfma_kernel(NinArgs a) {
+    constexpr int NP = NMT / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int pl = lane & 15, q = lane >> 4;
+    const int H = a.H, W = a.W, Cout = a.Cout;
+    // A[row = channel(mt, lane & 15)][k = 8 q + j], k = 2 tap + ci
+    bf16x8_t wf[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+        const int co = c11_channel<NMT>(mt, pl >> 2, pl & 3);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * q + j, tap = k >> 1, ci = k & 1;
+            const bool ok = tap < 9 && ci < a.Cin && co < Cout;
+            v[j] = ok ? a.w[(long)co * a.ws_co + (long)ci * a.ws_ci + (long)tap * a.ws_tap] : 0.f;
+        }
+        unsigned pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[j] = (unsigned)f32_to_bf16(v[2 * j]) | ((unsigned)f32_to_bf16(v[2 * j + 1]) << 16);
+        wf[mt] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+    }
+    // this lane's four taps: offsets (dh, dw) of the input pixel against the output pixel
+    int dh[4], dw[4];
+    bool tv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int tap = 4 * q + j, kh = tap / 3, kw = tap % 3;
+        tv[j] = tap < 9;
+        dh[j] = a.transposed ? a.pad - kh : kh - a.pad;           // data gradient: the output pixel fed through tap (kh, kw)
+        dw[j] = a.transposed ? a.pad - kw : kw - a.pad;
+    }
+    const bool two = a.Cin > 1;
+    auto gather = [&](long it, unsigned (&bf)[G][4]) {
+        const long row = it / a.strips;                           // n * H + h
+        const int strip = (int)(it % a.strips);
+        const int h = (int)(row % H);
+        const long rbase = (row - h) * W;                          // pixel index of (n, 0, 0)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int wo = (strip * G + g) * 16 + pl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int hi = h + dh[j], wi = wo + dw[j];
+                const bool ok = tv[j] && hi >= 0 && hi < H && wi >= 0 && wi < W && wo < W;
+                const bf16_t* p = a.x + (ok ? (rbase + (long)hi * W + wi) * a.Cin : 0L);
+                unsigned v = two ? *reinterpret_cast<const unsigned*>(p) : (unsigned)*reinterpret_cast<const unsigned short*>(p);
+                bf[g][j] = ok ? v : 0u;
+            }
+        }
+    };
+    const long nwaves = (long)gridDim.x * 4;
+    long it = (long)blockIdx.x * 4 + wid;
+    unsigned bcur[G][4], bnext[G][4];
+    if (it < a.iters) gather(it, bcur);
+    while (it < a.iters) {
+        const long nit = it + nwaves;
+        if (nit < a.iters) gather(nit, bnext);
+        sched_fence();
+        const long row = it / a.strips;
+        const int strip = (int)(it % a.strips);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const bf16x8_t b = __builtin_bit_cast(bf16x8_t, make_uint4(bcur[g][0], bcur[g][1], bcur[g][2], bcur[g][3]));
+            f32x4_t acc[NMT];
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                acc[mt] = mfma_16x16x32_bf16(wf[mt], b, acc[mt]);
+            }
+            const int wo = (strip * G + g) * 16 + pl;
+            const long pix = row * W + wo;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[2 * p][i];
+                    v[4 + i] = acc[2 * p + 1][i];
+                }
+                if (wo < W && 32 * p + 8 * q < Cout) st8(a.y + pix * Cout + 32 * p + 8 * q, v);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bcur[g][j] = bnext[g][j];
+        it = nit;
+    }
+}
+
+bool conv3x3_narrowin_mfma_supported(const ledn_conv_desc& d) {
+    if (!(options().stream_fast & 64)) return false;
+    if (d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16 || !d.w) return false;
+    if (d.Cin > 2 || d.Cout % 32 || d.Cout > 128 || d.groups != 1 || d.stride != 1 || d.dil != 1) return false;
+    if (d.KH != 3 || d.KW != 3 || d.pad != 1 || d.Ho != d.H || d.Wo != d.W) return false;
+    if (d.xadd || d.in_scale || d.in_act != LEDN_ACT_NONE || d.out_scale || d.out_shift || d.stat_sum) return false;
+    return d.res_mode == LEDN_RES_NONE && d.act_out == LEDN_ACT_NONE;
+}
+
+int conv3x3_narrowin_mfma(const ledn_conv_desc& d, hipStream_t s) {
+    constexpr int G = 2;
+    NinArgs a;
+    a.x = (const bf16_t*)d.x; a.w = d.w; a.y = (bf16_t*)d.y;
+    a.ws_co = d.ws_co; a.ws_ci = d.ws_ci; a.ws_tap = d.ws_tap;
+    a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Cout = d.Cout; a.pad = d.pad; a.transposed = d.transposed ? 1 : 0;
+    a.strips = (int)cdiv(d.W, 16 * G);
+    a.iters = (long)d.N * d.H * a.strips;
+    long nb = cdiv(a.iters, 4);
+    const long cap = (long)options().conv_workgroups * 3;
+    if (nb > cap) nb = cap;
+    const int nmt = d.Cout / 16;
+    if (nmt == 2) LEDN_LAUNCH((conv3x3_narrowin_mfma_kernel<2, G>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else if (nmt == 4) LEDN_LAUNCH((conv3x3_narrowin_mfma_kernel<4, G>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else if (nmt == 8) LEDN_LAUNCH((conv3x3_narrowin_mfma_kernel<8, G>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else return LEDN_EINVAL;
+    return check_launch();
 }
 
 }  // namespace ledn

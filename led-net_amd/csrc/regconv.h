@@ -79,4 +79,21 @@ __device__ __forceinline__ int c11_red_index(int lane) {
     return idx;
 }
 
+// pre(x) on one fragment: 8 consecutive input channels of one pixel, per-channel coefficients in registers
+__device__ __forceinline__ bf16x8_t c11_prologue(bf16x8_t f, const float* sc, const float* sh, const float* ng) {
+    const uint4 v = __builtin_bit_cast(uint4, f);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+        lo = lo * sc[2 * i] + sh[2 * i];
+        hi = hi * sc[2 * i + 1] + sh[2 * i + 1];
+        lo = fmaxf(lo, 0.f) + ng[2 * i] * fminf(lo, 0.f);          // none: ng = 1, relu: 0, prelu: slope
+        hi = fmaxf(hi, 0.f) + ng[2 * i + 1] * fminf(hi, 0.f);
+        o[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+    }
+    return __builtin_bit_cast(bf16x8_t, make_uint4(o[0], o[1], o[2], o[3]));
+}
+
 }  // namespace ledn

@@ -125,3 +125,39 @@ def test_conv3x3_many_tasks_per_wave(be, wgs):
         torch.testing.assert_close(stats[0].cpu(), want.sum((0, 2, 3)), rtol=1e-3, atol=2e-3 * 3 * 37 * 70)
     finally:
         lib.set_option(0, 0)
+
+
+@pytest.mark.parametrize('cout,pro,f32out,nhw', [(2, True, False, (2, 13, 45)), (2, True, True, (1, 17, 32)), (2, False, False, (1, 9, 33)),
+                                                 (4, True, False, (1, 20, 19)), (1, True, True, (1, 5, 70))])
+def test_conv3x3_narrow_head_forward(be, cout, pro, f32out, nhw):
+    """the two-class heads' convolution in training (led_head.py:44-51,84-99: BatchNorm -> ReLU -> conv3x3 32 -> 2, then its
+    own BatchNorm): input prologue folded in (zero padding AFTER the activation), bias, raw bf16 / f32 output --
+    conv3x3_reg_kernel<.., C33_NARROW> against torch and against conv_mfma_kernel's narrow epilogue"""
+    from led_net_amd import ops, _lib
+    N, H, W = nhw
+    x = r16(torch.randn(N, 32, H, W))
+    w = r16(torch.randn(cout, 32, 3, 3) / 17.0)
+    b = torch.randn(cout) * 0.3
+    s_in, b_in = torch.rand(32) + 0.5, torch.randn(32) * 0.3
+    xin = r16(F.relu(x * s_in.view(1, -1, 1, 1) + b_in.view(1, -1, 1, 1))) if pro else x
+    want = F.conv2d(xin, w, b, padding=1)
+    kw = dict(pad=1, out_shift=D(b), w_bf16=ops.pack_conv_weights(D(w), 0))
+    lib = _lib.get_lib()
+    lib.set_option(2, MASK + 128)          # (the narrow variant is opt-in: bit 7)
+    if pro:
+        kw.update(in_scale=D(s_in), in_shift=D(b_in), in_act=ops.ACT_RELU)
+    if f32out:
+        kw.update(out_dtype=torch.float32)
+    xb = nhwc(x).bfloat16()
+    assert ops.conv2d_kernel_id(xb, D(w), **kw) == 3
+    got = ops.conv2d(xb, D(w), **kw)
+    assert got.dtype == (torch.float32 if f32out else torch.bfloat16)
+    tol = dict(rtol=1e-3, atol=2e-3) if f32out else dict(rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(nchw(got), want, **tol)
+    lib.set_option(2, 27)
+    try:
+        assert ops.conv2d_kernel_id(xb, D(w), **kw) == 1
+        ref = ops.conv2d(xb, D(w), **kw)
+    finally:
+        lib.set_option(2, MASK)
+    torch.testing.assert_close(got.float().cpu(), ref.float().cpu(), rtol=8e-3, atol=2e-3)

@@ -112,11 +112,20 @@ def test_conv2d_wgrad_vector_paths(be, n, cin, cout, k, stride, groups, hw):
 
 @pytest.mark.parametrize('cin,cout,k,transposed,dt', [
     (32, 2, 3, True, torch.bfloat16), (32, 2, 3, True, torch.float32), (64, 1, 3, True, torch.float32),
-    (64, 2, 1, True, torch.bfloat16), (2, 32, 3, False, torch.float32), (2, 64, 1, False, torch.bfloat16)])
+    (64, 2, 1, True, torch.bfloat16), (2, 32, 3, False, torch.float32), (2, 64, 1, False, torch.bfloat16),
+    (2, 64, 3, False, torch.bfloat16), (128, 2, 3, True, torch.bfloat16), (32, 1, 3, True, torch.bfloat16)])
 def test_conv2d_narrow_input_kernel(be, cin, cout, k, transposed, dt):
     """conv_narrowin_kernel: <= 4 channels in, wide out, stride 1, plain epilogue -- the data
-    gradient of LEDHead's 32->2 heads (transposed: dz [.,2] -> dx [.,32]) and plain narrow convs."""
+    gradient of LEDHead's 32->2 heads (transposed: dz [.,2] -> dx [.,32]) and plain narrow convs.  The 3x3 bf16 cases
+    with 32 k output channels run on conv3x3_narrowin_mfma_kernel (csrc/conv3x3.hip: the 3 x 3 x 2 neighbourhood as one
+    K = 32 fragment, weights rounded to bf16 as on every matrix-core path)."""
     from led_net_amd import ops
+    if dt == torch.bfloat16 and k == 3:
+        kin, kout = (cout, cin) if transposed else (cin, cout)
+        xq = torch.zeros(1, 4, 4, kin, dtype=dt, device=_DEV[0])
+        kid = ops.conv2d_kernel_id(xq, D(torch.zeros(cout, cin, k, k)), pad=1, transposed=transposed,
+                                   **(dict(out_hw=(4, 4)) if transposed else {}))
+        assert kid == 4, kid
     pad = k // 2
     w = torch.randn(cout, cin, k, k) * 0.2
     if transposed:

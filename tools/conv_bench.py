@@ -30,6 +30,7 @@ SHAPES = [
     ('dgrad', 32, 32, 3, 2, 1, 16, 512, 512),
     ('wgrad', 32, 32, 3, 2, 1, 16, 512, 512),
     ('fwd', 32, 2, 3, 1, 1, 16, 512, 512),
+    ('fwdpro', 32, 2, 3, 1, 1, 16, 512, 512),        # training: BatchNorm + ReLU prologue, bias, raw bf16 output, no statistics
     ('dgrad', 32, 2, 3, 1, 1, 16, 512, 512),
     ('wgrad', 32, 2, 3, 1, 1, 16, 512, 512),
     ('fwd', 64, 64, 1, 1, 4, 16, 128, 128),
@@ -77,6 +78,12 @@ def main():
         if kind == 'fwd':
             wp = ops.pack_conv_weights(w, 0, grp) if ops.mfma_weight_ok(w, grp) else None
             fn = lambda: ops.conv2d(x, w, stride=s, pad=pad, groups=grp, stats=stats, w_bf16=wp)
+            nbytes = x.numel() * 2 + dz.numel() * 2
+        elif kind == 'fwdpro':
+            wp = ops.pack_conv_weights(w, 0, grp)
+            isc, ish, bias = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1, torch.randn(co, device=dev)
+            fn = lambda: ops.conv2d(x, w, stride=s, pad=pad, groups=grp, in_scale=isc, in_shift=ish, in_act=ops.ACT_RELU,
+                                    out_shift=bias, w_bf16=wp)
             nbytes = x.numel() * 2 + dz.numel() * 2
         elif kind == 'dgrad':
             wp = ops.pack_conv_weights(w, 1, grp) if ops.mfma_weight_ok(w, grp) else None
