@@ -430,6 +430,14 @@ def main():
                     alg_gbs=round(gbs, 1), alg_tflops=round(tfl, 3), mfma_frac=round(tfl / peak_t, 5),
                     arithmetic_intensity=round(f['flops'] / max(1, f['bytes']), 1),
                     share_of_gpu_time=round(f['ms'] / max(1e-9, sum(v['ms'] for v in fam.values())), 4))
+        # the other kernel functions by time, each against the same two roofs (the convolution work is spread over five
+        # matrix-core kernels since round 3: the dominant one alone no longer describes it)
+        roof['by_kernel'] = []
+        for kn, ff in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])[:8]:
+            g_, t_ = ff['bytes'] / (ff['ms'] * 1e-3) / 1e9, ff['flops'] / (ff['ms'] * 1e-3) / 1e12
+            roof['by_kernel'].append(dict(kernel=kn, ms_per_step=round(ff['ms'] / k_steps, 3), launches_per_step=ff['n'] // k_steps,
+                                          avg_us=round(ff['ms'] / ff['n'] * 1e3, 2), alg_gbs=round(g_, 1), hbm_frac=round(g_ / HBM_PEAK_GBS, 4),
+                                          alg_tflops=round(t_, 2), mfma_frac=round(t_ / peak_t, 4)))
         total_flops = sum(v['flops'] * v['n'] for k, v in agg.items() if k[0] in ('ledn_conv2d', 'ledn_conv2d_wgrad', 'ledn_window_attn'))
         total_bytes = sum(v['bytes'] * v['n'] for v in agg.values())
         gpu_ms = sum(v['ms'] for v in agg.values())
