@@ -164,6 +164,13 @@ int ledn_stem_conv(const void* x, int dtype_x, const void* wp, void* y, int N, i
                    int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
                    float pad_val, const float* out_scale, const float* out_shift, int act_out, float* stat_sum,
                    float* stat_sqsum, void* stream);
+/* Its weight gradient from the same planar batch (autograd of F.conv2d in ddrnet.py:123-130):
+ *   dw[co][c][kh][kw] (f32, OIHW, [32][3][3][3]) += sum over output pixels of dz[n,ho,wo,co] * pre(x)[n,c,2ho-1+kh,2wo-1+kw]
+ * with pre = the normalisation / channel map / batch padding of ledn_stem_conv (zero outside the image).  dz [N,Ho,Wo,32]
+ * bf16.  Uses the bound workspace (>= 864 floats per workgroup). */
+int ledn_stem_conv_wgrad(const void* x, int dtype_x, const void* dz, float* dw, int N, int H, int W, int C, int Ho, int Wo,
+                         int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
+                         float pad_val, void* stream);
 
 /* Weight (and bias) gradient of the same convolution:
  *   dw(co,ci,tap) += sum_{n,ho,wo} pre(x)[n, ho*s-pad+kh*dil, .., ci] * dz[n,ho,wo,co]

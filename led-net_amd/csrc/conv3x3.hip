@@ -633,4 +633,359 @@ int conv3x3_narrowin_mfma(const ledn_conv_desc& d, hipStream_t s) {
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------
+// The first stem convolution (3x3, stride 2, pad 1, 3 -> 32; ddrnet.py:123-130) from the planar input batch, register-
+// direct: the 27 patch values of an output pixel are ONE K = 32 fragment (k = (kh 3 + kw) 3 + c, the order of
+// ledn_im2col_stem / stem_weight_as_1x1), lane (pixel, q) gathers its eight with byte (f32 / bf16) loads that hit L1 / L2
+// (every input byte serves ~2 output pixels x 3 kw), normalises them (SegDataPreProcessor: channel map, x scale + shift,
+// batch padding = pad_val in the normalised domain) and packs them to bf16 in registers; two matrix instructions per 16
+// pixels; stores and statistics as conv1x1.hip.  No LDS, no barrier, no patch matrix (268 MB at 16 x 1024^2 written by
+// ledn_im2col_stem_planar and read back by the 1x1 GEMM), no workgroup-wide window staging (stem_conv_kernel:
+// 182 us).  Iteration = output row x strip of 32 pixels, grid-stride, next iteration's gathers in flight.
+// ---------------------------------------------------------------------------
+struct StemRArgs {
+    const void* x;
+    const bf16_t* wp;            // [32 cout][32 k] bf16
+    bf16_t* y;
+    const float *in_scale, *in_shift, *out_scale, *out_shift;
+    const int* map;
+    const int* valid_hw;
+    float* stat_sum;
+    float* stat_sqsum;
+    float* part;
+    int N, H, W, Ho, Wo, act_out, strips;
+    long iters;
+    float pad_val;
+};
+
+__device__ __forceinline__ float stem_ld(const unsigned char* p) { return (float)*p; }
+__device__ __forceinline__ float stem_ld(const float* p) { return *p; }
+__device__ __forceinline__ float stem_ld(const bf16_t* p) { return bf16_to_f32(p->v); }
+
+template <typename TX, bool FULL>
+__global__ void __launch_bounds__(256, 4) stem_conv_reg_kernel(StemRArgs a) {
+    constexpr int G = 2, NMT = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int pl = lane & 15, q = lane >> 4;
+    const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo;
+    const TX* x = reinterpret_cast<const TX*>(a.x);
+    bf16x8_t wf[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+        const int co = c11_channel<NMT>(mt, pl >> 2, pl & 3);
+        wf[mt] = *reinterpret_cast<const bf16x8_t*>(a.wp + co * 32 + 8 * q);
+    }
+    // this lane's eight patch elements k = 8 q + j
+    long koff[8];
+    int kh[8], kw[8];
+    bool kv[8];
+    float isc[8], ish[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j, tap = k / 3, c = k - 3 * tap;
+        kv[j] = k < 27;
+        kh[j] = kv[j] ? tap / 3 : 0;
+        kw[j] = kv[j] ? tap % 3 : 0;
+        const int cs = a.map ? a.map[c] : c;
+        koff[j] = (long)cs * H * W + (long)kh[j] * W + kw[j];
+        isc[j] = a.in_scale ? a.in_scale[c] : 1.f;
+        ish[j] = a.in_shift ? a.in_shift[c] : 0.f;
+    }
+    const int cl = 8 * q;
+    float osc[FULL ? 8 : 1], osh[FULL ? 8 : 1];
+    if constexpr (FULL) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            osc[i] = a.out_scale ? a.out_scale[cl + i] : 1.f;
+            osh[i] = a.out_shift ? a.out_shift[cl + i] : 0.f;
+        }
+    }
+    const float hi_clip = a.act_out == LEDN_ACT_RELU6 ? 6.f : 3.0e38f;
+    constexpr int NST = FULL ? 1 : 8;
+    float st1[NST], st2[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
+
+    auto gather = [&](long it, float (&rw)[G][8]) {
+        const int row = (int)(it / a.strips), strip = (int)(it % a.strips);
+        const int n = row / Ho, o = row - n * Ho;
+        const TX* xn = x + (long)n * 3 * H * W;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int xo = (strip * G + g) * 16 + pl;
+            const long base = (long)(2 * o - 1) * W + (2 * xo - 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int hi = 2 * o - 1 + kh[j], wi = 2 * xo - 1 + kw[j];
+                const bool ok = kv[j] && hi >= 0 && hi < H && wi >= 0 && wi < W && xo < Wo;
+                rw[g][j] = stem_ld(xn + (ok ? base + koff[j] : 0L));
+            }
+        }
+    };
+    const long nwaves = (long)gridDim.x * 4;
+    long it = (long)blockIdx.x * 4 + wid;
+    float bcur[G][8], bnext[G][8];
+    if (it < a.iters) gather(it, bcur);
+    while (it < a.iters) {
+        const long nit = it + nwaves;
+        if (nit < a.iters) gather(nit, bnext);
+        sched_fence();
+        const int row = (int)(it / a.strips), strip = (int)(it % a.strips);
+        const int n = row / Ho, o = row - n * Ho;
+        const int vh = a.valid_hw ? a.valid_hw[2 * n] : H, vw = a.valid_hw ? a.valid_hw[2 * n + 1] : W;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int xo = (strip * G + g) * 16 + pl;
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int hi = 2 * o - 1 + kh[j], wi = 2 * xo - 1 + kw[j];
+                const bool ok = kv[j] && hi >= 0 && hi < H && wi >= 0 && wi < W && xo < Wo;
+                float v = bcur[g][j] * isc[j] + ish[j];
+                v = (hi < vh && wi < vw) ? v : a.pad_val;           // batch padding (stack_batch), normalised domain
+                e[j] = ok ? f32_to_bf16(v) : (unsigned short)0;      // the convolution's own zero padding
+            }
+            const bf16x8_t b = __builtin_bit_cast(bf16x8_t, make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16),
+                                                                       e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)));
+            f32x4_t acc[NMT];
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                acc[mt] = mfma_16x16x32_bf16(wf[mt], b, acc[mt]);
+            }
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = acc[0][i];
+                v[4 + i] = acc[1][i];
+            }
+            const bool pok = xo < Wo;
+            if constexpr (FULL) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = v[i] * osc[i] + osh[i];
+                    if (a.act_out != LEDN_ACT_NONE) v[i] = fminf(fmaxf(v[i], 0.f), hi_clip);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float vm = pok ? v[i] : 0.f;
+                    st1[i] += vm;
+                    st2[i] = fmaf(vm, vm, st2[i]);
+                }
+            }
+            if (pok) st8(a.y + ((long)row * Wo + xo) * 32 + cl, v);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bcur[g][j] = bnext[g][j];
+        it = nit;
+    }
+    if constexpr (!FULL) {
+        if (!a.stat_sum) return;
+        __shared__ float s_st[4][2][32];
+        const float t1 = c11_reduce16<8>(st1, lane), t2 = c11_reduce16<8>(st2, lane);
+        const int vi = c11_red_index<8>(lane);
+        if ((lane & 15) < 8) {
+            s_st[wid][0][cl + vi] = t1;
+            s_st[wid][1][cl + vi] = t2;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int jj = tid >> 5, c = tid & 31;
+            const float t = (s_st[0][jj][c] + s_st[1][jj][c]) + (s_st[2][jj][c] + s_st[3][jj][c]);
+            if (a.part) a.part[(long)blockIdx.x * 64 + jj * 32 + c] = t;
+            else atomicAdd((jj ? a.stat_sqsum : a.stat_sum) + c, t);
+        }
+    }
+}
+
+bool stem_conv_reg_enabled() { return (options().stream_fast & 64) != 0; }
+
+int stem_conv_reg_impl(const void* x, int dtype_x, const void* wp, void* y, int N, int H, int W, int Ho, int Wo,
+                       const float* in_scale, const float* in_shift, const int* map, const int* valid_hw, float pad_val,
+                       const float* out_scale, const float* out_shift, int act_out, float* stat_sum, float* stat_sqsum,
+                       hipStream_t s) {
+    const bool full = out_scale || out_shift || act_out != LEDN_ACT_NONE;
+    StemRArgs a;
+    a.x = x; a.wp = (const bf16_t*)wp; a.y = (bf16_t*)y;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
+    a.map = map; a.valid_hw = valid_hw; a.stat_sum = stat_sum; a.stat_sqsum = stat_sqsum;
+    a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.act_out = act_out; a.pad_val = pad_val;
+    a.strips = (int)cdiv(Wo, 32);
+    a.iters = (long)N * Ho * a.strips;
+    long nb = cdiv(a.iters, 4);
+    const long cap = (long)options().conv_workgroups * 4;
+    if (nb > cap) nb = cap;
+    a.part = (stat_sum && nb > 16) ? ws_take(nb * 64) : nullptr;
+#define LEDN_STEMR(TX)                                                                                       \
+    do {                                                                                                     \
+        if (full) LEDN_LAUNCH((stem_conv_reg_kernel<TX, true>), dim3((unsigned)nb), dim3(256), 0, s, a);     \
+        else LEDN_LAUNCH((stem_conv_reg_kernel<TX, false>), dim3((unsigned)nb), dim3(256), 0, s, a);         \
+    } while (0)
+    if (dtype_x == LEDN_U8) LEDN_STEMR(unsigned char);
+    else if (dtype_x == LEDN_F32) LEDN_STEMR(float);
+    else if (dtype_x == LEDN_BF16) LEDN_STEMR(bf16_t);
+    else return LEDN_EINVAL;
+#undef LEDN_STEMR
+    if (a.part) return finish_partials(a.part, (int)nb, 32, 2, stat_sum, stat_sqsum, nullptr, s);
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// Weight gradient of that stem convolution straight from the planar input batch:
+//   dW[co][c][kh][kw] = sum over output pixels of dz[px][co] * pre(x)[c][2 ho - 1 + kh][2 wo - 1 + kw].
+// As a matrix product dW^T[k][co] with K = pixels: BOTH operands are needed pixel-major per lane, which NHWC / planar
+// memory is not -- the general weight-gradient kernel stages pixel tiles in LDS and reads them back transposed.  Here
+// both fragments are GATHERED (8 narrow loads each: the patch byte of 8 consecutive output pixels -- stride 2 -- for
+// A[k][pixel], the bf16 of 8 consecutive pixels -- stride 64 B -- for B[pixel][co]; all L1 / L2 hits, a 32-pixel
+// strip is 2 KB of dz and ~400 B of image), 4 matrix instructions per 32 pixels accumulate the whole 32 x 32 tile in
+// 16 registers for the lifetime of the wave.  The 268 MB patch matrix is never read (the im2col'ed form: 126 us + the
+// 203 us that wrote it).  One 864-float partial row per workgroup (OIHW order), finish_partials adds them into dW.
+// ---------------------------------------------------------------------------
+struct StemWArgs {
+    const void* x;
+    const bf16_t* dz;            // [N][Ho][Wo][32]
+    float* part;                 // [gridDim.x][864]
+    const float *in_scale, *in_shift;
+    const int* map;
+    const int* valid_hw;
+    int N, H, W, Ho, Wo, strips;
+    long iters;
+    float pad_val;
+};
+
+template <typename TX>
+__global__ void __launch_bounds__(256, 3) stem_wgrad_reg_kernel(StemWArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo;
+    const TX* x = reinterpret_cast<const TX*>(a.x);
+    // A rows of this lane: patch elements k = 16 mt + m16
+    long koff[2];
+    int kh[2], kw[2];
+    bool kv[2];
+    float isc[2], ish[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int k = 16 * mt + m16, tap = k / 3, c = k - 3 * tap;
+        kv[mt] = k < 27;
+        kh[mt] = kv[mt] ? tap / 3 : 0;
+        kw[mt] = kv[mt] ? tap % 3 : 0;
+        const int cs = a.map ? a.map[c] : c;
+        koff[mt] = (long)cs * H * W + (long)kh[mt] * W + kw[mt];
+        isc[mt] = a.in_scale ? a.in_scale[c] : 1.f;
+        ish[mt] = a.in_shift ? a.in_shift[c] : 0.f;
+    }
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto gather = [&](long it, float (&ra)[2][8], unsigned short (&rb)[2][8]) {
+        const int row = (int)(it / a.strips), strip = (int)(it % a.strips);
+        const int n = row / Ho, o = row - n * Ho;
+        const TX* xn = x + (long)n * 3 * H * W;
+        const bf16_t* zr = a.dz + (long)row * Wo * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int px = strip * 32 + 8 * q + j;
+            const bool pok = px < Wo;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int hi = 2 * o - 1 + kh[mt], wi = 2 * px - 1 + kw[mt];
+                const bool ok = pok && kv[mt] && hi >= 0 && hi < H && wi >= 0 && wi < W;
+                ra[mt][j] = stem_ld(xn + (ok ? (long)(2 * o - 1) * W + (2 * px - 1) + koff[mt] : 0L));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) rb[nt][j] = pok ? zr[(long)px * 32 + 16 * nt + m16].v : (unsigned short)0;
+        }
+    };
+    const long nwaves = (long)gridDim.x * 4;
+    long it = (long)blockIdx.x * 4 + wid;
+    float acur[2][8], anext[2][8];
+    unsigned short bcur[2][8], bnext[2][8];
+    if (it < a.iters) gather(it, acur, bcur);
+    while (it < a.iters) {
+        const long nit = it + nwaves;
+        if (nit < a.iters) gather(nit, anext, bnext);
+        sched_fence();
+        const int row = (int)(it / a.strips), strip = (int)(it % a.strips);
+        const int n = row / Ho, o = row - n * Ho;
+        const int vh = a.valid_hw ? a.valid_hw[2 * n] : H, vw = a.valid_hw ? a.valid_hw[2 * n + 1] : W;
+        bf16x8_t af[2], bfr[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int px = strip * 32 + 8 * q + j;
+                const int hi = 2 * o - 1 + kh[mt], wi = 2 * px - 1 + kw[mt];
+                const bool ok = px < Wo && kv[mt] && hi >= 0 && hi < H && wi >= 0 && wi < W;
+                float v = acur[mt][j] * isc[mt] + ish[mt];
+                v = (hi < vh && wi < vw) ? v : a.pad_val;
+                e[j] = ok ? f32_to_bf16(v) : (unsigned short)0;
+            }
+            af[mt] = __builtin_bit_cast(bf16x8_t, make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16),
+                                                             e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)));
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            bfr[nt] = __builtin_bit_cast(bf16x8_t, make_uint4(bcur[nt][0] | ((unsigned)bcur[nt][1] << 16), bcur[nt][2] | ((unsigned)bcur[nt][3] << 16),
+                                                              bcur[nt][4] | ((unsigned)bcur[nt][5] << 16), bcur[nt][6] | ((unsigned)bcur[nt][7] << 16)));
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acur[t][j] = anext[t][j];
+                bcur[t][j] = bnext[t][j];
+            }
+        it = nit;
+    }
+    // acc[mt][nt][i] = dW^T[k = 16 mt + 4 q + i][co = 16 nt + m16]: the four waves meet in LDS, one OIHW row per workgroup
+    __shared__ float s_red[4][32][33];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_red[wid][16 * mt + 4 * q + i][16 * nt + m16] = acc[mt][nt][i];
+    __syncthreads();
+    for (int e = tid; e < 27 * 32; e += 256) {
+        const int k = e / 32, co = e % 32;
+        const float t = (s_red[0][k][co] + s_red[1][k][co]) + (s_red[2][k][co] + s_red[3][k][co]);
+        const int tap = k / 3, c = k - 3 * tap;                 // k = (kh 3 + kw) 3 + c  ->  OIHW [co][c][kh][kw]
+        a.part[(long)blockIdx.x * 864 + co * 27 + c * 9 + tap] = t;
+    }
+}
+
+int stem_conv_wgrad_impl(const void* x, int dtype_x, const void* dz, float* dw, int N, int H, int W, int C, int Ho, int Wo,
+                         int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
+                         float pad_val, hipStream_t s) {
+    LEDN_REQUIRE(x && dz && dw && N > 0 && H > 0 && W > 0 && C == 3 && Cout == 32);
+    LEDN_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1);
+    LEDN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
+    StemWArgs a;
+    a.x = x; a.dz = (const bf16_t*)dz; a.in_scale = in_scale; a.in_shift = in_shift; a.map = map; a.valid_hw = valid_hw;
+    a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad_val = pad_val;
+    a.strips = (int)cdiv(Wo, 32);
+    a.iters = (long)N * Ho * a.strips;
+    long nb = cdiv(a.iters, 4 * 8);                              // >= 8 strips per wave
+    if (nb < 1) nb = 1;
+    const long cap = (long)options().conv_workgroups * 2;
+    if (nb > cap) nb = cap;
+    a.part = ws_take(nb * 864);
+    if (dtype_x == LEDN_U8) LEDN_LAUNCH((stem_wgrad_reg_kernel<unsigned char>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else if (dtype_x == LEDN_F32) LEDN_LAUNCH((stem_wgrad_reg_kernel<float>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else if (dtype_x == LEDN_BF16) LEDN_LAUNCH((stem_wgrad_reg_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else return LEDN_EINVAL;
+    return finish_partials(a.part, (int)nb, 864, 1, dw, nullptr, nullptr, s);
+}
+
 }  // namespace ledn

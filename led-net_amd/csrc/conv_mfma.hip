@@ -1056,6 +1056,12 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(StemArgs a) {
     }
 }
 
+bool stem_conv_reg_enabled();
+int stem_conv_reg_impl(const void* x, int dtype_x, const void* wp, void* y, int N, int H, int W, int Ho, int Wo,
+                       const float* in_scale, const float* in_shift, const int* map, const int* valid_hw, float pad_val,
+                       const float* out_scale, const float* out_shift, int act_out, float* stat_sum, float* stat_sqsum,
+                       hipStream_t s);
+
 int stem_conv_impl(const void* x, int dtype_x, const void* wp, void* y, int N, int H, int W, int C, int Ho, int Wo,
                    int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
                    float pad_val, const float* out_scale, const float* out_shift, int act_out, float* stat_sum,
@@ -1066,6 +1072,9 @@ int stem_conv_impl(const void* x, int dtype_x, const void* wp, void* y, int N, i
     LEDN_REQUIRE(act_out == LEDN_ACT_NONE || act_out == LEDN_ACT_RELU || act_out == LEDN_ACT_RELU6);
     const bool full = out_scale || out_shift || act_out != LEDN_ACT_NONE;
     LEDN_REQUIRE(!(full && stat_sum));                        // inference epilogue XOR training statistics
+    if (stem_conv_reg_enabled())                              // the register-direct form (conv3x3.hip)
+        return stem_conv_reg_impl(x, dtype_x, wp, y, N, H, W, Ho, Wo, in_scale, in_shift, map, valid_hw, pad_val, out_scale,
+                                  out_shift, act_out, stat_sum, stat_sqsum, s);
     StemArgs a;
     a.x = x; a.wp = (const bf16_t*)wp; a.y = (bf16_t*)y;
     a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;

@@ -350,6 +350,27 @@ def stem_conv(x, w_pack, scale=None, shift=None, chan_map=None, valid=None, pad_
     return y
 
 
+def stem_conv_wgrad(x, dz, dw, scale=None, shift=None, chan_map=None, valid=None, pad_val=0.0):
+    """dw [32,3,3,3] f32 += weight gradient of stem_conv from the planar batch x [N,3,H,W] and dz [N,Ho,Wo,32] bf16
+    (ledn_stem_conv_wgrad: no patch matrix).  -> dw"""
+    lib = _lib.get_lib()
+    N, Cc, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if Cc != 3 or x.dtype not in (torch.uint8, torch.float32, torch.bfloat16):
+        raise LednError('stem_conv_wgrad: uint8/f32/bf16 input with 3 channels required')
+    if dz.dtype != torch.bfloat16 or tuple(dz.shape) != (N, Ho, Wo, 32) or not dz.is_contiguous():
+        raise LednError('stem_conv_wgrad: dz must be contiguous bf16 [N,Ho,Wo,32]')
+    if dw.dtype != torch.float32 or dw.numel() != 32 * 27 or not dw.is_contiguous():
+        raise LednError('stem_conv_wgrad: dw must be contiguous f32 [32,3,3,3]')
+    _check(lib, x, dz, dw, scale, shift, chan_map, valid)
+    dtx = {torch.uint8: _lib.U8, torch.float32: F32, torch.bfloat16: BF16}[x.dtype]
+    valid = _valid_hw(valid, N, x)
+    _run(lib, 'ledn_stem_conv_wgrad', x, _p(x), dtx, _p(dz), _p(dw), N, H, W, Cc, Ho, Wo, 32,
+         _p(_f32(scale, Cc)), _p(_f32(shift, Cc)), _p(chan_map), _p(valid), float(pad_val),
+         work=_TIMING is not None and (f'stem_conv_wgrad {N}x{H}x{W}', _nb(x, dz), 2 * dz.numel() * 27, 'stem_wgrad_reg_kernel'))
+    return dw
+
+
 def stem_weight_as_1x1(w):
     """[Cout][3][3][3] OIHW -> [Cout][32][1][1] matching im2col_stem's column order (differentiable)."""
     co, ci, kh, kw = w.shape

@@ -779,6 +779,32 @@ class MfafTailFn(Function):
         return (dx, dr, *draws, None, None, None, *dgb)
 
 
+STEM_DIRECT = int(_os.environ.get('LEDN_STEM_DIRECT', '1'))
+
+
+class StemConvFn(Function):
+    """z = conv3x3/s2 (3 -> 32) of the normalised planar batch + per-channel statistics of z (ledn_stem_conv), weight
+    gradient from the same batch (ledn_stem_conv_wgrad); the input needs no gradient (ddrnet.py:123-130)."""
+
+    @staticmethod
+    def forward(ctx, x, w, pre, stats):
+        s, b, mp, valid, pad_val = pre
+        wp = ops.pack_conv_weights(ops.stem_weight_as_1x1(w.detach()), 0)
+        z = ops.stem_conv(x, wp, s, b, mp, valid, pad_val, stats=(stats[0], stats[1]), defer_stats=_Env.sync_bn is None)
+        ctx.save_for_backward(x, s, b, mp, valid)
+        ctx.pad_val = pad_val
+        ctx.sink = _Sinks.get(w)
+        ctx.wshape = tuple(w.shape)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, s, b, mp, valid = ctx.saved_tensors
+        dw = ctx.sink if ctx.sink is not None else ops.zeros_f32(ctx.wshape, dz.device)
+        ops.stem_conv_wgrad(x, _c(dz), dw, s, b, mp, valid, ctx.pad_val)
+        return None, (None if ctx.sink is not None else dw), None, None
+
+
 class GradReadyFn(Function):
     """Identity.  Its backward runs when every consumer of `x` has delivered its gradient, i.e. when all
     backward kernels downstream of this point have been issued: the Trainer starts the gradient all-reduce
@@ -1132,7 +1158,15 @@ def lednet_forward_train(m, x, pre=None):
     out_size = (math.ceil(H / 8), math.ceil(W / 8))
     s, b, mp, valid, pad_val = (tuple(pre) + (None, 0.0))[:5] if pre is not None else (None, None, None, None, 0.0)
     s0 = m.stem['0']
-    if m.act_dtype == torch.bfloat16 and 9 * m.in_channels <= 32 and m.channels % 32 == 0:
+    if (STEM_DIRECT and m.act_dtype == torch.bfloat16 and m.in_channels == 3 and m.channels == 32
+            and x.dtype in (torch.uint8, torch.float32, torch.bfloat16) and s0.conv.bias is None):
+        # the first stem convolution and its weight gradient straight from the planar batch (ledn_stem_conv /
+        # ledn_stem_conv_wgrad): the [pixels][32] patch matrix of the form below (268 MB at 16 x 1024^2, written once and
+        # read twice per step) is never materialised
+        st = _stats(m.channels, x)
+        z = StemConvFn.apply(x.contiguous(), s0.conv.weight, (s, b, mp, valid, pad_val), st)
+        x1 = BNActFn.apply(z, s0.bn.weight, s0.bn.bias, None, None, st, s0.bn, ACT_RELU, RES_NONE, None)
+    elif m.act_dtype == torch.bfloat16 and 9 * m.in_channels <= 32 and m.channels % 32 == 0:
         # stem as a K=32 GEMM on the MFMA path: im2col patches straight from the planar batch
         # (normalisation folded in; the input needs no gradient) x reshaped weight
         st = _stats(m.channels, x)

@@ -161,3 +161,49 @@ def test_conv3x3_narrow_head_forward(be, cout, pro, f32out, nhw):
     finally:
         lib.set_option(2, MASK)
     torch.testing.assert_close(got.float().cpu(), ref.float().cpu(), rtol=8e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize('shape,valid', [((2, 3, 64, 128), None), ((1, 3, 70, 150), None), ((2, 3, 72, 136), [(72, 136), (50, 101)]),
+                                         ((1, 3, 33, 47), [(20, 31)])])
+def test_stem_conv_register_direct(be, shape, valid):
+    """ledn_stem_conv on stem_conv_reg_kernel (LEDN_OPT_STREAM_FAST bit 6: the 27 patch values of a pixel gathered into
+    one K = 32 fragment, no LDS): the same comparisons as the LDS-window form in tests/test_conv_mfma.py -- against
+    ledn_im2col_stem_planar + ledn_conv2d (inference epilogue; raw + statistics) and against torch's conv2d on the
+    normalised, batch-padded input (ddrnet.py:123-130, data_preprocessor.py:98-151)."""
+    from test_conv_mfma import test_fused_stem_conv_equals_im2col_plus_gemm as case
+    case(be, shape, valid)
+
+
+@pytest.mark.parametrize('shape,valid', [((2, 3, 64, 128), None), ((1, 3, 70, 150), None), ((2, 3, 72, 136), [(72, 136), (50, 101)]),
+                                         ((1, 3, 33, 47), [(20, 31)])])
+def test_stem_conv_wgrad_from_planar_batch(be, shape, valid):
+    """ledn_stem_conv_wgrad (both MFMA operands gathered pixel-major, no patch matrix) against torch autograd of the
+    stem convolution on the normalised, batch-padded input (bf16-rounded operands), accumulated INTO dw; and against the
+    im2col'ed path it replaces (ledn_im2col_stem_planar + ledn_conv2d_wgrad of the 1x1 view)."""
+    from led_net_amd import ops
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(H * W + 1)
+    x = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+    mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
+    sc, sh = 1.0 / std, -mean / std
+    xn = x.float()[:, [2, 1, 0]] * sc.view(1, 3, 1, 1) + sh.view(1, 3, 1, 1)
+    if valid is not None:
+        for i, (vh, vw) in enumerate(valid):
+            xn[i, :, vh:, :] = 0.25
+            xn[i, :, :, vw:] = 0.25
+    xn = r16(xn)
+    w = torch.zeros(32, 3, 3, 3, requires_grad=True)
+    z = F.conv2d(xn, w, stride=2, padding=1)
+    dz = r16(torch.randn(z.shape, generator=g))
+    z.backward(dz)
+    cmap = torch.tensor([2, 1, 0], dtype=torch.int32, device=_DEV[0])
+    vt = torch.tensor(valid, dtype=torch.int32, device=_DEV[0]) if valid is not None else None
+    dw = torch.full((32, 3, 3, 3), 0.5, device=_DEV[0])
+    out = ops.stem_conv_wgrad(D(x), nhwc(dz).bfloat16(), dw, D(sc), D(sh), cmap, vt, 0.25)
+    assert out is dw
+    scale = float(w.grad.abs().max())
+    torch.testing.assert_close(dw.cpu() - 0.5, w.grad, rtol=2e-3, atol=2e-3 * scale)
+    patches = ops.im2col_stem_planar(D(x), D(sc), D(sh), cmap, vt, 0.25)
+    dw1, _ = ops.conv2d_wgrad(patches, nhwc(dz).bfloat16(), (32, 32, 1, 1))
+    ref = dw1.reshape(32, 32)[:, :27].reshape(32, 3, 3, 3).permute(0, 3, 1, 2)     # columns (kh 3 + kw) 3 + c -> OIHW
+    torch.testing.assert_close(dw.cpu() - 0.5, ref.cpu(), rtol=1e-3, atol=1e-3 * scale)
