@@ -104,3 +104,14 @@ def be(request):
     else:
         assert torch.cuda.is_available(), 'gpu-marked test needs a HIP device'
         yield Backend('cuda:0')
+
+
+def slow_on_emu(dev):
+    """whole-network tests that take 2-5 minutes each on the CPU emulator AND have a -m gpu twin (same test body on
+    libledn_hip.so) run on the emulator only with LEDN_EMU_SLOW=1: the default CPU suite keeps one whole-step test per
+    kind (f32 step vs oracle, world-2 = world-1, collective order, resume, bf16 fan-in chains) plus every block-level
+    test of the same kernels."""
+    import os
+    import pytest as _pytest
+    if getattr(dev, 'type', str(dev)) == 'cpu' and not int(os.environ.get('LEDN_EMU_SLOW', '0')):
+        _pytest.skip('whole-network test on the emulator: set LEDN_EMU_SLOW=1 (the GPU twin always runs)')

@@ -63,6 +63,8 @@ def test_predict_bf16_vs_oracle(be):
 
 
 def test_train_step_bf16_vs_oracle(be):
+    from conftest import slow_on_emu
+    slow_on_emu(be.dev)
     L, cfg, model, sd = _model(3)
     g = torch.Generator().manual_seed(11)
     img = torch.randint(0, 256, (2, 3, 320, 320), dtype=torch.uint8, generator=g)

@@ -201,6 +201,9 @@ def test_reconstruction_flags_vs_oracle(be, flags):
     each variant: inference features + fused logits and the training-mode loss against the oracle with the same
     flags."""
     import led_net_amd as L
+    if flags not in (VARIANTS[0], VARIANTS[2]):       # (emulator default: the pooling tail and the cascade depth; GPU: all five)
+        from conftest import slow_on_emu
+        slow_on_emu(be.dev)
     torch.manual_seed(304)
     cfg = L.load_config(os.path.join(os.path.dirname(__file__), 'data', 'lednet_test_config.py'))
     cfg['model']['backbone'].update(flags)

@@ -265,6 +265,8 @@ def test_direct_gradient_sinks_match_autograd_accumulation(be):
     autograd-accumulated path gives; the run-to-run noise floor of the latter (f32 atomics order ->
     ReLU kinks, SEAM percentile) is measured with a second reference pass and bounds the check."""
     import led_net_amd as L
+    from conftest import slow_on_emu
+    slow_on_emu(_DEV[0])
     torch.manual_seed(304)
     cfg = L.load_config(os.path.join(os.path.dirname(__file__), 'data', 'lednet_test_config.py'))
     cfg['model']['decode_head']['loss_decode'][0]['min_kept'] = 5000
