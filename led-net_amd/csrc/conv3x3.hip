@@ -634,14 +634,22 @@ int conv3x3_narrowin_mfma(const ledn_conv_desc& d, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
-// The first stem convolution (3x3, stride 2, pad 1, 3 -> 32; ddrnet.py:123-130) from the planar input batch, register-
-// direct: the 27 patch values of an output pixel are ONE K = 32 fragment (k = (kh 3 + kw) 3 + c, the order of
-// ledn_im2col_stem / stem_weight_as_1x1), lane (pixel, q) gathers its eight with byte (f32 / bf16) loads that hit L1 / L2
-// (every input byte serves ~2 output pixels x 3 kw), normalises them (SegDataPreProcessor: channel map, x scale + shift,
-// batch padding = pad_val in the normalised domain) and packs them to bf16 in registers; two matrix instructions per 16
-// pixels; stores and statistics as conv1x1.hip.  No LDS, no barrier, no patch matrix (268 MB at 16 x 1024^2 written by
-// ledn_im2col_stem_planar and read back by the 1x1 GEMM), no workgroup-wide window staging (stem_conv_kernel:
-// 182 us).  Iteration = output row x strip of 32 pixels, grid-stride, next iteration's gathers in flight.
+// The first stem convolution (3x3, stride 2, pad 1, 3 -> 32; ddrnet.py:123-130) and its weight gradient straight from
+// the planar input batch (no [pixels][32] patch matrix: 268 MB at 16 x 1024^2, written once and read twice per step by
+// ledn_im2col_stem_planar + the 1x1 GEMM and its weight gradient).
+//
+// Shared gather ("patch rows").  Patch element k = (kh 3 + kw) 3 + c of 8 CONSECUTIVE output pixels is 8 bytes at
+// stride 2 of one image row: one 16-byte window.  Lane (k = lane & 15 (+ 16 mt), q = lane >> 4) loads the 4-byte-
+// aligned 20 bytes around it (dwordx4 + dword), picks its bytes with 64-bit shifts, normalises (SegDataPreProcessor:
+// channel map, x scale + shift, batch padding = pad_val in the normalised domain, zero outside the image) and holds
+// A[k][pixel 8 q .. 8 q + 7] as bf16.  The first version gathered single bytes (8 loads per fragment): both kernels
+// then ran at the issue rate of byte loads -- 2.1 M load instructions x ~64 cycles = 210 us each, whatever else they
+// did.  Other input types (f32 / bf16: tests, pre-normalised inputs) keep the scalar loads.
+//   weight gradient: dW^T[k][co] = sum over pixels A[k][px] * dz[px][co] -- A is this fragment as it is; B = dz^T through a
+//     wave-private LDS tile and ds_read_b64_tr_b16 (4 consecutive PIXELS of a lane's channel per read);
+//   forward: z[px][co] = sum over k W[co][k] * patch[px][k] needs the 8 consecutive k of ONE pixel per lane: the same
+//     rows are written to a wave-private LDS tile [k][pixel] and read back transposed by ds_read_b64_tr_b16.
+// No workgroup barrier in either main loop; next iteration's windows are in flight during the current one.
 // ---------------------------------------------------------------------------
 struct StemRArgs {
     const void* x;
@@ -662,35 +670,137 @@ __device__ __forceinline__ float stem_ld(const unsigned char* p) { return (float
 __device__ __forceinline__ float stem_ld(const float* p) { return *p; }
 __device__ __forceinline__ float stem_ld(const bf16_t* p) { return bf16_to_f32(p->v); }
 
+constexpr int ST_PIXB = 80;     // LDS bytes per 32-element bf16 row of the wave-private tiles (64 + 16)
+
+// raw patch-row values of one lane and iteration: 8 pixels of element k (before normalisation)
+template <typename TX> struct StemRaw { float v[8]; };
+template <> struct StemRaw<unsigned char> { unsigned w[5]; int d; };
+
+// the lane's constants for patch element k
+struct StemK {
+    long plane;      // element offset of (channel map[c], row kh, column kw) against (row 2 o - 1, column -1) of plane 0
+    int kh, kw;
+    bool valid;
+    float sc, sh;
+};
+__device__ __forceinline__ StemK stem_k(int k, const int* map, const float* in_scale, const float* in_shift, int H, int W) {
+    StemK r;
+    const int tap = k / 3, c = k - 3 * tap;
+    r.valid = k < 27;
+    r.kh = r.valid ? tap / 3 : 0;
+    r.kw = r.valid ? tap % 3 : 0;
+    const int cs = map ? map[c] : c;
+    r.plane = (long)cs * H * W + (long)r.kh * W + r.kw;
+    r.sc = in_scale ? in_scale[c] : 1.f;
+    r.sh = in_shift ? in_shift[c] : 0.f;
+    return r;
+}
+
+// loads for pixels px0 .. px0 + 7 of output row o of image n (xn = image base, img = elements per image)
+template <typename TX>
+__device__ __forceinline__ void stem_fetch(StemRaw<TX>& r, const TX* xn, long img, const StemK& K, int o, int px0, int H, int W, int Wo) {
+    const int hi = 2 * o - 1 + K.kh;
+    const bool rok = K.valid && hi >= 0 && hi < H;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int px = px0 + j, wi = 2 * px - 1 + K.kw;
+        const bool ok = rok && px < Wo && wi >= 0 && wi < W;
+        r.v[j] = stem_ld(xn + (ok ? (long)(2 * o - 1) * W + (2 * px - 1) + K.plane : 0L));
+    }
+}
+template <>
+__device__ __forceinline__ void stem_fetch<unsigned char>(StemRaw<unsigned char>& r, const unsigned char* xn, long img, const StemK& K,
+                                                          int o, int px0, int H, int W, int Wo) {
+    const int hi = 2 * o - 1 + K.kh;
+    const bool rok = K.valid && hi >= 0 && hi < H && px0 < Wo;
+    // address of pixel px0's element (one byte in front of the image for column -1).  The 20-byte window is aligned on
+    // the ADDRESS (an image need not start on a 4-byte boundary) and clamped into this image (>= 24 bytes, checked by the
+    // launcher; the tensor base is 4-byte aligned, checked too): the extraction follows with d
+    const long start = rok ? (long)(2 * o - 1) * W + (2 * px0 - 1) + K.plane : 0L;
+    const unsigned long long ax = (unsigned long long)xn;
+    const long mis = (long)(ax & 3ull);                         // xn = aligned address + mis
+    long base = ((start + mis) & ~3L) - mis;                    // element index of an aligned address <= start
+    const long lo = mis ? 4 - mis : 0, last = ((img + mis - 20) & ~3L) - mis;
+    base = base < lo ? lo : (base > last ? last : base);
+    r.d = (int)(start - base);
+    // 4-byte aligned, not 16: a 4-aligned 20-byte aggregate = global_load_dwordx4 + dword on the device, unaligned
+    // moves on the emulator (a plain uint4 load there is an aligned SSE move and faults)
+    struct __attribute__((packed, aligned(4))) Win { unsigned w[5]; };
+    const Win wv = *reinterpret_cast<const Win*>(xn + base);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r.w[i] = wv.w[i];
+}
+
+// -> the 8 values as floats (raw domain)
+template <typename TX>
+__device__ __forceinline__ void stem_bytes(const StemRaw<TX>& r, float (&f)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = r.v[j];
+}
+template <>
+__device__ __forceinline__ void stem_bytes<unsigned char>(const StemRaw<unsigned char>& r, float (&f)[8]) {
+    unsigned w[6] = {r.w[0], r.w[1], r.w[2], r.w[3], r.w[4], 0u};
+    int s = r.d & 3;
+    const int dd = r.d >> 2;                        // whole dwords the window was clamped by (0 almost always)
+    if (dd != 0) {                                  // rare: first / last bytes of the image
+        unsigned t[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            unsigned v = 0u;
+#pragma unroll
+            for (int k2 = 0; k2 < 5; ++k2) v = (i + dd == k2) ? r.w[k2] : v;
+            t[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = t[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                   // byte s + 2 j of the window
+        const unsigned long long pair = ((unsigned long long)w[(j >> 1) + 1] << 32) | w[j >> 1];
+        f[j] = (float)((unsigned)(pair >> (8 * (s + 2 * (j & 1)))) & 0xffu);
+    }
+}
+
+// normalise, pad, mask -> bf16 x 8 (A[k][pixel px0 .. px0 + 7])
+template <typename TX>
+__device__ __forceinline__ uint4 stem_row(const StemRaw<TX>& r, const StemK& K, int o, int px0, int H, int W, int Wo, int vh, int vw,
+                                          float pad_val) {
+    float f[8];
+    stem_bytes<TX>(r, f);
+    const int hi = 2 * o - 1 + K.kh;
+    const bool rok = K.valid && hi >= 0 && hi < H;
+    unsigned short e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int px = px0 + j, wi = 2 * px - 1 + K.kw;
+        const bool ok = rok && px < Wo && wi >= 0 && wi < W;
+        float v = f[j] * K.sc + K.sh;
+        v = (hi < vh && wi < vw) ? v : pad_val;              // batch padding (stack_batch), normalised domain
+        e[j] = ok ? f32_to_bf16(v) : (unsigned short)0;       // the convolution's own zero padding
+    }
+    return make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
+                      e[6] | ((unsigned)e[7] << 16));
+}
+
 template <typename TX, bool FULL>
 __global__ void __launch_bounds__(256, 4) stem_conv_reg_kernel(StemRArgs a) {
-    constexpr int G = 2, NMT = 2;
+    constexpr int NMT = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char s_t[4][32 * ST_PIXB];     // per wave: [k][32 pixels] bf16
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int pl = lane & 15, q = lane >> 4;
     const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo;
+    const long img = 3L * H * W;
     const TX* x = reinterpret_cast<const TX*>(a.x);
+    unsigned char* st = s_t[wid];
     bf16x8_t wf[NMT];
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) {
         const int co = c11_channel<NMT>(mt, pl >> 2, pl & 3);
         wf[mt] = *reinterpret_cast<const bf16x8_t*>(a.wp + co * 32 + 8 * q);
     }
-    // this lane's eight patch elements k = 8 q + j
-    long koff[8];
-    int kh[8], kw[8];
-    bool kv[8];
-    float isc[8], ish[8];
+    StemK K[2];                                              // gather role: patch elements k = pl and 16 + pl
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 8 * q + j, tap = k / 3, c = k - 3 * tap;
-        kv[j] = k < 27;
-        kh[j] = kv[j] ? tap / 3 : 0;
-        kw[j] = kv[j] ? tap % 3 : 0;
-        const int cs = a.map ? a.map[c] : c;
-        koff[j] = (long)cs * H * W + (long)kh[j] * W + kw[j];
-        isc[j] = a.in_scale ? a.in_scale[c] : 1.f;
-        ish[j] = a.in_shift ? a.in_shift[c] : 0.f;
-    }
+    for (int t = 0; t < 2; ++t) K[t] = stem_k(16 * t + pl, a.map, a.in_scale, a.in_shift, H, W);
     const int cl = 8 * q;
     float osc[FULL ? 8 : 1], osh[FULL ? 8 : 1];
     if constexpr (FULL) {
@@ -706,47 +816,36 @@ __global__ void __launch_bounds__(256, 4) stem_conv_reg_kernel(StemRArgs a) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
 
-    auto gather = [&](long it, float (&rw)[G][8]) {
+    auto gather = [&](long it, StemRaw<TX> (&rw)[2]) {
         const int row = (int)(it / a.strips), strip = (int)(it % a.strips);
         const int n = row / Ho, o = row - n * Ho;
-        const TX* xn = x + (long)n * 3 * H * W;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int xo = (strip * G + g) * 16 + pl;
-            const long base = (long)(2 * o - 1) * W + (2 * xo - 1);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int hi = 2 * o - 1 + kh[j], wi = 2 * xo - 1 + kw[j];
-                const bool ok = kv[j] && hi >= 0 && hi < H && wi >= 0 && wi < W && xo < Wo;
-                rw[g][j] = stem_ld(xn + (ok ? base + koff[j] : 0L));
-            }
-        }
+        for (int t = 0; t < 2; ++t) stem_fetch<TX>(rw[t], x + (long)n * img, img, K[t], o, strip * 32 + 8 * q, H, W, Wo);
     };
     const long nwaves = (long)gridDim.x * 4;
     long it = (long)blockIdx.x * 4 + wid;
-    float bcur[G][8], bnext[G][8];
-    if (it < a.iters) gather(it, bcur);
+    StemRaw<TX> rcur[2], rnext[2];
+    if (it < a.iters) gather(it, rcur);
     while (it < a.iters) {
         const long nit = it + nwaves;
-        if (nit < a.iters) gather(nit, bnext);
+        if (nit < a.iters) gather(nit, rnext);
         sched_fence();
         const int row = (int)(it / a.strips), strip = (int)(it % a.strips);
         const int n = row / Ho, o = row - n * Ho;
         const int vh = a.valid_hw ? a.valid_hw[2 * n] : H, vw = a.valid_hw ? a.valid_hw[2 * n + 1] : W;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int xo = (strip * G + g) * 16 + pl;
-            unsigned short e[8];
+        for (int t = 0; t < 2; ++t)                            // row k = 16 t + pl, pixels 8 q .. 8 q + 7
+            *reinterpret_cast<uint4*>(st + (16 * t + pl) * ST_PIXB + q * 16) =
+                stem_row<TX>(rcur[t], K[t], o, strip * 32 + 8 * q, H, W, Wo, vh, vw, a.pad_val);
+        wave_sync();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int hi = 2 * o - 1 + kh[j], wi = 2 * xo - 1 + kw[j];
-                const bool ok = kv[j] && hi >= 0 && hi < H && wi >= 0 && wi < W && xo < Wo;
-                float v = bcur[g][j] * isc[j] + ish[j];
-                v = (hi < vh && wi < vw) ? v : a.pad_val;           // batch padding (stack_batch), normalised domain
-                e[j] = ok ? f32_to_bf16(v) : (unsigned short)0;      // the convolution's own zero padding
-            }
-            const bf16x8_t b = __builtin_bit_cast(bf16x8_t, make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16),
-                                                                       e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)));
+        for (int g = 0; g < 2; ++g) {
+            // lane 4 r + p supplies row k = 8 q + r (+ 4), pixels 16 g + 4 p ..: lane i receives k = 8 q .. 8 q + 7 of pixel 16 g + i
+            const unsigned char* tp = st + (8 * q + (pl >> 2)) * ST_PIXB + (16 * g + 4 * (pl & 3)) * 2;
+            const bf16x4_t lo = lds_read_tr16(tp), hi4 = lds_read_tr16(tp + 4 * ST_PIXB);
+            bf16x8_t b;
+            b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
+            b[4] = hi4[0]; b[5] = hi4[1]; b[6] = hi4[2]; b[7] = hi4[3];
             f32x4_t acc[NMT];
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) {
@@ -759,6 +858,7 @@ __global__ void __launch_bounds__(256, 4) stem_conv_reg_kernel(StemRArgs a) {
                 v[i] = acc[0][i];
                 v[4 + i] = acc[1][i];
             }
+            const int xo = strip * 32 + 16 * g + pl;
             const bool pok = xo < Wo;
             if constexpr (FULL) {
 #pragma unroll
@@ -776,10 +876,9 @@ __global__ void __launch_bounds__(256, 4) stem_conv_reg_kernel(StemRArgs a) {
             }
             if (pok) st8(a.y + ((long)row * Wo + xo) * 32 + cl, v);
         }
+        wave_sync();                                             // the tile is rewritten by the next iteration
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bcur[g][j] = bnext[g][j];
+        for (int t = 0; t < 2; ++t) rcur[t] = rnext[t];
         it = nit;
     }
     if constexpr (!FULL) {
@@ -808,6 +907,7 @@ int stem_conv_reg_impl(const void* x, int dtype_x, const void* wp, void* y, int 
                        const float* out_scale, const float* out_shift, int act_out, float* stat_sum, float* stat_sqsum,
                        hipStream_t s) {
     const bool full = out_scale || out_shift || act_out != LEDN_ACT_NONE;
+    LEDN_REQUIRE(3L * H * W >= 28 && ((unsigned long long)x & 3ull) == 0);
     StemRArgs a;
     a.x = x; a.wp = (const bf16_t*)wp; a.y = (bf16_t*)y;
     a.in_scale = in_scale; a.in_shift = in_shift; a.out_scale = out_scale; a.out_shift = out_shift;
@@ -834,15 +934,10 @@ int stem_conv_reg_impl(const void* x, int dtype_x, const void* wp, void* y, int 
 }
 
 // ---------------------------------------------------------------------------
-// Weight gradient of that stem convolution straight from the planar input batch:
-//   dW[co][c][kh][kw] = sum over output pixels of dz[px][co] * pre(x)[c][2 ho - 1 + kh][2 wo - 1 + kw].
-// As a matrix product dW^T[k][co] with K = pixels: BOTH operands are needed pixel-major per lane, which NHWC / planar
-// memory is not -- the general weight-gradient kernel stages pixel tiles in LDS and reads them back transposed.  Here
-// both fragments are GATHERED (8 narrow loads each: the patch byte of 8 consecutive output pixels -- stride 2 -- for
-// A[k][pixel], the bf16 of 8 consecutive pixels -- stride 64 B -- for B[pixel][co]; all L1 / L2 hits, a 32-pixel
-// strip is 2 KB of dz and ~400 B of image), 4 matrix instructions per 32 pixels accumulate the whole 32 x 32 tile in
-// 16 registers for the lifetime of the wave.  The 268 MB patch matrix is never read (the im2col'ed form: 126 us + the
-// 203 us that wrote it).  One 864-float partial row per workgroup (OIHW order), finish_partials adds them into dW.
+// Weight gradient of the stem convolution (see above): dW[co][c][kh][kw] = sum over output pixels of
+// dz[px][co] * pre(x)[c][2 ho - 1 + kh][2 wo - 1 + kw].  4 matrix instructions per 32 pixels accumulate the whole
+// 32 x 32 tile dW^T[k][co] in 16 registers for the lifetime of the wave; one 864-float partial row per workgroup (OIHW
+// order), finish_partials adds them into dW.
 // ---------------------------------------------------------------------------
 struct StemWArgs {
     const void* x;
@@ -858,94 +953,76 @@ struct StemWArgs {
 
 template <typename TX>
 __global__ void __launch_bounds__(256, 3) stem_wgrad_reg_kernel(StemWArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_z[4][32 * ST_PIXB];     // per wave: [pixel][32 channels] bf16
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int m16 = lane & 15, q = lane >> 4;
     const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo;
+    const long img = 3L * H * W;
     const TX* x = reinterpret_cast<const TX*>(a.x);
-    // A rows of this lane: patch elements k = 16 mt + m16
-    long koff[2];
-    int kh[2], kw[2];
-    bool kv[2];
-    float isc[2], ish[2];
+    unsigned char* sz = s_z[wid];
+    StemK K[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int k = 16 * mt + m16, tap = k / 3, c = k - 3 * tap;
-        kv[mt] = k < 27;
-        kh[mt] = kv[mt] ? tap / 3 : 0;
-        kw[mt] = kv[mt] ? tap % 3 : 0;
-        const int cs = a.map ? a.map[c] : c;
-        koff[mt] = (long)cs * H * W + (long)kh[mt] * W + kw[mt];
-        isc[mt] = a.in_scale ? a.in_scale[c] : 1.f;
-        ish[mt] = a.in_shift ? a.in_shift[c] : 0.f;
-    }
+    for (int mt = 0; mt < 2; ++mt) K[mt] = stem_k(16 * mt + m16, a.map, a.in_scale, a.in_shift, H, W);
     f32x4_t acc[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    auto gather = [&](long it, float (&ra)[2][8], unsigned short (&rb)[2][8]) {
+    auto gather = [&](long it, StemRaw<TX> (&ra)[2], uint4 (&rz)[2]) {
         const int row = (int)(it / a.strips), strip = (int)(it % a.strips);
         const int n = row / Ho, o = row - n * Ho;
-        const TX* xn = x + (long)n * 3 * H * W;
         const bf16_t* zr = a.dz + (long)row * Wo * 32;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int px = strip * 32 + 8 * q + j;
+        for (int mt = 0; mt < 2; ++mt) stem_fetch<TX>(ra[mt], x + (long)n * img, img, K[mt], o, strip * 32 + 8 * q, H, W, Wo);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                            // piece e = lane + 64 t: pixel e >> 2, channels 8 (e & 3) ..
+            const int e = lane + 64 * t, px = strip * 32 + (e >> 2);
             const bool pok = px < Wo;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int hi = 2 * o - 1 + kh[mt], wi = 2 * px - 1 + kw[mt];
-                const bool ok = pok && kv[mt] && hi >= 0 && hi < H && wi >= 0 && wi < W;
-                ra[mt][j] = stem_ld(xn + (ok ? (long)(2 * o - 1) * W + (2 * px - 1) + koff[mt] : 0L));
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) rb[nt][j] = pok ? zr[(long)px * 32 + 16 * nt + m16].v : (unsigned short)0;
+            uint4 v = *reinterpret_cast<const uint4*>(zr + (pok ? (long)px * 32 + 8 * (e & 3) : 0L));
+            if (!pok) v = make_uint4(0u, 0u, 0u, 0u);
+            rz[t] = v;
         }
     };
     const long nwaves = (long)gridDim.x * 4;
     long it = (long)blockIdx.x * 4 + wid;
-    float acur[2][8], anext[2][8];
-    unsigned short bcur[2][8], bnext[2][8];
-    if (it < a.iters) gather(it, acur, bcur);
+    StemRaw<TX> acur[2], anext[2];
+    uint4 zcur[2], znext[2];
+    if (it < a.iters) gather(it, acur, zcur);
     while (it < a.iters) {
         const long nit = it + nwaves;
-        if (nit < a.iters) gather(nit, anext, bnext);
+        if (nit < a.iters) gather(nit, anext, znext);
         sched_fence();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int e = lane + 64 * t;
+            *reinterpret_cast<uint4*>(sz + (e >> 2) * ST_PIXB + (e & 3) * 16) = zcur[t];
+        }
+        wave_sync();
         const int row = (int)(it / a.strips), strip = (int)(it % a.strips);
         const int n = row / Ho, o = row - n * Ho;
         const int vh = a.valid_hw ? a.valid_hw[2 * n] : H, vw = a.valid_hw ? a.valid_hw[2 * n + 1] : W;
         bf16x8_t af[2], bfr[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            unsigned short e[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int px = strip * 32 + 8 * q + j;
-                const int hi = 2 * o - 1 + kh[mt], wi = 2 * px - 1 + kw[mt];
-                const bool ok = px < Wo && kv[mt] && hi >= 0 && hi < H && wi >= 0 && wi < W;
-                float v = acur[mt][j] * isc[mt] + ish[mt];
-                v = (hi < vh && wi < vw) ? v : a.pad_val;
-                e[j] = ok ? f32_to_bf16(v) : (unsigned short)0;
-            }
-            af[mt] = __builtin_bit_cast(bf16x8_t, make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16),
-                                                             e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)));
+        for (int nt = 0; nt < 2; ++nt) {                         // lane 4 r + p supplies pixel 8 q + r (+ 4), channels 16 nt + 4 p ..
+            const unsigned char* zp = sz + (8 * q + (m16 >> 2)) * ST_PIXB + (16 * nt + 4 * (m16 & 3)) * 2;
+            const bf16x4_t lo = lds_read_tr16(zp), hi4 = lds_read_tr16(zp + 4 * ST_PIXB);
+            bfr[nt][0] = lo[0]; bfr[nt][1] = lo[1]; bfr[nt][2] = lo[2]; bfr[nt][3] = lo[3];
+            bfr[nt][4] = hi4[0]; bfr[nt][5] = hi4[1]; bfr[nt][6] = hi4[2]; bfr[nt][7] = hi4[3];
         }
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            bfr[nt] = __builtin_bit_cast(bf16x8_t, make_uint4(bcur[nt][0] | ((unsigned)bcur[nt][1] << 16), bcur[nt][2] | ((unsigned)bcur[nt][3] << 16),
-                                                              bcur[nt][4] | ((unsigned)bcur[nt][5] << 16), bcur[nt][6] | ((unsigned)bcur[nt][7] << 16)));
+        for (int mt = 0; mt < 2; ++mt)
+            af[mt] = __builtin_bit_cast(bf16x8_t, stem_row<TX>(acur[mt], K[mt], o, strip * 32 + 8 * q, H, W, Wo, vh, vw, a.pad_val));
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt]);
+        wave_sync();                                             // the tile is rewritten by the next iteration
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                acur[t][j] = anext[t][j];
-                bcur[t][j] = bnext[t][j];
-            }
+        for (int t = 0; t < 2; ++t) {
+            zcur[t] = znext[t];
+            acur[t] = anext[t];
+        }
         it = nit;
     }
     // acc[mt][nt][i] = dW^T[k = 16 mt + 4 q + i][co = 16 nt + m16]: the four waves meet in LDS, one OIHW row per workgroup
@@ -971,6 +1048,7 @@ int stem_conv_wgrad_impl(const void* x, int dtype_x, const void* dz, float* dw, 
     LEDN_REQUIRE(x && dz && dw && N > 0 && H > 0 && W > 0 && C == 3 && Cout == 32);
     LEDN_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1);
     LEDN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
+    LEDN_REQUIRE(3L * H * W >= 28 && ((unsigned long long)x & 3ull) == 0);
     StemWArgs a;
     a.x = x; a.dz = (const bf16_t*)dz; a.in_scale = in_scale; a.in_shift = in_shift; a.map = map; a.valid_hw = valid_hw;
     a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad_val = pad_val;

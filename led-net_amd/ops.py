@@ -346,7 +346,7 @@ def stem_conv(x, w_pack, scale=None, shift=None, chan_map=None, valid=None, pad_
     _run_stats(lib, 'ledn_stem_conv', x, stats, defer_stats, _p(x), dtx, _p(w_pack), _p(y), N, H, W, Cc, Ho, Wo, 32,
                _p(_f32(scale, Cc)), _p(_f32(shift, Cc)), _p(chan_map), _p(valid), float(pad_val),
                _p(_f32(out_scale, 32)), _p(_f32(out_shift, 32)), int(act), s0, s1,
-               work=_TIMING is not None and (f'stem_conv {N}x{H}x{W}', _nb(x, y), 2 * y.numel() * 27, 'stem_conv_kernel'))
+               work=_TIMING is not None and (f'stem_conv {N}x{H}x{W}', _nb(x, y), 2 * y.numel() * 27, 'stem_conv_reg_kernel'))
     return y
 
 
