@@ -554,13 +554,20 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(MfmaConvArgs a) {
                     if constexpr (vec) {
                         pk[q][0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
                         pk[q][1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                    } else if (q == 0) {   // narrow heads (Cout < 8): channels 4*lh + j, scalar stores
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (pix_ok && c4 + j < a.Cout) {
-                                if (a.y_f32) reinterpret_cast<float*>(a.y)[pix + c4 + j] = v[j];
-                                else st(a.y + pix + c4 + j, v[j]);
+                    } else if (q == 0) {   // narrow heads (Cout < 8): channels 4*lh + j
+                        if (a.Cout == 2) {   // the two-class heads: ONE store per pixel (2-byte stores are partial writes)
+                            if (pix_ok && lh == 0) {
+                                if (a.y_f32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(a.y) + pix) = make_float2(v[0], v[1]);
+                                else *reinterpret_cast<unsigned*>(a.y + pix) = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
                             }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (pix_ok && c4 + j < a.Cout) {
+                                    if (a.y_f32) reinterpret_cast<float*>(a.y)[pix + c4 + j] = v[j];
+                                    else st(a.y + pix + c4 + j, v[j]);
+                                }
+                        }
                     }
                 }
                 if constexpr (vec) {

@@ -198,7 +198,9 @@ def test_mfma_narrow_head_f32_output(be, cin, cout, k):
                      out_scale=D(sc), out_shift=D(sh), act=ops.ACT_RELU, out_dtype=torch.float32,
                      w_bf16=ops.pack_conv_weights(D(w), 0))
     assert got.dtype == torch.float32
-    torch.testing.assert_close(nchw(got), want, rtol=1e-3, atol=2e-3)   # f32 store: no output rounding
+    # f32 store: no output rounding; one prologue value on a bf16 rounding boundary (fma in the kernel, two roundings in
+    # the reference) moves an output by ~|w| 2^-8 |x|: seen 2.6e-3 once in 2340 values
+    torch.testing.assert_close(nchw(got), want, rtol=1e-3, atol=5e-3)
 
 
 @pytest.mark.parametrize('dt,hw', [(torch.uint8, (37, 50)), (torch.float32, (16, 21))])
