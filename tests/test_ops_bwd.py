@@ -458,7 +458,9 @@ def test_mfaf_context_mlps_fused_with_trailing_batchnorm(be):
     import copy
     import torch.nn as nn
     g = torch.Generator().manual_seed(8)
-    N, Cc, Ci = 2, 64, 16
+    N, Cc, Ci = 4, 64, 16        # (4 samples: with 2 the 1x1 scale's BatchNorms see two values per channel -- x_hat = +-1 whatever
+                                 #  they are -- and a channel whose two values nearly coincide turns the GPU's summation order into
+                                 #  O(1e-2) output differences: seen once in ~20 runs)
     sizes = (4, 8, 16, 1)
     seqs, tails, ref = [], [], []
     for S in sizes:
