@@ -18,6 +18,8 @@ bool conv3x3_narrowin_mfma_supported(const ledn_conv_desc& d);
 int conv3x3_narrowin_mfma(const ledn_conv_desc& d, hipStream_t s);
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d);
 bool conv_wgrad_cout2_supported(const ledn_wgrad_desc& d);
+bool conv_wgrad_narrow_reg_supported(const ledn_wgrad_desc& d);
+int conv_wgrad_narrow_reg(const ledn_wgrad_desc& d, hipStream_t s);
 int conv_wgrad_cout2(const ledn_wgrad_desc& d, hipStream_t s);
 int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s);
 int pack_conv_weights_multi_impl(const ledn_pack_entry* table_dev, int n, long long max_elems, hipStream_t s);
@@ -243,6 +245,7 @@ int ledn_conv2d_uses_mfma(const ledn_conv_desc* d) {
     return conv1x1_reg_supported(*d) ? 2 : (conv3x3_reg_supported(*d) ? 3 : 1);
 }
 int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d) {
+    if (d && !conv_wgrad_cout2_supported(*d) && conv_wgrad_narrow_reg_supported(*d)) return 2;
     return d && !conv_wgrad_cout2_supported(*d) && wgrad_mfma_supported(*d) ? 1 : 0;
 }
 
@@ -269,6 +272,12 @@ int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream) {
     const int rc = wgrad_validate(*d);
     if (rc != LEDN_OK) return rc;
     if (conv_wgrad_cout2_supported(*d)) return conv_wgrad_cout2(*d, S(stream));   // two-class heads
+    if (conv_wgrad_narrow_reg_supported(*d)) {                                     // ... their 3x3 layers
+        const int r2 = conv_wgrad_narrow_reg(*d, S(stream));
+        if (r2 != LEDN_OK || !d->db) return r2;
+        return channel_stats_impl(d->dz, nullptr, (long long)d->N * d->Ho * d->Wo, d->Cout, d->dtype_dz, d->db,
+                                  nullptr, S(stream));
+    }
     if (wgrad_mfma_supported(*d)) {
         const int r2 = conv_wgrad_mfma(*d, S(stream));
         if (r2 != LEDN_OK || !d->db) return r2;
@@ -279,7 +288,9 @@ int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream) {
 }
 
 long long ledn_conv2d_wgrad_partial_floats(const ledn_wgrad_desc* d) {
-    if (!d || wgrad_validate(*d) != LEDN_OK || conv_wgrad_cout2_supported(*d) || !wgrad_mfma_supported(*d)) return 0;
+    if (!d || wgrad_validate(*d) != LEDN_OK || conv_wgrad_cout2_supported(*d) || conv_wgrad_narrow_reg_supported(*d) ||
+        !wgrad_mfma_supported(*d))
+        return 0;
     ledn_wgrad_finish_entry e;
     if (conv_wgrad_mfma_partial(*d, nullptr, 0, &e, true, nullptr) != LEDN_OK || e.nbx <= 4) return 0;
     return (long long)e.nbx * e.pairs * e.KK * 1024;

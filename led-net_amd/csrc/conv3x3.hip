@@ -1066,4 +1066,222 @@ int stem_conv_wgrad_impl(const void* x, int dtype_x, const void* dz, float* dw, 
     return finish_partials(a.part, (int)nb, 864, 1, dw, nullptr, nullptr, s);
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient of the two-class heads' 3x3 convolution (32 -> 2; led_head.py:44-51) -- and of any 3x3 stride-1 layer
+// with 32 inputs and <= 16 outputs --, wave-autonomous:
+//   dW[co][ci][kh][kw] = sum over pixels of dz[px][co] * pre(x)[px + (kh - 1, kw - 1)][ci],   pre = BatchNorm + ReLU folded in.
+// Per tap a product D[ci][co] with K = pixels.  A = x^T needs 8 consecutive PIXELS of a lane's channel: the wave keeps
+// the three input rows of its 32-pixel strip in a private LDS ring ([pixel][32 ch], prologue applied while writing, zero
+// outside the image) and ds_read_b64_tr_b16 hands out the transposed fragments -- the kw / kh shifts are address
+// offsets.  B = dz: for two channels the 8 pixels of a lane are 32 contiguous bytes (two 16-byte loads, the lane picks its
+// channel).  36 transposing reads + 18 matrix instructions per 32 pixels; 9 x 2 accumulator tiles (72 VGPRs) live for the
+// whole wave; one new input row per iteration, requested one iteration ahead; no workgroup barrier in the loop.
+// conv_wgrad_mfma_kernel ran this layer as a 32 x 32 output tile (30 of 32 columns padding) with an element-wise dz
+// staging: 195 us for the 268 MB of x at 16 x 512^2.
+// ---------------------------------------------------------------------------
+struct WnArgs {
+    const bf16_t* x;
+    const bf16_t* dz;
+    float* part;               // [gridDim.x][Cout * 288]
+    const float *in_scale, *in_shift, *in_slope;
+    int in_act;
+    int N, H, W, Cout;
+    int strips, segs, RS;
+    long tasks;
+};
+
+constexpr int WN_PW = 34;      // pixels of a ring row: x0 - 1 .. x0 + 32
+
+template <bool PRO>     // (the prologue's 24 coefficient registers: 196 VGPRs, two waves per SIMD; without: 168 at three)
+__global__ void __launch_bounds__(256, PRO ? 2 : 3) conv3x3_wgrad_narrow_kernel(WnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_x[4][3][WN_PW * ST_PIXB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    const int H = a.H, W = a.W, Cout = a.Cout;
+    unsigned char* ring = &s_x[wid][0][0];
+    // load role: piece e = lane + 64 t (t = 0..2) of a ring row: pixel e >> 2, channel octet e & 3 = lane & 3
+    const int oct = lane & 3;
+    float psc[8], psh[8], png[8];
+    if constexpr (PRO) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = 8 * oct + i;
+            psc[i] = a.in_scale ? a.in_scale[c] : 1.f;
+            psh[i] = a.in_shift ? a.in_shift[c] : 0.f;
+            png[i] = a.in_act == LEDN_ACT_PRELU ? a.in_slope[c] : (a.in_act == LEDN_ACT_NONE ? 1.f : 0.f);
+        }
+    }
+    f32x4_t acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[t][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const long nwaves = (long)gridDim.x * 4;
+    for (long task = (long)blockIdx.x * 4 + wid; task < a.tasks; task += nwaves) {
+        const int strip = (int)(task % a.strips);
+        const int seg = (int)((task / a.strips) % a.segs);
+        const int n = (int)(task / ((long)a.strips * a.segs));
+        const int x0 = strip * 32, r0 = seg * a.RS, r1 = min(r0 + a.RS, H);
+        const bf16_t* xn = a.x + (long)n * H * W * 32;
+        const bf16_t* zn = a.dz + (long)n * H * W * Cout;
+
+        auto fetch_x = [&](int ir, uint4 (&rw)[3]) {
+            const bool rok = ir >= 0 && ir < H;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int e = lane + 64 * t, px = x0 - 1 + (e >> 2);
+                const bool ok = rok && e < WN_PW * 4 && px >= 0 && px < W;
+                uint4 v = *reinterpret_cast<const uint4*>(xn + (ok ? ((long)ir * W + px) * 32 + 8 * oct : 0L));
+                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                rw[t] = v;
+            }
+        };
+        auto commit_x = [&](int ir, int slot, const uint4 (&rw)[3]) {
+            const bool rok = ir >= 0 && ir < H;
+            unsigned char* row = ring + slot * (WN_PW * ST_PIXB);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int e = lane + 64 * t, px = x0 - 1 + (e >> 2);
+                if (e >= WN_PW * 4) continue;
+                uint4 v = rw[t];
+                if constexpr (PRO) {
+                    const bool ok = rok && px >= 0 && px < W;
+                    v = __builtin_bit_cast(uint4, c11_prologue(__builtin_bit_cast(bf16x8_t, v), psc, psh, png));
+                    if (!ok) v = make_uint4(0u, 0u, 0u, 0u);             // padding is zero AFTER the activation
+                }
+                *reinterpret_cast<uint4*>(row + (e >> 2) * ST_PIXB + oct * 16) = v;
+            }
+        };
+        // B fragment of output row o: lane (co = m16, q) holds dz[(o, x0 + 8 q + j)][co], j = 0..7
+        auto fetch_z = [&](int o, uint4 (&rz)[2]) {
+            const bool live = m16 < Cout && o < r1;
+            const int px0 = x0 + 8 * q;
+            if (Cout == 2) {                                             // 8 pixels x 2 channels = 32 contiguous bytes
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool ok = live && px0 + 4 * h < W;             // (W % 4 == 0: whole pieces)
+                    uint4 v = *reinterpret_cast<const uint4*>(zn + (ok ? ((long)o * W + px0 + 4 * h) * 2 : 0L));
+                    if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                    rz[h] = v;
+                }
+            } else {
+                unsigned short e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = live && px0 + j < W;
+                    const unsigned short v = zn[ok ? ((long)o * W + px0 + j) * Cout + m16 : 0L].v;
+                    e[j] = ok ? v : (unsigned short)0;
+                }
+                rz[0] = make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
+                                   e[6] | ((unsigned)e[7] << 16));
+                rz[1] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        };
+        auto frag_z = [&](const uint4 (&rz)[2]) {
+            if (Cout != 2) return __builtin_bit_cast(bf16x8_t, rz[0]);
+            // dwords = pixels (lo half channel 0, hi half channel 1): pick this lane's channel of the 8 pixels
+            const unsigned w[8] = {rz[0].x, rz[0].y, rz[0].z, rz[0].w, rz[1].x, rz[1].y, rz[1].z, rz[1].w};
+            unsigned o4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned lo = m16 ? (w[2 * i] >> 16) : (w[2 * i] & 0xffffu);
+                const unsigned hi = m16 ? (w[2 * i + 1] >> 16) : (w[2 * i + 1] & 0xffffu);
+                o4[i] = lo | (hi << 16);
+            }
+            return __builtin_bit_cast(bf16x8_t, make_uint4(o4[0], o4[1], o4[2], o4[3]));
+        };
+
+        // ring slot of image row ir: (ir - (r0 - 1)) % 3
+        uint4 xr[3], zr[2], zr_next[2];
+        fetch_x(r0 - 1, xr);
+        commit_x(r0 - 1, 0, xr);
+        fetch_x(r0, xr);
+        commit_x(r0, 1, xr);
+        fetch_x(r0 + 1, xr);                                            // row r0 + 1: committed in the first iteration
+        fetch_z(r0, zr);
+        int slot_new = 2;                                                // slot the row o + 1 goes to
+        for (int o = r0; o < r1; ++o) {
+            wave_sync();                                                 // the previous iteration's reads of slot_new are done
+            commit_x(o + 1, slot_new, xr);
+            if (o + 1 < r1) {
+                fetch_x(o + 2, xr);
+                fetch_z(o + 1, zr_next);
+            }
+            wave_sync();
+            const bf16x8_t b = frag_z(zr);
+            const int s_top = slot_new == 2 ? 0 : slot_new + 1;          // slot of row o - 1 (the oldest)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                int sl = s_top + kh;
+                sl = sl >= 3 ? sl - 3 : sl;
+                const unsigned char* row = ring + sl * (WN_PW * ST_PIXB);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        // ring pixel index of (output pixel x0 + 8 q + j, tap kw) = 8 q + j + kw; lane 4 r + p supplies
+                        // pixel 8 q + kw + r (+ 4), channels 16 mt + 4 p ..
+                        const unsigned char* ap = row + (8 * q + kw + (m16 >> 2)) * ST_PIXB + (16 * mt + 4 * (m16 & 3)) * 2;
+                        const bf16x4_t lo = lds_read_tr16(ap), hi4 = lds_read_tr16(ap + 4 * ST_PIXB);
+                        bf16x8_t af;
+                        af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3];
+                        af[4] = hi4[0]; af[5] = hi4[1]; af[6] = hi4[2]; af[7] = hi4[3];
+                        acc[kh * 3 + kw][mt] = mfma_16x16x32_bf16(af, b, acc[kh * 3 + kw][mt]);
+                    }
+            }
+            zr[0] = zr_next[0];
+            zr[1] = zr_next[1];
+            slot_new = slot_new == 2 ? 0 : slot_new + 1;
+        }
+        wave_sync();                                                     // the next task rewrites the ring
+    }
+    // acc[t][mt][i] = dW[co = m16][ci = 16 mt + 4 q + i][tap t]: the four waves meet in LDS, one OIHW row per workgroup
+    __syncthreads();
+    float* s_red = reinterpret_cast<float*>(&s_x[0][0][0]);              // [4][Cout <= 16][288]: 4 x 16 x 288 x 4 B > ring?  only Cout rows used
+    if (m16 < Cout) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_red[(wid * Cout + m16) * 288 + (16 * mt + 4 * q + i) * 9 + t] = acc[t][mt][i];
+    }
+    __syncthreads();
+    const int nel = Cout * 288;
+    for (int e = tid; e < nel; e += 256)
+        a.part[(long)blockIdx.x * nel + e] = (s_red[e] + s_red[nel + e]) + (s_red[2 * nel + e] + s_red[3 * nel + e]);
+}
+
+bool conv_wgrad_narrow_reg_supported(const ledn_wgrad_desc& d) {
+    if (!(options().stream_fast & 64)) return false;
+    if (d.dtype_x != LEDN_BF16 || d.dtype_dz != LEDN_BF16 || d.xadd || d.groups != 1) return false;
+    if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.dil != 1 || d.Ho != d.H || d.Wo != d.W) return false;
+    if (d.Cin != 32 || d.Cout > 7) return false;                         // (4 x Cout x 288 floats of reduction space inside the ring)
+    if (d.Cout == 2 && d.W % 4) return false;
+    if ((d.in_scale == nullptr) != (d.in_shift == nullptr)) return false;
+    if (d.in_act != LEDN_ACT_NONE && d.in_act != LEDN_ACT_RELU && !(d.in_act == LEDN_ACT_PRELU && d.in_slope)) return false;
+    return d.ws_tap == 1 && d.ws_ci == 9 && d.ws_co == 288;              // natural OIHW: the partial rows use dW's own index
+}
+
+int conv_wgrad_narrow_reg(const ledn_wgrad_desc& d, hipStream_t s) {
+    WnArgs a;
+    a.x = (const bf16_t*)d.x; a.dz = (const bf16_t*)d.dz;
+    a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_slope = d.in_slope; a.in_act = d.in_act;
+    a.N = d.N; a.H = d.H; a.W = d.W; a.Cout = d.Cout;
+    a.strips = (int)cdiv(d.W, 32);
+    a.RS = c33_rows((long)d.N * a.strips, d.H);
+    a.segs = (int)cdiv(d.H, a.RS);
+    a.tasks = (long)d.N * a.segs * a.strips;
+    long nb = cdiv(a.tasks, 4);
+    const long cap = (long)options().conv_workgroups * 2;
+    if (nb > cap) nb = cap;
+    const int nel = d.Cout * 288;
+    a.part = ws_take(nb * nel);
+    if (!a.part) return LEDN_EINVAL;
+    if (d.in_scale || d.in_act != LEDN_ACT_NONE) LEDN_LAUNCH((conv3x3_wgrad_narrow_kernel<true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else LEDN_LAUNCH((conv3x3_wgrad_narrow_kernel<false>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    return finish_partials(a.part, (int)nb, nel, 1, d.dw, nullptr, nullptr, s);
+}
+
 }  // namespace ledn

@@ -441,10 +441,11 @@ class WgradDefer:
 
 
 def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None,
-                 in_shift=None, in_act=ACT_NONE, in_slope=None, bias=False, dw_out=None, db_out=None):
+                 in_shift=None, in_act=ACT_NONE, in_slope=None, bias=False, dw_out=None, db_out=None, _query=False):
     """Returns (dw [OIHW f32], db or None) of conv2d(pre(x), w).  dw_out / db_out: contiguous f32
     tensors the gradients are ACCUMULATED into (the trainer's flat gradient buffer) instead of
-    fresh zeroed ones."""
+    fresh zeroed ones.  _query: no launch -> ledn_conv2d_wgrad_uses_mfma (0 VALU kernels, 1 conv_wgrad_mfma_kernel,
+    2 conv3x3_wgrad_narrow_kernel)."""
     lib = _lib.get_lib()
     N, H, W, Cin = x.shape
     cof, cigf, KH, KW = w_shape
@@ -468,6 +469,8 @@ def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None,
     d.KH, d.KW, d.stride, d.pad, d.dil, d.groups = KH, KW, stride, pad, dil, groups
     d.in_act, d.dtype_x, d.dtype_dz = in_act, _dt(x), _dt(dz)
     flops = 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW
+    if _query:
+        return int(lib.cdll.ledn_conv2d_wgrad_uses_mfma(d))
     if WgradDefer.active and dw_out is not None:
         nfl = int(lib.cdll.ledn_conv2d_wgrad_partial_floats(d))
         if nfl > 0:
@@ -483,7 +486,7 @@ def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None,
             return dw, db
     _run(lib, 'ledn_conv2d_wgrad', x, d,
          work=_TIMING is not None and (f'wgrad{KH}x{KW} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W}', _nb(x, xadd, dz, dw), flops,
-                                       'conv_wgrad_mfma_kernel' if lib.cdll.ledn_conv2d_wgrad_uses_mfma(d) else 'conv_wgrad_direct'))
+                                       ('conv_wgrad_direct', 'conv_wgrad_mfma_kernel', 'conv3x3_wgrad_narrow_kernel')[lib.cdll.ledn_conv2d_wgrad_uses_mfma(d)]))
     return dw, db
 
 

@@ -207,3 +207,51 @@ def test_stem_conv_wgrad_from_planar_batch(be, shape, valid):
     dw1, _ = ops.conv2d_wgrad(patches, nhwc(dz).bfloat16(), (32, 32, 1, 1))
     ref = dw1.reshape(32, 32)[:, :27].reshape(32, 3, 3, 3).permute(0, 3, 1, 2)     # columns (kh 3 + kw) 3 + c -> OIHW
     torch.testing.assert_close(dw.cpu() - 0.5, ref.cpu(), rtol=1e-3, atol=1e-3 * scale)
+
+
+@pytest.mark.parametrize('cout,pro,nhw', [(2, True, (3, 21, 44)), (2, False, (1, 35, 64)), (1, True, (2, 9, 70)), (4, True, (1, 17, 33)),
+                                          (2, True, (2, 40, 100))])
+def test_narrow_output_wgrad_lds_ring(be, cout, pro, nhw):
+    """conv3x3_wgrad_narrow_kernel (weight gradient of the two-class heads' 3x3 layers, led_head.py:44-51: x^T through a
+    wave-private LDS ring + transposing reads, prologue = the BatchNorm + ReLU in front applied while writing the ring):
+    against torch autograd on the bf16-rounded operands, accumulated INTO the caller's buffer, bias gradient included;
+    and against conv_wgrad_mfma_kernel's narrow path (bit 6 off)."""
+    from led_net_amd import ops, _lib
+    N, H, W = nhw
+    x = r16(torch.randn(N, 32, H, W))
+    s_in, b_in = torch.rand(32) + 0.5, torch.randn(32) * 0.3
+    w = (torch.randn(cout, 32, 3, 3) * 0.1).requires_grad_(True)
+    pre = r16(F.relu(x * s_in.view(1, -1, 1, 1) + b_in.view(1, -1, 1, 1))) if pro else x
+    z = F.conv2d(pre, w, padding=1)
+    dz = r16(torch.randn_like(z))
+    z.backward(dz)
+    kw = dict(pad=1, bias=True)
+    if pro:
+        kw.update(in_scale=D(s_in), in_shift=D(b_in), in_act=ops.ACT_RELU)
+    xb, dzb = nhwc(x).bfloat16(), nhwc(dz).bfloat16()
+    assert ops.conv2d_wgrad(xb, dzb, tuple(w.shape), _query=True, **kw) == 2
+    base = torch.randn_like(w.detach())
+    sink = D(base.clone())
+    dw, db = ops.conv2d_wgrad(xb, dzb, tuple(w.shape), dw_out=sink, **kw)
+    assert dw is sink
+    n = N * H * W
+    scale = float(w.grad.abs().max())
+    torch.testing.assert_close(dw.cpu() - base, w.grad, rtol=5e-3, atol=2e-5 * n ** 0.5 + 5e-3 * scale)
+    torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3)), rtol=1e-3, atol=1e-3 * n ** 0.5)
+    lib = _lib.get_lib()
+    lib.set_option(2, 27)
+    try:
+        assert ops.conv2d_wgrad(xb, dzb, tuple(w.shape), _query=True, **kw) == 1
+        ref, _ = ops.conv2d_wgrad(xb, dzb, tuple(w.shape), **kw)
+    finally:
+        lib.set_option(2, MASK)
+    torch.testing.assert_close(dw.cpu() - base, ref.cpu(), rtol=5e-3, atol=5e-3 * scale)
+
+
+def test_narrow_output_wgrad_unaligned_width_falls_back(be):
+    """two output channels and a width that is not a multiple of 4 (the dz fragment's 16-byte pieces would straddle rows):
+    the general kernel"""
+    from led_net_amd import ops
+    x = torch.zeros(1, 9, 45, 32, dtype=torch.bfloat16, device=_DEV[0])
+    dz = torch.zeros(1, 9, 45, 2, dtype=torch.bfloat16, device=_DEV[0])
+    assert ops.conv2d_wgrad(x, dz, (2, 32, 3, 3), pad=1, _query=True) == 1

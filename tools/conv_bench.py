@@ -33,6 +33,7 @@ SHAPES = [
     ('fwdpro', 32, 2, 3, 1, 1, 16, 512, 512),        # training: BatchNorm + ReLU prologue, bias, raw bf16 output, no statistics
     ('dgrad', 32, 2, 3, 1, 1, 16, 512, 512),
     ('wgrad', 32, 2, 3, 1, 1, 16, 512, 512),
+    ('wgradpro', 32, 2, 3, 1, 1, 16, 512, 512),      # training: BatchNorm + ReLU prologue, bias gradient
     ('fwd', 64, 64, 1, 1, 4, 16, 128, 128),
     ('dgrad', 64, 64, 1, 1, 4, 16, 128, 128),
     ('wgrad', 64, 64, 1, 1, 4, 16, 128, 128),
@@ -84,6 +85,11 @@ def main():
             isc, ish, bias = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1, torch.randn(co, device=dev)
             fn = lambda: ops.conv2d(x, w, stride=s, pad=pad, groups=grp, in_scale=isc, in_shift=ish, in_act=ops.ACT_RELU,
                                     out_shift=bias, w_bf16=wp)
+            nbytes = x.numel() * 2 + dz.numel() * 2
+        elif kind == 'wgradpro':
+            isc, ish = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.1
+            fn = lambda: ops.conv2d_wgrad(x, dz, tuple(w.shape), stride=s, pad=pad, groups=grp, in_scale=isc, in_shift=ish,
+                                          in_act=ops.ACT_RELU, bias=True)
             nbytes = x.numel() * 2 + dz.numel() * 2
         elif kind == 'dgrad':
             wp = ops.pack_conv_weights(w, 1, grp) if ops.mfma_weight_ok(w, grp) else None
