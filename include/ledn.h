@@ -192,7 +192,7 @@ typedef struct {
     const float* in_slope; /* [Cin] when in_act == PRELU */
 } ledn_wgrad_desc;
 int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream);
-int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d);   /* same query for the weight gradient: 1 conv_wgrad_mfma_kernel, 2 conv3x3_wgrad_narrow_kernel (csrc/conv3x3.hip), 0 the VALU kernels */
+int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d);   /* same query for the weight gradient: 1 conv_wgrad_mfma_kernel, 2 conv3x3_wgrad_narrow_kernel, 3 conv1x1_wgrad_reg_kernel (csrc/conv3x3.hip), 0 the VALU kernels */
 /* Deferred reduction of the weight gradient.  ledn_conv2d_wgrad runs the MFMA kernel (per-workgroup partial tiles into the
  * stream's workspace) and then a small summing launch -- ~55 of them per training step, each on the critical path of the
  * stream although nothing reads dW before the optimizer.  ledn_conv2d_wgrad_partial instead writes the partial tiles into a

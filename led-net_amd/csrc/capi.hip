@@ -19,6 +19,7 @@ int conv3x3_narrowin_mfma(const ledn_conv_desc& d, hipStream_t s);
 bool wgrad_mfma_supported(const ledn_wgrad_desc& d);
 bool conv_wgrad_cout2_supported(const ledn_wgrad_desc& d);
 bool conv_wgrad_narrow_reg_supported(const ledn_wgrad_desc& d);
+bool conv1x1_wgrad_reg_applies(const ledn_wgrad_desc& d);
 int conv_wgrad_narrow_reg(const ledn_wgrad_desc& d, hipStream_t s);
 int conv_wgrad_cout2(const ledn_wgrad_desc& d, hipStream_t s);
 int conv_wgrad_mfma(const ledn_wgrad_desc& d, hipStream_t s);
@@ -246,6 +247,7 @@ int ledn_conv2d_uses_mfma(const ledn_conv_desc* d) {
 }
 int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d) {
     if (d && !conv_wgrad_cout2_supported(*d) && conv_wgrad_narrow_reg_supported(*d)) return 2;
+    if (d && !conv_wgrad_cout2_supported(*d) && conv1x1_wgrad_reg_applies(*d)) return 3;
     return d && !conv_wgrad_cout2_supported(*d) && wgrad_mfma_supported(*d) ? 1 : 0;
 }
 

@@ -1284,4 +1284,176 @@ int conv_wgrad_narrow_reg(const ledn_wgrad_desc& d, hipStream_t s) {
     return finish_partials(a.part, (int)nb, nel, 1, d.dw, nullptr, nullptr, s);
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient of the 1x1 stride-1 convolutions (Cin, Cout <= 128), wave-autonomous: dW[co][ci] = sum over pixels of
+// dz[px][co] * x[px][ci] -- K = pixels, so BOTH operands are needed pixel-major per lane.  A wave takes 32 consecutive
+// pixels per iteration: their x rows (32 x Cin) and dz rows (32 x Cout) go into a wave-private LDS tile with 16-byte
+// loads / writes (next iteration's loads in flight), ds_read_b64_tr_b16 hands out A[ci][8 pixels] and B[8 pixels][co], and
+// NM x NN matrix instructions (16 x 16 x 32) accumulate the whole [Cin][Cout] product in registers for the lifetime of
+// the wave.  No workgroup barrier in the loop.  conv_wgrad_mfma_kernel<1, 1> stages 8 x 32-pixel tiles for four waves
+// behind two barriers per tile, one 32 x 32 (ci, co) pair per workgroup -- every pair re-reads x and dz -- and runs
+// these layers at 1.3-2.9 TB/s.  The partial tiles have that kernel's layout ([workgroup][pair][32 co][32 ci]), so its
+// summing kernels (conv_wgrad_finish_kernel / _finish_multi) serve both.  DIAG: only the pairs on the 32 x 32 block
+// diagonal (grouped convolutions whose groups lie inside them) are formed.
+// ---------------------------------------------------------------------------
+struct W11Args {
+    const bf16_t* x;           // [P][Cin]
+    const bf16_t* dz;          // [P][Cout]
+    float* part;               // [gridDim.x][pairs][1024]
+    long P, iters;             // iters = ceil(P / 32)
+    int Cin, Cout, ci_tiles;
+};
+
+template <int NM, int NN, bool DIAG>
+__global__ void __launch_bounds__(256, 2) conv1x1_wgrad_reg_kernel(W11Args a) {
+    constexpr int XB = NM * 32 + 16, ZB = NN * 32 + 16;        // LDS bytes per pixel row of the x / dz tiles
+    constexpr int NA = DIAG ? 2 : NN;                          // n-tiles kept per m-tile
+    constexpr int TB = 32 * (XB + ZB) > 4096 ? 32 * (XB + ZB) : 4096;   // (>= 4 KB per wave: the final reduction reuses it as [4][1024] floats)
+    __shared__ __attribute__((aligned(16))) unsigned char s_t[4][TB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m16 = lane & 15, q = lane >> 4;
+    unsigned char* sx = s_t[wid];
+    unsigned char* sz = sx + 32 * XB;
+    f32x4_t acc[NM][NA];
+#pragma unroll
+    for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+        for (int j = 0; j < NA; ++j) acc[mt][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int PX = NM * 2, PZ = NN * 2;                    // 16-byte pieces per pixel
+    constexpr int LX = (32 * PX + 63) / 64, LZ = (32 * PZ + 63) / 64;
+    auto fetch = [&](long it, uint4 (&rx)[LX], uint4 (&rz)[LZ]) {
+        const long p0 = it * 32;
+#pragma unroll
+        for (int t = 0; t < LX; ++t) {
+            const int e = lane + 64 * t, px = e / PX, pc = e % PX;
+            const bool ok = e < 32 * PX && p0 + px < a.P && pc * 8 < a.Cin;
+            uint4 v = *reinterpret_cast<const uint4*>(a.x + (ok ? (p0 + px) * a.Cin + pc * 8 : 0L));
+            if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+            rx[t] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < LZ; ++t) {
+            const int e = lane + 64 * t, px = e / PZ, pc = e % PZ;
+            const bool ok = e < 32 * PZ && p0 + px < a.P && pc * 8 < a.Cout;
+            uint4 v = *reinterpret_cast<const uint4*>(a.dz + (ok ? (p0 + px) * a.Cout + pc * 8 : 0L));
+            if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+            rz[t] = v;
+        }
+    };
+    const long nwaves = (long)gridDim.x * 4;
+    long it = (long)blockIdx.x * 4 + wid;
+    uint4 xcur[LX], zcur[LZ], xnext[LX], znext[LZ];
+    if (it < a.iters) fetch(it, xcur, zcur);
+    while (it < a.iters) {
+        const long nit = it + nwaves;
+        if (nit < a.iters) fetch(nit, xnext, znext);
+        sched_fence();
+#pragma unroll
+        for (int t = 0; t < LX; ++t) {
+            const int e = lane + 64 * t;
+            if (e < 32 * PX) *reinterpret_cast<uint4*>(sx + (e / PX) * XB + (e % PX) * 16) = xcur[t];
+        }
+#pragma unroll
+        for (int t = 0; t < LZ; ++t) {
+            const int e = lane + 64 * t;
+            if (e < 32 * PZ) *reinterpret_cast<uint4*>(sz + (e / PZ) * ZB + (e % PZ) * 16) = zcur[t];
+        }
+        wave_sync();
+        // lane 4 r + p supplies pixel 8 q + r (+ 4), channels 16 t + 4 p ..: lane i receives 8 pixels of channel 16 t + i
+        bf16x8_t bz[NN];
+#pragma unroll
+        for (int nt = 0; nt < NN; ++nt) {
+            const unsigned char* zp = sz + (8 * q + (m16 >> 2)) * ZB + (16 * nt + 4 * (m16 & 3)) * 2;
+            const bf16x4_t lo = lds_read_tr16(zp), hi = lds_read_tr16(zp + 4 * ZB);
+            bz[nt][0] = lo[0]; bz[nt][1] = lo[1]; bz[nt][2] = lo[2]; bz[nt][3] = lo[3];
+            bz[nt][4] = hi[0]; bz[nt][5] = hi[1]; bz[nt][6] = hi[2]; bz[nt][7] = hi[3];
+        }
+#pragma unroll
+        for (int mt = 0; mt < NM; ++mt) {
+            const unsigned char* xp = sx + (8 * q + (m16 >> 2)) * XB + (16 * mt + 4 * (m16 & 3)) * 2;
+            const bf16x4_t lo = lds_read_tr16(xp), hi = lds_read_tr16(xp + 4 * XB);
+            bf16x8_t ax;
+            ax[0] = lo[0]; ax[1] = lo[1]; ax[2] = lo[2]; ax[3] = lo[3];
+            ax[4] = hi[0]; ax[5] = hi[1]; ax[6] = hi[2]; ax[7] = hi[3];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int nt = DIAG ? 2 * (mt >> 1) + j : j;
+                acc[mt][j] = mfma_16x16x32_bf16(ax, bz[nt < NN ? nt : 0], acc[mt][j]);
+            }
+        }
+        wave_sync();                                             // the tiles are rewritten by the next iteration
+#pragma unroll
+        for (int t = 0; t < LX; ++t) xcur[t] = xnext[t];
+#pragma unroll
+        for (int t = 0; t < LZ; ++t) zcur[t] = znext[t];
+        it = nit;
+    }
+    // acc[mt][j][i] = dW[co = 16 nt + m16][ci = 16 mt + 4 q + i]: pair by pair (32 co x 32 ci) through LDS, the four waves summed
+    __syncthreads();
+    float* s_red = reinterpret_cast<float*>(&s_t[0][0]);        // [4][1024] floats = 16 KB (< 4 x 32 x (XB + ZB) for every shape offered)
+    const int co_tiles = (NN + 1) / 2;
+    for (int cot = 0; cot < co_tiles; ++cot)
+        for (int cit = 0; cit < (NM + 1) / 2; ++cit) {
+            if (DIAG && cot != cit) continue;
+#pragma unroll
+            for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    const int nt = DIAG ? 2 * (mt >> 1) + j : j;
+                    if ((mt >> 1) != cit || (nt >> 1) != cot) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        s_red[wid * 1024 + (16 * (nt & 1) + m16) * 32 + 16 * (mt & 1) + 4 * q + i] = acc[mt][j][i];
+                }
+            if (NM == 1 || NN == 1) {                           // half-filled pair: the other half is zero
+                // (rows / columns 16..31 of the pair were never written: clear them once per pair below)
+            }
+            __syncthreads();
+            float* dst = a.part + ((long)blockIdx.x * (co_tiles * a.ci_tiles) + cot * a.ci_tiles + cit) * 1024;
+            for (int e = tid; e < 1024; e += 256) {
+                const int col = e >> 5, cil = e & 31;
+                const bool have = (NN > 1 || col < 16) && (NM > 1 || cil < 16);
+                dst[e] = have ? (s_red[e] + s_red[1024 + e]) + (s_red[2048 + e] + s_red[3072 + e]) : 0.f;
+            }
+            __syncthreads();
+        }
+}
+
+// 0 = not offered.  pairs / ci_tiles as conv_wgrad_mfma_kernel's grid (co_tile * ci_tiles + ci_tile)
+bool conv1x1_wgrad_reg_ok(int Cin, int Cout, int groups) {
+    if (!(options().stream_fast & 64)) return false;
+    if (Cin % 16 || Cout % 16 || Cin > 128 || Cout > 128) return false;
+    const int nm = Cin / 16, nn = Cout / 16;
+    if (!(nm == 1 || nm == 2 || nm == 4 || nm == 8) || !(nn == 1 || nn == 2 || nn == 4 || nn == 8)) return false;
+    if (nm * nn <= 16) return true;                            // (32 tiles = 128 accumulator registers + staging: scratch)
+    if (nm != 8 || nn != 8) return false;
+    // 128 x 128: only as block-diagonal (every group inside one 32 x 32 block)
+    const int cig = Cin / groups, cog = Cout / groups;
+    return groups > 1 && Cin == Cout && cig <= 32 && 32 % cig == 0 && cog == cig;
+}
+
+int conv1x1_wgrad_reg_partial(const void* x, const void* dz, float* part, long P, int Cin, int Cout, int groups, int nbx,
+                              hipStream_t s) {
+    W11Args a;
+    a.x = (const bf16_t*)x; a.dz = (const bf16_t*)dz; a.part = part; a.P = P; a.iters = cdiv(P, 32);
+    a.Cin = Cin; a.Cout = Cout; a.ci_tiles = (int)cdiv(Cin, 32);
+    const int nm = Cin / 16, nn = Cout / 16;
+    const dim3 grid((unsigned)nbx);
+#define LEDN_W11(NM_, NN_)                                                                                      \
+    if (nm == NM_ && nn == NN_) {                                                                               \
+        if constexpr (NM_ * NN_ <= 16) {                                                                        \
+            LEDN_LAUNCH((conv1x1_wgrad_reg_kernel<NM_, NN_, false>), grid, dim3(256), 0, s, a);                 \
+            return check_launch();                                                                              \
+        } else if constexpr (NM_ == 8 && NN_ == 8) {                                                            \
+            LEDN_LAUNCH((conv1x1_wgrad_reg_kernel<NM_, NN_, true>), grid, dim3(256), 0, s, a);                  \
+            return check_launch();                                                                              \
+        }                                                                                                       \
+    }
+    LEDN_W11(1, 1) LEDN_W11(1, 2) LEDN_W11(1, 4) LEDN_W11(1, 8) LEDN_W11(2, 1) LEDN_W11(2, 2) LEDN_W11(2, 4) LEDN_W11(2, 8)
+    LEDN_W11(4, 1) LEDN_W11(4, 2) LEDN_W11(4, 4) LEDN_W11(4, 8) LEDN_W11(8, 1) LEDN_W11(8, 2) LEDN_W11(8, 4) LEDN_W11(8, 8)
+#undef LEDN_W11
+    (void)groups;
+    return LEDN_EINVAL;
+}
+
 }  // namespace ledn

@@ -1389,6 +1389,16 @@ struct WgradDefer {
     bool query;                      // only report the buffer size in entry->nbx/pairs/KK
 };
 
+bool conv1x1_wgrad_reg_ok(int Cin, int Cout, int groups);
+int conv1x1_wgrad_reg_partial(const void* x, const void* dz, float* part, long P, int Cin, int Cout, int groups, int nbx,
+                              hipStream_t s);
+
+// does ledn_conv2d_wgrad run this descriptor on conv1x1_wgrad_reg_kernel?  (the same test as in launch_wgrad<1, 1>)
+bool conv1x1_wgrad_reg_applies(const ledn_wgrad_desc& d) {
+    return wgrad_mfma_supported(d) && d.KH == 1 && d.stride == 1 && !d.in_scale && d.in_act == LEDN_ACT_NONE &&
+           (long)d.N * d.Ho * d.Wo >= 32768 && conv1x1_wgrad_reg_ok(d.Cin, d.Cout, d.groups);
+}
+
 template <int K, int S>
 static int launch_wgrad(MfmaWgradArgs a, hipStream_t s, WgradDefer* df = nullptr) {
     a.tiles_h = (int)cdiv(a.Ho, S == 2 ? 4 : 8);
@@ -1396,6 +1406,34 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s, WgradDefer* df = nullptr
     a.ci_tiles = (int)cdiv(a.Cin, 32);
     const long ntiles = (long)a.N * a.tiles_h * a.tiles_w;
     const int pairs = a.ci_tiles * (int)cdiv(a.Cout, 32);
+    if constexpr (K == 1 && S == 1) {
+        // the wave-autonomous form (conv3x3.hip: conv1x1_wgrad_reg_kernel): every workgroup forms ALL pairs from one read
+        // of x and dz and writes them in this kernel's partial-tile layout -- the summing kernels below serve both
+        const long P = (long)a.N * a.Ho * a.Wo;
+        if (!a.in_scale && a.in_act == LEDN_ACT_NONE && P >= 32768 && conv1x1_wgrad_reg_ok(a.Cin, a.Cout, a.groups)) {
+            long nb = cdiv(P, 32 * 4 * 4);                       // >= 4 iterations per wave
+            if (nb > options().wgrad_workgroups) nb = options().wgrad_workgroups;
+            const int nbx = (int)nb;
+            if (df) {
+                ledn_wgrad_finish_entry& e = *df->entry;
+                e.nbx = nbx; e.pairs = pairs; e.KK = 1; e.ci_tiles = a.ci_tiles; e.Cin = a.Cin; e.Cout = a.Cout;
+                e.groups = a.groups; e.chunk0 = 0;
+                e.ws_co = a.ws_co; e.ws_ci = a.ws_ci; e.ws_tap = a.ws_tap;
+                e.dw = a.dw; e.part = df->part;
+                if (df->query) return LEDN_OK;
+                if (!df->part || df->part_floats < (long long)nbx * pairs * 1024) return LEDN_EINVAL;
+                return conv1x1_wgrad_reg_partial(a.x, a.dz, df->part, P, a.Cin, a.Cout, a.groups, nbx, s);
+            }
+            a.part = ws_take((long)nbx * pairs * 1024);
+            if (a.part) {
+                const int rc = conv1x1_wgrad_reg_partial(a.x, a.dz, a.part, P, a.Cin, a.Cout, a.groups, nbx, s);
+                if (rc != LEDN_OK) return rc;
+                LEDN_LAUNCH((conv_wgrad_finish_kernel<1>), dim3((unsigned)(1024 / 64), (unsigned)pairs), dim3(1024), 0, s, a, nbx,
+                            pairs);
+                return check_launch();
+            }
+        }
+    }
     long blocks_x = cdiv(options().wgrad_workgroups, pairs);   // partial tiles go to the workspace
     if (blocks_x < 32) blocks_x = 32;
     if (blocks_x > ntiles) blocks_x = ntiles;

@@ -445,7 +445,7 @@ def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None,
     """Returns (dw [OIHW f32], db or None) of conv2d(pre(x), w).  dw_out / db_out: contiguous f32
     tensors the gradients are ACCUMULATED into (the trainer's flat gradient buffer) instead of
     fresh zeroed ones.  _query: no launch -> ledn_conv2d_wgrad_uses_mfma (0 VALU kernels, 1 conv_wgrad_mfma_kernel,
-    2 conv3x3_wgrad_narrow_kernel)."""
+    2 conv3x3_wgrad_narrow_kernel, 3 conv1x1_wgrad_reg_kernel)."""
     lib = _lib.get_lib()
     N, H, W, Cin = x.shape
     cof, cigf, KH, KW = w_shape
@@ -481,12 +481,13 @@ def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None,
             e = _lib.WgradFinishEntry()
             _run(lib, 'ledn_conv2d_wgrad_partial', x, d, buf.data_ptr(), nfl, C.byref(e),
                  work=_TIMING is not None and (f'wgrad{KH}x{KW} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W}',
-                                               _nb(x, xadd, dz, dw), flops, 'conv_wgrad_mfma_kernel'))
+                                               _nb(x, xadd, dz, dw), flops,
+                                               'conv1x1_wgrad_reg_kernel' if lib.cdll.ledn_conv2d_wgrad_uses_mfma(d) == 3 else 'conv_wgrad_mfma_kernel'))
             WgradDefer.pending.append((key, e, buf))
             return dw, db
     _run(lib, 'ledn_conv2d_wgrad', x, d,
          work=_TIMING is not None and (f'wgrad{KH}x{KW} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W}', _nb(x, xadd, dz, dw), flops,
-                                       ('conv_wgrad_direct', 'conv_wgrad_mfma_kernel', 'conv3x3_wgrad_narrow_kernel')[lib.cdll.ledn_conv2d_wgrad_uses_mfma(d)]))
+                                       ('conv_wgrad_direct', 'conv_wgrad_mfma_kernel', 'conv3x3_wgrad_narrow_kernel', 'conv1x1_wgrad_reg_kernel')[lib.cdll.ledn_conv2d_wgrad_uses_mfma(d)]))
     return dw, db
 
 

@@ -255,3 +255,37 @@ def test_narrow_output_wgrad_unaligned_width_falls_back(be):
     x = torch.zeros(1, 9, 45, 32, dtype=torch.bfloat16, device=_DEV[0])
     dz = torch.zeros(1, 9, 45, 2, dtype=torch.bfloat16, device=_DEV[0])
     assert ops.conv2d_wgrad(x, dz, (2, 32, 3, 3), pad=1, _query=True) == 1
+
+
+@pytest.mark.parametrize('cin,cout,g', [(64, 64, 1), (64, 64, 4), (64, 16, 4), (16, 64, 1), (128, 128, 4), (128, 32, 1), (32, 128, 1),
+                                        (16, 16, 1), (128, 16, 1)])
+def test_conv1x1_wgrad_wave_autonomous(be, cin, cout, g):
+    """conv1x1_wgrad_reg_kernel (weight gradient of the 1x1 stride-1 layers: both operands through wave-private LDS tiles
+    and transposing reads, every (ci, co) pair from ONE read of x and dz; partial tiles in conv_wgrad_mfma_kernel's layout,
+    summed by its kernels): against torch autograd on the bf16-rounded operands, accumulated INTO the caller's buffer, and
+    against conv_wgrad_mfma_kernel (bit 6 off).  32 773 pixels: ragged last 32-pixel chunk, above the 32 768-pixel gate.
+    Reference layers: the 1x1 ConvModules / CBR of nn_layers/espnet_utils.py:22-36, eesp.py:39,70, model_utils.py:360-400."""
+    from led_net_amd import ops, _lib
+    N, H, W = 1, 113, 290 + 0
+    x = r16(torch.randn(N, cin, H, W))
+    w = (torch.randn(cout, cin // g, 1, 1) * 0.1).requires_grad_(True)
+    z = F.conv2d(x, w, groups=g)
+    dz = r16(torch.randn_like(z))
+    z.backward(dz)
+    xb, dzb = nhwc(x).bfloat16(), nhwc(dz).bfloat16()
+    base = torch.randn_like(w.detach())
+    sink = D(base.clone())
+    assert ops.conv2d_wgrad(xb, dzb, tuple(w.shape), groups=g, _query=True) == 3
+    dw, _ = ops.conv2d_wgrad(xb, dzb, tuple(w.shape), groups=g, dw_out=sink)
+    assert dw is sink
+    n = N * H * W
+    scale = float(w.grad.abs().max())
+    torch.testing.assert_close(dw.cpu() - base, w.grad, rtol=2e-3, atol=2e-5 * n ** 0.5 + 2e-3 * scale)
+    lib = _lib.get_lib()
+    lib.set_option(2, 27)
+    try:
+        assert ops.conv2d_wgrad(xb, dzb, tuple(w.shape), groups=g, _query=True) == 1
+        ref, _ = ops.conv2d_wgrad(xb, dzb, tuple(w.shape), groups=g)
+    finally:
+        lib.set_option(2, MASK)
+    torch.testing.assert_close(dw.cpu() - base, ref.cpu(), rtol=2e-3, atol=2e-3 * scale)
