@@ -481,12 +481,13 @@ int conv3x3_reg(const ledn_conv_desc& d, hipStream_t s) {
         a.segs = (int)cdiv(a.H, a.RS);
         a.tasks = (long)a.N * a.segs * a.strips;
         long nb = cdiv(a.tasks, 4);
-        const long cap = (long)options().conv_workgroups * 2;
+        const bool pro = d.in_scale || d.in_act != LEDN_ACT_NONE;
+        const long cap = (long)options().conv_workgroups * (pro ? 2 : 3);
         if (nb > cap) nb = cap;
-        if (d.in_scale || d.in_act != LEDN_ACT_NONE)
+        if (pro)
             LEDN_LAUNCH((conv3x3_reg_kernel<1, G, C33_NARROW, 2, 1, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
         else
-            LEDN_LAUNCH((conv3x3_reg_kernel<1, G, C33_NARROW, 2, 1, false>), dim3((unsigned)nb), dim3(256), 0, s, a);
+            LEDN_LAUNCH((conv3x3_reg_kernel<1, G, C33_NARROW, 3, 1, false>), dim3((unsigned)nb), dim3(256), 0, s, a);
         return check_launch();
     }
     const int epi = c33_full(d) ? C33_FULL : (d.res_mode == LEDN_RES_ADD ? C33_ACC : (d.stat_sum ? C33_STATS : C33_RAW));

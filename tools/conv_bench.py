@@ -21,6 +21,7 @@ SHAPES = [
     ('fwd', 32, 32, 3, 1, 1, 16, 256, 256),
     ('dgrad', 32, 32, 3, 1, 1, 16, 256, 256),
     ('wgrad', 32, 32, 3, 1, 1, 16, 256, 256),
+    ('fwd', 32, 32, 3, 1, 1, 16, 512, 512),          # (not a layer of the network: the 1/4-resolution kernel at 4 x the pixels)
     ('fwd', 64, 64, 3, 1, 1, 16, 128, 128),
     ('dgrad', 64, 64, 3, 1, 1, 16, 128, 128),
     ('wgrad', 64, 64, 3, 1, 1, 16, 128, 128),
@@ -30,6 +31,7 @@ SHAPES = [
     ('dgrad', 32, 32, 3, 2, 1, 16, 512, 512),
     ('wgrad', 32, 32, 3, 2, 1, 16, 512, 512),
     ('fwd', 32, 2, 3, 1, 1, 16, 512, 512),
+    ('fwdraw', 32, 2, 3, 1, 1, 16, 512, 512),        # no statistics, no prologue
     ('fwdpro', 32, 2, 3, 1, 1, 16, 512, 512),        # training: BatchNorm + ReLU prologue, bias, raw bf16 output, no statistics
     ('dgrad', 32, 2, 3, 1, 1, 16, 512, 512),
     ('wgrad', 32, 2, 3, 1, 1, 16, 512, 512),
@@ -79,6 +81,10 @@ def main():
         if kind == 'fwd':
             wp = ops.pack_conv_weights(w, 0, grp) if ops.mfma_weight_ok(w, grp) else None
             fn = lambda: ops.conv2d(x, w, stride=s, pad=pad, groups=grp, stats=stats, w_bf16=wp)
+            nbytes = x.numel() * 2 + dz.numel() * 2
+        elif kind == 'fwdraw':
+            wp = ops.pack_conv_weights(w, 0, grp)
+            fn = lambda: ops.conv2d(x, w, stride=s, pad=pad, groups=grp, w_bf16=wp)
             nbytes = x.numel() * 2 + dz.numel() * 2
         elif kind == 'fwdpro':
             wp = ops.pack_conv_weights(w, 0, grp)
