@@ -33,6 +33,7 @@
 //   address offsets.  3x3: the nine taps are split over the four waves (3 accumulator tiles per wave,
 //   no cross-wave reduction); 1x1: the waves split the pixels and reduce through LDS.  Per-workgroup
 //   partial tiles go to the workspace and a second kernel sums them (no same-address atomics).
+#include <cstdlib>
 #include "ledn_rt.h"
 
 namespace ledn {
@@ -1411,7 +1412,8 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s, WgradDefer* df = nullptr
         // of x and dz and writes them in this kernel's partial-tile layout -- the summing kernels below serve both
         const long P = (long)a.N * a.Ho * a.Wo;
         if (!a.in_scale && a.in_act == LEDN_ACT_NONE && P >= 32768 && conv1x1_wgrad_reg_ok(a.Cin, a.Cout, a.groups)) {
-            long nb = cdiv(P, 32 * 4 * 4);                       // >= 4 iterations per wave
+            static const int ipw = getenv("LEDN_W11_ITERS") ? atoi(getenv("LEDN_W11_ITERS")) : 4;   // (A/B knob)
+            long nb = cdiv(P, 32L * 4 * (ipw > 0 ? ipw : 4));    // >= ipw iterations of 32 pixels per wave
             if (nb > options().wgrad_workgroups) nb = options().wgrad_workgroups;
             const int nbx = (int)nb;
             if (df) {
