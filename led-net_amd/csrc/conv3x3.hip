@@ -24,6 +24,7 @@
 //   * Segments of RS output rows re-read 2 halo rows (L2 hits of the neighbouring segment's rows).
 // Epilogue flavours as conv1x1.hip: raw, raw + per-channel statistics, raw + addend (gradient fan-in), full (scale /
 // shift, residual add | gate, activation: inference).
+#include <cstdlib>
 #include "regconv.h"
 
 namespace ledn {
@@ -391,6 +392,8 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_reg_kernel(C33Args a) {
 // rows per segment: the longest of 32 / 16 / 8 that still yields one task per resident wave (2 per SIMD); a task
 // re-reads 2 halo rows and starts with an exposed load round trip, so fewer, longer tasks win once the chip is full
 static int c33_rows(long columns, int H) {
+    static const int forced = getenv("LEDN_C33_RS") ? atoi(getenv("LEDN_C33_RS")) : 0;      // (A/B knob)
+    if (forced > 0) return forced;
     if (columns * cdiv(H, 32) >= 2048) return 32;
     if (columns * cdiv(H, 16) >= 1024) return 16;
     return 8;
