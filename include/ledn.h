@@ -61,7 +61,8 @@ enum {
                                        bit 6: 3x3 stride-1 convolutions with 32 input channels on the register-direct wave-autonomous kernel
                                        (csrc/conv3x3.hip), and 3x3 convolutions with <= 2 input channels and 32 k output channels (the data
                                        gradient of the two-class heads) as one K = 32 fragment per pixel; bit 7 (off): the two-class heads'
-                                       forward convolution on that kernel too (measured slower than conv_mfma_kernel's narrow epilogue);
+                                       forward convolution on that kernel too (measured slower than conv_mfma_kernel's narrow epilogue); bit 8 (off): 3x3 stride-1
+                                       convolutions with 64 input channels through a wave-private LDS ring (conv3x3_ring64_kernel: measured 10 % slower);
                                        0: the generic kernels (A/B measurements); < 0: the default mask */
 };
 int ledn_set_option(int option, long long value);

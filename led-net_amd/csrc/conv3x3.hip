@@ -427,6 +427,9 @@ static int c33_epi(const C33Args& a, int epi, hipStream_t s) {
     }
 }
 
+template <int EPI>
+static int c33_ring64_launch(C33Args a, hipStream_t s);     // (64 input channels: below)
+
 static bool c33_full(const ledn_conv_desc& d) {
     return d.out_scale || d.act_out != LEDN_ACT_NONE || d.res_mode == LEDN_RES_GATE || (d.res_mode == LEDN_RES_ADD && d.out_shift);
 }
@@ -454,9 +457,10 @@ bool conv3x3_reg_supported(const ledn_conv_desc& d) {
     if (d.dtype_y != LEDN_BF16 && !c33_narrow(d)) return false;
     if (c33_narrow(d)) return true;
     if (d.in_scale || d.in_shift || d.in_act != LEDN_ACT_NONE) return false;
-    // 64 input channels (36 weight fragments = 144 VGPRs: one wave per SIMD) measured 60 us against conv_mfma_kernel's
-    // 37 us at 16 x 128 x 128 (r03): not offered
-    if (d.Cin != 32 || d.Cout % 32 || d.Cout > 128) return false;
+    // 64 input channels (36 weight fragments = 144 VGPRs): in the register form one wave per SIMD, 60 us against
+    // conv_mfma_kernel's 37 us at 16 x 128 x 128 (r03) -- offered only as conv3x3_ring64_kernel (bit 8)
+    if (d.Cin == 64 && !(options().stream_fast & 256)) return false;
+    if ((d.Cin != 32 && d.Cin != 64) || d.Cout % 32 || d.Cout > 128) return false;
     if (d.Ho != d.H || d.Wo != d.W) return false;
     if (c33_full(d)) {
         if (d.stat_sum || d.act_out == LEDN_ACT_SIGMOID || (d.act_out == LEDN_ACT_PRELU && !d.slope)) return false;
@@ -494,7 +498,215 @@ int conv3x3_reg(const ledn_conv_desc& d, hipStream_t s) {
         return check_launch();
     }
     const int epi = c33_full(d) ? C33_FULL : (d.res_mode == LEDN_RES_ADD ? C33_ACC : (d.stat_sum ? C33_STATS : C33_RAW));
+    if (d.Cin == 64) {
+        switch (epi) {
+            case C33_STATS: return c33_ring64_launch<C33_STATS>(a, s);
+            case C33_ACC: return c33_ring64_launch<C33_ACC>(a, s);
+            case C33_FULL: return c33_ring64_launch<C33_FULL>(a, s);
+            default: return c33_ring64_launch<C33_RAW>(a, s);
+        }
+    }
     return c33_epi<1, 2>(a, epi, s);
+}
+
+// ---------------------------------------------------------------------------
+// The same convolution for 64 INPUT channels (36 weight fragments = 144 VGPRs): the input rows of a wave's 16-pixel strip go
+// through a wave-private LDS ring instead of registers -- one row of 18 pixels x 128 B per iteration (16-byte pieces, next
+// row's loads in flight), the B fragment of tap (kh, kw) and chunk kc is ONE ds_read_b128 at pixel offset kw of ring row
+// kh (no DPP, no halo registers, no register prefetch ring) -- which is what lets the weights stay resident next to two
+// waves per SIMD.  Raw / + statistics / + addend / full epilogues as conv3x3_reg_kernel; 32 output channels per workgroup
+// slice.  Opt-in (LEDN_OPT_STREAM_FAST bit 8): measured 35-41 us against conv_mfma_kernel's 31-37 us at 16 x 128 x 128
+// (r03; neither two rows in flight nor the occupancy moved it) -- correct and tested, not the default.
+// ---------------------------------------------------------------------------
+constexpr int R64_PW = 18, R64_PIXB = 144;      // ring row: pixels x0 - 1 .. x0 + 16, 128 B + 16 pad per pixel
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) conv3x3_ring64_kernel(C33Args a) {
+    constexpr int NKC = 2, NMT = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char s_ring[4][3][R64_PW * R64_PIXB];
+    __shared__ float s_par[EPI == C33_FULL ? 96 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int pl = lane & 15, q = lane >> 4;
+    const int Cout = a.Cout, H = a.H, W = a.W;
+    const int co0 = blockIdx.y * 32;
+    unsigned char* ring = &s_ring[wid][0][0];
+    if constexpr (EPI == C33_FULL) {
+        if (tid < 32) {
+            const bool ok = co0 + tid < Cout;
+            s_par[tid] = (a.out_scale && ok) ? a.out_scale[co0 + tid] : 1.f;
+            s_par[32 + tid] = (a.bias && ok) ? a.bias[co0 + tid] : 0.f;
+            s_par[64 + tid] = a.act_out == LEDN_ACT_PRELU ? (ok ? a.slope[co0 + tid] : 0.f) : (a.act_out == LEDN_ACT_NONE ? 1.f : 0.f);
+        }
+        __syncthreads();
+    }
+    const int cl = 8 * q, cg = co0 + cl;
+    const bool c_ok = cg < Cout;
+    const float act_hi = a.act_out == LEDN_ACT_RELU6 ? 6.f : 3.0e38f;
+    constexpr int NST = EPI == C33_STATS ? 8 : 1;
+    float st1[NST], st2[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) st1[i] = st2[i] = 0.f;
+    bf16x8_t wf[9][NKC][NMT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                const int co = co0 + c11_channel<NMT>(mt, pl >> 2, pl & 3);
+                const bool ok = co < Cout;
+                uint4 v = *reinterpret_cast<const uint4*>(a.wp + (ok ? ((long)t * Cout + co) * 64 + 32 * kc + 8 * q : 0L));
+                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                wf[t][kc][mt] = __builtin_bit_cast(bf16x8_t, v);
+            }
+    // load role: piece e = lane + 64 t (t = 0..2) of a ring row (18 pixels x 8 pieces = 144): pixel e >> 3, piece e & 7
+    const long nwaves = (long)gridDim.x * 4;
+    for (long task = (long)blockIdx.x * 4 + wid; task < a.tasks; task += nwaves) {
+        const int strip = (int)(task % a.strips);
+        const int seg = (int)((task / a.strips) % a.segs);
+        const int n = (int)(task / ((long)a.strips * a.segs));
+        const int x0 = strip * 16, r0 = seg * a.RS, r1 = min(r0 + a.RS, H);
+        const bf16_t* xn = a.x + (long)n * H * W * 64;
+        auto fetch_x = [&](int ir, uint4 (&rw)[3]) {
+            const bool rok = ir >= 0 && ir < H;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int e = lane + 64 * t, px = x0 - 1 + (e >> 3);
+                const bool ok = rok && e < R64_PW * 8 && px >= 0 && px < W;
+                uint4 v = *reinterpret_cast<const uint4*>(xn + (ok ? ((long)ir * W + px) * 64 + 8 * (e & 7) : 0L));
+                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                rw[t] = v;
+            }
+        };
+        auto commit_x = [&](int slot, const uint4 (&rw)[3]) {
+            unsigned char* row = ring + slot * (R64_PW * R64_PIXB);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int e = lane + 64 * t;
+                if (e < R64_PW * 8) *reinterpret_cast<uint4*>(row + (e >> 3) * R64_PIXB + (e & 7) * 16) = rw[t];
+            }
+        };
+        auto finish = [&](int o, f32x4_t (&ac)[NMT]) {
+            const int px = x0 + pl;
+            const bool pok = px < W && c_ok;
+            const long off = (((long)n * H + o) * W + px) * Cout + cg;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = ac[0][i];
+                v[4 + i] = ac[1][i];
+            }
+            if (EPI != C33_FULL && a.bias) {
+                float bb[8];
+                ld8(a.bias + (c_ok ? cg : 0), bb);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += bb[i];
+            }
+            if constexpr (EPI == C33_STATS) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float vm = px < W ? v[i] : 0.f;
+                    st1[i] += vm;
+                    st2[i] = fmaf(vm, vm, st2[i]);
+                }
+            }
+            if constexpr (EPI == C33_ACC) {
+                float r[8];
+                const uint4 rv = *reinterpret_cast<const uint4*>(a.res + (pok ? off : 0L));
+                ld8(reinterpret_cast<const bf16_t*>(&rv), r);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = bf16_to_f32(f32_to_bf16(v[i])) + r[i];
+            }
+            if constexpr (EPI == C33_FULL) {
+                float fsc[8], fsh[8], fng[8];
+                ld8(s_par + cl, fsc);
+                ld8(s_par + 32 + cl, fsh);
+                ld8(s_par + 64 + cl, fng);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = v[i] * fsc[i] + fsh[i];
+                if (a.res_mode != LEDN_RES_NONE) {
+                    float r[8];
+                    const uint4 rv = *reinterpret_cast<const uint4*>(a.res + (pok ? off : 0L));
+                    ld8(reinterpret_cast<const bf16_t*>(&rv), r);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = a.res_mode == LEDN_RES_ADD ? v[i] + r[i] : v[i] * r[i] + r[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(v[i], 0.f) + fng[i] * fminf(v[i], 0.f), act_hi);
+            }
+            if (pok) st8(a.y + off, v);
+        };
+        // ring slot of image row ir: (ir - (r0 - 1)) % 3; output row o needs rows o - 1, o, o + 1
+        uint4 xr[3];                                             // (two rows in flight instead of one measured the same)
+        fetch_x(r0 - 1, xr);
+        commit_x(0, xr);
+        fetch_x(r0, xr);
+        commit_x(1, xr);
+        fetch_x(r0 + 1, xr);
+        int slot_new = 2;
+        for (int o = r0; o < r1; ++o) {
+            wave_sync();
+            commit_x(slot_new, xr);
+            if (o + 1 < r1) fetch_x(o + 2, xr);
+            wave_sync();
+            f32x4_t acc[NMT];
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const int s_top = slot_new == 2 ? 0 : slot_new + 1;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                int sl = s_top + kh;
+                sl = sl >= 3 ? sl - 3 : sl;
+                const unsigned char* row = ring + sl * (R64_PW * R64_PIXB);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        // ring pixel (output pixel pl, tap kw) = pl + kw; channels 32 kc + 8 q ..
+                        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(row + (pl + kw) * R64_PIXB + (32 * kc + 8 * q) * 2);
+#pragma unroll
+                        for (int mt = 0; mt < NMT; ++mt) acc[mt] = mfma_16x16x32_bf16(wf[kh * 3 + kw][kc][mt], b, acc[mt]);
+                    }
+            }
+            finish(o, acc);
+            slot_new = slot_new == 2 ? 0 : slot_new + 1;
+        }
+        wave_sync();
+    }
+    if constexpr (EPI == C33_STATS) {
+        __shared__ float s_st[4][2][32];
+        const float t1 = c11_reduce16<8>(st1, lane), t2 = c11_reduce16<8>(st2, lane);
+        const int vi = c11_red_index<8>(lane);
+        if ((lane & 15) < 8) {
+            s_st[wid][0][cl + vi] = t1;
+            s_st[wid][1][cl + vi] = t2;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int jj = tid >> 5, c = tid & 31;
+            const float t = (s_st[0][jj][c] + s_st[1][jj][c]) + (s_st[2][jj][c] + s_st[3][jj][c]);
+            if (co0 + c < Cout) {
+                if (a.part) a.part[(long)blockIdx.x * 2 * Cout + (long)jj * Cout + co0 + c] = t;
+                else atomicAdd((jj ? a.stat_sqsum : a.stat_sum) + co0 + c, t);
+            }
+        }
+    }
+}
+
+template <int EPI>
+static int c33_ring64_launch(C33Args a, hipStream_t s) {
+    a.strips = (int)cdiv(a.W, 16);
+    const int slices = a.Cout / 32;
+    a.RS = c33_rows((long)a.N * a.strips * slices, a.H);
+    a.segs = (int)cdiv(a.H, a.RS);
+    a.tasks = (long)a.N * a.segs * a.strips;
+    long nb = cdiv(a.tasks, 4);
+    const long cap = cdiv((long)options().conv_workgroups * 2, slices);
+    if (nb > cap) nb = cap;
+    a.part = (EPI == C33_STATS && a.stat_sum && nb > 16) ? ws_take(nb * 2 * a.Cout) : nullptr;
+    LEDN_LAUNCH((conv3x3_ring64_kernel<EPI>), dim3((unsigned)nb, (unsigned)slices), dim3(256), 0, s, a);
+    if (a.part) return finish_partials(a.part, (int)nb, a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
+    return check_launch();
 }
 
 // ---------------------------------------------------------------------------
@@ -828,6 +1040,7 @@ __global__ void __launch_bounds__(256, 4) stem_conv_reg_kernel(StemRArgs a) {
     };
     const long nwaves = (long)gridDim.x * 4;
     long it = (long)blockIdx.x * 4 + wid;
+    // (two iterations of windows in flight instead of one measured the same: 122 vs 119 us)
     StemRaw<TX> rcur[2], rnext[2];
     if (it < a.iters) gather(it, rcur);
     while (it < a.iters) {

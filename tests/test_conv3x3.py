@@ -289,3 +289,53 @@ def test_conv1x1_wgrad_wave_autonomous(be, cin, cout, g):
     finally:
         lib.set_option(2, MASK)
     torch.testing.assert_close(dw.cpu() - base, ref.cpu(), rtol=2e-3, atol=2e-3 * scale)
+
+
+@pytest.mark.parametrize('cout,nhw', [(64, (2, 9, 33)), (64, (1, 17, 16)), (32, (1, 5, 40)), (128, (1, 3, 17)), (64, (1, 35, 50))])
+def test_conv3x3_ring64_forward_and_dgrad(be, cout, nhw):
+    """conv3x3_ring64_kernel (64 input channels: input rows through a wave-private LDS ring, one ds_read_b128 per tap and
+    chunk; opt-in, LEDN_OPT_STREAM_FAST bit 8): forward raw + bias, + statistics, inference epilogue, and the data
+    gradient of a 64 -> 64 layer with a fan-in addend -- against torch and against conv_mfma_kernel."""
+    from led_net_amd import ops, _lib
+    lib = _lib.get_lib()
+    lib.set_option(2, MASK + 256)
+    N, H, W = nhw
+    x = r16(torch.randn(N, 64, H, W))
+    w = torch.randn(cout, 64, 3, 3) / 24.0
+    b = torch.randn(cout) * 0.3
+    want = F.conv2d(x, r16(w), b, padding=1)
+    wp = ops.pack_conv_weights(D(w), 0, 1)
+    xb = nhwc(x).bfloat16()
+    assert ops.conv2d_kernel_id(xb, D(w), pad=1, w_bf16=wp, out_shift=D(b)) == 3
+    got = ops.conv2d(xb, D(w), pad=1, out_shift=D(b), w_bf16=wp)
+    torch.testing.assert_close(nchw(got), want, rtol=1e-2, atol=2e-2)
+    stats = (D(torch.zeros(cout)), D(torch.zeros(cout)))
+    got2 = ops.conv2d(xb, D(w), pad=1, out_shift=D(b), stats=stats, w_bf16=wp)
+    torch.testing.assert_close(nchw(got2), want, rtol=1e-2, atol=2e-2)
+    npx = N * H * W
+    torch.testing.assert_close(stats[0].cpu(), want.sum((0, 2, 3)), rtol=1e-3, atol=2e-3 * npx)
+    torch.testing.assert_close(stats[1].cpu(), (want * want).sum((0, 2, 3)), rtol=2e-3, atol=2e-3 * npx)
+    sc, sh = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2
+    res = r16(torch.randn(N, cout, H, W))
+    want3 = torch.relu(F.conv2d(x, r16(w), None, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+    got3 = ops.conv2d(xb, D(w), pad=1, out_scale=D(sc), out_shift=D(sh), act=ops.ACT_RELU, res=nhwc(res).bfloat16(),
+                      res_mode=ops.RES_ADD, w_bf16=wp)
+    torch.testing.assert_close(nchw(got3), want3, rtol=1e-2, atol=3e-2)
+    lib.set_option(2, 27)
+    try:
+        ref = ops.conv2d(xb, D(w), pad=1, out_shift=D(b), w_bf16=wp)
+    finally:
+        lib.set_option(2, MASK + 256)
+    torch.testing.assert_close(got.float().cpu(), ref.float().cpu(), rtol=8e-3, atol=2e-3)
+    if cout == 64:      # data gradient of a 64 -> 64 layer (+ addend)
+        xg = r16(torch.randn(N, 64, H, W)).requires_grad_(True)
+        wg = r16(torch.randn(64, 64, 3, 3) / 24.0).requires_grad_(True)
+        z = F.conv2d(xg, wg, padding=1)
+        dz = r16(torch.randn_like(z))
+        z.backward(dz)
+        wp1 = ops.pack_conv_weights(D(wg.detach()), 1, 1)
+        prev = r16(torch.randn(N, 64, H, W))
+        dx2 = ops.conv2d(nhwc(dz).bfloat16(), D(wg.detach()), pad=1, transposed=True, out_hw=(H, W), w_bf16=wp1,
+                         res=nhwc(prev).bfloat16(), res_mode=ops.RES_ADD)
+        scale = float(xg.grad.abs().max())
+        torch.testing.assert_close(nchw(dx2), r16(xg.grad) + prev, rtol=1e-2, atol=1.5e-2 * max(scale, 1.0))
