@@ -907,8 +907,8 @@ __device__ __forceinline__ StemK stem_k(int k, const int* map, const float* in_s
     r.kw = r.valid ? tap % 3 : 0;
     const int cs = map ? map[c] : c;
     r.plane = (long)cs * H * W + (long)r.kh * W + r.kw;
-    r.sc = in_scale ? in_scale[c] : 1.f;
-    r.sh = in_shift ? in_shift[c] : 0.f;
+    r.sc = r.valid ? (in_scale ? in_scale[c] : 1.f) : 0.f;      // (k = 27..31: the fragment's padding rows are zero)
+    r.sh = r.valid ? (in_shift ? in_shift[c] : 0.f) : 0.f;
     return r;
 }
 
@@ -953,10 +953,18 @@ __device__ __forceinline__ void stem_bytes(const StemRaw<TX>& r, float (&f)[8]) 
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = r.v[j];
 }
+// ({hi, lo} >> 8 s)[31:0], s = 0..3 (v_alignbyte_b32)
+__device__ __forceinline__ unsigned stem_alignbyte(unsigned hi, unsigned lo, int s) {
+#ifdef LEDN_CPU_EMU
+    return (unsigned)((((unsigned long long)hi << 32) | lo) >> (8 * (s & 3)));
+#else
+    return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)s);
+#endif
+}
 template <>
 __device__ __forceinline__ void stem_bytes<unsigned char>(const StemRaw<unsigned char>& r, float (&f)[8]) {
     unsigned w[6] = {r.w[0], r.w[1], r.w[2], r.w[3], r.w[4], 0u};
-    int s = r.d & 3;
+    const int s = r.d & 3;
     const int dd = r.d >> 2;                        // whole dwords the window was clamped by (0 almost always)
     if (dd != 0) {                                  // rare: first / last bytes of the image
         unsigned t[6];
@@ -970,14 +978,19 @@ __device__ __forceinline__ void stem_bytes<unsigned char>(const StemRaw<unsigned
 #pragma unroll
         for (int i = 0; i < 6; ++i) w[i] = t[i];
     }
+    // the 16 bytes from offset s as four aligned dwords: elements 2 i, 2 i + 1 are bytes 0 and 2 of dword i
+    // (v_alignbyte_b32 + v_cvt_f32_ubyte0 / 2: 12 instructions for the 8 values; the first version shifted 64-bit pairs)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {                   // byte s + 2 j of the window
-        const unsigned long long pair = ((unsigned long long)w[(j >> 1) + 1] << 32) | w[j >> 1];
-        f[j] = (float)((unsigned)(pair >> (8 * (s + 2 * (j & 1)))) & 0xffu);
+    for (int i = 0; i < 4; ++i) {
+        const unsigned al = stem_alignbyte(w[i + 1], w[i], s);
+        f[2 * i] = (float)(al & 0xffu);
+        f[2 * i + 1] = (float)((al >> 16) & 0xffu);
     }
 }
 
-// normalise, pad, mask -> bf16 x 8 (A[k][pixel px0 .. px0 + 7])
+// normalise, pad, mask -> bf16 x 8 (A[k][pixel px0 .. px0 + 7]).  Interior fragments (every tap of the 8 pixels inside the
+// image and inside the valid extent: all but the border strips / rows) skip the per-element tests -- the patch-row
+// arithmetic was the bound of both stem kernels (compiled out: 134 -> 89 us, tools/gpu_exp_sw.sh).
 template <typename TX>
 __device__ __forceinline__ uint4 stem_row(const StemRaw<TX>& r, const StemK& K, int o, int px0, int H, int W, int Wo, int vh, int vw,
                                           float pad_val) {
@@ -985,14 +998,22 @@ __device__ __forceinline__ uint4 stem_row(const StemRaw<TX>& r, const StemK& K, 
     stem_bytes<TX>(r, f);
     const int hi = 2 * o - 1 + K.kh;
     const bool rok = K.valid && hi >= 0 && hi < H;
+    const int wi0 = 2 * px0 - 1 + K.kw, wi7 = wi0 + 14;
     unsigned short e[8];
+    // (the lanes of the five padding elements k = 27..31 take the fast path too -- their scale and shift are zeroed by the
+    //  caller: with them on the slow path EVERY wave ran both branches)
+    if (!K.valid || (rok && hi < vh && wi0 >= 0 && wi7 < W && wi7 < vw && px0 + 7 < Wo)) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int px = px0 + j, wi = 2 * px - 1 + K.kw;
-        const bool ok = rok && px < Wo && wi >= 0 && wi < W;
-        float v = f[j] * K.sc + K.sh;
-        v = (hi < vh && wi < vw) ? v : pad_val;              // batch padding (stack_batch), normalised domain
-        e[j] = ok ? f32_to_bf16(v) : (unsigned short)0;       // the convolution's own zero padding
+        for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16(f[j] * K.sc + K.sh);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int px = px0 + j, wi = wi0 + 2 * j;
+            const bool ok = rok && px < Wo && wi >= 0 && wi < W;
+            float v = f[j] * K.sc + K.sh;
+            v = (hi < vh && wi < vw) ? v : pad_val;              // batch padding (stack_batch), normalised domain
+            e[j] = ok ? f32_to_bf16(v) : (unsigned short)0;       // the convolution's own zero padding
+        }
     }
     return make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16),
                       e[6] | ((unsigned)e[7] << 16));
@@ -1168,6 +1189,9 @@ struct StemWArgs {
     float pad_val;
 };
 
+#ifndef LEDN_SW_EXP
+#define LEDN_SW_EXP 0      // cost experiments (tools/gpu_exp_sw.sh; uint8 inputs only): 1 no matrix instructions, 2 no LDS tile, 3 no patch-row arithmetic
+#endif
 template <typename TX>
 __global__ void __launch_bounds__(256, 3) stem_wgrad_reg_kernel(StemWArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char s_z[4][32 * ST_PIXB];     // per wave: [pixel][32 channels] bf16
@@ -1210,31 +1234,65 @@ __global__ void __launch_bounds__(256, 3) stem_wgrad_reg_kernel(StemWArgs a) {
         const long nit = it + nwaves;
         if (nit < a.iters) gather(nit, anext, znext);
         sched_fence();
+        const bool exp_lds = LEDN_SW_EXP != 2 || a.N < 0;
+        if (exp_lds) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int e = lane + 64 * t;
             *reinterpret_cast<uint4*>(sz + (e >> 2) * ST_PIXB + (e & 3) * 16) = zcur[t];
         }
         wave_sync();
+        }
         const int row = (int)(it / a.strips), strip = (int)(it % a.strips);
         const int n = row / Ho, o = row - n * Ho;
         const int vh = a.valid_hw ? a.valid_hw[2 * n] : H, vw = a.valid_hw ? a.valid_hw[2 * n + 1] : W;
         bf16x8_t af[2], bfr[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {                         // lane 4 r + p supplies pixel 8 q + r (+ 4), channels 16 nt + 4 p ..
+            if (exp_lds) {
             const unsigned char* zp = sz + (8 * q + (m16 >> 2)) * ST_PIXB + (16 * nt + 4 * (m16 & 3)) * 2;
             const bf16x4_t lo = lds_read_tr16(zp), hi4 = lds_read_tr16(zp + 4 * ST_PIXB);
             bfr[nt][0] = lo[0]; bfr[nt][1] = lo[1]; bfr[nt][2] = lo[2]; bfr[nt][3] = lo[3];
             bfr[nt][4] = hi4[0]; bfr[nt][5] = hi4[1]; bfr[nt][6] = hi4[2]; bfr[nt][7] = hi4[3];
+            } else {
+                bfr[nt] = __builtin_bit_cast(bf16x8_t, zcur[nt]);
+            }
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-            af[mt] = __builtin_bit_cast(bf16x8_t, stem_row<TX>(acur[mt], K[mt], o, strip * 32 + 8 * q, H, W, Wo, vh, vw, a.pad_val));
+        for (int mt = 0; mt < 2; ++mt) {
+            if (LEDN_SW_EXP == 4 || LEDN_SW_EXP == 5) {               // 4: byte extraction only, 5: + conversion to bf16
+                float f8[8];
+                stem_bytes<TX>(acur[mt], f8);
+                if (LEDN_SW_EXP == 4) {
+                    af[mt] = __builtin_bit_cast(bf16x8_t, make_uint4(__float_as_uint(f8[0]) + __float_as_uint(f8[1]), __float_as_uint(f8[2]) + __float_as_uint(f8[3]),
+                                                                     __float_as_uint(f8[4]) + __float_as_uint(f8[5]), __float_as_uint(f8[6]) + __float_as_uint(f8[7])));
+                } else {
+                    float o8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o8[j] = f8[j] * K[mt].sc + K[mt].sh;
+                    bf16_t tmp[8];
+                    st8(tmp, o8);
+                    uint4 rawv;
+                    __builtin_memcpy(&rawv, tmp, 16);
+                    af[mt] = __builtin_bit_cast(bf16x8_t, rawv);
+                }
+            } else if (LEDN_SW_EXP != 3 || a.N < 0)
+                af[mt] = __builtin_bit_cast(bf16x8_t, stem_row<TX>(acur[mt], K[mt], o, strip * 32 + 8 * q, H, W, Wo, vh, vw, a.pad_val));
+            else if (LEDN_SW_EXP == 3) {
+                uint4 rawv;
+                __builtin_memcpy(&rawv, &acur[mt], 16);
+                af[mt] = __builtin_bit_cast(bf16x8_t, rawv);
+            }
+        }
+        if (LEDN_SW_EXP != 1 || a.N < 0) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt]);
-        wave_sync();                                             // the tile is rewritten by the next iteration
+        } else {
+            acc[0][0][0] += __builtin_bit_cast(uint4, af[0]).x + __builtin_bit_cast(uint4, af[1]).y + __builtin_bit_cast(uint4, bfr[0]).x + __builtin_bit_cast(uint4, bfr[1]).y;
+        }
+        if (exp_lds) wave_sync();                                // the tile is rewritten by the next iteration
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             zcur[t] = znext[t];
