@@ -653,21 +653,29 @@ __global__ void __launch_bounds__(256, 2) conv3x3_ring64_kernel(C33Args a) {
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             const int s_top = slot_new == 2 ? 0 : slot_new + 1;
+            // 18 product steps (kh, kw, kc): the fragment of step i + 1 (one ds_read_b128) is requested BEFORE the two matrix
+            // instructions of step i -- read right in front of its use, every step paid the LDS round trip
+            const unsigned char* rows[3];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 int sl = s_top + kh;
                 sl = sl >= 3 ? sl - 3 : sl;
-                const unsigned char* row = ring + sl * (R64_PW * R64_PIXB);
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                    for (int kc = 0; kc < NKC; ++kc) {
-                        // ring pixel (output pixel pl, tap kw) = pl + kw; channels 32 kc + 8 q ..
-                        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(row + (pl + kw) * R64_PIXB + (32 * kc + 8 * q) * 2);
-#pragma unroll
-                        for (int mt = 0; mt < NMT; ++mt) acc[mt] = mfma_16x16x32_bf16(wf[kh * 3 + kw][kc][mt], b, acc[mt]);
-                    }
+                rows[kh] = ring + sl * (R64_PW * R64_PIXB) + pl * R64_PIXB + 16 * q;
             }
+            auto frag = [&](int i) {                             // i = (kh * 3 + kw) * 2 + kc: ring pixel pl + kw, channels 32 kc + 8 q ..
+                const int t = i >> 1, kc = i & 1, kh = t / 3, kw = t - 3 * kh;
+                return *reinterpret_cast<const bf16x8_t*>(rows[kh] + kw * R64_PIXB + kc * 64);
+            };
+            bf16x8_t b_next = frag(0);
+            c11_for<18>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const bf16x8_t b = b_next;
+                if constexpr (i + 1 < 18) b_next = frag(i + 1);
+                sched_fence();
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt) acc[mt] = mfma_16x16x32_bf16(wf[i >> 1][i & 1][mt], b, acc[mt]);
+                sched_fence();
+            });
             finish(o, acc);
             slot_new = slot_new == 2 ? 0 : slot_new + 1;
         }
