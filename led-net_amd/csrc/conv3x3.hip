@@ -922,7 +922,8 @@ __device__ __forceinline__ StemK stem_k(int k, const int* map, const float* in_s
 
 // loads for pixels px0 .. px0 + 7 of output row o of image n (xn = image base, img = elements per image)
 template <typename TX>
-__device__ __forceinline__ void stem_fetch(StemRaw<TX>& r, const TX* xn, long img, const StemK& K, int o, int px0, int H, int W, int Wo) {
+__device__ __forceinline__ void stem_fetch(StemRaw<TX>& r, const TX* xn, long front, long rest, const StemK& K, int o, int px0, int H, int W,
+                                           int Wo) {
     const int hi = 2 * o - 1 + K.kh;
     const bool rok = K.valid && hi >= 0 && hi < H;
 #pragma unroll
@@ -933,22 +934,22 @@ __device__ __forceinline__ void stem_fetch(StemRaw<TX>& r, const TX* xn, long im
     }
 }
 template <>
-__device__ __forceinline__ void stem_fetch<unsigned char>(StemRaw<unsigned char>& r, const unsigned char* xn, long img, const StemK& K,
-                                                          int o, int px0, int H, int W, int Wo) {
+__device__ __forceinline__ void stem_fetch<unsigned char>(StemRaw<unsigned char>& r, const unsigned char* xn, long front, long rest,
+                                                          const StemK& K, int o, int px0, int H, int W, int Wo) {
+    // xn = this image, front / rest = bytes from the START OF THE TENSOR (4-byte aligned) to xn / from xn to its END.  The window is aligned on the address and may reach
+    // into the neighbouring images; it is clamped only at the two ends of the tensor: below at the first aligned address
+    // inside it (the element in front of the very first byte is column -1: masked), above so that it ends at the tensor's
+    // end rounded up to 4 bytes (an aligned dword that holds a valid byte cannot cross a page).  The extraction follows
+    // with d = offset of the first wanted byte in the window.
     const int hi = 2 * o - 1 + K.kh;
     const bool rok = K.valid && hi >= 0 && hi < H && px0 < Wo;
-    // address of pixel px0's element (one byte in front of the image for column -1).  The 20-byte window is aligned on
-    // the ADDRESS (an image need not start on a 4-byte boundary) and clamped into this image (>= 24 bytes, checked by the
-    // launcher; the tensor base is 4-byte aligned, checked too): the extraction follows with d
     const long start = rok ? (long)(2 * o - 1) * W + (2 * px0 - 1) + K.plane : 0L;
     const unsigned long long ax = (unsigned long long)xn;
     const long mis = (long)(ax & 3ull);                         // xn = aligned address + mis
-    long base = ((start + mis) & ~3L) - mis;                    // element index of an aligned address <= start
-    const long lo = mis ? 4 - mis : 0, last = ((img + mis - 20) & ~3L) - mis;
-    base = base < lo ? lo : (base > last ? last : base);
+    long base = ((start + mis) & ~3L) - mis;                    // element index (from xn) of an aligned address <= start
+    const long last = ((rest + mis + 3) & ~3L) - mis - 20;
+    base = base < -front ? -front : (base > last ? last : base);
     r.d = (int)(start - base);
-    // 4-byte aligned, not 16: a 4-aligned 20-byte aggregate = global_load_dwordx4 + dword on the device, unaligned
-    // moves on the emulator (a plain uint4 load there is an aligned SSE move and faults)
     struct __attribute__((packed, aligned(4))) Win { unsigned w[5]; };
     const Win wv = *reinterpret_cast<const Win*>(xn + base);
 #pragma unroll
@@ -1065,7 +1066,7 @@ __global__ void __launch_bounds__(256, 4) stem_conv_reg_kernel(StemRArgs a) {
         const int row = (int)(it / a.strips), strip = (int)(it % a.strips);
         const int n = row / Ho, o = row - n * Ho;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) stem_fetch<TX>(rw[t], x + (long)n * img, img, K[t], o, strip * 32 + 8 * q, H, W, Wo);
+        for (int t = 0; t < 2; ++t) stem_fetch<TX>(rw[t], x + (long)n * img, (long)n * img, (long)(a.N - n) * img, K[t], o, strip * 32 + 8 * q, H, W, Wo);
     };
     const long nwaves = (long)gridDim.x * 4;
     long it = (long)blockIdx.x * 4 + wid;
@@ -1223,7 +1224,7 @@ __global__ void __launch_bounds__(256, 3) stem_wgrad_reg_kernel(StemWArgs a) {
         const int n = row / Ho, o = row - n * Ho;
         const bf16_t* zr = a.dz + (long)row * Wo * 32;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) stem_fetch<TX>(ra[mt], x + (long)n * img, img, K[mt], o, strip * 32 + 8 * q, H, W, Wo);
+        for (int mt = 0; mt < 2; ++mt) stem_fetch<TX>(ra[mt], x + (long)n * img, (long)n * img, (long)(a.N - n) * img, K[mt], o, strip * 32 + 8 * q, H, W, Wo);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {                            // piece e = lane + 64 t: pixel e >> 2, channels 8 (e & 3) ..
             const int e = lane + 64 * t, px = strip * 32 + (e >> 2);

@@ -335,6 +335,8 @@ def stem_conv(x, w_pack, scale=None, shift=None, chan_map=None, valid=None, pad_
     if chan_map is not None and (chan_map.dtype != torch.int32 or chan_map.numel() != Cc):
         raise LednError('stem_conv: chan_map must be int32[C]')
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if x.data_ptr() % 4:      # (a slice of a uint8 batch with an odd image size: the kernel reads 4-byte aligned windows)
+        x = x.clone()
     y = torch.empty((N, Ho, Wo, 32), dtype=torch.bfloat16, device=x.device)
     _check(lib, x, w_pack, y, scale, shift, chan_map, valid, out_scale, out_shift)
     dtx = {torch.uint8: _lib.U8, torch.float32: F32, torch.bfloat16: BF16}[x.dtype]
@@ -362,6 +364,8 @@ def stem_conv_wgrad(x, dz, dw, scale=None, shift=None, chan_map=None, valid=None
         raise LednError('stem_conv_wgrad: dz must be contiguous bf16 [N,Ho,Wo,32]')
     if dw.dtype != torch.float32 or dw.numel() != 32 * 27 or not dw.is_contiguous():
         raise LednError('stem_conv_wgrad: dw must be contiguous f32 [32,3,3,3]')
+    if x.data_ptr() % 4:
+        x = x.clone()
     _check(lib, x, dz, dw, scale, shift, chan_map, valid)
     dtx = {torch.uint8: _lib.U8, torch.float32: F32, torch.bfloat16: BF16}[x.dtype]
     valid = _valid_hw(valid, N, x)

@@ -339,3 +339,49 @@ def test_conv3x3_ring64_forward_and_dgrad(be, cout, nhw):
                          res=nhwc(prev).bfloat16(), res_mode=ops.RES_ADD)
         scale = float(xg.grad.abs().max())
         torch.testing.assert_close(nchw(dx2), r16(xg.grad) + prev, rtol=1e-2, atol=1.5e-2 * max(scale, 1.0))
+
+
+def test_stem_conv_misaligned_batch_slice(be):
+    """a slice of a uint8 batch whose images have an odd byte count starts on an odd address: the wrapper realigns it (the
+    kernel reads 4-byte aligned windows and rejects a misaligned base loudly).  RAW-domain inputs (0..255) and no valid
+    extents: a wrong byte at the image / tensor ends (the clamped windows: images of 4653 bytes do not start on 4-byte
+    boundaries) is an error of tens -- with normalised inputs and padded extents such bytes hid inside the tolerance / the
+    padded area."""
+    from led_net_amd import ops
+    g = torch.Generator().manual_seed(77)
+    full = torch.randint(0, 256, (3, 3, 33, 47), dtype=torch.uint8, generator=g).to(_DEV[0])      # 4653 bytes per image
+    x = full[1:]
+    assert x.data_ptr() % 4 != 0 and x.is_contiguous()
+    w = (0.2 * torch.randn(32, 3, 3, 3, generator=g)).to(_DEV[0])
+    wp = ops.pack_conv_weights(ops.stem_weight_as_1x1(w), 0)
+    got = ops.stem_conv(x, wp)
+    want = ops.stem_conv(x.clone(), wp)
+    assert torch.equal(got.cpu(), want.cpu())
+    ref = F.conv2d(r16(x.float().cpu()), r16(w.cpu()), stride=2, padding=1).permute(0, 2, 3, 1)
+    torch.testing.assert_close(got.float().cpu(), ref, rtol=1e-2, atol=2.0)
+    dz = torch.randn(2, 17, 24, 32, generator=g).to(_DEV[0], torch.bfloat16)
+    dw1 = ops.stem_conv_wgrad(x, dz, torch.zeros(32, 3, 3, 3, device=_DEV[0]))
+    dw2 = ops.stem_conv_wgrad(x.clone(), dz, torch.zeros(32, 3, 3, 3, device=_DEV[0]))
+    torch.testing.assert_close(dw1.cpu(), dw2.cpu(), rtol=1e-5, atol=1e-2)
+    wr = w.detach().cpu().clone().requires_grad_(True)
+    F.conv2d(x.float().cpu(), wr, stride=2, padding=1).backward(dz.float().cpu().permute(0, 3, 1, 2))
+    torch.testing.assert_close(dw1.cpu(), wr.grad, rtol=1e-4, atol=1e-4 * float(wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(3, 3, 9, 11), (1, 3, 5, 7), (2, 3, 33, 47), (2, 3, 31, 64)])
+def test_stem_kernels_raw_domain_every_border(be, shape):
+    """both stem kernels on raw uint8 values without normalisation or padded extents, image sizes whose byte counts are
+    not multiples of 4 (window alignment / clamping at every image and tensor end), against torch"""
+    from led_net_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+    w = r16(0.2 * torch.randn(32, 3, 3, 3, generator=g))
+    wp = ops.pack_conv_weights(ops.stem_weight_as_1x1(D(w)), 0)
+    got = ops.stem_conv(D(x), wp)
+    wr = w.clone().requires_grad_(True)
+    z = F.conv2d(x.float(), wr, stride=2, padding=1)
+    torch.testing.assert_close(got.float().cpu(), z.detach().permute(0, 2, 3, 1), rtol=1e-2, atol=2.0)
+    dz = r16(torch.randn(z.shape, generator=g))
+    z.backward(dz)
+    dw = ops.stem_conv_wgrad(D(x), nhwc(dz).bfloat16(), torch.zeros(32, 3, 3, 3, device=_DEV[0]))
+    torch.testing.assert_close(dw.cpu(), wr.grad, rtol=1e-4, atol=1e-4 * float(wr.grad.abs().max()))
