@@ -85,3 +85,62 @@ def test_train_step_bf16_vs_oracle(be):
     # separate elementwise adds: 11 SESP shortcuts, 4 BasicBlocks, x1 / x2 / c3 heads, 2 x MFAF (x, r), stage ReLUs
     c = TR._Acc.counters
     assert c['chained'] >= 15 and c['added'] <= 4, c
+
+
+@pytest.mark.parametrize('hw', [(352, 488), (340, 372)])
+def test_specialised_kernels_equal_general_kernels_whole_network(be, hw):
+    """The round-3 kernels (LEDN_OPT_STREAM_FAST default 91: register-direct 1x1 / 3x3 convolutions, the stem from the planar
+    batch, the heads' data / weight gradients, wave-autonomous 1x1 weight gradients) against the general kernels (mask 11:
+    conv_mfma_kernel / conv_wgrad_mfma_kernel / the VALU head kernels for all of them) on the WHOLE network at sizes that
+    are not multiples of the tile sizes: inference logits, one training step's losses, and per-parameter gradient cosines.
+    Noise floor (tools/ab_whole_net.py, batch 6, MI355X): the SAME mask twice gives median 0.968 / p10 0.952 (bf16
+    activations + summation order -> activation masks; at batch 2 the 2-sample BatchNorms of the pooled contexts flip signs and
+    the floor is useless: stem weight 0.37 / -0.81); the two kernel sets against each other 0.938 / 0.903.  A mis-indexed
+    kernel gives ~0 for its own parameters and everything upstream."""
+    from conftest import slow_on_emu
+    slow_on_emu(be.dev)
+    from led_net_amd import _lib
+    lib = _lib.get_lib()
+    H, W = hw
+    B = 6
+    g = torch.Generator().manual_seed(H + W)
+    img = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=g)
+    lab = torch.randint(0, 2, (B, 1, H, W), dtype=torch.int64, generator=g)
+    lab[:, :, :5, :] = 255
+    res = {}
+    for mask in (91, 11):
+        lib.set_option(2, mask)
+        try:
+            L, cfg, model, sd = _model(5)
+            model.eval()
+            with torch.no_grad():
+                out = model(D(img[:2]), mode='predict')
+            logits = torch.stack([o.seg_logits.data for o in out]).float().cpu()
+            model.train()
+            tr = L.Trainer(model, cfg, max_iters=1000)
+            tr.base_lr = 0.0                                  # (gradients only: the momentum buffer takes them)
+            losses = tr.train_step(D(img), [L.SegDataSample(gt=D(lab[i])) for i in range(B)])
+            name_of = {id(p): k for k, p in model.named_parameters()}
+            grads = {name_of[id(p)]: m.detach().float().cpu().clone() for p, m in zip(tr.params, tr.moms)}
+            res[mask] = (logits, {k: float(v.float().reshape(-1)[0]) for k, v in losses.items()}, grads)
+        finally:
+            lib.set_option(2, -1)
+    (la, lossa, ga), (lb, lossb, gb) = res[91], res[11]
+    scale = lb.abs().max().item()
+    assert (la - lb).abs().max().item() <= 0.03 * scale, ((la - lb).abs().max().item(), scale)
+    for k in ('decode.loss_context', 'decode.loss_spatial'):
+        assert abs(lossa[k] - lossb[k]) <= 2e-2 * abs(lossb[k]) + 1e-3, (k, lossa[k], lossb[k])
+    rows = []
+    for k in gb:
+        a, b = ga[k].flatten(), gb[k].flatten()
+        if b.norm().item() > 1e-8:
+            rows.append((float(a @ b / (a.norm() * b.norm() + 1e-30)), k))
+    rows.sort()
+    med, p10 = rows[len(rows) // 2][0], rows[len(rows) // 10][0]
+    print(f'specialised vs general kernels {hw}: gradient cosine median {med:.3f}, p10 {p10:.3f}, worst {rows[:3]}')
+    assert med >= 0.85 and p10 >= 0.7, (med, p10, rows[:6])
+    cos = dict((k, c) for c, k in rows)
+    for k in cos:
+        if (k.endswith('stem.0.conv.weight') or '.head_x1.0.conv.weight' in k or '.head_x2.0.conv.weight' in k
+                or 'stem.2.0.conv1.conv.weight' in k):
+            assert cos[k] >= 0.7, (k, cos[k])
