@@ -1,6 +1,7 @@
 // stencil_bf16.hip -- vectorised bf16 kernels (see stencil.h) for the depthwise weight gradient
 // and the SESP pyramid forward / data gradient / weight gradient.  Each returns -1 when the shape
 // is outside its gate so that the caller (dwconv.hip / backward.hip) falls back to the generic kernel.
+#include <cstdlib>
 #include "stencil.h"
 
 namespace ledn {
@@ -93,7 +94,11 @@ int dw3x3_bwd_weight_bf16(const ledn_dwbwd_desc& d, hipStream_t s) {
     for (int g = 0; g * d.group_size < d.C; ++g)
         if (d.pad >= 0 && d.pad != d.dil[g]) return -1;
     const int rows = 256 / cvn;
-    long nb = cdiv((long)d.N * d.H * d.W, rows * 8);
+    // 16 pixels per thread (512 workgroups at 16 x 128 x 128 x 64): 28.8 / 36.6 us against 34.0 / 39.7 with 8 (graph replay,
+    // r03); 32 and 64 are slower again.  Cost experiments of the same visit: every tap reading the centre pixel, only one tap
+    // accumulated, next pixel's loads requested ahead -- none moved the time
+    static const int ppt = getenv("LEDN_DW_PPT") ? atoi(getenv("LEDN_DW_PPT")) : 16;     // (A/B knob)
+    long nb = cdiv((long)d.N * d.H * d.W, rows * (ppt > 0 ? ppt : 16));
     if (nb > 1024) nb = 1024;
     float* part = nb > 32 ? ws_take(nb * 9 * d.C) : nullptr;
     if (!part && nb > 128) nb = 128;
