@@ -167,21 +167,32 @@ def test_replay_with_new_batch_equals_eager_step():
     torch.cuda.synchronize()
     assert tr.iter == 1 and abs(float(tr._lr_dev[0]) - lr0) < 1e-9 and tr.lr() < lr0
     w_r = [p.detach().clone() for p in tr.params]
-    with torch.no_grad():
-        for p, v in zip(tr.params, state[0]):
-            p.copy_(v)
-        tr.flat_mom.copy_(state[1])
-        for b, v in zip(model.buffers(), state[2]):
-            b.copy_(v)
-    tr.iter = 0
+
+    def restore():
+        with torch.no_grad():
+            for p, v in zip(tr.params, state[0]):
+                p.copy_(v)
+            tr.flat_mom.copy_(state[1])
+            for b, v in zip(model.buffers(), state[2]):
+                b.copy_(v)
+        tr.iter = 0
+    restore()
     out_e = {k: float(v.reshape(-1)[0]) for k, v in tr.train_step(*b1).items()}
     torch.cuda.synchronize()
-    for k in out_e:
-        assert abs(out_r[k] - out_e[k]) <= 5e-3 * abs(out_e[k]) + 1e-6, (k, out_r[k], out_e[k])    # (two GPU passes: 2e-3)
-    # a replay with the CAPTURE batch's padding extents (the frozen-graph bug) would normalise 48 padded columns /
-    # rows as data: the losses above differ by > 1e-2 then (checked by breaking it); weights: same step taken
     upd = torch.cat([(a - s).flatten() for a, s in zip(w_r, state[0])])
     upd_e = torch.cat([(p.detach() - s).flatten() for p, s in zip(tr.params, state[0])])
+    # the frozen-graph bug, made on purpose: the same pixels and labels with the CAPTURE batch's extents (no padding)
+    restore()
+    wrong = [L.SegDataSample(gt=ds.gt_sem_seg.data, metainfo=m.metainfo) for ds, m in zip(b1[1], b0[1])]
+    out_w = {k: float(v.reshape(-1)[0]) for k, v in tr.train_step(b1[0], wrong).items()}
+    torch.cuda.synchronize()
+    print(f'replay(new batch) vs eager: wrong-extents eager step {out_w}')
+    # two GPU passes of the same step differ by the order of the statistics' atomics (measured over 12 runs on the MI355X:
+    # loss_spatial <= 6e-4, loss_context <= 5e-3 relative -- the pooled-context BatchNorms over 4 samples amplify it)
+    assert abs(out_r['decode.loss_spatial'] - out_e['decode.loss_spatial']) <= 3e-3 * out_e['decode.loss_spatial'], (out_r, out_e)
+    assert abs(out_r['decode.loss_context'] - out_e['decode.loss_context']) <= 1e-2 * out_e['decode.loss_context'], (out_r, out_e)
+    # ... and the bound on loss_spatial does tell the bug apart: the wrong extents move it by 2.3 % (measured, 6 runs)
+    assert abs(out_w['decode.loss_spatial'] - out_e['decode.loss_spatial']) >= 1e-2 * out_e['decode.loss_spatial'], (out_w, out_e)
     rel = ((upd - upd_e).norm() / upd_e.norm()).item()
     print(f'replay(new batch) vs eager: losses {out_r} / {out_e}, update rel-L2 {rel:.3e}')
     assert rel < 0.35        # (bf16 step, two passes of the same code on the GPU: ~0.25 by atomics order alone)
