@@ -108,3 +108,19 @@ print('--- trailing gaps >= 5 us: kernel (grid) -> next kernel: count/step, mean
 for key, nxt in sorted(follow.items(), key=lambda kv: -sum(v[1] for v in kv[1].values()))[:12]:
     for nk, (c, tot_gap) in sorted(nxt.items(), key=lambda kv: -kv[1][1])[:3]:
         print(f'  {key[0]} {key[1]} -> {nk}: {c / nsteps:.1f}/step, {tot_gap / c / 1e3:.1f} us')
+# the largest idle gaps of the LAST step with the kernels around them (what was the device waiting for?)
+last_step = rows[ends[-2] + 1:ends[-1] + 1]
+gaps = []
+run_end = last_step[0][1]
+for i in range(1, len(last_step)):
+    s = last_step[i][0]
+    if s > run_end:
+        gaps.append((s - run_end, i))
+    run_end = max(run_end, last_step[i][1])
+print('--- largest idle gaps of the last step: gap us | two kernels before -> two kernels after (name grid dur us)')
+for g, i in sorted(gaps, reverse=True)[:24]:
+    def fmt(r):
+        return f'{r[2]}{r[3][:2]} {(r[1] - r[0]) / 1e3:.1f}'
+    before = ' ; '.join(fmt(r) for r in last_step[max(0, i - 2):i])
+    after = ' ; '.join(fmt(r) for r in last_step[i:i + 2])
+    print(f'{g / 1e3:7.1f} | {before}  ->  {after}')
