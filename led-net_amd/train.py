@@ -314,7 +314,7 @@ class BNActFn(Function):
 
 
 WGRAD_DEFER = int(_os.environ.get('LEDN_WGRAD_DEFER', '1'))   # one summing launch for all weight gradients of a step (ops.WgradDefer)
-WGRAD_SLOT = int(_os.environ.get('LEDN_WGRAD_SLOT', '0'))   # auxiliary stream of the weight gradients, 0 = launch stream (measured r02n: 782 img/s on its own stream vs 892 on the launch stream)
+WGRAD_SLOT = int(_os.environ.get('LEDN_WGRAD_SLOT', '0'))   # auxiliary stream of the weight gradients, 0 = launch stream (measured r02n: 782 img/s on its own stream vs 892 on the launch stream; round-3 kernels: 1098 vs 1225)
 
 
 def _conv_wgrad(x, dz, w_shape, sw, sb, **kw):
@@ -1033,8 +1033,8 @@ def getb(m, x):
 
 TEST_HOOKS = {}     # tests only: 'edge' -> a given SEAM edge map [N,h,w,1] f32 instead of the kernel's (freezes the
                     # percentile binarisation for the deterministic whole-step gradient test)
-CTX_FORKS = int(_os.environ.get('LEDN_CTX_FORKS', '7'))    # bit s: context branch of stage 3+s on the aux stream
-SEAM_SLOT = int(_os.environ.get('LEDN_SEAM_SLOT', '0'))     # stream of the SEAM edge map: 0 = main (measured 895 vs 878 img/s on its own stream)
+CTX_FORKS = int(_os.environ.get('LEDN_CTX_FORKS', '7'))    # bit s: context branch of stage 3+s on the aux stream (round 3: 7 -> 1225 img/s, 3 -> 1170, 0 -> 1139)
+SEAM_SLOT = int(_os.environ.get('LEDN_SEAM_SLOT', '0'))     # stream of the SEAM edge map: 0 = main (measured 895 vs 878 img/s on its own stream; round 3: 1225 vs 1204)
 MFAF_FORK = int(_os.environ.get('LEDN_MFAF_FORK', '0'))   # measured: 785 vs 876 img/s with the forks in TRAINING (inference gains 4 %: blocks.MFAF)
 
 
