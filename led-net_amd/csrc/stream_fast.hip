@@ -364,8 +364,11 @@ int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
     if (d.P * d.C / 8 < 4096) return -1;
     constexpr int UNR = 4;
     const int rows = 256 / (d.C >> 3);
-    long nb = cdiv(d.P, (long)rows * UNR);           // one trip per lane up to 2048 workgroups
-    if (nb > 2048) nb = 2048;
+    // one trip per lane up to 1024 workgroups = ONE resident round (4 workgroups per CU by the 34 KB of LDS); whole step,
+    // one box: cap 2048 13.13 ms, 1280 13.19, 1024 13.03 (three runs each), 768 13.05, 512 13.11  (LEDN_BNR_CAP: A/B knob)
+    long nb = cdiv(d.P, (long)rows * UNR);
+    static const long cap = getenv("LEDN_BNR_CAP") ? atol(getenv("LEDN_BNR_CAP")) : 1024;
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     float* part = d.rows ? nullptr : ws_take(nb * 3 * d.C);
     if (!part && !d.rows) return -1;
