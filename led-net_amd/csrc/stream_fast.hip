@@ -365,7 +365,9 @@ int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
     constexpr int UNR = 4;
     const int rows = 256 / (d.C >> 3);
     // one trip per lane up to 1024 workgroups = ONE resident round (4 workgroups per CU by the 34 KB of LDS); whole step,
-    // one box: cap 2048 13.13 ms, 1280 13.19, 1024 13.03 (three runs each), 768 13.05, 512 13.11  (LEDN_BNR_CAP: A/B knob)
+    // one box: cap 2048 13.13 ms, 1280 13.19, 1024 13.03 (three runs each), 768 13.05, 512 13.11  (LEDN_BNR_CAP: A/B knob).
+    // A second register buffer (next trip's loads issued before this trip's arithmetic; plain / ReLU variants, 124 VGPRs)
+    // measured 13.15 against 13.08 ms, three alternating runs: not kept.
     long nb = cdiv(d.P, (long)rows * UNR);
     static const long cap = getenv("LEDN_BNR_CAP") ? atol(getenv("LEDN_BNR_CAP")) : 1024;
     if (nb > cap) nb = cap;
