@@ -161,8 +161,10 @@ int ledn_abi_version(void) { return LEDN_ABI_VERSION; }
 
 int ledn_set_workspace(void* ptr, long long nfloats) {
     if (nfloats < 0 || (ptr == nullptr) != (nfloats == 0)) return LEDN_EINVAL;
-    workspace().ptr = (float*)ptr;
-    workspace().nfloats = (long)nfloats;
+    // the process default (streams without a binding pick it up in enter_stream) and this thread's current view
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    g_ws = Workspace{(float*)ptr, (long)nfloats};
+    if (g_ws_by_stream.find(tls_stream) == g_ws_by_stream.end()) tls_ws = g_ws;
     return LEDN_OK;
 }
 

@@ -1343,6 +1343,7 @@ int stem_conv_wgrad_impl(const void* x, int dtype_x, const void* dz, float* dw, 
     const long cap = (long)options().conv_workgroups * 2;
     if (nb > cap) nb = cap;
     a.part = ws_take(nb * 864);
+    if (!a.part) return LEDN_EINVAL;        // the kernel writes its partial tiles unconditionally: no workspace, no launch
     if (dtype_x == LEDN_U8) LEDN_LAUNCH((stem_wgrad_reg_kernel<unsigned char>), dim3((unsigned)nb), dim3(256), 0, s, a);
     else if (dtype_x == LEDN_F32) LEDN_LAUNCH((stem_wgrad_reg_kernel<float>), dim3((unsigned)nb), dim3(256), 0, s, a);
     else if (dtype_x == LEDN_BF16) LEDN_LAUNCH((stem_wgrad_reg_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, s, a);

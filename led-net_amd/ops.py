@@ -412,25 +412,33 @@ class WgradDefer:
     convolution on the critical stream: ~55 per step).  The buffers and the device table persist from step to step
     (the same convolutions arrive in the same order), so a captured hipGraph replays them unchanged."""
     active = False
-    bufs = {}          # (dw.data_ptr(), floats) -> partial-tile buffer
-    pending = []       # [(key, WgradFinishEntry)] of the current step
-    table = None       # (keys, device table tensor, host keep-alive, n, total_chunks)
+    bufs = {}          # (dw.data_ptr(), floats) -> partial-tile buffer (persistent: nbx * pairs * KK * 1024 floats per convolution)
+    pending = []       # [(key, WgradFinishEntry, buffer)] of the current step
+    tables = {}        # keys -> (device table, entries, total chunks, reference tensor, pinned host staging buffer)
 
     @staticmethod
     def reset():
-        WgradDefer.active, WgradDefer.bufs, WgradDefer.pending, WgradDefer.table = False, {}, [], None
+        WgradDefer.active, WgradDefer.bufs, WgradDefer.pending, WgradDefer.tables = False, {}, [], {}
 
     @staticmethod
     def finish():
-        """sum every recorded convolution's partial tiles into its gradient sink: one launch"""
+        """sum every recorded convolution's partial tiles into its gradient sink: one launch.  A step may call this
+        more than once with different sets (the overlapped gradient exchange flushes the non-stem convolutions first,
+        the stem's follow at the end of the backward): every set has its own table, built once in the eager warm-up
+        steps and kept -- with its host staging buffer -- for as long as the buffers live, so a captured graph never
+        sees a host-to-device copy, nor a table freed under a recorded launch."""
         pend = WgradDefer.pending
         if not pend:
             return
         WgradDefer.pending = []
         lib = _lib.get_lib()
         keys = tuple(p[0] for p in pend)
-        tab = WgradDefer.table
-        if tab is None or tab[0] != keys:
+        tab = WgradDefer.tables.get(keys)
+        if tab is None:
+            dev = pend[0][2].device
+            if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                raise LednError('WgradDefer.finish: a new set of weight gradients arrived inside a graph capture '
+                                '(run the same step eagerly first: Trainer.capture does)')
             arr = (_lib.WgradFinishEntry * len(pend))()
             chunk = 0
             for i, (_, e, _buf) in enumerate(pend):
@@ -438,10 +446,11 @@ class WgradDefer:
                 arr[i].chunk0 = chunk
                 chunk += e.pairs * e.KK * 16
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            tab = WgradDefer.table = (keys, host.to(pend[0][2].device), len(pend), chunk, pend[0][2])
-        ref = tab[4]
-        _run(lib, 'ledn_conv2d_wgrad_finish_multi', ref, tab[1].data_ptr(), tab[2], tab[3],
-             work=_TIMING is not None and (f'wgrad_finish_multi x{tab[2]}', 0, 0, 'conv_wgrad_finish_multi_kernel'))
+            if dev.type == 'cuda':
+                host = host.pin_memory()
+            tab = WgradDefer.tables[keys] = (host.to(dev), len(pend), chunk, pend[0][2], host)
+        _run(lib, 'ledn_conv2d_wgrad_finish_multi', tab[3], tab[0].data_ptr(), tab[1], tab[2],
+             work=_TIMING is not None and (f'wgrad_finish_multi x{tab[1]}', 0, 0, 'conv_wgrad_finish_multi_kernel'))
 
 
 def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None,
@@ -479,6 +488,11 @@ def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None,
         nfl = int(lib.cdll.ledn_conv2d_wgrad_partial_floats(d))
         if nfl > 0:
             key = (dw.data_ptr(), nfl)
+            if any(p[0] == key for p in WgradDefer.pending):
+                # the same weight applied twice before its gradients were summed (a shared module): one partial buffer
+                # and one table entry per weight -- the second use takes the immediate path, which accumulates
+                nfl = 0
+        if nfl > 0:
             buf = WgradDefer.bufs.get(key)
             if buf is None:
                 buf = WgradDefer.bufs[key] = torch.empty(nfl, dtype=torch.float32, device=x.device)

@@ -1603,6 +1603,7 @@ class Trainer:
         if tag == 'post_stem' and self._ready[tag] == 3 and not self._early_done:
             self._early_done = True
             _DwBanks.flush()            # (every depthwise filter lives outside the stem: their gradients are complete)
+            self._join_side_streams()   # (LEDN_WGRAD_SLOT: the partial tiles are written on the auxiliary stream)
             ops.WgradDefer.finish()     # (and the non-stem convolution weight gradients: summed into the buffer now)
             self._exchange(self.n_late, self.flat_grad.numel())
 
@@ -1626,8 +1627,8 @@ class Trainer:
                 total = v if total is None else total + v
         total.backward()
         _DwBanks.flush()                    # all depthwise bank gradients -> the filters' gradient views, one launch
+        self._join_side_streams()           # (the summing launch reads partial tiles an auxiliary stream may have written)
         ops.WgradDefer.finish()             # all convolution weight gradients: partial tiles -> gradient views, one launch
-        self._join_side_streams()
         if first:
             # Parameters that never receive a gradient (SEAM conv_1: the binarised edge
             # map is non-differentiable) are skipped, as torch.optim.SGD skips grad=None.
@@ -1698,6 +1699,7 @@ class Trainer:
         self._static_samples = [SegDataSample(gt=self._static_lab[i], metainfo=dict(getattr(ds, 'metainfo', {}) or {}))
                                 for i, ds in enumerate(data_samples)]
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._valid_host = None         # (a second capture() starts from the new batch's padding extents)
         if inputs.dtype == torch.uint8 and getattr(self.model, 'pre_scale', None) is not None:
             # per-image valid extents (batch padding) live in a resident buffer the graph reads: replay() refreshes it
             self.model._valid_static = self.model.valid_extents(inputs.shape[2:], data_samples, inputs.shape[0]).to(dev)
@@ -1748,7 +1750,7 @@ class Trainer:
             else:
                 for i, lb in enumerate(labs):
                     self._static_lab[i].copy_(lb, non_blocking=True)
-            if self.model._valid_static is not None:
+            if getattr(self.model, '_valid_static', None) is not None:
                 ext = self.model.valid_extents(inputs.shape[2:], data_samples, inputs.shape[0])
                 if getattr(self, '_valid_host', None) is None or not torch.equal(ext, self._valid_host):
                     self._valid_host = ext

@@ -137,3 +137,33 @@ def test_two_streams_keep_their_own_workspace():
         torch.testing.assert_close(st[0], x.float().sum((0, 1, 2)), rtol=1e-3, atol=1e-2)
         assert lib.cdll.ledn_bind_workspace(sa, None, 0) == 0 and lib.cdll.ledn_bind_workspace(sb, None, 0) == 0
         del used_a
+
+
+def test_set_workspace_alone_serves_unbound_streams():
+    """ledn_set_workspace keeps the PROCESS DEFAULT scratch: a caller that never binds a stream (the C micro-benchmarks
+    under tools/micro) must get its partial rows there -- round 3's setter only wrote the calling thread's snapshot,
+    which the next entry point overwrote with the still-empty default."""
+    import ctypes as C
+    from conftest import bind_emu
+    with bind_emu() as lib:
+        ws = torch.zeros(1 << 16)
+        s = C.c_void_p(0x30)                                     # a stream nobody bound
+        assert lib.cdll.ledn_bind_workspace(s, None, 0) == 0
+        assert lib.cdll.ledn_set_workspace(C.c_void_p(ws.data_ptr()), C.c_longlong(ws.numel())) == 0
+        try:
+            x = torch.randn(4, 64, 64, 8).bfloat16()         # 16 K pixels: the streaming statistics kernel, partial rows
+            st = (torch.zeros(8), torch.zeros(8))
+            lib.call('ledn_channel_stats', x.data_ptr(), None, x.numel() // 8, 8, 1, st[0].data_ptr(), st[1].data_ptr(), s)
+            assert bool(ws.abs().sum() > 0), 'the default workspace was not used by a launch on an unbound stream'
+            torch.testing.assert_close(st[0], x.float().sum((0, 1, 2)), rtol=1e-3, atol=5e-2)
+            # the stem weight gradient writes its partial tiles unconditionally: without any workspace it must refuse
+            assert lib.cdll.ledn_set_workspace(None, C.c_longlong(0)) == 0
+            img = torch.zeros(1, 3, 16, 16, dtype=torch.uint8)
+            dz = torch.zeros(1, 8, 8, 32).bfloat16()
+            dw = torch.zeros(32, 3, 3, 3)
+            rc = lib.cdll.ledn_stem_conv_wgrad(C.c_void_p(img.data_ptr()), 2, C.c_void_p(dz.data_ptr()),
+                                               C.c_void_p(dw.data_ptr()), 1, 16, 16, 3, 8, 8, 32, None, None, None, None,
+                                               C.c_float(0.0), s)
+            assert rc == 1, 'ledn_stem_conv_wgrad without a workspace must return LEDN_EINVAL'
+        finally:
+            lib.cdll.ledn_set_workspace(None, C.c_longlong(0))

@@ -138,6 +138,11 @@ def main():
                           meta=dict(iter=it, dataset_meta=dict(classes=('background', 'foreground'), palette=None)))
 
     use_graph = not args.eager
+    if use_graph and trainer.dist is not None and trainer.comm is None:
+        # 'auto' collectives fell back to torch.distributed: its all-reduces cannot be recorded into a hipGraph
+        print('[tools/train.py] direct RCCL communicator unavailable: training with eager launches (as --eager)',
+              file=sys.stderr, flush=True)
+        use_graph = False
     if start < max_iters and use_graph:
         # capture on the first batch, free of side effects (restore=True: weights, momentum, running statistics and
         # the iteration counter are put back after the warm-up steps): the loop below replays every iteration of
