@@ -247,6 +247,8 @@ def main():
     ap.add_argument('--local-bn', action='store_true',
                     help='N>1: per-rank BatchNorm statistics instead of the config\'s SyncBN (one all-reduce per BN and direction)')
     ap.add_argument('--backbone', default='', help="reconstruction flags of LEDNet as key=value,... (e.g. cespb_depth=(2,3),context_tail='pappm'); default: the survey's contract")
+    ap.add_argument('--deterministic', action='store_true',
+                    help='run the whole bench in deterministic mode (LEDN_OPT_DETERMINISTIC: fixed-order reductions, no f32 atomics)')
     ap.add_argument('--trace-only', action='store_true',
                     help='stop after the timed region (for rocprofv3 timeline traces: no instrumented eager pass, no JSON)')
     args = ap.parse_args()
@@ -277,6 +279,8 @@ def main():
 
     import led_net_amd as L
     from led_net_amd import ops
+    if args.deterministic:
+        L.set_deterministic(True)
     has_train = hasattr(L, 'Trainer')
     mode = args.mode or ('train' if has_train else 'infer')
     bs = args.batch or (16 if mode == 'train' else 8)
@@ -478,6 +482,26 @@ def main():
                        'gpu_busy_frac': round(gpu_ms / k_steps / (dt / args.steps * 1e3), 3)},
             'roofline': roof,
         }
+        out['config']['deterministic'] = bool(L.is_deterministic())
+        if mode == 'train' and world == 1 and graphed and not L.is_deterministic():
+            # the price of deterministic mode on this box, measured after the timed region: the same step re-captured
+            # with every reduction in a fixed order (partial rows + ordered summing launches instead of f32 atomics)
+            try:
+                L.set_deterministic(True)
+                trainer.capture(img, samples, warmup=2)
+                for _ in range(3):
+                    trainer.replay()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    trainer.replay()
+                torch.cuda.synchronize(dev)
+                out['deterministic_mode'] = {'ms_per_step': round((time.perf_counter() - t1) / 10 * 1e3, 3), 'steps': 10,
+                                             'default_ms_per_step': out['ms_per_step']}
+            except Exception as e:   # noqa: BLE001 -- a note, never the bench line
+                out['deterministic_mode'] = {'error': repr(e)}
+            finally:
+                L.set_deterministic(False)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(mode, H, W, args.cpu_baseline_seconds)
             try:

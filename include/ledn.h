@@ -51,7 +51,7 @@ int ledn_bind_workspace(void* stream, void* ptr, long long nfloats);
 enum {
     LEDN_OPT_CONV_WORKGROUPS = 0,   /* persistent workgroups of the MFMA conv (default 512) */
     LEDN_OPT_WGRAD_WORKGROUPS = 1,  /* pixel-range workgroups of the MFMA weight gradient (default 512) */
-    LEDN_OPT_STREAM_FAST = 2        /* bit mask, default 91.  bit 0: 16-B-per-lane streaming kernels (csrc/stream_fast.hip) for
+    LEDN_OPT_STREAM_FAST = 2,       /* bit mask, default 91.  bit 0: 16-B-per-lane streaming kernels (csrc/stream_fast.hip) for
                                        the bf16 elementwise / BatchNorm passes; bit 1: LDS-tiled depthwise 3x3
                                        (csrc/dwconv.hip); bit 2: MFMA conv tiles handed out round-robin instead of
                                        as contiguous ranges (off); bit 3: 8-row MFMA conv tiles when a launch has fewer
@@ -64,6 +64,17 @@ enum {
                                        forward convolution on that kernel too (measured slower than conv_mfma_kernel's narrow epilogue); bit 8 (off): 3x3 stride-1
                                        convolutions with 64 input channels through a wave-private LDS ring (conv3x3_ring64_kernel: measured 10 % slower);
                                        0: the generic kernels (A/B measurements); < 0: the default mask */
+    LEDN_OPT_DETERMINISTIC = 3      /* 1: every cross-workgroup reduction of the library (BatchNorm statistics and their
+                                       backward sums, weight / bias gradients, pooled contexts and their gradients, the
+                                       attention's bias gradient and the gradients of reflect-padded windows) runs in a
+                                       FIXED order: per-workgroup partial rows in the bound workspace + an ordered summing
+                                       launch instead of f32 atomics, whatever the grid size; an entry point that cannot
+                                       (no workspace bound, non-natural dW strides) returns LEDN_EINVAL instead of falling
+                                       back to atomics.  Two runs of the same step on the same device are then bit-identical,
+                                       eager or replayed from a hipGraph (PyTorch's deterministic mode, which the reference
+                                       stack offers as randomness=dict(seed=.., deterministic=True): configs/LED_Net/
+                                       ddrnet_23_in1k-pre_2xb6-120k_cityscapes-1024x1024.py:100).  0 (default): small grids
+                                       end in bounded atomics. */
 };
 int ledn_set_option(int option, long long value);
 

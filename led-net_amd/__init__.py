@@ -5,6 +5,7 @@ Public surface = the reference's plugin names:
 Compute is in csrc/libledn_hip.so (C ABI: include/ledn.h); there is no CPU path.
 """
 from . import _lib, ops  # noqa: F401
+from ._lib import is_deterministic, set_deterministic  # noqa: F401
 from .registry import BACKBONES, HEADS, LOSSES, MODELS, SEGMENTORS, register_into_mmseg  # noqa: F401
 from .lednet import LEDNet
 from .led_head import LEDHead

@@ -17,7 +17,7 @@ OK, EINVAL, ELAUNCH = 0, 1, 2
 F32, BF16, U8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_GATE = 0, 1, 2
-OPT_CONV_WORKGROUPS, OPT_WGRAD_WORKGROUPS, OPT_STREAM_FAST = 0, 1, 2
+OPT_CONV_WORKGROUPS, OPT_WGRAD_WORKGROUPS, OPT_STREAM_FAST, OPT_DETERMINISTIC = 0, 1, 2, 3
 
 vp, fp, i32, i64 = C.c_void_p, C.c_void_p, C.c_int, C.c_longlong
 
@@ -278,6 +278,23 @@ class Library:
 
 _hip = None
 _override = None
+# deterministic mode (include/ledn.h LEDN_OPT_DETERMINISTIC): every cross-workgroup reduction in a fixed order, no f32
+# atomics -- two runs of a step are bit-identical.  LEDN_DETERMINISTIC=1 or set_deterministic(True); the reference stack's
+# switch for the same thing is randomness=dict(seed=..., deterministic=True) (mmengine Runner -> torch.use_deterministic_algorithms)
+_DET = bool(int(os.environ.get('LEDN_DETERMINISTIC', '0')))
+
+
+def set_deterministic(flag=True):
+    """switch the library's deterministic mode on / off (for the library in use now and any loaded later)"""
+    global _DET
+    _DET = bool(flag)
+    for lib in (_hip, _override):
+        if lib is not None:
+            lib.set_option(OPT_DETERMINISTIC, int(_DET))
+
+
+def is_deterministic():
+    return _DET
 
 
 def get_lib():
@@ -292,6 +309,7 @@ def get_lib():
                 _hip.set_option(opt, int(os.environ[env]))
         if os.environ.get('LEDN_STREAM_FAST') is not None:      # A/B measurements: bit 0 = BatchNorm / affine streaming
             _hip.set_option(OPT_STREAM_FAST, int(os.environ['LEDN_STREAM_FAST']))   # kernels, bit 1 = LDS-tiled depthwise 3x3
+        _hip.set_option(OPT_DETERMINISTIC, int(_DET))
     return _hip
 
 
@@ -301,6 +319,7 @@ def use_library(lib):
     global _override
     prev = _override
     _override = lib
+    lib.set_option(OPT_DETERMINISTIC, int(_DET))
     try:
         yield lib
     finally:

@@ -21,7 +21,7 @@ template <typename T, int D, bool PADDED>
 __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T* qkv, const float* biasT, const T* dout,
                                                              float* dqkv, float* dbiasT, int N, int H,
                                                              int W, int C, int heads, int hh, int ww,
-                                                             float* part) {
+                                                             float* part, float* pad_out) {
     // LDS per wavefront: K, V, Q, dO (16 KB at D = 16) + ONE 64 x 65 score matrix that holds P and is then
     // overwritten by dS (dV = P^T dO is taken in between), the bias-gradient rows live in registers:
     // 33 KB -> four wavefronts per CU (the first version kept P, dS and the bias rows in LDS: 66 KB, two
@@ -139,7 +139,12 @@ __global__ void __launch_bounds__(64) window_attn_bwd_kernel(const T* qkv, const
         float* o = dqkv + src * (3L * C) + head * D;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            if (PADDED) {
+            if (PADDED && pad_out) {    // deterministic mode: every padded position is stored once, window_attn_fold_kernel
+                float* po = pad_out + (((long)n * (hh * WS) + y) * (ww * WS) + x) * (3L * C) + head * D;   // adds the copies
+                po[j] = dq[j] * scale;
+                po[C + j] = dk[j] * scale;
+                po[2 * C + j] = dv[j];
+            } else if (PADDED) {
                 atomicAdd(o + j, dq[j] * scale);
                 atomicAdd(o + C + j, dk[j] * scale);
                 atomicAdd(o + 2 * C + j, dv[j]);
@@ -366,6 +371,26 @@ __global__ void __launch_bounds__(64) window_attn_bwd_mfma_kernel(const bf16_t* 
             }
 }
 
+// reflect-padded windows, deterministic mode: dqkv[n, ys, xs, :] += the gradients of the (up to four) padded positions whose
+// source pixel is (ys, xs) -- itself, its mirror image in the bottom band, in the right band, in the corner -- in that order
+__global__ void __launch_bounds__(256) window_attn_fold_kernel(const float* pad, float* dqkv, int N, int H, int W, int Hp,
+                                                               int Wp, int C3) {
+    const long total = (long)N * H * W * C3;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C3);
+    const long pix = idx / C3;
+    const int xs = (int)(pix % W), ys = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    const int ym = 2 * H - 2 - ys, xm = 2 * W - 2 - xs;
+    const bool my = ym >= H && ym < Hp, mx = xm >= W && xm < Wp;
+    const float* base = pad + (long)n * Hp * Wp * C3 + c;
+    float t = base[((long)ys * Wp + xs) * C3];
+    if (my) t += base[((long)ym * Wp + xs) * C3];
+    if (mx) t += base[((long)ys * Wp + xm) * C3];
+    if (my && mx) t += base[((long)ym * Wp + xm) * C3];
+    dqkv[idx] += t;
+}
+
 int window_attn_bwd_impl(const void* qkv, const float* biasT, const void* dout, float* dqkv, float* dbiasT,
                          int N, int H, int W, int C, int heads, int ws, int dtype, hipStream_t s) {
     LEDN_REQUIRE(qkv && biasT && dout && dqkv && dbiasT && N > 0 && H > 0 && W > 0 && C > 0 && heads > 0);
@@ -376,7 +401,11 @@ int window_attn_bwd_impl(const void* qkv, const float* biasT, const void* dout, 
     const bool padded = (H % ws) || (W % ws);
     long nb = (long)N * hh * ww;
     if (nb > 256) nb = 256;                                   // wavefronts per head (each walks its windows)
-    float* part = nb > 8 ? ws_take(nb * heads * 64 * 64) : nullptr;
+    const long part_floats = nb * heads * 64 * 64;
+    const long pad_floats = (padded && det()) ? (long)N * hh * ws * ww * ws * 3 * C : 0;
+    float* part = (nb > 8 || det()) ? ws_take(part_floats + pad_floats) : nullptr;
+    if (det() && !part) return LEDN_EINVAL;
+    float* pad_out = pad_floats ? part + part_floats : nullptr;
     if (!part && nb > 32) nb = 32;                            // atomics fallback: <= 32 per table entry
     const dim3 grid((unsigned)nb, (unsigned)heads);
     if (dtype == LEDN_BF16 && D == 16 && !padded && C % 8 == 0) {   // matrix-core variant
@@ -389,10 +418,10 @@ int window_attn_bwd_impl(const void* qkv, const float* biasT, const void* dout, 
     do {                                                                                                \
         if (padded)                                                                                     \
             LEDN_LAUNCH((window_attn_bwd_kernel<T, DD, true>), grid, dim3(64), 0, s, (const T*)qkv, biasT, \
-                        (const T*)dout, dqkv, dbiasT, N, H, W, C, heads, hh, ww, part);                 \
+                        (const T*)dout, dqkv, dbiasT, N, H, W, C, heads, hh, ww, part, pad_out);        \
         else                                                                                            \
             LEDN_LAUNCH((window_attn_bwd_kernel<T, DD, false>), grid, dim3(64), 0, s, (const T*)qkv, biasT, \
-                        (const T*)dout, dqkv, dbiasT, N, H, W, C, heads, hh, ww, part);                 \
+                        (const T*)dout, dqkv, dbiasT, N, H, W, C, heads, hh, ww, part, (float*)nullptr); \
     } while (0)
 #define LEDN_WBD(T)                        \
     do {                                   \
@@ -406,6 +435,11 @@ int window_attn_bwd_impl(const void* qkv, const float* biasT, const void* dout, 
     else return LEDN_EINVAL;
 #undef LEDN_WBD
 #undef LEDN_WB
+    if (pad_out) {
+        const long total = (long)N * H * W * 3 * C;
+        LEDN_LAUNCH(window_attn_fold_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, pad_out, dqkv, N, H, W,
+                    hh * ws, ww * ws, 3 * C);
+    }
     if (part) return finish_partials(part, (int)nb, heads * 64 * 64, 1, dbiasT, nullptr, nullptr, s);
     return check_launch();
 }

@@ -239,7 +239,7 @@ int bn_act_bwd_reduce_impl(const ledn_bnbwd_desc& d0, hipStream_t s) {
     long nb = cdiv(d.P, bn_rows(d) * 8);
     float* part = nullptr;
     if (nb > 2048) nb = 2048;
-    if (nb > 64) part = ws_take(nb * 3 * d.C);
+    if (nb > 64 || det()) part = ws_take(nb * 3 * d.C);
     if (!part && nb > 256) nb = 256;     // atomics fallback: keep the grid bounded
     const dim3 grid((unsigned)nb);
     LEDN_BNB_DISPATCH(bn_bwd_reduce_kernel, d, part);
@@ -600,7 +600,7 @@ int dw_bwd_weight_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
         const int rows = 256 / (d.C / 4);
         long nb = cdiv(npix, rows * 8);
         if (nb > 1024) nb = 1024;
-        float* part = nb > 32 ? ws_take(nb * 9 * d.C) : nullptr;
+        float* part = (nb > 32 || det()) ? ws_take(nb * 9 * d.C) : nullptr;
         if (!part && nb > 128) nb = 128;
         const dim3 g3((unsigned)nb);
         if (d.dtype == LEDN_F32) LEDN_LAUNCH((dw_bwd_weight3x3_kernel<float, 4>), g3, dim3(256), 0, s, d, part);
@@ -614,7 +614,7 @@ int dw_bwd_weight_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
         long ppb = cdiv(npix * d.KH, 4096);
         ppb = cdiv(ppb < 64 ? 64 : ppb, rows) * rows;
         long nbx = cdiv(npix, ppb);
-        float* part = nbx > 8 ? ws_take(nbx * d.KH * 8 * d.C) : nullptr;
+        float* part = (nbx > 8 || det()) ? ws_take(nbx * d.KH * 8 * d.C) : nullptr;
         if (!part && nbx > 64) {
             ppb = cdiv(cdiv(npix, 64), rows) * rows;
             nbx = cdiv(npix, ppb);
@@ -632,7 +632,7 @@ int dw_bwd_weight_impl(const ledn_dwbwd_desc& d, hipStream_t s) {
     long ppb = cdiv(npix * taps, 8192);
     if (ppb < 128) ppb = 128;
     long nbx = cdiv(npix, ppb);
-    float* part = nbx > 8 ? ws_take(nbx * taps * d.C) : nullptr;
+    float* part = (nbx > 8 || det()) ? ws_take(nbx * taps * d.C) : nullptr;
     if (!part) {
         ppb = cdiv(npix * taps, 2048);
         if (ppb < 128) ppb = 128;
@@ -815,7 +815,7 @@ int pyr_bwd_weight_impl(const ledn_pyrbwd_desc& d, hipStream_t s) {
     const int rows = 256 / cvn;
     long nb = cdiv(npix, rows * 8);
     if (nb > 512) nb = 512;
-    float* part = nb > 32 ? ws_take(nb * 36 * d.n) : nullptr;
+    float* part = (nb > 32 || det()) ? ws_take(nb * 36 * d.n) : nullptr;
     if (!part && nb > 128) nb = 128;
     const dim3 grid((unsigned)nb, 4u);
 #define LEDN_K(T)                                                                              \
@@ -1163,7 +1163,7 @@ int getb_pool_bwd_impl(const void* dout, void* da, int N, int H, int W, int C, i
 // otherwise receive one same-address atomic per pixel.
 constexpr int MFAF_SEG = 128, MFAF_SLOTS = 18;
 template <typename T, int V>
-__global__ void __launch_bounds__(256) mfaf_gate_bwd_kernel(ledn_mfafbwd_desc d) {
+__global__ void __launch_bounds__(256) mfaf_gate_bwd_kernel(ledn_mfafbwd_desc d, int ctx_sums) {
     __shared__ float s_ctx[4 * MFAF_SLOTS * 128];
     const int cvn = d.C / V;
     const int slots = 256 / cvn;
@@ -1214,7 +1214,7 @@ __global__ void __launch_bounds__(256) mfaf_gate_bwd_kernel(ledn_mfafbwd_desc d)
                 if (sx > S - 1) sx = S - 1;
                 const int slot = sx - sx_first[k];
                 if (slot != cur[k]) {
-                    if (cur[k] >= 0) {
+                    if (cur[k] >= 0 && ctx_sums) {
 #pragma unroll
                         for (int v = 0; v < V; ++v) {
                             atomicAdd(&s_ctx[(k * MFAF_SLOTS + cur[k]) * d.C + c + v], acc[k][v]);
@@ -1255,11 +1255,12 @@ __global__ void __launch_bounds__(256) mfaf_gate_bwd_kernel(ledn_mfafbwd_desc d)
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (cur[k] >= 0) {
+            if (cur[k] >= 0 && ctx_sums) {
 #pragma unroll
                 for (int v = 0; v < V; ++v) atomicAdd(&s_ctx[(k * MFAF_SLOTS + cur[k]) * d.C + c + v], acc[k][v]);
             }
     }
+    if (!ctx_sums) return;      // deterministic mode: mfaf_dctx_det_kernel sums ds per context cell in a fixed order
     __syncthreads();
     for (int k = 0; k < 4; ++k) {
         const int S = d.ctx_size[k];
@@ -1275,6 +1276,59 @@ __global__ void __launch_bounds__(256) mfaf_gate_bwd_kernel(ledn_mfafbwd_desc d)
     }
 }
 
+// Deterministic form of the context-map gradients: dctx[k][n, cy, cx, :] += sum of ds over the pixels whose nearest-
+// upsampling source is that cell (the same float index rule as the gate kernels), one workgroup per (cell, level):
+// thread = (4 channels, pixel slot), slots walk the cell's rectangle in a fixed order, LDS tree in slot order.
+template <typename T>
+__global__ void __launch_bounds__(256) mfaf_dctx_det_kernel(ledn_mfafbwd_desc d, int level) {
+    __shared__ float s_acc[256 * 4];
+    const int S = d.ctx_size[level];
+    const int cell = blockIdx.x % (S * S), n = blockIdx.x / (S * S);
+    const int cy = cell / S, cx = cell % S;
+    const int cvn = d.C / 4, slots = 256 / cvn;
+    const int cv = threadIdx.x % cvn, slot = threadIdx.x / cvn;
+    // rows / columns of the cell: y with min(int(y * S / H), S - 1) == cy  (monotone: a contiguous range)
+    __shared__ int s_box[4];
+    if (threadIdx.x < 2) {
+        const int L = threadIdx.x == 0 ? d.H : d.W, want = threadIdx.x == 0 ? cy : cx;
+        int lo = L, hi = -1;
+        for (int i = 0; i < L; ++i) {
+            int t = (int)((float)i * ((float)S / (float)L));
+            if (t > S - 1) t = S - 1;
+            if (t == want) {
+                if (i < lo) lo = i;
+                hi = i;
+            }
+        }
+        s_box[threadIdx.x * 2] = lo;
+        s_box[threadIdx.x * 2 + 1] = hi;
+    }
+    __syncthreads();
+    const int y0 = s_box[0], y1 = s_box[1], x0 = s_box[2], x1 = s_box[3];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (slot < slots && y1 >= y0 && x1 >= x0) {
+        const int bw = x1 - x0 + 1, np = (y1 - y0 + 1) * bw;
+        for (int p = slot; p < np; p += slots) {
+            const int y = y0 + p / bw, x = x0 + p % bw;
+            float t[4];
+            ldv<4>(reinterpret_cast<const T*>(d.ds) + (((long)n * d.H + y) * d.W + x) * d.C + cv * 4, t);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] += t[v];
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s_acc[threadIdx.x * 4 + v] = acc[v];
+    __syncthreads();
+    if (threadIdx.x < cvn) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float t = 0.f;
+            for (int sl = 0; sl < slots; ++sl) t += s_acc[(sl * cvn + threadIdx.x) * 4 + v];
+            d.dctx[level][((long)n * S * S + cell) * d.C + threadIdx.x * 4 + v] += t;
+        }
+    }
+}
+
 int mfaf_gate_bwd_impl(const ledn_mfafbwd_desc& d, hipStream_t s) {
     LEDN_REQUIRE(d.x && d.r && d.xl && d.dout && d.dx && d.dr && d.ds);
     LEDN_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.C % 4 == 0 && d.C <= 128);
@@ -1286,9 +1340,17 @@ int mfaf_gate_bwd_impl(const ledn_mfafbwd_desc& d, hipStream_t s) {
     }
     for (int k = 0; k < 5; ++k) LEDN_REQUIRE(d.scale[k] && d.shift[k]);
     const dim3 grid((unsigned)(d.N * d.H), (unsigned)cdiv(d.W, MFAF_SEG));
-    if (d.dtype == LEDN_F32) LEDN_LAUNCH((mfaf_gate_bwd_kernel<float, 4>), grid, dim3(256), 0, s, d);
-    else if (d.dtype == LEDN_BF16) LEDN_LAUNCH((mfaf_gate_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, d);
-    else return LEDN_EINVAL;
+    const int ctx_sums = det() ? 0 : 1;
+    if (d.dtype != LEDN_F32 && d.dtype != LEDN_BF16) return LEDN_EINVAL;
+    if (d.dtype == LEDN_F32) LEDN_LAUNCH((mfaf_gate_bwd_kernel<float, 4>), grid, dim3(256), 0, s, d, ctx_sums);
+    else LEDN_LAUNCH((mfaf_gate_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, s, d, ctx_sums);
+    if (!ctx_sums) {
+        for (int k = 0; k < 4; ++k) {
+            const dim3 g2((unsigned)(d.N * d.ctx_size[k] * d.ctx_size[k]));
+            if (d.dtype == LEDN_F32) LEDN_LAUNCH((mfaf_dctx_det_kernel<float>), g2, dim3(256), 0, s, d, k);
+            else LEDN_LAUNCH((mfaf_dctx_det_kernel<bf16_t>), g2, dim3(256), 0, s, d, k);
+        }
+    }
     return check_launch();
 }
 

@@ -146,7 +146,7 @@ static hipStream_t enter_stream(void* stream) {         // every extern "C" entr
     return (hipStream_t)stream;
 }
 Workspace& workspace() { return tls_ws; }
-static Options g_opt = {512, 512, 91};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3, bit 2 round-robin conv tiles (off), bit 3 8-row conv tiles for under-filled grids, bit 4 register-direct 1x1 conv (conv1x1.hip), bit 5 resident 3x3 weights for 32 < Cin <= 64 (off: measured slower, r3l), bit 6 register-direct 3x3 conv for 32 input channels (conv3x3.hip)
+static Options g_opt = {512, 512, 91, 0};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3, bit 2 round-robin conv tiles (off), bit 3 8-row conv tiles for under-filled grids, bit 4 register-direct 1x1 conv (conv1x1.hip), bit 5 resident 3x3 weights for 32 < Cin <= 64 (off: measured slower, r3l), bit 6 register-direct 3x3 conv for 32 input channels (conv3x3.hip)
 Options& options() { return g_opt; }
 static thread_local DeferredStats g_defer = {false, nullptr, 0};
 DeferredStats& deferred_stats() { return g_defer; }
@@ -182,6 +182,7 @@ int ledn_set_option(int option, long long value) {
         case LEDN_OPT_CONV_WORKGROUPS: options().conv_workgroups = value > 0 ? (int)value : 512; return LEDN_OK;
         case LEDN_OPT_WGRAD_WORKGROUPS: options().wgrad_workgroups = value > 0 ? (int)value : 512; return LEDN_OK;
         case LEDN_OPT_STREAM_FAST: options().stream_fast = value < 0 ? 91 : (int)value; return LEDN_OK;   // (< 0: the default mask)
+        case LEDN_OPT_DETERMINISTIC: options().deterministic = value > 0 ? 1 : 0; return LEDN_OK;
         default: return LEDN_EINVAL;
     }
 }

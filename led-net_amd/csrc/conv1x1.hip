@@ -304,7 +304,7 @@ static int c11_launch(C11Args a, hipStream_t s) {
     long nb = cdiv(a.iters, 4);
     const long cap = (long)options().conv_workgroups * OCC;                  // default 512 x OCC: two rounds of resident workgroups
     if (nb > cap) nb = cap;
-    a.part = (EPI == C11_STATS && a.stat_sum && nb > 16) ? ws_take(nb * 2 * a.Cout) : nullptr;
+    a.part = (EPI == C11_STATS && a.stat_sum && (nb > 16 || det())) ? ws_take(nb * 2 * a.Cout) : nullptr;
     const bool pro = a.in_scale || a.in_act != LEDN_ACT_NONE;
     if constexpr (NKS <= 2) {        // (prologue coefficients: 24 VGPRs per k-step -- offered for Cin <= 64)
         if (pro) LEDN_LAUNCH((conv1x1_mfma_kernel<NKS, NMT, DIAG, G, EPI, 2, true>), dim3((unsigned)nb), dim3(256), 0, s, a);

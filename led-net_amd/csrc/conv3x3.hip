@@ -411,7 +411,7 @@ static int c33_launch(C33Args a, hipStream_t s) {
     long nb = cdiv(a.tasks, 4);
     const long cap = cdiv((long)options().conv_workgroups * OCC, slices);
     if (nb > cap) nb = cap;
-    a.part = (EPI == C33_STATS && a.stat_sum && nb > 16) ? ws_take(nb * 2 * a.Cout) : nullptr;
+    a.part = (EPI == C33_STATS && a.stat_sum && (nb > 16 || det())) ? ws_take(nb * 2 * a.Cout) : nullptr;
     LEDN_LAUNCH((conv3x3_reg_kernel<NKC, G, EPI, OCC>), dim3((unsigned)nb, (unsigned)slices), dim3(256), 0, s, a);
     if (a.part) return finish_partials(a.part, (int)nb, a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
     return check_launch();
@@ -711,7 +711,7 @@ static int c33_ring64_launch(C33Args a, hipStream_t s) {
     long nb = cdiv(a.tasks, 4);
     const long cap = cdiv((long)options().conv_workgroups * 2, slices);
     if (nb > cap) nb = cap;
-    a.part = (EPI == C33_STATS && a.stat_sum && nb > 16) ? ws_take(nb * 2 * a.Cout) : nullptr;
+    a.part = (EPI == C33_STATS && a.stat_sum && (nb > 16 || det())) ? ws_take(nb * 2 * a.Cout) : nullptr;
     LEDN_LAUNCH((conv3x3_ring64_kernel<EPI>), dim3((unsigned)nb, (unsigned)slices), dim3(256), 0, s, a);
     if (a.part) return finish_partials(a.part, (int)nb, a.Cout, 2, a.stat_sum, a.stat_sqsum, nullptr, s);
     return check_launch();
@@ -1165,7 +1165,7 @@ int stem_conv_reg_impl(const void* x, int dtype_x, const void* wp, void* y, int 
     long nb = cdiv(a.iters, 4);
     const long cap = (long)options().conv_workgroups * 4;
     if (nb > cap) nb = cap;
-    a.part = (stat_sum && nb > 16) ? ws_take(nb * 64) : nullptr;
+    a.part = (stat_sum && (nb > 16 || det())) ? ws_take(nb * 64) : nullptr;
 #define LEDN_STEMR(TX)                                                                                       \
     do {                                                                                                     \
         if (full) LEDN_LAUNCH((stem_conv_reg_kernel<TX, true>), dim3((unsigned)nb), dim3(256), 0, s, a);     \

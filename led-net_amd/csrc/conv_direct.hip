@@ -16,7 +16,7 @@
 namespace ledn {
 
 template <typename TX, typename TY, int CO_T, int VEC>
-__global__ void __launch_bounds__(256) conv_direct_kernel(ledn_conv_desc d) {
+__global__ void __launch_bounds__(256) conv_direct_kernel(ledn_conv_desc d, float* part) {
     // weights of this workgroup's CO_T output channels, one ci-chunk at a time:
     // s_w[(tap * cib + ci) * CO_T + j]; every lane reads the same address (LDS broadcast)
     constexpr int CIB = 32;
@@ -166,9 +166,13 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(ledn_conv_desc d) {
         if (threadIdx.x < 2 * CO_T) {
             const float t = s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x] + s_stat[2][threadIdx.x] +
                             s_stat[3][threadIdx.x];
-            float* dst = threadIdx.x < CO_T ? d.stat_sum + co0 + threadIdx.x
-                                            : d.stat_sqsum + co0 + threadIdx.x - CO_T;
-            atomicAdd(dst, t);
+            if (part) {     // one row [sum | sum of squares] per workgroup column, added up in row order by finish_partials
+                part[(long)blockIdx.x * 2 * d.Cout + (threadIdx.x < CO_T ? co0 + threadIdx.x : d.Cout + co0 + threadIdx.x - CO_T)] = t;
+            } else {
+                float* dst = threadIdx.x < CO_T ? d.stat_sum + co0 + threadIdx.x
+                                                : d.stat_sqsum + co0 + threadIdx.x - CO_T;
+                atomicAdd(dst, t);
+            }
         }
     }
 }
@@ -181,10 +185,14 @@ static int launch_vec(const ledn_conv_desc& d, hipStream_t s) {
     if (gx > cap) gx = cap;
     const dim3 grid((unsigned)gx, (unsigned)(d.Cout / CO_T));
     const int cig = d.Cin / d.groups;
+    // statistics: deterministic mode (or > 16 workgroup columns) -> partial rows + ordered summing launch
+    float* part = (d.stat_sum && (gx > 16 || det())) ? ws_take(gx * 2 * d.Cout) : nullptr;
+    if (d.stat_sum && det() && !part) return LEDN_EINVAL;
     if (cig % 4 == 0 && d.ws_ci != 0)
-        LEDN_LAUNCH((conv_direct_kernel<TX, TY, CO_T, 4>), grid, dim3(256), 0, s, d);
+        LEDN_LAUNCH((conv_direct_kernel<TX, TY, CO_T, 4>), grid, dim3(256), 0, s, d, part);
     else
-        LEDN_LAUNCH((conv_direct_kernel<TX, TY, CO_T, 1>), grid, dim3(256), 0, s, d);
+        LEDN_LAUNCH((conv_direct_kernel<TX, TY, CO_T, 1>), grid, dim3(256), 0, s, d, part);
+    if (part) return finish_partials(part, (int)gx, d.Cout, 2, d.stat_sum, d.stat_sqsum, nullptr, s);
     return check_launch();
 }
 
@@ -535,7 +543,7 @@ static int launch_narrow(const ledn_wgrad_desc& d, hipStream_t s) {
     long ppb = cdiv(npix, 2048);
     if (ppb < 64) ppb = 64;
     long nb = cdiv(npix, ppb);
-    float* part = (wgrad_natural_strides(d) && nb > 8) ? ws_take(nb * numel) : nullptr;
+    float* part = (wgrad_natural_strides(d) && (nb > 8 || det())) ? ws_take(nb * numel) : nullptr;
     if (!part) {
         ppb = cdiv(npix, 256);
         if (ppb < 64) ppb = 64;
@@ -672,7 +680,7 @@ int conv_wgrad_cout2(const ledn_wgrad_desc& d, hipStream_t s) {
     long nb = cdiv(npix, (long)slots * 16);           // >= 16 pixels per thread
     if (nb > 1024) nb = 1024;
     const long numel = (long)d.Cout * d.Cin * d.KH * d.KW;
-    float* part = nb > 4 ? ws_take(nb * numel) : nullptr;
+    float* part = (nb > 4 || det()) ? ws_take(nb * numel) : nullptr;
     if (!part && nb > 16) nb = 16;
     const dim3 grid((unsigned)nb);
 #define LEDN_C2(TZ)                                                                                   \
@@ -755,7 +763,7 @@ static int conv_wgrad_cin1(const ledn_wgrad_desc& d, hipStream_t s) {
     long nb = cdiv(npix, (long)slots * 8);
     if (nb > 512) nb = 512;
     const long numel = (long)d.Cout * d.KH * d.KW;
-    float* part = nb > 4 ? ws_take(nb * numel) : nullptr;
+    float* part = (nb > 4 || det()) ? ws_take(nb * numel) : nullptr;
     if (!part && nb > 16) nb = 16;
     const dim3 grid((unsigned)nb);
 #define LEDN_C1(TX, TZ)                                                                                       \
@@ -795,7 +803,7 @@ int conv_wgrad_direct(const ledn_wgrad_desc& d, hipStream_t s) {
     const long numel = (long)d.Cout * (d.Cin / d.groups) * d.KH * d.KW;
     long nbx = cdiv(1024, tiles);
     if (nbx > cdiv(npix, WG_PC)) nbx = cdiv(npix, WG_PC);
-    float* part = (wgrad_natural_strides(d) && nbx > 4) ? ws_take(nbx * numel) : nullptr;
+    float* part = (wgrad_natural_strides(d) && (nbx > 4 || det())) ? ws_take(nbx * numel) : nullptr;
     if (!part && nbx > 16) nbx = 16;
     long ppb = cdiv(cdiv(npix, nbx), WG_PC) * WG_PC;
     nbx = cdiv(npix, ppb);

@@ -666,7 +666,7 @@ static int launch_epi(MfmaConvArgs a, hipStream_t s) {
     nbx = cdiv(ntiles, a.tiles_per_block);
     a.tile_stride = (options().stream_fast & 4) ? (int)nbx : 0;
     const dim3 grid((unsigned)nbx, (unsigned)gy);
-    a.part = (epi_stats(EPI) && a.stat_sum && nbx > 16) ? ws_take(nbx * 2 * a.Cout) : nullptr;
+    a.part = (epi_stats(EPI) && a.stat_sum && (nbx > 16 || det())) ? ws_take(nbx * 2 * a.Cout) : nullptr;
     if constexpr (WN == 2 && K == 3 && S == 1) {     // 64 output channels per workgroup, 3x3: one workgroup per CU anyway
         if (a.Cin > CK && a.Cin <= 2 * CK && (a.Cout & 7) == 0 && (options().stream_fast & 32)) {
             LEDN_LAUNCH((conv_mfma_kernel<WM, WN, MT, K, S, UP, EPI, true, 2>), grid, dim3(256), 0, s, a);
@@ -1090,7 +1090,7 @@ int stem_conv_impl(const void* x, int dtype_x, const void* wp, void* y, int N, i
     a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.act_out = act_out; a.pad_val = pad_val;
     const long ntiles = (long)N * cdiv(Ho, 4) * cdiv(Wo, 64);
     long nb = ntiles < 2048 ? ntiles : 2048;      // (one-shot workgroups measured slower: 198 vs 182 us)
-    a.part = (stat_sum && nb > 16) ? ws_take(nb * 64) : nullptr;
+    a.part = (stat_sum && (nb > 16 || det())) ? ws_take(nb * 64) : nullptr;
 #define LEDN_STEM(TX)                                                                                      \
     do {                                                                                                   \
         if (full) LEDN_LAUNCH((stem_conv_kernel<TX, true>), dim3((unsigned)nb), dim3(256), 0, s, a);       \
@@ -1455,7 +1455,7 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s, WgradDefer* df = nullptr
         LEDN_LAUNCH((conv_wgrad_mfma_kernel<K, S>), grid, dim3(256), 0, s, a);
         return check_launch();
     }
-    a.part = nbx > 4 ? ws_take((long)nbx * pairs * K * K * 1024) : nullptr;
+    a.part = (nbx > 4 || det()) ? ws_take((long)nbx * pairs * K * K * 1024) : nullptr;
     LEDN_LAUNCH((conv_wgrad_mfma_kernel<K, S>), grid, dim3(256), 0, s, a);
     if (a.part)
         LEDN_LAUNCH((conv_wgrad_finish_kernel<K * K>), dim3((unsigned)(K * K * 1024 / 64), (unsigned)pairs), dim3(1024), 0,

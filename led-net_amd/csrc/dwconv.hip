@@ -781,7 +781,7 @@ int dwconv_impl(const ledn_dw_desc& d, hipStream_t s) {
         if (nb8 > 2048) nb8 = 2048;
         float* part8 = nullptr;
         if (d.stat_sum) {
-            if (nb8 > 64) part8 = ws_take(nb8 * 2 * d.C);
+            if (nb8 > 64 || det()) part8 = ws_take(nb8 * 2 * d.C);
             if (!part8 && nb8 > 256) nb8 = 256;
         }
         LEDN_LAUNCH((dw3x3_bf16_kernel<0>), dim3((unsigned)nb8), dim3(256), 0, s, d, (const bf16_t*)nullptr, part8);
@@ -797,7 +797,7 @@ int dwconv_impl(const ledn_dw_desc& d, hipStream_t s) {
     if (nb > 2048) nb = 2048;
     float* part = nullptr;
     if (d.stat_sum) {
-        if (nb > 64) part = ws_take(nb * 2 * d.C);
+        if (nb > 64 || det()) part = ws_take(nb * 2 * d.C);
         if (!part && nb > 256) nb = 256;
     }
     const dim3 grid((unsigned)nb);

@@ -23,7 +23,40 @@
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <map>
+#include <string>
 #include <vector>
+
+#ifdef LEDN_EMU_DEFINE_SWITCH
+namespace ledn_emu_census {
+static std::map<std::pair<std::string, int>, long>* g_sites = nullptr;
+static int g_on = -1;
+}
+extern "C" void ledn_emu_atomic_note(const char* file, int line) {
+    using namespace ledn_emu_census;
+    if (g_on < 0) g_on = getenv("LEDN_EMU_ATOMIC_CENSUS") ? 1 : 0;
+    if (!g_on) return;
+    if (!g_sites) g_sites = new std::map<std::pair<std::string, int>, long>();
+    const char* b = strrchr(file, '/');
+    ++(*g_sites)[{std::string(b ? b + 1 : file), line}];
+}
+// (python: lib.cdll.ledn_emu_atomic_census(path, reset)) writes "file:line count" lines and optionally clears the table
+extern "C" int ledn_emu_atomic_census(const char* path, int reset) {
+    using namespace ledn_emu_census;
+    g_on = 1;
+    FILE* f = path ? fopen(path, "w") : nullptr;
+    int n = 0;
+    if (g_sites) {
+        for (auto& kv : *g_sites) {
+            if (f) fprintf(f, "%s:%d %ld\n", kv.first.first.c_str(), kv.first.second, kv.second);
+            ++n;
+        }
+        if (reset) g_sites->clear();
+    }
+    if (f) fclose(f);
+    return n;
+}
+#endif
 
 namespace emu {
 
@@ -239,7 +272,11 @@ inline float __logf(float x) { return logf(x); }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 
-inline float atomicAdd(float* p, float v) {
+// census of the FLOAT atomic sites a run goes through (LEDN_EMU_ATOMIC_CENSUS=<file>: "source:line count" per site at
+// exit): how tests/test_deterministic.py proves that the deterministic mode reaches no float atomic at all
+extern "C" void ledn_emu_atomic_note(const char* file, int line);
+inline float atomicAdd(float* p, float v, const char* file = __builtin_FILE(), int line = __builtin_LINE()) {
+    ledn_emu_atomic_note(file, line);
     unsigned* u = reinterpret_cast<unsigned*>(p);
     unsigned old = __atomic_load_n(u, __ATOMIC_RELAXED), nw;
     float f;

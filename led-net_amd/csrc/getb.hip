@@ -303,11 +303,21 @@ __global__ void __launch_bounds__(256) relpos_bias_kernel(const float* table, co
 // the table column (LDS atomics: a few hundred distinct addresses) and adds the column to dtable -- one writer per
 // (entry, head), no global atomics.  (The first version ran one workgroup per table entry, each scanning the whole
 // index map once per head with a tree reduction: 61 us for 2 x 32 K values on the context branch's exposed tail.)
+template <bool DET>
 __global__ void __launch_bounds__(256) relpos_bias_bwd_kernel(const float* dbias, const long long* index, float* dtable,
                                                               int R, int heads, int T) {
     constexpr int RMAX = 1024;
     __shared__ float s_t[RMAX];
     const int h = blockIdx.x;
+    if (DET) {          // deterministic mode: thread = table row, walks the whole index map in order (no LDS atomics)
+        for (int r = threadIdx.x; r < R; r += 256) {
+            float t = 0.f;
+            for (int e = 0; e < T * T; ++e)
+                if (index[e] == (long long)r) t += dbias[((long)h * T + e % T) * T + e / T];
+            dtable[(long)r * heads + h] += t;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < R; i += 256) s_t[i] = 0.f;
     __syncthreads();
     for (int e = threadIdx.x; e < T * T; e += 256) {
@@ -329,7 +339,8 @@ int relpos_bias_impl(const float* table, const long long* index, float* out, int
 int relpos_bias_bwd_impl(const float* dbias, const long long* index, float* dtable, int R, int heads, int T,
                          hipStream_t s) {
     LEDN_REQUIRE(dbias && index && dtable && R > 0 && R <= 1024 && heads > 0 && T > 0);
-    LEDN_LAUNCH(relpos_bias_bwd_kernel, dim3((unsigned)heads), dim3(256), 0, s, dbias, index, dtable, R, heads, T);
+    if (det()) LEDN_LAUNCH(relpos_bias_bwd_kernel<true>, dim3((unsigned)heads), dim3(256), 0, s, dbias, index, dtable, R, heads, T);
+    else LEDN_LAUNCH(relpos_bias_bwd_kernel<false>, dim3((unsigned)heads), dim3(256), 0, s, dbias, index, dtable, R, heads, T);
     return check_launch();
 }
 

@@ -296,8 +296,11 @@ struct Options {
     int conv_workgroups;
     int wgrad_workgroups;
     int stream_fast;
+    int deterministic;      // LEDN_OPT_DETERMINISTIC: every cross-workgroup reduction in a fixed order (no f32 atomics)
 };
 Options& options();
+// deterministic mode: reductions that would end in float atomics for small grids take the partial-row path too
+inline bool det() { return options().deterministic != 0; }
 // ledn_conv2d_deferred_stats: the MFMA conv leaves its per-workgroup statistic rows [rows][2][C] in the
 // workspace (no finish launch) and reports them here; ledn_bn_finalize_rows sums them itself
 struct DeferredStats {

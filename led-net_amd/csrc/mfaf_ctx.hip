@@ -11,6 +11,9 @@ namespace ledn {
 
 constexpr int MC_C = 64, MC_CI = 16, MC_PX = 256;
 
+struct ledn_mfafctx_P {
+    int P[4];
+};
 struct McBlock {
     int s;        // scale
     int p0;       // first pixel of the workgroup inside the scale
@@ -46,8 +49,58 @@ __device__ __forceinline__ float mc_wave_sum(float v) {
     return v;
 }
 
+// Deterministic mode (LEDN_OPT_DETERMINISTIC): the workgroups of a launch write their partial sums as rows
+// part[blockIdx.x][K] instead of adding them atomically, and this kernel adds every scale's rows up in block order.
+struct McDst {
+    float* p[4];
+};
+__global__ void __launch_bounds__(256) mfaf_ctx_finish_kernel(const float* part, int K, McDst dst, ledn_mfafctx_P P) {
+    const int s = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K || !dst.p[s]) return;
+    int b0 = 0;
+    for (int q = 0; q < s; ++q) b0 += (P.P[q] + MC_PX - 1) / MC_PX;
+    const int nb = (P.P[s] + MC_PX - 1) / MC_PX;
+    float t = 0.f;
+    for (int b = 0; b < nb; ++b) t += part[(long)(b0 + b) * K + k];
+    dst.p[s][k] += t;
+}
+static int mc_finish(const float* part, int K, float* d0, float* d1, float* d2, float* d3, const int* P, hipStream_t s) {
+    McDst dst;
+    dst.p[0] = d0; dst.p[1] = d1; dst.p[2] = d2; dst.p[3] = d3;
+    ledn_mfafctx_P pp;
+    for (int k = 0; k < 4; ++k) pp.P[k] = P[k];
+    LEDN_LAUNCH(mfaf_ctx_finish_kernel, dim3((unsigned)cdiv(K, 256), 4u), dim3(256), 0, s, part, K, dst, pp);
+    return check_launch();
+}
+
+// rows [KWT filter-gradient elements | CA bias-gradient elements] -> dw[s], db[s] (db[s] may be null)
+__global__ void __launch_bounds__(256) mfaf_ctx_finish_w_kernel(const float* part, int KWT, int CA, McDst dw, McDst db,
+                                                                ledn_mfafctx_P P) {
+    const int s = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x, K = KWT + CA;
+    if (k >= K) return;
+    float* dst = k < KWT ? (dw.p[s] ? dw.p[s] + k : nullptr) : (db.p[s] ? db.p[s] + (k - KWT) : nullptr);
+    if (!dst) return;
+    int b0 = 0;
+    for (int q = 0; q < s; ++q) b0 += (P.P[q] + MC_PX - 1) / MC_PX;
+    const int nb = (P.P[s] + MC_PX - 1) / MC_PX;
+    float t = 0.f;
+    for (int b = 0; b < nb; ++b) t += part[(long)(b0 + b) * K + k];
+    *dst += t;
+}
+static int mc_finish_w(const float* part, int KWT, int CA, float* const* dw, float* const* db, const int* P, hipStream_t s) {
+    McDst a, b;
+    ledn_mfafctx_P pp;
+    for (int k = 0; k < 4; ++k) {
+        a.p[k] = dw[k];
+        b.p[k] = db[k];
+        pp.P[k] = P[k];
+    }
+    LEDN_LAUNCH(mfaf_ctx_finish_w_kernel, dim3((unsigned)cdiv(KWT + CA, 256), 4u), dim3(256), 0, s, part, KWT, CA, a, b, pp);
+    return check_launch();
+}
+
 // ---- forward 1: z1 = W1 x + b1, per-scale sums of z1 -------------------------------------------------
-__global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd1_kernel(ledn_mfafctx_desc d, int training) {
+__global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd1_kernel(ledn_mfafctx_desc d, int training, float* part) {
     __shared__ float s_w[MC_CI * MC_C];
     __shared__ float s_red[4][2 * MC_CI];
     const McBlock blk = mc_block(d.P);
@@ -87,21 +140,23 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd1_kernel(ledn_mfafctx_desc 
         }
     }
     __syncthreads();
-    if (tid < 2 * MC_CI)
-        atomicAdd(d.stats1 + s * 2 * MC_CI + tid, (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]));
+    if (tid < 2 * MC_CI) {
+        const float t = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+        if (part) part[(long)blockIdx.x * 2 * MC_CI + tid] = t;
+        else atomicAdd(d.stats1 + s * 2 * MC_CI + tid, t);
+    }
 }
 
 // ---- forward 2: BatchNorm (batch or running statistics) + ReLU, z2 = W2 mid + b2 ----------------------
-__global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd2_kernel(ledn_mfafctx_desc d, int training) {
+__global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd2_kernel(ledn_mfafctx_desc d, int training, float* part) {
     __shared__ float s_w[MC_C * MC_CI];
     __shared__ float s_bn[2 * MC_CI];
-    __shared__ float s_st[2 * MC_C];
+    __shared__ float s_st[4][2 * MC_C];           // one row per wave, added up in wave order (no LDS atomics)
     const McBlock blk = mc_block(d.P);
     if (blk.s < 0) return;
     const int s = blk.s, tid = threadIdx.x;
     const bool tail = training && d.stats2 != nullptr;
     for (int i = tid; i < MC_C * MC_CI; i += MC_PX) s_w[i] = d.w2[s][i];
-    if (tid < 2 * MC_C) s_st[tid] = 0.f;
     if (tid < MC_CI) {
         float mean, var;
         if (training) {
@@ -164,15 +219,19 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_fwd2_kernel(ledn_mfafctx_desc 
                 const float v = ok ? o[j] : 0.f;
                 const float a = mc_wave_sum(v), b = mc_wave_sum(v * v);
                 if ((tid & 63) == 0) {
-                    atomicAdd(&s_st[4 * q + j], a);
-                    atomicAdd(&s_st[MC_C + 4 * q + j], b);
+                    s_st[tid >> 6][4 * q + j] = a;
+                    s_st[tid >> 6][MC_C + 4 * q + j] = b;
                 }
             }
         }
     }
     if (!tail) return;
     __syncthreads();
-    if (tid < 2 * MC_C) atomicAdd(d.stats2 + s * 2 * MC_C + tid, s_st[tid]);
+    if (tid < 2 * MC_C) {
+        const float t = (s_st[0][tid] + s_st[1][tid]) + (s_st[2][tid] + s_st[3][tid]);
+        if (part) part[(long)blockIdx.x * 2 * MC_C + tid] = t;
+        else atomicAdd(d.stats2 + s * 2 * MC_C + tid, t);
+    }
 }
 
 // ---- finalize of the trailing BatchNorms: one workgroup per scale, thread = channel ----------------------
@@ -194,16 +253,13 @@ __global__ void __launch_bounds__(MC_C) mfaf_ctx_fin2_kernel(ledn_mfafctx_desc d
 }
 
 // ---- backward of the trailing BatchNorms, reduce half: sums of dy and dy * xhat2 per scale ---------------
-__global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwdT_kernel(ledn_mfafctx_bwd_desc d) {
+__global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwdT_kernel(ledn_mfafctx_bwd_desc d, float* part) {
     __shared__ float s_bn[2 * MC_C];
-    __shared__ float s_st[2 * MC_C];
+    __shared__ float s_st[4][2 * MC_C];
     const McBlock blk = mc_block(d.P);
     if (blk.s < 0) return;
     const int s = blk.s, tid = threadIdx.x;
-    if (tid < 2 * MC_C) {
-        s_bn[tid] = d.bn2[s][2 * MC_C + tid];        // mean | invstd
-        s_st[tid] = 0.f;
-    }
+    if (tid < 2 * MC_C) s_bn[tid] = d.bn2[s][2 * MC_C + tid];        // mean | invstd
     __syncthreads();
     const int p = blk.p0 + tid;
     const bool ok = p < d.P[s];
@@ -220,17 +276,21 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwdT_kernel(ledn_mfafctx_bwd_d
             const float xh = (za[j] - s_bn[c]) * s_bn[MC_C + c];
             const float a = mc_wave_sum(g), b = mc_wave_sum(g * xh);
             if ((tid & 63) == 0) {
-                atomicAdd(&s_st[c], a);
-                atomicAdd(&s_st[MC_C + c], b);
+                s_st[tid >> 6][c] = a;
+                s_st[tid >> 6][MC_C + c] = b;
             }
         }
     }
     __syncthreads();
-    if (tid < 2 * MC_C) atomicAdd(d.sums2 + s * 2 * MC_C + tid, s_st[tid]);
+    if (tid < 2 * MC_C) {
+        const float t = (s_st[0][tid] + s_st[1][tid]) + (s_st[2][tid] + s_st[3][tid]);
+        if (part) part[(long)blockIdx.x * 2 * MC_C + tid] = t;
+        else atomicAdd(d.sums2 + s * 2 * MC_C + tid, t);
+    }
 }
 
 // ---- backward 2: dmid = W2^T dz2, g = dmid * relu'(bn(z1)) (stored), per-scale sums of g and g * xhat ------
-__global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwd2_kernel(ledn_mfafctx_bwd_desc d) {
+__global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwd2_kernel(ledn_mfafctx_bwd_desc d, float* part) {
     __shared__ float s_w[MC_C * MC_CI];
     __shared__ float s_bn[4 * MC_CI];
     __shared__ float s_red[4][2 * MC_CI];
@@ -250,9 +310,9 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwd2_kernel(ledn_mfafctx_bwd_d
         s_t[2 * MC_C + tid] = d.bn2[s][3 * MC_C + tid];
         s_t[3 * MC_C + tid] = s1 * inv_n;
         s_t[4 * MC_C + tid] = s2 * inv_n;
-        if (blk.p0 == 0) {
-            atomicAdd(d.dbeta2[s] + tid, loc[s * 2 * MC_C + tid]);
-            atomicAdd(d.dgamma2[s] + tid, loc[s * 2 * MC_C + MC_C + tid]);
+        if (blk.p0 == 0) {          // (one workgroup per scale: the only adder of these entries in this launch)
+            d.dbeta2[s][tid] += loc[s * 2 * MC_C + tid];
+            d.dgamma2[s][tid] += loc[s * 2 * MC_C + MC_C + tid];
         }
     }
     __syncthreads();
@@ -312,8 +372,11 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwd2_kernel(ledn_mfafctx_bwd_d
         }
     }
     __syncthreads();
-    if (tid < 2 * MC_CI)
-        atomicAdd(d.sums + s * 2 * MC_CI + tid, (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]));
+    if (tid < 2 * MC_CI) {
+        const float t = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+        if (part) part[(long)blockIdx.x * 2 * MC_CI + tid] = t;
+        else atomicAdd(d.sums + s * 2 * MC_CI + tid, t);
+    }
 }
 
 // ---- backward 1: dz1 = BatchNorm-backward(g) (written over g), dpooled = W1^T dz1, d gamma / d beta -----------
@@ -330,8 +393,8 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwd1_kernel(ledn_mfafctx_bwd_d
     __syncthreads();
     if (blk.p0 == 0 && tid < MC_CI) {      // parameter gradients of the BatchNorm: this rank's own sums
         const float* loc = d.sums_local ? d.sums_local : d.sums;
-        atomicAdd(d.dbeta[s] + tid, loc[s * 2 * MC_CI + tid]);
-        atomicAdd(d.dgamma[s] + tid, loc[s * 2 * MC_CI + MC_CI + tid]);
+        d.dbeta[s][tid] += loc[s * 2 * MC_CI + tid];          // (the scale's first workgroup: the only adder in this launch)
+        d.dgamma[s][tid] += loc[s * 2 * MC_CI + MC_CI + tid];
     }
     const int p = blk.p0 + tid;
     if (p >= d.P[s]) return;
@@ -371,7 +434,7 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_bwd1_kernel(ledn_mfafctx_bwd_d
 // MODE 1: A = dz1 (held in g, Ci), B = pooled (C)               -> dw1 [Ci][C], db1
 // thread = four consecutive b of one a; the workgroup's <= 256 pixels are staged in LDS in two halves.
 template <int MODE>
-__global__ void __launch_bounds__(MC_PX) mfaf_ctx_wgrad_kernel(ledn_mfafctx_bwd_desc d) {
+__global__ void __launch_bounds__(MC_PX) mfaf_ctx_wgrad_kernel(ledn_mfafctx_bwd_desc d, float* part) {
     constexpr int CA = MODE == 0 ? MC_C : MC_CI, CB = MODE == 0 ? MC_CI : MC_C, HALF = 128;
     __shared__ float s_a[HALF * CA];
     __shared__ float s_b[HALF * CB];
@@ -410,6 +473,13 @@ __global__ void __launch_bounds__(MC_PX) mfaf_ctx_wgrad_kernel(ledn_mfafctx_bwd_
     }
     float* dw = MODE == 0 ? d.dw2[s] : d.dw1[s];
     float* db = MODE == 0 ? d.db2[s] : d.db1[s];
+    if (part) {         // row = [CA x CB filter gradient | CA bias gradient]
+        float* row = part + (long)blockIdx.x * (CA * CB + CA);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row[a * CB + b0 + j] = acc[j];
+        if (b0 == 0) row[CA * CB + a] = accb;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) atomicAdd(dw + (long)a * CB + b0 + j, acc[j]);
     if (b0 == 0 && db) atomicAdd(db + a, accb);
@@ -435,10 +505,25 @@ int mfaf_ctx_fwd_impl(const ledn_mfafctx_desc& d, int training, hipStream_t s) {
         for (int k = 0; k < 4; ++k)
             LEDN_REQUIRE(d.gamma2[k] && d.beta2[k] && d.running_mean2[k] && d.running_var2[k] && d.bn2[k]);
     }
-    const dim3 grid((unsigned)mc_blocks(d.P));
+    const int nblk = mc_blocks(d.P);
+    const dim3 grid((unsigned)nblk);
     const int ph = d.phase ? d.phase : 7;
-    if (ph & 1) LEDN_LAUNCH(mfaf_ctx_fwd1_kernel, grid, dim3(MC_PX), 0, s, d, training);
-    if (ph & 2) LEDN_LAUNCH(mfaf_ctx_fwd2_kernel, grid, dim3(MC_PX), 0, s, d, training);
+    float* part = (training && det()) ? ws_take((long)nblk * 2 * MC_C) : nullptr;
+    if (training && det() && !part) return LEDN_EINVAL;
+    if (ph & 1) {
+        LEDN_LAUNCH(mfaf_ctx_fwd1_kernel, grid, dim3(MC_PX), 0, s, d, training, part);
+        if (part) {
+            rc = mc_finish(part, 2 * MC_CI, d.stats1, d.stats1 + 2 * MC_CI, d.stats1 + 4 * MC_CI, d.stats1 + 6 * MC_CI, d.P, s);
+            if (rc != LEDN_OK) return rc;
+        }
+    }
+    if (ph & 2) {
+        LEDN_LAUNCH(mfaf_ctx_fwd2_kernel, grid, dim3(MC_PX), 0, s, d, training, d.stats2 ? part : nullptr);
+        if (part && d.stats2) {
+            rc = mc_finish(part, 2 * MC_C, d.stats2, d.stats2 + 2 * MC_C, d.stats2 + 4 * MC_C, d.stats2 + 6 * MC_C, d.P, s);
+            if (rc != LEDN_OK) return rc;
+        }
+    }
     if ((ph & 4) && d.stats2) LEDN_LAUNCH(mfaf_ctx_fin2_kernel, dim3(4), dim3(MC_C), 0, s, d);
     return check_launch();
 }
@@ -451,25 +536,45 @@ int mfaf_ctx_bwd_impl(const ledn_mfafctx_bwd_desc& d, hipStream_t s) {
         LEDN_REQUIRE(d.dw1[k] && d.dw2[k] && d.dgamma[k] && d.dbeta[k]);
     }
     LEDN_REQUIRE(d.sums);
-    const dim3 grid((unsigned)mc_blocks(d.P));
+    const int nblk = mc_blocks(d.P);
+    const dim3 grid((unsigned)nblk);
     const int ph = d.phase ? d.phase : 7;
+    constexpr int KW = MC_C * MC_CI + MC_C;         // widest partial row: a filter gradient + its bias gradient
+    float* part = det() ? ws_take((long)nblk * KW) : nullptr;
+    if (det() && !part) return LEDN_EINVAL;
     if (d.sums2) {
         for (int k = 0; k < 4; ++k) LEDN_REQUIRE(d.z2[k] && d.bn2[k] && d.dz2s[k] && d.dgamma2[k] && d.dbeta2[k]);
         if (ph & 1) {
             ledn_mfafctx_bwd_desc dl = d;            // this launch accumulates the LOCAL sums
             if (d.sums2_local) dl.sums2 = const_cast<float*>(d.sums2_local);
-            LEDN_LAUNCH(mfaf_ctx_bwdT_kernel, grid, dim3(MC_PX), 0, s, dl);
+            LEDN_LAUNCH(mfaf_ctx_bwdT_kernel, grid, dim3(MC_PX), 0, s, dl, part);
+            if (part) {
+                rc = mc_finish(part, 2 * MC_C, dl.sums2, dl.sums2 + 2 * MC_C, dl.sums2 + 4 * MC_C, dl.sums2 + 6 * MC_C, d.P, s);
+                if (rc != LEDN_OK) return rc;
+            }
         }
     }
     if (ph & 2) {
         ledn_mfafctx_bwd_desc dl = d;                // reads the global sums2, accumulates the LOCAL sums
         if (d.sums_local) dl.sums = const_cast<float*>(d.sums_local);
-        LEDN_LAUNCH(mfaf_ctx_bwd2_kernel, grid, dim3(MC_PX), 0, s, dl);
-        LEDN_LAUNCH(mfaf_ctx_wgrad_kernel<0>, grid, dim3(MC_PX), 0, s, d);
+        LEDN_LAUNCH(mfaf_ctx_bwd2_kernel, grid, dim3(MC_PX), 0, s, dl, part);
+        if (part) {
+            rc = mc_finish(part, 2 * MC_CI, dl.sums, dl.sums + 2 * MC_CI, dl.sums + 4 * MC_CI, dl.sums + 6 * MC_CI, d.P, s);
+            if (rc != LEDN_OK) return rc;
+        }
+        LEDN_LAUNCH(mfaf_ctx_wgrad_kernel<0>, grid, dim3(MC_PX), 0, s, d, part);
+        if (part) {
+            rc = mc_finish_w(part, MC_C * MC_CI, MC_C, d.dw2, d.db2, d.P, s);
+            if (rc != LEDN_OK) return rc;
+        }
     }
     if (ph & 4) {
         LEDN_LAUNCH(mfaf_ctx_bwd1_kernel, grid, dim3(MC_PX), 0, s, d);
-        LEDN_LAUNCH(mfaf_ctx_wgrad_kernel<1>, grid, dim3(MC_PX), 0, s, d);
+        LEDN_LAUNCH(mfaf_ctx_wgrad_kernel<1>, grid, dim3(MC_PX), 0, s, d, part);
+        if (part) {
+            rc = mc_finish_w(part, MC_C * MC_CI, MC_CI, d.dw1, d.db1, d.P, s);
+            if (rc != LEDN_OK) return rc;
+        }
     }
     return check_launch();
 }

@@ -65,6 +65,7 @@ struct FinishOuts {
 // second stage of the two-stage reductions: workgroup (k-tile of 16 outputs, row split) sums
 // its share of the partial rows with 16 row-slots per output, LDS-reduces the slots and adds the
 // result with ONE atomic per output (<= 32 splits per address).
+template <bool SOLE>
 __global__ void __launch_bounds__(256) finish_partials_kernel(const float* part, int nblk, int C, int nout,
                                                               FinishOuts outs) {
     __shared__ float s_red[256];
@@ -90,7 +91,10 @@ __global__ void __launch_bounds__(256) finish_partials_kernel(const float* part,
 #pragma unroll
         for (int sl = 0; sl < 16; ++sl) t += s_red[sl * 16 + threadIdx.x];
         float* dst = outs.o[k / C];
-        if (dst) atomicAdd(dst + k % C, t);
+        if (dst) {
+            if (SOLE) dst[k % C] += t;      // deterministic mode, gridDim.y == 1: this lane is the only adder of its output
+            else atomicAdd(dst + k % C, t);
+        }
     }
 }
 
@@ -106,8 +110,12 @@ int finish_partials(const float* part, int nblk, int C, int nout, float* o0, flo
     long split = cdiv(nblk, 16 * 16);      // <= 16 rows per slot per workgroup
     if (split > 32) split = 32;
     if (split < 1) split = 1;
-    LEDN_LAUNCH(finish_partials_kernel, dim3((unsigned)cdiv((long)C * nout, 16), (unsigned)split), dim3(256), 0,
-                s, part, nblk, C, nout, outs);
+    if (det())                             // one workgroup column walks every row: a fixed summation order, one adder
+        LEDN_LAUNCH(finish_partials_kernel<true>, dim3((unsigned)cdiv((long)C * nout, 16), 1u), dim3(256), 0,
+                    s, part, nblk, C, nout, outs);
+    else
+        LEDN_LAUNCH(finish_partials_kernel<false>, dim3((unsigned)cdiv((long)C * nout, 16), (unsigned)split), dim3(256), 0,
+                    s, part, nblk, C, nout, outs);
     return check_launch();
 }
 
@@ -125,7 +133,7 @@ int channel_stats_impl(const void* x, const void* xadd, long long P, int C, int 
     long nb = cdiv(P, (256 / (C / V)) * 8);
     float* part = nullptr;
     if (nb > 2048) nb = 2048;
-    if (nb > 64) part = ws_take(nb * 2 * C);
+    if (nb > 64 || det()) part = ws_take(nb * 2 * C);
     if (!part && nb > 256) nb = 256;     // atomics fallback: one per channel per workgroup, bounded grid
     const dim3 grid((unsigned)nb);
 #define LEDN_CS(T)                                                                              \

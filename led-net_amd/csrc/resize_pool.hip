@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(256) adaptive_avgpool_kernel(const T* x, const
             // part: one row of per-cell sums per row chunk, added up in chunk order by finish_partials
             // (a fixed summation order: inference is bit-reproducible; atomics onto y are not)
             if (part) part[((long)blockIdx.y * gridDim.x + cell) * C + cv * V + v] = r0 < r1 ? t * inv : 0.f;
+            else if (gridDim.y == 1) y[(long)cell * C + cv * V + v] = t * inv;     // the cell's only workgroup (y zeroed)
             else atomicAdd(y + (long)cell * C + cv * V + v, t * inv);
         }
     }

@@ -100,7 +100,7 @@ int dw3x3_bwd_weight_bf16(const ledn_dwbwd_desc& d, hipStream_t s) {
     static const int ppt = getenv("LEDN_DW_PPT") ? atoi(getenv("LEDN_DW_PPT")) : 16;     // (A/B knob)
     long nb = cdiv((long)d.N * d.H * d.W, rows * (ppt > 0 ? ppt : 16));
     if (nb > 1024) nb = 1024;
-    float* part = nb > 32 ? ws_take(nb * 9 * d.C) : nullptr;
+    float* part = (nb > 32 || det()) ? ws_take(nb * 9 * d.C) : nullptr;
     if (!part && nb > 128) nb = 128;
     LEDN_LAUNCH(dw3x3_bwd_weight_bf16_kernel, dim3((unsigned)nb), dim3(256), (size_t)(36 * d.C) * sizeof(float), s, d,
                 part);
@@ -421,7 +421,7 @@ int pyr_bwd_weight_bf16(const ledn_pyrbwd_desc& d, hipStream_t s) {
     const int rows = 256 / cvn;
     long nb = cdiv((long)d.N * d.Ho * d.Wo, rows * 8);
     if (nb > 512) nb = 512;
-    float* part = nb > 32 ? ws_take(nb * 36 * d.n) : nullptr;
+    float* part = (nb > 32 || det()) ? ws_take(nb * 36 * d.n) : nullptr;
     if (!part && nb > 128) nb = 128;
     LEDN_LAUNCH(pyr_bwd_weight_bf16_kernel, dim3((unsigned)nb, 4u), dim3(256), (size_t)(36 * d.n) * sizeof(float), s, d,
                 part, pyr_tile_applies(d));
