@@ -132,7 +132,8 @@ int ledn_conv2d_deferred_stats(const ledn_conv_desc* d, float** part, int* rows,
 int ledn_stats_defer_begin(void);
 int ledn_stats_defer_end(float** part, int* rows);
 /* Pure query, no launch: 1 if ledn_conv2d would run this descriptor on conv_mfma_kernel, 2 if on
- * conv1x1_mfma_kernel, 3 if on conv3x3_reg_kernel, 4 if on conv3x3_narrowin_mfma_kernel (all matrix cores), 0 if on
+ * conv1x1_mfma_kernel, 3 if on conv3x3_reg_kernel, 4 if on conv3x3_narrowin_mfma_kernel, 5 if on conv_f32_mfma_kernel
+ * (f32 activations on v_mfma_f32_32x32x2_f32, csrc/conv_f32.hip) (all matrix cores), 0 if on
  * conv_direct_kernel / conv_narrowin_kernel (VALU).  bench.py names the kernel in its
  * roofline with it. */
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d);
@@ -204,7 +205,7 @@ typedef struct {
     const float* in_slope; /* [Cin] when in_act == PRELU */
 } ledn_wgrad_desc;
 int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream);
-int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d);   /* same query for the weight gradient: 1 conv_wgrad_mfma_kernel, 2 conv3x3_wgrad_narrow_kernel, 3 conv1x1_wgrad_reg_kernel (csrc/conv3x3.hip), 0 the VALU kernels */
+int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d);   /* same query for the weight gradient: 1 conv_wgrad_mfma_kernel, 2 conv3x3_wgrad_narrow_kernel, 3 conv1x1_wgrad_reg_kernel (csrc/conv3x3.hip), 4 conv_wgrad_f32_mfma_kernel (f32 activations, csrc/conv_f32.hip), 0 the VALU kernels */
 /* Deferred reduction of the weight gradient.  ledn_conv2d_wgrad runs the MFMA kernel (per-workgroup partial tiles into the
  * stream's workspace) and then a small summing launch -- ~55 of them per training step, each on the critical path of the
  * stream although nothing reads dW before the optimizer.  ledn_conv2d_wgrad_partial instead writes the partial tiles into a

@@ -6,6 +6,10 @@ namespace ledn {
 int conv_validate(const ledn_conv_desc& d);
 int conv_direct(const ledn_conv_desc& d, hipStream_t s);
 bool conv_mfma_supported(const ledn_conv_desc& d);
+bool conv_f32_mfma_supported(const ledn_conv_desc& d);
+int conv_f32_mfma(const ledn_conv_desc& d, hipStream_t s);
+bool conv_wgrad_f32_mfma_supported(const ledn_wgrad_desc& d);
+int conv_wgrad_f32_mfma(const ledn_wgrad_desc& d, hipStream_t s);
 int conv_mfma(const ledn_conv_desc& d, hipStream_t s);
 int conv_wgrad_mfma_partial(const ledn_wgrad_desc& d, float* part, long long part_floats, ledn_wgrad_finish_entry* entry,
                             bool query, hipStream_t s);
@@ -197,6 +201,7 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
         return conv_mfma(*d, S(stream));
     }
     if (conv3x3_narrowin_mfma_supported(*d)) return conv3x3_narrowin_mfma(*d, S(stream));
+    if (conv_f32_mfma_supported(*d)) return conv_f32_mfma(*d, S(stream));       // f32 activations: v_mfma_f32_32x32x2_f32
     return conv_direct(*d, S(stream));
 }
 
@@ -245,13 +250,15 @@ int ledn_bn_finalize_rows(const float* part, int rows, double count, const float
 
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d) {
     if (d && !conv_mfma_supported(*d) && conv3x3_narrowin_mfma_supported(*d)) return 4;
+    if (d && !conv_mfma_supported(*d) && conv_validate(*d) == LEDN_OK && conv_f32_mfma_supported(*d)) return 5;
     if (!d || !conv_mfma_supported(*d)) return 0;
     return conv1x1_reg_supported(*d) ? 2 : (conv3x3_reg_supported(*d) ? 3 : 1);
 }
 int ledn_conv2d_wgrad_uses_mfma(const ledn_wgrad_desc* d) {
     if (d && !conv_wgrad_cout2_supported(*d) && conv_wgrad_narrow_reg_supported(*d)) return 2;
     if (d && !conv_wgrad_cout2_supported(*d) && conv1x1_wgrad_reg_applies(*d)) return 3;
-    return d && !conv_wgrad_cout2_supported(*d) && wgrad_mfma_supported(*d) ? 1 : 0;
+    if (d && !conv_wgrad_cout2_supported(*d) && wgrad_mfma_supported(*d)) return 1;
+    return d && !conv_wgrad_cout2_supported(*d) && conv_wgrad_f32_mfma_supported(*d) ? 4 : 0;
 }
 
 int ledn_pack_conv_weights_multi(const ledn_pack_entry* table_dev, int n, long long max_elems, void* stream) {
@@ -288,6 +295,10 @@ int ledn_conv2d_wgrad(const ledn_wgrad_desc* d, void* stream) {
         if (r2 != LEDN_OK || !d->db) return r2;
         return channel_stats_impl(d->dz, nullptr, (long long)d->N * d->Ho * d->Wo, d->Cout, d->dtype_dz, d->db,
                                   nullptr, S(stream));
+    }
+    if (conv_wgrad_f32_mfma_supported(*d)) {          // f32 activations: v_mfma_f32_32x32x2_f32 (needs the bound workspace)
+        const int r2 = conv_wgrad_f32_mfma(*d, S(stream));
+        if (r2 >= 0) return r2;
     }
     return conv_wgrad_direct(*d, S(stream));
 }

@@ -271,7 +271,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
     _run_stats(lib, 'ledn_conv2d', x, stats, defer_stats, d, work=_TIMING is not None and (
         f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}',
         _nb(x, xadd, y, res, w), 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW,
-        ('conv_direct_kernel', 'conv_mfma_kernel', 'conv1x1_mfma_kernel', 'conv3x3_reg_kernel', 'conv3x3_narrowin_mfma_kernel')[lib.cdll.ledn_conv2d_uses_mfma(d)]))
+        ('conv_direct_kernel', 'conv_mfma_kernel', 'conv1x1_mfma_kernel', 'conv3x3_reg_kernel', 'conv3x3_narrowin_mfma_kernel', 'conv_f32_mfma_kernel')[lib.cdll.ledn_conv2d_uses_mfma(d)]))
     return y
 
 
@@ -505,7 +505,7 @@ def conv2d_wgrad(x, dz, w_shape, *, stride=1, pad=0, dil=1, groups=1, xadd=None,
             return dw, db
     _run(lib, 'ledn_conv2d_wgrad', x, d,
          work=_TIMING is not None and (f'wgrad{KH}x{KW} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W}', _nb(x, xadd, dz, dw), flops,
-                                       ('conv_wgrad_direct', 'conv_wgrad_mfma_kernel', 'conv3x3_wgrad_narrow_kernel', 'conv1x1_wgrad_reg_kernel')[lib.cdll.ledn_conv2d_wgrad_uses_mfma(d)]))
+                                       ('conv_wgrad_direct', 'conv_wgrad_mfma_kernel', 'conv3x3_wgrad_narrow_kernel', 'conv1x1_wgrad_reg_kernel', 'conv_wgrad_f32_mfma_kernel')[lib.cdll.ledn_conv2d_wgrad_uses_mfma(d)]))
     return dw, db
 
 

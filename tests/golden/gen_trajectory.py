@@ -82,7 +82,7 @@ def oracle_curve(steps=STEPS, log=None):
         for gr in opt.param_groups:
             gr['lr'] = poly_lr(it)
         opt.step()
-        rows.append([float(out['decode.loss_context']), float(out['decode.loss_spatial']), float(out['decode.acc_seg'])])
+        rows.append([float(out[k].detach()) for k in ("decode.loss_context", "decode.loss_spatial", "decode.acc_seg")])
         if log:
             log(it, rows[-1])
     return np.asarray(rows, np.float64)
