@@ -468,7 +468,7 @@ def main():
                        'rccl_nranks_all': (trainer.comm.nranks_all if mode == 'train' and trainer.comm is not None else None),
                        'collective_path': (None if mode != 'train' or trainer._all_reduce is None else
                                            ('one launch stream, one ordered collective sequence per rank (default for N > 1)'
-                                            if trainer._single_stream else 'LEDN_MULTI_COMM=1: one communicator per branch stream')),
+                                            if trainer._single_stream else 'LEDN_EXPERIMENTAL=1 LEDN_MULTI_COMM=1: one communicator per branch stream')),
                        'collectives_per_step': (None if not coll_log else
                                                 sum(1 for c in coll_log if c[1] == 'all_reduce') // k_steps),
                        'collective_launches_per_step': (None if not coll_log else _coll_launches(coll_log) // k_steps),

@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.environ.get('LEDN_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libledn_hip.so')   # (override: A/B of library builds)
+from ._env import knob as _knob  # noqa: E402
+HIP_LIB_PATH = _knob('LEDN_HIP_LIB', None) or os.path.join(_HERE, 'csrc', 'libledn_hip.so')   # (override: A/B of library builds)
 
 OK, EINVAL, ELAUNCH = 0, 1, 2
 F32, BF16, U8 = 0, 1, 2
@@ -305,10 +306,10 @@ def get_lib():
     if _hip is None:
         _hip = Library(HIP_LIB_PATH, is_hip=True)
         for env, opt in (('LEDN_CONV_WGS', 0), ('LEDN_WGRAD_WGS', 1)):      # A/B measurements of the launch-shape knobs
-            if os.environ.get(env) is not None:
-                _hip.set_option(opt, int(os.environ[env]))
-        if os.environ.get('LEDN_STREAM_FAST') is not None:      # A/B measurements: bit 0 = BatchNorm / affine streaming
-            _hip.set_option(OPT_STREAM_FAST, int(os.environ['LEDN_STREAM_FAST']))   # kernels, bit 1 = LDS-tiled depthwise 3x3
+            if _knob(env, None) is not None:                                 # (experimental: _env.py)
+                _hip.set_option(opt, int(_knob(env, None)))
+        if _knob('LEDN_STREAM_FAST', None) is not None:         # A/B measurements: bit 0 = BatchNorm / affine streaming
+            _hip.set_option(OPT_STREAM_FAST, int(_knob('LEDN_STREAM_FAST', None)))   # kernels, bit 1 = LDS-tiled depthwise 3x3
         _hip.set_option(OPT_DETERMINISTIC, int(_DET))
     return _hip
 

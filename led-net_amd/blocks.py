@@ -403,7 +403,8 @@ def _aff_seq(c, inter, pool=None):
 
 
 import os as _os
-FUSE_MFAF_CTX = int(_os.environ.get('LEDN_FUSE_MFAF_CTX', '1'))
+from ._env import knob_int as _knob_int  # noqa: E402
+FUSE_MFAF_CTX = _knob_int('LEDN_FUSE_MFAF_CTX', 1)
 
 
 class MFAF(Block):

@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_reg_kernel(C33Args a) {
 // rows per segment: the longest of 32 / 16 / 8 that still yields one task per resident wave (2 per SIMD); a task
 // re-reads 2 halo rows and starts with an exposed load round trip, so fewer, longer tasks win once the chip is full
 static int c33_rows(long columns, int H) {
-    static const int forced = getenv("LEDN_C33_RS") ? atoi(getenv("LEDN_C33_RS")) : 0;      // (A/B knob)
+    static const int forced = (int)exp_knob("LEDN_C33_RS", 0);      // (A/B knob)
     if (forced > 0) return forced;
     if (columns * cdiv(H, 32) >= 2048) return 32;
     if (columns * cdiv(H, 16) >= 1024) return 16;

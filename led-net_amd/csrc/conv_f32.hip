@@ -46,21 +46,22 @@ __global__ void __launch_bounds__(256) conv_f32_mfma_kernel(ledn_conv_desc d, fl
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lp = lane & 31, lh = lane >> 5;
     const int taps = d.KH * d.KW;
-    const long npix = (long)d.N * d.Ho * d.Wo;
+    const int npix = d.N * d.Ho * d.Wo;            // (tensors below 2^31 elements: conv_f32_mfma_supported)
     const int cog = d.Cout / d.groups, cig = d.Cin / d.groups;
     const int co0 = blockIdx.y * NT;
     // pixels of this lane: tile pt covers pixels base + pt * 32 + lp
-    const long base = ((long)blockIdx.x * 4 + wave) * (32 * PT);
+    const int base = (blockIdx.x * 4 + wave) * (32 * PT);
     int pn[PT], pho[PT], pwo[PT];
     bool pok[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-        const long pix = base + pt * 32 + lp;
+        const int pix = base + pt * 32 + lp;
         pok[pt] = pix < npix;
-        const long q = pok[pt] ? pix : 0;
-        pwo[pt] = (int)(q % d.Wo);
-        pho[pt] = (int)((q / d.Wo) % d.Ho);
-        pn[pt] = (int)(q / ((long)d.Wo * d.Ho));
+        const int q = pok[pt] ? pix : 0;
+        const int t = q / d.Wo;
+        pwo[pt] = q - t * d.Wo;
+        pn[pt] = t / d.Ho;
+        pho[pt] = t - pn[pt] * d.Ho;
     }
     f32x16_t acc[PT][CT];
 #pragma unroll
@@ -83,24 +84,31 @@ __global__ void __launch_bounds__(256) conv_f32_mfma_kernel(ledn_conv_desc d, fl
         const int cib = min(cibmax, c_hi - cb);       // multiple of 8
         const int Q = cib >> 3;
         __syncthreads();                              // the previous chunk's fragment reads are done
-        // stage W(co, ci, tap) of the chunk: element e -> (tap, q, h, co, j), channel ci = cb + 8 q + 4 h + j
-        for (int e = threadIdx.x; e < taps * Q * 2 * NT * 4; e += 256) {
-            const int j = e & 3, co = (e >> 2) % NT, h = ((e >> 2) / NT) & 1, qq = (((e >> 2) / NT) >> 1) % Q,
-                      tap = (((e >> 2) / NT) >> 1) / Q;
-            const int cg = co0 + co, ci = cb + 8 * qq + 4 * h + j;       // global output / input channel (kernel space)
-            float v = 0.f;
-            if (cg < d.Cout) {
-                const int g = cg / cog;
-                const int cil = ci - g * cig;
-                if (cil >= 0 && cil < cig) {
-                    // forward: W(co global, ci local); transposed: W(ci global_fwd-output = kernel ci, co local) -- the
-                    // addressing of conv_direct_kernel
-                    const long wb = d.transposed ? (long)(cg - g * cog) * d.ws_co + (long)ci * d.ws_ci
-                                                 : (long)cg * d.ws_co + (long)cil * d.ws_ci;
-                    v = d.w[wb + (long)tap * d.ws_tap];
+        // stage W(co, ci, tap) of the chunk: s_w[tap][q][h][co][j], channel ci = cb + 8 q + 4 h + j.  Index arithmetic by
+        // shifts only (NT, Q powers of two): a division per element cost as much as the matrix work of the chunk.
+        {
+            const int lq = Q == 4 ? 2 : (Q == 2 ? 1 : 0);
+            constexpr int LNT = CT == 2 ? 6 : 5;
+            const int per_tap = Q * 2 * NT * 4;
+            for (int i = threadIdx.x; i < per_tap; i += 256) {
+                const int j = i & 3, co = (i >> 2) & (NT - 1), h = (i >> (2 + LNT)) & 1, qq = (i >> (3 + LNT)) & ((1 << lq) - 1);
+                const int cg = co0 + co, ci = cb + 8 * qq + 4 * h + j;       // global output / input channel (kernel space)
+                long wb = -1;
+                if (cg < d.Cout) {
+                    int g = 0, cil = ci;
+                    if (d.groups > 1) {
+                        g = cg / cog;
+                        cil = ci - g * cig;
+                    }
+                    if (cil >= 0 && cil < cig)
+                        // forward: W(co global, ci local); transposed: W(kernel ci = forward output channel, global; co local)
+                        // -- the addressing of conv_direct_kernel
+                        wb = d.transposed ? (long)(cg - g * cog) * d.ws_co + (long)ci * d.ws_ci
+                                          : (long)cg * d.ws_co + (long)cil * d.ws_ci;
                 }
+                for (int tap = 0; tap < taps; ++tap)
+                    s_w[tap * per_tap + i] = wb >= 0 ? d.w[wb + (long)tap * d.ws_tap] : 0.f;
             }
-            s_w[e] = v;
         }
         __syncthreads();
         // prologue coefficients of this lane's channels (chunk-invariant over taps)
@@ -116,69 +124,88 @@ __global__ void __launch_bounds__(256) conv_f32_mfma_kernel(ledn_conv_desc d, fl
                                                               : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        for (int tap = 0; tap < taps; ++tap) {
-            const int kh = tap / d.KW, kw = tap - kh * d.KW;
-            long off[PT];
-            bool val[PT];
+        for (int kh = 0; kh < d.KH; ++kh) {
+            // input row of every pixel tile for this filter row (32-bit element offsets: the launcher checks the size)
+            int rowoff[PT];
+            bool rowok[PT];
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
-                int hi, wi;
+                int hi;
                 bool v = pok[pt];
                 if (!d.transposed) {
                     hi = pho[pt] * d.stride - d.pad + kh * d.dil;
-                    wi = pwo[pt] * d.stride - d.pad + kw * d.dil;
                 } else {
-                    const int th = pho[pt] + d.pad - kh * d.dil, tw = pwo[pt] + d.pad - kw * d.dil;
-                    v = v && th >= 0 && tw >= 0 && (th % d.stride) == 0 && (tw % d.stride) == 0;
-                    hi = th / d.stride;
-                    wi = tw / d.stride;
+                    const int th = pho[pt] + d.pad - kh * d.dil;
+                    if (d.stride == 1) hi = th;
+                    else if (d.stride == 2) { v = v && !(th & 1); hi = th >> 1; }
+                    else { v = v && th >= 0 && (th % d.stride) == 0; hi = th >= 0 ? th / d.stride : -1; }
                 }
-                v = v && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
-                val[pt] = v;
-                off[pt] = v ? (((long)pn[pt] * d.H + hi) * d.W + wi) * d.Cin + cb + 4 * lh : 0L;
+                rowok[pt] = v && hi >= 0 && hi < d.H;
+                rowoff[pt] = (pn[pt] * d.H + hi) * d.W;
             }
-            const float* wt = s_w + (long)tap * Q * 2 * NT * 4 + (lh * NT + lp) * 4;
+            for (int kw = 0; kw < d.KW; ++kw) {
+                const int tap = kh * d.KW + kw;
+                int off[PT];
+                bool val[PT];
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                if (qq < Q) {
-                    float4 a[PT];
-#pragma unroll
-                    for (int pt = 0; pt < PT; ++pt) {
-                        a[pt] = *reinterpret_cast<const float4*>(x + off[pt] + 8 * qq);
-                        if (PRO) {
-                            if (xadd) {
-                                const float4 u = *reinterpret_cast<const float4*>(xadd + off[pt] + 8 * qq);
-                                a[pt].x += u.x; a[pt].y += u.y; a[pt].z += u.z; a[pt].w += u.w;
-                            }
-                            a[pt].x = a[pt].x * psc[qq].x + psh[qq].x;
-                            a[pt].y = a[pt].y * psc[qq].y + psh[qq].y;
-                            a[pt].z = a[pt].z * psc[qq].z + psh[qq].z;
-                            a[pt].w = a[pt].w * psc[qq].w + psh[qq].w;
-                            if (d.in_act == LEDN_ACT_RELU) {
-                                a[pt].x = fmaxf(a[pt].x, 0.f); a[pt].y = fmaxf(a[pt].y, 0.f);
-                                a[pt].z = fmaxf(a[pt].z, 0.f); a[pt].w = fmaxf(a[pt].w, 0.f);
-                            } else if (d.in_act == LEDN_ACT_PRELU) {
-                                a[pt].x = a[pt].x > 0.f ? a[pt].x : a[pt].x * psl[qq].x;
-                                a[pt].y = a[pt].y > 0.f ? a[pt].y : a[pt].y * psl[qq].y;
-                                a[pt].z = a[pt].z > 0.f ? a[pt].z : a[pt].z * psl[qq].z;
-                                a[pt].w = a[pt].w > 0.f ? a[pt].w : a[pt].w * psl[qq].w;
-                            }
-                        }
-                        if (!val[pt]) a[pt] = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding AFTER the prologue
+                for (int pt = 0; pt < PT; ++pt) {
+                    int wi;
+                    bool v = rowok[pt];
+                    if (!d.transposed) {
+                        wi = pwo[pt] * d.stride - d.pad + kw * d.dil;
+                    } else {
+                        const int tw = pwo[pt] + d.pad - kw * d.dil;
+                        if (d.stride == 1) wi = tw;
+                        else if (d.stride == 2) { v = v && !(tw & 1); wi = tw >> 1; }
+                        else { v = v && tw >= 0 && (tw % d.stride) == 0; wi = tw >= 0 ? tw / d.stride : -1; }
                     }
-                    float4 b[CT];
+                    v = v && wi >= 0 && wi < d.W;
+                    val[pt] = v;
+                    off[pt] = v ? (rowoff[pt] + wi) * d.Cin + cb + 4 * lh : 0;
+                }
+                const float* wt = s_w + tap * Q * 2 * NT * 4 + (lh * NT + lp) * 4;
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        b[ct] = *reinterpret_cast<const float4*>(wt + (long)qq * 2 * NT * 4 + ct * 32 * 4);
+                for (int qq = 0; qq < 4; ++qq) {
+                    if (qq < Q) {
+                        float4 a[PT];
 #pragma unroll
-                    for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) {
-                            acc[pt][ct] = mfma_32x32x2_f32(a[pt].x, b[ct].x, acc[pt][ct]);
-                            acc[pt][ct] = mfma_32x32x2_f32(a[pt].y, b[ct].y, acc[pt][ct]);
-                            acc[pt][ct] = mfma_32x32x2_f32(a[pt].z, b[ct].z, acc[pt][ct]);
-                            acc[pt][ct] = mfma_32x32x2_f32(a[pt].w, b[ct].w, acc[pt][ct]);
+                        for (int pt = 0; pt < PT; ++pt) {
+                            a[pt] = *reinterpret_cast<const float4*>(x + off[pt] + 8 * qq);
+                            if (PRO) {
+                                if (xadd) {
+                                    const float4 u = *reinterpret_cast<const float4*>(xadd + off[pt] + 8 * qq);
+                                    a[pt].x += u.x; a[pt].y += u.y; a[pt].z += u.z; a[pt].w += u.w;
+                                }
+                                a[pt].x = a[pt].x * psc[qq].x + psh[qq].x;
+                                a[pt].y = a[pt].y * psc[qq].y + psh[qq].y;
+                                a[pt].z = a[pt].z * psc[qq].z + psh[qq].z;
+                                a[pt].w = a[pt].w * psc[qq].w + psh[qq].w;
+                                if (d.in_act == LEDN_ACT_RELU) {
+                                    a[pt].x = fmaxf(a[pt].x, 0.f); a[pt].y = fmaxf(a[pt].y, 0.f);
+                                    a[pt].z = fmaxf(a[pt].z, 0.f); a[pt].w = fmaxf(a[pt].w, 0.f);
+                                } else if (d.in_act == LEDN_ACT_PRELU) {
+                                    a[pt].x = a[pt].x > 0.f ? a[pt].x : a[pt].x * psl[qq].x;
+                                    a[pt].y = a[pt].y > 0.f ? a[pt].y : a[pt].y * psl[qq].y;
+                                    a[pt].z = a[pt].z > 0.f ? a[pt].z : a[pt].z * psl[qq].z;
+                                    a[pt].w = a[pt].w > 0.f ? a[pt].w : a[pt].w * psl[qq].w;
+                                }
+                            }
+                            if (!val[pt]) a[pt] = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding AFTER the prologue
                         }
+                        float4 b[CT];
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            b[ct] = *reinterpret_cast<const float4*>(wt + qq * 2 * NT * 4 + ct * 32 * 4);
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct) {
+                                acc[pt][ct] = mfma_32x32x2_f32(a[pt].x, b[ct].x, acc[pt][ct]);
+                                acc[pt][ct] = mfma_32x32x2_f32(a[pt].y, b[ct].y, acc[pt][ct]);
+                                acc[pt][ct] = mfma_32x32x2_f32(a[pt].z, b[ct].z, acc[pt][ct]);
+                                acc[pt][ct] = mfma_32x32x2_f32(a[pt].w, b[ct].w, acc[pt][ct]);
+                            }
+                    }
                 }
             }
         }
@@ -199,17 +226,17 @@ __global__ void __launch_bounds__(256) conv_f32_mfma_kernel(ledn_conv_desc d, fl
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const long pix = base + pt * 32 + row;
+                const int pix = base + pt * 32 + row;
                 if (pix < npix && cok) {
                     float v = acc[pt][ct][r] * sc + sh;
                     st1 += v;
                     st2 = fmaf(v, v, st2);
                     if (d.res_mode != LEDN_RES_NONE) {
-                        const float rv = res[pix * d.Cout + co];
+                        const float rv = res[(long)pix * d.Cout + co];
                         v = d.res_mode == LEDN_RES_ADD ? v + rv : v * rv + rv;
                     }
                     if (d.act_out != LEDN_ACT_NONE) v = act_apply(d.act_out, v, sl);
-                    y[pix * d.Cout + co] = v;
+                    y[(long)pix * d.Cout + co] = v;
                 }
             }
         }
@@ -242,7 +269,7 @@ bool conv_f32_mfma_supported(const ledn_conv_desc& d) {
     if (d.groups > 1 && (cig % 8)) return false;          // chunk bounds are multiples of 8 channels
     if (d.KH * d.KW > 9) return false;
     if ((long)d.N * d.Ho * d.Wo < 2048) return false;     // tiny maps: the direct kernel's launch is cheaper
-    if (d.in_scale && (d.Cin % 4)) return false;
+    if ((long)d.N * d.H * d.W * d.Cin >= (1L << 31) || (long)d.N * d.Ho * d.Wo * d.Cout >= (1L << 31)) return false;   // 32-bit offsets
     return true;
 }
 
@@ -284,16 +311,17 @@ int conv_f32_mfma(const ledn_conv_desc& d, hipStream_t s) {
 // grid: x = pixel ranges, y = (cout tile, cin tile) pairs over the DENSE channel ranges.  part[(bx * pairs + pair) * taps
 // + tap][1024]: element r * 64 + lane = D[row = (r&3) + 8 (r>>2) + 4 (lane>>5)][col = lane & 31], rows = cout, cols = cin.
 template <int TAPS>
-__global__ void __launch_bounds__(256) conv_wgrad_f32_mfma_kernel(ledn_wgrad_desc d, int ppb, int ci_tiles, float* part) {
+__global__ void __launch_bounds__(256, 2) conv_wgrad_f32_mfma_kernel(ledn_wgrad_desc d, int ppb, int ci_tiles, float* part) {
     __shared__ float s_red[3][16 * 64];           // waves 1..3 hand their accumulators over, one tap at a time
+    constexpr int U = TAPS == 9 ? 2 : 8;          // pixel pairs (K steps) per pipeline stage: U x (1 + TAPS) loads in flight per lane
+                                                  // (3x3: two stages of 20 registers next to the 144 accumulators = two waves per SIMD)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lc = lane & 31, lh = lane >> 5;
     const int pair = blockIdx.y, cot = pair / ci_tiles, cit = pair % ci_tiles;
     const int co = cot * 32 + lc, ci = cit * 32 + lc;
     const bool co_ok = co < d.Cout, ci_ok = ci < d.Cin;
-    const long npix = (long)d.N * d.Ho * d.Wo;
-    const long p_begin = (long)blockIdx.x * ppb, p_end = min(npix, p_begin + ppb);
-    // the four waves take interleaved pixel pairs: wave w handles pairs w, w + 4, ...
+    const int npix = d.N * d.Ho * d.Wo;           // (< 2^31: checked by the launcher)
+    const int p_begin = blockIdx.x * ppb, p_end = min(npix, p_begin + ppb);
     const float* x = reinterpret_cast<const float*>(d.x);
     const float* xadd = reinterpret_cast<const float*>(d.xadd);
     const float* dz = reinterpret_cast<const float*>(d.dz);
@@ -306,30 +334,70 @@ __global__ void __launch_bounds__(256) conv_wgrad_f32_mfma_kernel(ledn_wgrad_des
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (long p0 = p_begin + 2 * wave; p0 < p_end; p0 += 8) {
-        const long pix = p0 + lh;
-        const bool pok = pix < p_end;
-        const long q = pok ? pix : 0;
-        const int wo = (int)(q % d.Wo), ho = (int)((q / d.Wo) % d.Ho), n = (int)(q / ((long)d.Wo * d.Ho));
-        const float a = (pok && co_ok) ? dz[q * d.Cout + co] : 0.f;
-        float b[TAPS];
+    // wave w walks the pixel pairs w, w + 4, ... of the workgroup's range; stage = U consecutive pairs of the wave.
+    // Coordinates advance incrementally (no division in the loop): this lane's pixel = p0 + 8 u + lh.
+    float a_cur[U], b_cur[U][TAPS], a_nxt[U], b_nxt[U][TAPS];
+    constexpr int KS = TAPS == 9 ? 3 : 1;         // square filters: 3 x 3 or 1 x 1
+    auto fetch = [&](int p0, float (&av)[U], float (&bv)[U][TAPS]) {
+        int pix = p0 + lh;
+        int t = pix / d.Wo;
+        int wo = pix - t * d.Wo;
+        int n = t / d.Ho;
+        int ho = t - n * d.Ho;
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            const int kh = t / d.KW, kw = t - kh * d.KW;
-            const int hi = ho * d.stride - d.pad + kh * d.dil, wi = wo * d.stride - d.pad + kw * d.dil;
-            const bool v = pok && ci_ok && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W;
-            const long off = v ? (((long)n * d.H + hi) * d.W + wi) * d.Cin + ci : 0L;
-            float xv = x[off];
-            if (pro) {
-                if (xadd) xv += xadd[off];
-                xv = xv * psc + psh;
-                if (d.in_act == LEDN_ACT_RELU) xv = fmaxf(xv, 0.f);
-                else if (d.in_act == LEDN_ACT_PRELU) xv = xv > 0.f ? xv : xv * psl;
+        for (int u = 0; u < U; ++u) {
+            const bool pok = pix < p_end;
+            av[u] = (pok && co_ok) ? dz[pix * d.Cout + co] : 0.f;
+            // 32-bit element offsets (the launcher checks the tensor sizes); per tap: one add and two mask tests
+            const int h0 = ho * d.stride - d.pad, w0 = wo * d.stride - d.pad;
+            const int base = ((n * d.H + h0) * d.W + w0) * d.Cin + ci;
+            bool rok[KS], cok[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                rok[k] = (unsigned)(h0 + k * d.dil) < (unsigned)d.H;
+                cok[k] = (unsigned)(w0 + k * d.dil) < (unsigned)d.W;
             }
-            b[t] = v ? xv : 0.f;
-        }
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) acc[t] = mfma_32x32x2_f32(a, b[t], acc[t]);
+            for (int tp = 0; tp < TAPS; ++tp) {
+                const int kh = tp / KS, kw = tp % KS;
+                const bool v = pok && ci_ok && rok[kh] && cok[kw];
+                const int off = v ? base + (kh * d.dil * d.W + kw * d.dil) * d.Cin : 0;
+                float xv = x[off];
+                if (pro) {
+                    if (xadd) xv += xadd[off];
+                    xv = xv * psc + psh;
+                    if (d.in_act == LEDN_ACT_RELU) xv = fmaxf(xv, 0.f);
+                    else if (d.in_act == LEDN_ACT_PRELU) xv = xv > 0.f ? xv : xv * psl;
+                }
+                bv[u][tp] = v ? xv : 0.f;
+            }
+            pix += 8;
+            wo += 8;
+            while (wo >= d.Wo) {
+                wo -= d.Wo;
+                if (++ho >= d.Ho) {
+                    ho = 0;
+                    ++n;
+                }
+            }
+        }
+    };
+    int p0 = p_begin + 2 * wave;
+    if (p0 < p_end) fetch(p0, a_cur, b_cur);
+    while (p0 < p_end) {
+        const int pn = p0 + 8 * U;
+        if (pn < p_end) fetch(pn, a_nxt, b_nxt);           // the next stage's loads fly under this stage's products
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[t] = mfma_32x32x2_f32(a_cur[u], b_cur[u][t], acc[t]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a_cur[u] = a_nxt[u];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) b_cur[u][t] = b_nxt[u][t];
+        }
+        p0 = pn;
     }
     // waves 1..3 -> wave 0, tap by tap, in wave order (fixed summation order)
     float* out = part + ((long)blockIdx.x * gridDim.y + pair) * TAPS * 1024;
@@ -374,8 +442,12 @@ bool conv_wgrad_f32_mfma_supported(const ledn_wgrad_desc& d) {
     if (d.dtype_x != LEDN_F32 || d.dtype_dz != LEDN_F32) return false;
     if (!wgrad_f32_taps_ok(d.KH * d.KW)) return false;
     if (d.groups > 1 && d.KH != 1) return false;
-    if (d.Cout < 16 || d.Cin < 8) return false;
+    // (any input width: lanes beyond Cin load zeros -- the 3 -> 32 stem included: 3.2 -> 1.6 ms at 16 x 1024^2; the two-class
+    //  heads' 32 -> 2 layers measured SLOWER here than on the VALU kernel, 4.4 vs 2.3 ms: 30 of 32 tile rows empty)
+    if (d.Cout < 16) return false;
     if ((long)d.N * d.Ho * d.Wo < 2048) return false;
+    if ((long)d.N * d.H * d.W * d.Cin >= (1L << 31) || (long)d.N * d.Ho * d.Wo * d.Cout >= (1L << 31)) return false;   // 32-bit offsets
+    if (d.KH != d.KW) return false;
     return true;
 }
 

@@ -1412,7 +1412,7 @@ static int launch_wgrad(MfmaWgradArgs a, hipStream_t s, WgradDefer* df = nullptr
         // of x and dz and writes them in this kernel's partial-tile layout -- the summing kernels below serve both
         const long P = (long)a.N * a.Ho * a.Wo;
         if (!a.in_scale && a.in_act == LEDN_ACT_NONE && P >= 32768 && conv1x1_wgrad_reg_ok(a.Cin, a.Cout, a.groups)) {
-            static const int ipw = getenv("LEDN_W11_ITERS") ? atoi(getenv("LEDN_W11_ITERS")) : 8;   // (A/B knob: 4 and 8 measured equal, 8 = half the partial tiles)
+            static const int ipw = (int)exp_knob("LEDN_W11_ITERS", 8);   // (A/B knob: 4 and 8 measured equal, 8 = half the partial tiles)
             long nb = cdiv(P, 32L * 4 * (ipw > 0 ? ipw : 8));    // >= ipw iterations of 32 pixels per wave
             if (nb > options().wgrad_workgroups) nb = options().wgrad_workgroups;
             const int nbx = (int)nb;

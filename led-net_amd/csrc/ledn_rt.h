@@ -299,6 +299,13 @@ struct Options {
     int deterministic;      // LEDN_OPT_DETERMINISTIC: every cross-workgroup reduction in a fixed order (no f32 atomics)
 };
 Options& options();
+// A/B measurement knobs (getenv) are honoured only in experimental mode (LEDN_EXPERIMENTAL=1): an old shell export must
+// not change the launch shape of a normal run
+inline long exp_knob(const char* name, long def) {
+    const char* e = getenv("LEDN_EXPERIMENTAL");
+    const char* v = (e && atoi(e)) ? getenv(name) : nullptr;
+    return v ? atol(v) : def;
+}
 // deterministic mode: reductions that would end in float atomics for small grids take the partial-row path too
 inline bool det() { return options().deterministic != 0; }
 // ledn_conv2d_deferred_stats: the MFMA conv leaves its per-workgroup statistic rows [rows][2][C] in the

@@ -97,7 +97,7 @@ int dw3x3_bwd_weight_bf16(const ledn_dwbwd_desc& d, hipStream_t s) {
     // 16 pixels per thread (512 workgroups at 16 x 128 x 128 x 64): 28.8 / 36.6 us against 34.0 / 39.7 with 8 (graph replay,
     // r03); 32 and 64 are slower again.  Cost experiments of the same visit: every tap reading the centre pixel, only one tap
     // accumulated, next pixel's loads requested ahead -- none moved the time
-    static const int ppt = getenv("LEDN_DW_PPT") ? atoi(getenv("LEDN_DW_PPT")) : 16;     // (A/B knob)
+    static const int ppt = (int)exp_knob("LEDN_DW_PPT", 16);     // (A/B knob)
     long nb = cdiv((long)d.N * d.H * d.W, rows * (ppt > 0 ? ppt : 16));
     if (nb > 1024) nb = 1024;
     float* part = (nb > 32 || det()) ? ws_take(nb * 9 * d.C) : nullptr;

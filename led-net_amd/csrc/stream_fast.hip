@@ -369,7 +369,7 @@ int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
     // A second register buffer (next trip's loads issued before this trip's arithmetic; plain / ReLU variants, 124 VGPRs)
     // measured 13.15 against 13.08 ms, three alternating runs: not kept.
     long nb = cdiv(d.P, (long)rows * UNR);
-    static const long cap = getenv("LEDN_BNR_CAP") ? atol(getenv("LEDN_BNR_CAP")) : 1024;
+    static const long cap = exp_knob("LEDN_BNR_CAP", 1024);
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     float* part = d.rows ? nullptr : ws_take(nb * 3 * d.C);

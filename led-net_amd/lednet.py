@@ -36,8 +36,9 @@ def to_nchw_view(t):
 
 
 import os as _os
-SEAM_SLOT_EVAL = int(_os.environ.get('LEDN_SEAM_SLOT_EVAL', '2'))   # inference: SEAM edge map on its own stream
-FUSED_STEM = int(_os.environ.get('LEDN_FUSED_STEM', '1'))        # first stem conv as ONE kernel from the planar batch (ledn_stem_conv): on since its register-direct form (stem_conv_reg_kernel, r03: 103 us against 142 us for im2col + GEMM at 8 x 1024^2; the LDS-window form of round 2 measured 182 vs 161 and was off)
+from ._env import knob_int as _knob_int  # noqa: E402
+SEAM_SLOT_EVAL = _knob_int('LEDN_SEAM_SLOT_EVAL', 2)   # inference: SEAM edge map on its own stream
+FUSED_STEM = _knob_int('LEDN_FUSED_STEM', 1)        # first stem conv as ONE kernel from the planar batch (ledn_stem_conv): on since its register-direct form (stem_conv_reg_kernel, r03: 103 us against 142 us for im2col + GEMM at 8 x 1024^2; the LDS-window form of round 2 measured 182 vs 161 and was off)
 
 
 class LEDNet(Block):

@@ -198,7 +198,8 @@ def _run(lib, name, ref, *args, work=None):
 
 
 import os as _os
-DEFER_STATS = int(_os.environ.get('LEDN_DEFER_STATS', '3'))   # 0 off, 1 convolutions only, 3 all producers
+from ._env import knob_int as _knob_int  # noqa: E402
+DEFER_STATS = _knob_int('LEDN_DEFER_STATS', 3)   # 0 off, 1 convolutions only, 3 all producers
 
 
 def _run_stats(lib, name, ref, stats, defer, *args, work=None):

@@ -15,7 +15,8 @@ class _BnBwd:
     __slots__ = ('lib', 'd', 'z', 'bn', 'Cc', 'P', 'local', 'sunk', 'dz', 'dres', 'dslope', 'slope_sunk', 'keep')
 
 
-BN_ROWS = int(__import__('os').environ.get('LEDN_BN_ROWS', '0'))   # measured r3k: 13.85 vs 13.85 ms -- the 69 summing launches it removes were not on the critical path; off: keeps the reduction order fixed
+from ._env import knob_int as _knob_int  # noqa: E402
+BN_ROWS = _knob_int('LEDN_BN_ROWS', 0)   # measured r3k: 13.85 vs 13.85 ms -- the 69 summing launches it removes were not on the critical path; off: keeps the reduction order fixed
 
 
 def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,

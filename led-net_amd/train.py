@@ -19,6 +19,7 @@ from torch.autograd import Function
 from . import ops, ops_train as T
 from .ops import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_RELU6, RES_ADD, RES_GATE, RES_NONE
 
+from ._env import knob_int as _knob_int  # noqa: E402
 BN_MOMENTUM = 0.1
 
 
@@ -146,7 +147,7 @@ class FanoutFn(Function):
         return total, None, None
 
 
-FANIN_CHAIN = bool(int(_os.environ.get('LEDN_FANIN_CHAIN', '1')))
+FANIN_CHAIN = bool(_knob_int('LEDN_FANIN_CHAIN', 1))
 
 
 def fanout(x, k):
@@ -313,8 +314,8 @@ class BNActFn(Function):
         return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None, None, None
 
 
-WGRAD_DEFER = int(_os.environ.get('LEDN_WGRAD_DEFER', '1'))   # one summing launch for all weight gradients of a step (ops.WgradDefer)
-WGRAD_SLOT = int(_os.environ.get('LEDN_WGRAD_SLOT', '0'))   # auxiliary stream of the weight gradients, 0 = launch stream (measured r02n: 782 img/s on its own stream vs 892 on the launch stream; round-3 kernels: 1098 vs 1225)
+WGRAD_DEFER = _knob_int('LEDN_WGRAD_DEFER', 1)   # one summing launch for all weight gradients of a step (ops.WgradDefer)
+WGRAD_SLOT = _knob_int('LEDN_WGRAD_SLOT', 0)   # auxiliary stream of the weight gradients, 0 = launch stream (measured r02n: 782 img/s on its own stream vs 892 on the launch stream; round-3 kernels: 1098 vs 1225)
 
 
 def _conv_wgrad(x, dz, w_shape, sw, sb, **kw):
@@ -407,7 +408,7 @@ class BNActConvFn(Function):
 
 # BNActConvFn where a BatchNorm(+act) output feeds exactly one convolution: 0 = off, 1 = the norm->act->conv
 # modules of LEDHead only, 2 = also BasicBlock conv1->conv2 and the SESP expansion (LEDN_FUSE_BN_CONV)
-FUSE_BN_INTO_CONV = int(_os.environ.get('LEDN_FUSE_BN_CONV', '1'))   # measured: 0, 1, 2 within 0.3 % of each other (r01q)
+FUSE_BN_INTO_CONV = _knob_int('LEDN_FUSE_BN_CONV', 1)   # measured: 0, 1, 2 within 0.3 % of each other (r01q)
 
 
 class ActFn(Function):
@@ -779,7 +780,7 @@ class MfafTailFn(Function):
         return (dx, dr, *draws, None, None, None, *dgb)
 
 
-STEM_DIRECT = int(_os.environ.get('LEDN_STEM_DIRECT', '1'))
+STEM_DIRECT = _knob_int('LEDN_STEM_DIRECT', 1)
 
 
 class StemConvFn(Function):
@@ -1033,9 +1034,9 @@ def getb(m, x):
 
 TEST_HOOKS = {}     # tests only: 'edge' -> a given SEAM edge map [N,h,w,1] f32 instead of the kernel's (freezes the
                     # percentile binarisation for the deterministic whole-step gradient test)
-CTX_FORKS = int(_os.environ.get('LEDN_CTX_FORKS', '7'))    # bit s: context branch of stage 3+s on the aux stream (round 3: 7 -> 1225 img/s, 3 -> 1170, 0 -> 1139)
-SEAM_SLOT = int(_os.environ.get('LEDN_SEAM_SLOT', '0'))     # stream of the SEAM edge map: 0 = main (measured 895 vs 878 img/s on its own stream; round 3: 1225 vs 1204)
-MFAF_FORK = int(_os.environ.get('LEDN_MFAF_FORK', '0'))   # measured: 785 vs 876 img/s with the forks in TRAINING (inference gains 4 %: blocks.MFAF)
+CTX_FORKS = _knob_int('LEDN_CTX_FORKS', 7)    # bit s: context branch of stage 3+s on the aux stream (round 3: 7 -> 1225 img/s, 3 -> 1170, 0 -> 1139)
+SEAM_SLOT = _knob_int('LEDN_SEAM_SLOT', 0)     # stream of the SEAM edge map: 0 = main (measured 895 vs 878 img/s on its own stream; round 3: 1225 vs 1204)
+MFAF_FORK = _knob_int('LEDN_MFAF_FORK', 0)   # measured: 785 vs 876 img/s with the forks in TRAINING (inference gains 4 %: blocks.MFAF)
 
 
 class MfafCtxFn(Function):
@@ -1081,9 +1082,9 @@ class MfafCtxFn(Function):
         return (None, None, *dps, *[g if h else None for g, h in zip(flat, ctx.has)])
 
 
-FUSE_MFAF_CTX = int(_os.environ.get('LEDN_FUSE_MFAF_CTX', '1'))
-FUSE_MFAF_TAIL = int(_os.environ.get('LEDN_FUSE_MFAF_TAIL', '1'))   # ... and their trailing BatchNorms
-FUSE_MFAF_SYNC = int(_os.environ.get('LEDN_FUSE_MFAF_SYNC', '1'))   # ... under SyncBN too (phases + all-reduces in between)
+FUSE_MFAF_CTX = _knob_int('LEDN_FUSE_MFAF_CTX', 1)
+FUSE_MFAF_TAIL = _knob_int('LEDN_FUSE_MFAF_TAIL', 1)   # ... and their trailing BatchNorms
+FUSE_MFAF_SYNC = _knob_int('LEDN_FUSE_MFAF_SYNC', 1)   # ... under SyncBN too (phases + all-reduces in between)
 
 
 def mfaf(m, x, r, out_relu=False, pre=None):
@@ -1322,8 +1323,8 @@ class OhemUp2Fn(Function):
         return d0, d1, None, None, None, None
 
 
-FUSE_LOSS_RESIZE = int(_os.environ.get('LEDN_FUSE_LOSS_RESIZE', '1'))
-FUSE_LOSS_PAIR = int(_os.environ.get('LEDN_FUSE_LOSS_PAIR', '1'))     # both losses in one launch set (ohem_fused.hip)
+FUSE_LOSS_RESIZE = _knob_int('LEDN_FUSE_LOSS_RESIZE', 1)
+FUSE_LOSS_PAIR = _knob_int('LEDN_FUSE_LOSS_PAIR', 1)     # both losses in one launch set (ohem_fused.hip)
 
 
 def led_head_loss_by_feat(h, seg_logits, batch_data_samples):
@@ -1424,7 +1425,7 @@ class Trainer:
         # multi-communicator form (one communicator per branch stream, gradient exchange overlapped with the stem's
         # backward; validated on ONE rank only) deadlocks if two ranks ever start two communicators' kernels from a
         # shared hardware queue in opposite orders -- opt in with LEDN_MULTI_COMM=1 once an 8-GPU run has shown it.
-        self.multi_comm = bool(int(_os.environ.get('LEDN_MULTI_COMM', '0')))
+        self.multi_comm = bool(_knob_int('LEDN_MULTI_COMM', 0))     # (experimental: needs LEDN_EXPERIMENTAL=1)
         self._single_stream = (world_size > 1 or mode == 'rccl') and not self.multi_comm   # ('rccl' at N = 1: the self-test
         # of the N > 1 path on one GPU runs what N > 1 would run)
         self.comm = None
@@ -1462,7 +1463,7 @@ class Trainer:
                          if (self.coll is not None and dev.type == 'cuda' and not self._single_stream) else None)
         self._ready = {}
         self._early_done = False
-        self.overlap_exchange = bool(int(_os.environ.get('LEDN_OVERLAP_EXCHANGE', '1'))) and not self._single_stream
+        self.overlap_exchange = bool(_knob_int('LEDN_OVERLAP_EXCHANGE', 1)) and not self._single_stream
 
     @property
     def _all_reduce(self):      # (bench.py / older callers: "does this trainer exchange gradients")

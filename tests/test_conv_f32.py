@@ -128,3 +128,21 @@ def test_f32_mfma_equals_the_direct_kernel_to_rounding(be):
     ref = ops.conv2d(nhwc(x), D(w[:8].contiguous()), stride=1, pad=1)
     assert ops.conv2d(nhwc(x), D(w[:8].contiguous()), stride=1, pad=1, _query=True) == 0
     torch.testing.assert_close(got[..., :8].cpu(), ref.cpu(), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('cin,cout,stride,nhw', [(3, 32, 2, (2, 80, 84)), (1, 64, 1, (1, 48, 48)), (5, 16, 1, (1, 48, 48))])
+def test_f32_mfma_wgrad_narrow_channels(be, cin, cout, stride, nhw):
+    """the 3 -> 32 stem and SEAM's 1 -> 64 layer: lanes beyond Cin carry zeros (Cout < 16 stays on the VALU kernel)"""
+    from led_net_amd import ops
+    N, H, W = nhw
+    x = torch.randn(N, cin, H, W)
+    w = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    z = F.conv2d(x, w, b, stride=stride, padding=1)
+    dz = torch.randn_like(z)
+    z.backward(dz)
+    wk = dict(stride=stride, pad=1, bias=True)
+    assert ops.conv2d_wgrad(nhwc(x), nhwc(dz), tuple(w.shape), _query=True, **wk) == 4
+    dw, db = ops.conv2d_wgrad(nhwc(x), nhwc(dz), tuple(w.shape), **wk)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-3, atol=2e-4 * max(1.0, w.grad.abs().max().item()))
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3 * max(1.0, b.grad.abs().max().item()))

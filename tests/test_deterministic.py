@@ -45,11 +45,11 @@ def test_deterministic_mode_reaches_no_float_atomic(monkeypatch):
     assert n == 0, f'deterministic mode still reaches float atomics:\n{txt}'
 
 
-def _run_steps(dev, dtype, steps, deterministic, graph=False, hw=(320, 320), nb=2):
+def _run_steps(dev, dtype, steps, deterministic, graph=False, hw=(320, 320), nb=2, collectives=None):
     L, model, cfg, img, samples = _setup(dev, dtype, hw, nb)
     L.set_deterministic(deterministic)
     try:
-        tr = L.Trainer(model, cfg, max_iters=1000)
+        tr = L.Trainer(model, cfg, max_iters=1000, collectives=collectives)
         losses = []
         if graph:
             tr.capture(img, samples, warmup=2, restore=True)
@@ -154,3 +154,21 @@ def test_resumed_run_continues_bit_identically(tmp_path):
         assert not bad, bad[:5]
     finally:
         L.set_deterministic(False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('multi,forks', [('0', 7), ('1', 7), ('1', 0)])
+def test_rccl_step_graph_replay_equals_eager_bit_exact(multi, forks, monkeypatch):
+    """the N > 1 step on ONE rank (one-rank RCCL communicators: everything but the wire) in deterministic mode: the step
+    captured with its ncclAllReduce launches and replayed three times == the same three steps launched eagerly, bit for
+    bit -- for the default single-launch-stream plan (LEDN_MULTI_COMM=0), for the multi-communicator plan with the
+    context-branch streams (LEDN_CTX_FORKS=7) and without them (0).  A collective recorded on the wrong stream, dropped
+    from the graph or replayed against a stale buffer changes the weights."""
+    from led_net_amd import train as TR
+    monkeypatch.setenv('LEDN_EXPERIMENTAL', '1')
+    monkeypatch.setenv('LEDN_MULTI_COMM', multi)
+    monkeypatch.setattr(TR, 'CTX_FORKS', forks)
+    dev = torch.device('cuda:0')
+    a = _run_steps(dev, torch.bfloat16, 3, True, graph=False, nb=4, collectives='rccl')
+    b = _run_steps(dev, torch.bfloat16, 3, True, graph=True, nb=4, collectives='rccl')
+    _assert_bit_equal(a, b, f'rccl step (LEDN_MULTI_COMM={multi}, CTX_FORKS={forks}): hipGraph replay vs eager')

@@ -96,6 +96,7 @@ def _cmp_worker(rank, world, port, out_dir):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    os.environ['LEDN_EXPERIMENTAL'] = '1'
     os.environ['LEDN_MULTI_COMM'] = '1'      # the opt-in form: exchange of the non-stem gradients from inside the backward
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -172,6 +173,7 @@ def _order_worker(rank, world, port, out_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.pop('LEDN_MULTI_COMM', None)
+    os.environ.pop('LEDN_EXPERIMENTAL', None)
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import led_net_amd as L
@@ -234,6 +236,7 @@ def test_rccl_in_graph_single_rank(multi, monkeypatch):
     and replayed -- same parameters as the plain single-GPU trainer after three steps."""
     import copy
     sys.path.insert(0, ROOT)
+    monkeypatch.setenv('LEDN_EXPERIMENTAL', '1')
     monkeypatch.setenv('LEDN_MULTI_COMM', multi)     # '0': the default N > 1 path (one launch stream); '1': opt-in
     import led_net_amd as L
     assert torch.cuda.is_available()

@@ -1,8 +1,9 @@
 #!/bin/bash
+export LEDN_EXPERIMENTAL=1   # (this script sets A/B knobs: led-net_amd/_env.py)
 # A/B on ONE box (box-to-box spread is larger than most single changes): bench.py train under several env settings.
 # usage: bash tools/gpu_ab.sh TAG "ENV1=.. ENV2=.." "ENV1=.." ...   (each argument = one variant's environment; '-' = default)
 TAG=${1:-ab}; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-python __graft_entry__.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
+python __graft_entry__.py --incremental > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
 i=0
 for V in "$@"; do
   i=$((i+1)); [ "$V" = "-" ] && V=""

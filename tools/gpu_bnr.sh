@@ -1,8 +1,9 @@
 #!/bin/bash
+export LEDN_EXPERIMENTAL=1   # (this script sets A/B knobs: led-net_amd/_env.py)
 # BatchNorm-backward reduce kernel under its launch knobs, per shape (rocprofv3 kernel times of tools/stream_bench.py):
 #   bash tools/gpu_bnr.sh TAG "LEDN_BNR_CAP=1024" "LEDN_BNR_CAP=1024 LEDN_BNR_CONTIG=1" ...   ('-' = default)
 TAG=${1:-bnr}; shift; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-python __graft_entry__.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
+python __graft_entry__.py --incremental > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
 i=0
 for V in "$@"; do
   i=$((i+1)); [ "$V" = "-" ] && V=""

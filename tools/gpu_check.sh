@@ -5,10 +5,10 @@ TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python __graft_entry__.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
+python __graft_entry__.py --incremental > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
 timeout 1800 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
 tail -15 $OUT/pytest_gpu.log
-timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -6 $OUT/smoke.log
+timeout 600 python __graft_entry__.py --incremental smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -6 $OUT/smoke.log
 for MODE in train infer; do
   for DT in bf16 f32; do
     LEDN_BENCH_VERBOSE=1 timeout 1200 python bench.py --mode $MODE --steps 4 --warmup 2 --dtype $DT > $OUT/bench_${MODE}_$DT.json 2> $OUT/bench_${MODE}_$DT.err

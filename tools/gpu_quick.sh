@@ -2,7 +2,7 @@
 # short GPU visit: selected tests + bf16 train/infer benches (no CPU baseline).
 # usage: bash tools/gpu_quick.sh tag "pytest -k expr" [table-lines]
 TAG=${1:-q}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-python __graft_entry__.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
+python __graft_entry__.py --incremental > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
 timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "${2:-mfma or bf16}" > $OUT/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -6 $OUT/pytest.log
 [ $rc = 0 ] || exit $rc
 for MODE in train infer; do

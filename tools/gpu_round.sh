@@ -4,7 +4,7 @@
 # usage: bash tools/gpu_round.sh TAG [pytest]      (steps are chained: a failed GPU step stops the visit)
 TAG=${1:-r02}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 set -o pipefail
-python __graft_entry__.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
+python __graft_entry__.py --incremental > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
 if [ "$2" = pytest ]; then
   timeout -k 10 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -4 $OUT/pytest_gpu.log
   [ $rc = 0 ] || exit $rc

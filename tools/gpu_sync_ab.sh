@@ -1,7 +1,8 @@
 #!/bin/bash
+export LEDN_EXPERIMENTAL=1   # (this script sets A/B knobs: led-net_amd/_env.py)
 # A/B of the fused pooled-context sequence under SyncBN (one-rank RCCL self-test): bash tools/gpu_sync_ab.sh TAG
 TAG=${1:-sync}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-python __graft_entry__.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
+python __graft_entry__.py --incremental > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
 timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "mfaf or rccl or distributed" > $OUT/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 $OUT/pytest.log
 [ $rc = 0 ] || exit $rc
 for v in 1 0 1 0; do

@@ -1,7 +1,8 @@
 #!/bin/bash
+export LEDN_EXPERIMENTAL=1   # (this script sets A/B knobs: led-net_amd/_env.py)
 # where the SyncBN (one-rank RCCL) step differs from the plain one: bash tools/gpu_sync_gap.sh TAG
 TAG=${1:-gap}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-python __graft_entry__.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
+python __graft_entry__.py --incremental > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
 run() { # name, env..., -- args
   name=$1; shift
   env "$@" timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $ARGS > $OUT/$name.json 2> $OUT/$name.err || { tail -5 $OUT/$name.err; exit 1; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # generic GPU visit: bash tools/gpu_visit.sh TAG "pytest -k expr (or '-' for none)" [convbench] [bench]
 TAG=${1:-v}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-python __graft_entry__.py > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
+python __graft_entry__.py --incremental > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
 if [ "$2" != "-" ]; then
   timeout -k 10 1000 python -m pytest tests -m gpu -x -q -s -k "$2" > $OUT/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"
   grep -E "worst|frozen step|fan-in|passed|failed|Error" $OUT/pytest.log | cut -c1-400 | tail -20
