@@ -25,9 +25,9 @@
 extern "C" {
 #endif
 
-#define LEDN_ABI_VERSION 3
+#define LEDN_ABI_VERSION 4
 
-enum { LEDN_OK = 0, LEDN_EINVAL = 1, LEDN_ELAUNCH = 2 };
+enum { LEDN_OK = 0, LEDN_EINVAL = 1, LEDN_ELAUNCH = 2, LEDN_ESKIP = 3 /* optional fast path not applicable: use the general entry */ };
 enum { LEDN_F32 = 0, LEDN_BF16 = 1, LEDN_U8 = 2 };
 enum { LEDN_ACT_NONE = 0, LEDN_ACT_RELU = 1, LEDN_ACT_RELU6 = 2, LEDN_ACT_PRELU = 3, LEDN_ACT_SIGMOID = 4 };
 enum { LEDN_RES_NONE = 0, LEDN_RES_ADD = 1, LEDN_RES_GATE = 2 }; /* v+res | v*res+res */
@@ -64,6 +64,8 @@ enum {
                                        forward convolution on that kernel too (measured slower than conv_mfma_kernel's narrow epilogue); bit 8 (off): 3x3 stride-1
                                        convolutions with 64 input channels through a wave-private LDS ring (conv3x3_ring64_kernel: measured 10 % slower);
                                        0: the generic kernels (A/B measurements); < 0: the default mask */
+    LEDN_OPT_BN_FUSED = 4,          /* 1: ledn_bn_act_bwd_fused may launch its persistent one-pass kernel (default 0: it returns
+                                       LEDN_ESKIP); see that entry point */
     LEDN_OPT_DETERMINISTIC = 3      /* 1: every cross-workgroup reduction of the library (BatchNorm statistics and their
                                        backward sums, weight / bias gradients, pooled contexts and their gradients, the
                                        attention's bias gradient and the gradients of reflect-padded windows) runs in a
@@ -520,6 +522,19 @@ typedef struct {
 enum { LEDN_BNBWD_ROWS = 32 };
 int ledn_bn_act_bwd_reduce(const ledn_bnbwd_desc* d, void* stream);
 int ledn_bn_act_bwd_apply(const ledn_bnbwd_desc* d, void* stream);
+/* Both halves in ONE persistent launch (csrc/stream_fast.hip, bn_bwd_fused_kernel): z is read from memory once and kept in
+ * LDS across a grid-wide barrier (agent-scope release / acquire on an arrival counter in the bound workspace, bounded
+ * spin), dy a second time from the Infinity Cache; the [3][C] totals are float atomics.  Same descriptor and results as
+ * reduce + apply (sum_g / sum_gx / dslope accumulate the totals; summation order = atomics' arrival order).
+ * Returns LEDN_ESKIP -- nothing launched, call reduce + apply -- unless: bf16 tensors, C a power of two in 8..128,
+ * 64 K <= P*C/8 <= 2 M vectors, no `rows`, act in {none, ReLU, PReLU}, res_mode in {none, add}, a bound workspace,
+ * >= 256 compute units, not deterministic mode, and LEDN_OPT_BN_FUSED switched on.  The caller must launch it from ONE
+ * stream at a time (its workgroups wait for each other: two such launches running concurrently could starve each other
+ * of compute units) and never between the two halves of a SyncBN all-reduce.
+ * ledn_bn_act_bwd_fused_check: after a stream synchronisation, nonzero = the last fused launch gave up at its barrier
+ * (results of that launch are invalid); the fused form then stays off for the rest of the process. */
+int ledn_bn_act_bwd_fused(const ledn_bnbwd_desc* d, void* stream);
+int ledn_bn_act_bwd_fused_check(int C, void* stream);
 
 /* Depthwise convolution backward (geometry as ledn_dw_desc):
  *   data  : dx[N,H,W,C]  = sum_taps dz[...] * w   (+ `add` if given; ext1 folds the
@@ -572,7 +587,9 @@ int ledn_avgpool3x3s2_bwd(const void* dy, const void* add, void* dx, int N, int 
 
 /* Window attention backward.  dqkv [N,H,W,3C] f32 MUST be zeroed by the caller when
  * the map is reflect-padded (H or W not a multiple of ws): padded tokens add into
- * their source pixel.  dbiasT [heads][ws^2][ws^2] f32 is accumulated (caller zeroes). */
+ * their source pixel.  dbiasT [heads][ws^2][ws^2] f32 is accumulated (caller zeroes).
+ * Head dimension C / heads = 16 (LED-Net: 128 channels, 8 heads; UNetFormer_GETB.py:104-106) or 32; other head
+ * dimensions return LEDN_EINVAL (the head-dim-8 instance spilled 1.8-6 KB of registers per lane and was removed). */
 int ledn_window_attn_bwd(const void* qkv, const float* biasT, const void* dout, float* dqkv,
                          float* dbiasT, int N, int H, int W, int C, int heads, int ws, int dtype,
                          void* stream);

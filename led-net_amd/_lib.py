@@ -18,7 +18,8 @@ OK, EINVAL, ELAUNCH = 0, 1, 2
 F32, BF16, U8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_GATE = 0, 1, 2
-OPT_CONV_WORKGROUPS, OPT_WGRAD_WORKGROUPS, OPT_STREAM_FAST, OPT_DETERMINISTIC = 0, 1, 2, 3
+OPT_CONV_WORKGROUPS, OPT_WGRAD_WORKGROUPS, OPT_STREAM_FAST, OPT_DETERMINISTIC, OPT_BN_FUSED = 0, 1, 2, 3, 4
+ESKIP = 3
 
 vp, fp, i32, i64 = C.c_void_p, C.c_void_p, C.c_int, C.c_longlong
 
@@ -154,6 +155,8 @@ class SgdEntry(C.Structure):
 _PROTOS = {
     'ledn_bn_act_bwd_reduce': ([C.POINTER(BnBwdDesc), vp], i32),
     'ledn_bn_act_bwd_apply': ([C.POINTER(BnBwdDesc), vp], i32),
+    'ledn_bn_act_bwd_fused': ([C.POINTER(BnBwdDesc), vp], i32),
+    'ledn_bn_act_bwd_fused_check': ([i32, vp], i32),
     'ledn_dwconv2d_bwd_data': ([C.POINTER(DwBwdDesc), vp], i32),
     'ledn_dwconv2d_bwd_weight': ([C.POINTER(DwBwdDesc), vp], i32),
     'ledn_sesp_pyramid_bwd_data': ([C.POINTER(PyrBwdDesc), vp], i32),
@@ -224,7 +227,7 @@ _PROTOS = {
 EXPORTS = tuple(_PROTOS)
 
 
-ABI_VERSION = 3      # include/ledn.h LEDN_ABI_VERSION: bumped with every struct / signature change
+ABI_VERSION = 4      # include/ledn.h LEDN_ABI_VERSION: bumped with every struct / signature change
 
 
 class LednError(RuntimeError):

@@ -425,8 +425,7 @@ int window_attn_bwd_impl(const void* qkv, const float* biasT, const void* dout, 
     } while (0)
 #define LEDN_WBD(T)                        \
     do {                                   \
-        if (D == 8) LEDN_WB(T, 8);         \
-        else if (D == 16) LEDN_WB(T, 16);  \
+        if (D == 16) LEDN_WB(T, 16);       \
         else if (D == 32) LEDN_WB(T, 32);  \
         else return LEDN_EINVAL;           \
     } while (0)

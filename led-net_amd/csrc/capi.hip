@@ -150,7 +150,7 @@ static hipStream_t enter_stream(void* stream) {         // every extern "C" entr
     return (hipStream_t)stream;
 }
 Workspace& workspace() { return tls_ws; }
-static Options g_opt = {512, 512, 91, 0};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3, bit 2 round-robin conv tiles (off), bit 3 8-row conv tiles for under-filled grids, bit 4 register-direct 1x1 conv (conv1x1.hip), bit 5 resident 3x3 weights for 32 < Cin <= 64 (off: measured slower, r3l), bit 6 register-direct 3x3 conv for 32 input channels (conv3x3.hip)
+static Options g_opt = {512, 512, 91, 0, 0};   // stream_fast: bit 0 BatchNorm / affine streaming kernels, bit 1 LDS-tiled depthwise 3x3, bit 2 round-robin conv tiles (off), bit 3 8-row conv tiles for under-filled grids, bit 4 register-direct 1x1 conv (conv1x1.hip), bit 5 resident 3x3 weights for 32 < Cin <= 64 (off: measured slower, r3l), bit 6 register-direct 3x3 conv for 32 input channels (conv3x3.hip)
 Options& options() { return g_opt; }
 static thread_local DeferredStats g_defer = {false, nullptr, 0};
 DeferredStats& deferred_stats() { return g_defer; }
@@ -187,6 +187,7 @@ int ledn_set_option(int option, long long value) {
         case LEDN_OPT_WGRAD_WORKGROUPS: options().wgrad_workgroups = value > 0 ? (int)value : 512; return LEDN_OK;
         case LEDN_OPT_STREAM_FAST: options().stream_fast = value < 0 ? 91 : (int)value; return LEDN_OK;   // (< 0: the default mask)
         case LEDN_OPT_DETERMINISTIC: options().deterministic = value > 0 ? 1 : 0; return LEDN_OK;
+        case LEDN_OPT_BN_FUSED: options().bn_fused = value > 0 ? 1 : 0; return LEDN_OK;
         default: return LEDN_EINVAL;
     }
 }
@@ -431,6 +432,12 @@ int ledn_bn_act_bwd_reduce(const ledn_bnbwd_desc* d, void* stream) {
 int ledn_bn_act_bwd_apply(const ledn_bnbwd_desc* d, void* stream) {
     return d ? bn_act_bwd_apply_impl(*d, S(stream)) : LEDN_EINVAL;
 }
+int ledn_bn_act_bwd_fused(const ledn_bnbwd_desc* d, void* stream) {
+    if (!d) return LEDN_EINVAL;
+    if (!options().bn_fused) return LEDN_ESKIP;
+    return bn_act_bwd_fused(*d, S(stream));
+}
+int ledn_bn_act_bwd_fused_check(int C, void* stream) { return bn_act_bwd_fused_check(C, S(stream)); }
 int ledn_dwconv2d_bwd_data(const ledn_dwbwd_desc* d, void* stream) {
     return d ? dw_bwd_data_impl(*d, S(stream)) : LEDN_EINVAL;
 }

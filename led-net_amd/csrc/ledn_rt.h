@@ -297,6 +297,7 @@ struct Options {
     int wgrad_workgroups;
     int stream_fast;
     int deterministic;      // LEDN_OPT_DETERMINISTIC: every cross-workgroup reduction in a fixed order (no f32 atomics)
+    int bn_fused;           // LEDN_OPT_BN_FUSED: the persistent one-pass BatchNorm backward may be launched
 };
 Options& options();
 // A/B measurement knobs (getenv) are honoured only in experimental mode (LEDN_EXPERIMENTAL=1): an old shell export must
@@ -323,6 +324,8 @@ int finish_partials(const float* part, int nblk, int C, int nout, float* o0, flo
 int affine_act_fast(const ledn_affine_desc& d, hipStream_t s);
 int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s);
 int bn_act_bwd_apply_fast(const ledn_bnbwd_desc& d, hipStream_t s);
+int bn_act_bwd_fused(const ledn_bnbwd_desc& d, hipStream_t s);
+int bn_act_bwd_fused_check(int C, hipStream_t s);
 int channel_stats_fast(const void* x, const void* xadd, long long P, int C, int dtype, float* sum, float* sqsum,
                        hipStream_t s);
 

@@ -382,6 +382,290 @@ int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
 }
 
 // ===========================================================================
+// BatchNorm backward in ONE pass over memory (round 4): reduce + summing launch + apply fused into a persistent kernel.
+// The two-kernel form reads g and z twice (reduce: 2 tensors, apply: 2 tensors + 1 written = 167 MB at C = 64, 262144
+// pixels, bf16) and puts three launches on the critical stream.  Here every lane KEEPS its vectors of z and dy in
+// registers across the reduction (<= 256 workgroups x 512 lanes x 16 vectors x 16 B = 32 MB: the register files of the
+// chip hold the tensor); dy is read a second time, from the Infinity Cache its producer left it in: one launch, z read once:
+//   phase 1  load z, dy [, res], per-lane sums of (g, g*(z - mean), d slope) -> workgroup sums through LDS -> float
+//            atomics into the [3][C] totals (256 adders per address: ~2 us at the memory-side atomic units)
+//   barrier  agent-scope release + arrival counter, ONE lane polls (relaxed, s_sleep), agent-scope acquire
+//            (cdna_hip_programming.md Guideline 16); the spin is BOUNDED: a launch whose workgroups are not all resident
+//            gives up, raises the timeout word and the host falls back to the two-kernel form for good
+//   phase 2  A, B from the totals; dz = sc*g + A*z + B from the registers [+ fan-in addends], dres
+// Residency: grid <= 256 workgroups of 512 lanes on a 256-CU chip (one per CU fits whatever else runs: no other kernel
+// in this library waits on a resident peer, so every CU frees up in finite time).  Only launched from the step's main
+// stream (the host side decides), never in deterministic mode (atomics) nor under SyncBN (the all-reduce sits between
+// the two halves).  The CPU emulator runs workgroups one after another: no grid barrier there (entry returns LEDN_ESKIP).
+// MEASURED (MI355X, tools/bn_fused_bench.py, profiles/r04_bn_fused_bench.txt): correct (tests/test_stream_fast.py, 25 cases,
+// no barrier time-out) but SLOWER than the two kernels it replaces -- C = 64, 262144 pixels: 56.9 us against 50.6 us
+// (eager launches; 46.9 us inside the graph), the whole step 13.59 against 13.19 ms with the 25 eligible launches switched
+// over; 1024-lane workgroups (16 waves per CU, 128 registers): 69.6 us.  256 workgroups x 8 waves keep ~64 KB of loads in
+// flight per CU in 4-vector chunks; the two-kernel form has 2048 short workgroups retiring continuously.  OFF by default
+// (LEDN_OPT_BN_FUSED / LEDN_EXPERIMENTAL=1 LEDN_BN_FUSED=1); kept as the measured answer to "one pass instead of two".
+// ===========================================================================
+#ifndef LEDN_CPU_EMU
+constexpr int BF_T = 512, BF_G = 256;
+constexpr unsigned BF_SPIN_LIMIT = 1u << 21;        // x ~0.2 us per poll: gives up after ~0.4 s
+
+template <int ACT, int RES, bool HAS_DRES, bool HAS_ADD, int V>
+__global__ void __launch_bounds__(BF_T, 2) bn_bwd_fused_kernel(ledn_bnbwd_desc d, long nvec, float* tot, unsigned* sync) {
+    // z stays ON CHIP between the two phases, in LDS: 512 lanes x V = 16 vectors x 16 B = 128 KB of the CU's 160 KB.
+    // (Registers were the first choice -- 2 x 16 vectors per lane -- but every instance then spilled 0.2-2 KB per lane:
+    //  the arithmetic of a vector wants ~100 registers whatever scheduling fences are placed.)  dy is read a second time
+    //  from the Infinity Cache its producer left it in.
+    __shared__ uint4 s_z[V * BF_T];
+    __shared__ float s_par[5][128];         // sc, sh, sl, mean, invstd      (C <= 128)
+    __shared__ float s_ab[2][128];          // A, B of phase 2
+    __shared__ float s_redw[BF_T / 64][3 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < d.C; c += BF_T) {
+        s_par[0][c] = d.scale ? d.scale[c] : 1.f;
+        s_par[1][c] = d.shift ? d.shift[c] : 0.f;
+        s_par[2][c] = d.slope ? d.slope[c] : 0.f;
+        s_par[3][c] = d.bn_mode ? d.mean[c] : 0.f;
+        s_par[4][c] = d.bn_mode ? d.invstd[c] : 0.f;
+    }
+    __syncthreads();
+    const int cvn = d.C >> 3;               // <= 16: a wave holds 64 / cvn lanes per channel group
+    const int cg = (int)(tid % (unsigned)cvn);
+    const int c0 = cg * 8;
+    const long stride = (long)gridDim.x * BF_T;
+    const long first = (long)blockIdx.x * BF_T + tid;
+    float sc[8], sh[8], sl[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = s_par[0][c0 + k];
+        sh[k] = s_par[1][c0 + k];
+        sl[k] = ACT == LEDN_ACT_PRELU ? s_par[2][c0 + k] : 0.f;
+    }
+    {
+        float mean[8], a[8], b[8], e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            mean[k] = s_par[3][c0 + k];
+            a[k] = b[k] = e[k] = 0.f;
+        }
+        for (int v0 = 0; v0 < V; v0 += 4) {
+            uint4 zq[4], gq[4], rr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long i = first + (v0 + u) * stride;
+                const long j = i < nvec ? i : 0;
+                zq[u] = ldraw(d.z, j);
+                gq[u] = ldraw(d.dy, j);
+                if (RES != LEDN_RES_NONE) rr[u] = ldraw(d.res, j);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s_z[(v0 + u) * BF_T + tid] = zq[u];
+                if (first + (v0 + u) * stride >= nvec) continue;
+                float z[8], dy[8], rv[8];
+                unpack8(zq[u], z);
+                unpack8(gq[u], dy);
+                if (RES != LEDN_RES_NONE) unpack8(rr[u], rv);
+                BnG g;
+                bn_g8<ACT, RES>(z, dy, rv, sc, sh, sl, g);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    a[k] += g.gv[k];
+                    b[k] = fmaf(g.gv[k], z[k] - mean[k], b[k]);
+                    if (ACT == LEDN_ACT_PRELU) e[k] += g.dsl[k];
+                }
+            }
+        }
+        // lanes of one channel group inside the wave (cvn apart), then the 8 waves through LDS
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            for (int o = cvn; o < 64; o <<= 1) {
+                a[k] += __shfl_xor(a[k], o);
+                b[k] += __shfl_xor(b[k], o);
+                if (ACT == LEDN_ACT_PRELU) e[k] += __shfl_xor(e[k], o);
+            }
+        }
+        if (lane < cvn) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                s_redw[wave][c0 + k] = a[k];
+                s_redw[wave][d.C + c0 + k] = b[k];
+                s_redw[wave][2 * d.C + c0 + k] = e[k];
+            }
+        }
+    }
+    __syncthreads();
+    for (int o = tid; o < 3 * d.C; o += BF_T) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < BF_T / 64; ++w) t += s_redw[w][o];
+        if (o >= d.C && o < 2 * d.C) t *= s_par[4][o - d.C];
+        atomicAdd(tot + o, t);
+    }
+    // ---- grid barrier (Guideline 16): every adding wave drains, the workgroup meets, lane 0 releases + arrives + polls
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > BF_SPIN_LIMIT) {          // not every workgroup is resident: give up loudly, never hang
+                __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    // ---- phase 2: totals -> A, B (as bn_apply_fast_kernel), the first workgroup hands the totals to the gradient sinks
+    const float invn = (float)(1.0 / d.count);
+    for (int c = tid; c < d.C; c += BF_T) {
+        const float tg = __hip_atomic_load(tot + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float tgx = __hip_atomic_load(tot + d.C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float scc = s_par[0][c];
+        float A = 0.f, B = 0.f;
+        if (d.bn_mode) {
+            A = -scc * (tgx * invn) * s_par[4][c];
+            B = -scc * (tg * invn) - A * s_par[3][c];
+        }
+        if (blockIdx.x == 0) {
+            if (d.sum_g) d.sum_g[c] += tg;
+            if (d.sum_gx) d.sum_gx[c] += tgx;
+            if (d.dslope) d.dslope[c] += __hip_atomic_load(tot + 2 * d.C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_ab[0][c] = A;
+        s_ab[1][c] = B;
+    }
+    __syncthreads();
+    float A[8], B[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        A[k] = s_ab[0][c0 + k];
+        B[k] = s_ab[1][c0 + k];
+    }
+    const bool add_z = HAS_ADD && d.dz_add != nullptr, add_r = HAS_ADD && HAS_DRES && d.dres_add != nullptr;
+    for (int v0 = 0; v0 < V; v0 += 4) {
+        uint4 gq[4], rr[4], az[4], ar[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = first + (v0 + u) * stride;
+            const long j = i < nvec ? i : 0;
+            gq[u] = ldraw(d.dy, j);
+            if (RES != LEDN_RES_NONE) rr[u] = ldraw(d.res, j);
+            if (HAS_ADD) {
+                if (add_z) az[u] = ldraw(d.dz_add, j);
+                if (add_r) ar[u] = ldraw(d.dres_add, j);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = first + (v0 + u) * stride;
+            if (i >= nvec) continue;
+            float z[8], dy[8], rv[8];
+            unpack8(s_z[(v0 + u) * BF_T + tid], z);
+            unpack8(gq[u], dy);
+            if (RES != LEDN_RES_NONE) unpack8(rr[u], rv);
+            BnG g;
+            bn_g8<ACT, RES>(z, dy, rv, sc, sh, sl, g);
+            float dz[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dz[k] = fmaf(sc[k], g.gv[k], fmaf(A[k], z[k], B[k]));
+            if (HAS_ADD) {
+                if (add_z) {
+                    float t[8];
+                    unpack8(az[u], t);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) dz[k] += t[k];
+                }
+                if (add_r) {
+                    float t[8];
+                    unpack8(ar[u], t);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) g.gres[k] += t[k];
+                }
+            }
+            st8(reinterpret_cast<bf16_t*>(d.dz) + i * 8, dz);
+            if (HAS_DRES) st8(reinterpret_cast<bf16_t*>(d.dres) + i * 8, g.gres);
+        }
+    }
+}
+
+static int bf_state = 0;        // 0 untested, 1 usable, -1 disabled (fewer than 256 CUs, or a barrier timed out)
+
+// -> LEDN_OK handled | 3 (LEDN_ESKIP) not applicable: the caller runs ledn_bn_act_bwd_reduce + _apply
+int bn_act_bwd_fused(const ledn_bnbwd_desc& d, hipStream_t s) {
+    if (bf_state < 0 || det() || d.rows) return LEDN_ESKIP;
+    if (d.dtype_z != LEDN_BF16 || d.dtype_y != LEDN_BF16 || !sf_channels_ok(d.C) || d.C > 128) return LEDN_ESKIP;
+    if (d.act == LEDN_ACT_SIGMOID || d.act == LEDN_ACT_RELU6 || d.res_mode == LEDN_RES_GATE) return LEDN_ESKIP;
+    const bool has_dres = d.dres != nullptr;
+    if (has_dres && d.res_mode == LEDN_RES_NONE) return LEDN_ESKIP;
+    if (!d.bn_mode && d.slope == nullptr && false) return LEDN_ESKIP;
+    const long nvec = d.P * d.C / 8;
+    static const long vmin = exp_knob("LEDN_BNF_MIN", 1L << 16);
+    if (nvec < vmin || nvec > (long)BF_G * BF_T * 16) return LEDN_ESKIP;
+    if (bf_state == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            prop.multiProcessorCount < BF_G) {
+            bf_state = -1;
+            return LEDN_ESKIP;
+        }
+        bf_state = 1;
+    }
+    const long tot_floats = 3L * d.C + 16;
+    float* ws = ws_take(tot_floats);
+    if (!ws) return LEDN_ESKIP;
+    unsigned* sync = reinterpret_cast<unsigned*>(ws + 3 * d.C);
+    const int V = nvec > (long)BF_G * BF_T * 4 ? 16 : 4;
+    long G = cdiv(nvec, (long)BF_T * V);
+    if (G > BF_G) return LEDN_ESKIP;
+    // totals, arrival counter and timeout word start from zero EVERY launch (a memset node when captured)
+    if (hipMemsetAsync(ws, 0, sizeof(float) * (size_t)tot_floats, s) != hipSuccess) return LEDN_ELAUNCH;
+    const dim3 grid((unsigned)G);
+    const bool has_add = d.dz_add != nullptr || d.dres_add != nullptr;
+#define LEDN_BF(ACT_, RES_, DRES_)                                                                                  \
+    do {                                                                                                            \
+        if (V == 16) {                                                                                              \
+            if (has_add) LEDN_LAUNCH((bn_bwd_fused_kernel<ACT_, RES_, DRES_, true, 16>), grid, dim3(BF_T), 0, s, d, nvec, ws, sync);  \
+            else LEDN_LAUNCH((bn_bwd_fused_kernel<ACT_, RES_, DRES_, false, 16>), grid, dim3(BF_T), 0, s, d, nvec, ws, sync);         \
+        } else {                                                                                                    \
+            if (has_add) LEDN_LAUNCH((bn_bwd_fused_kernel<ACT_, RES_, DRES_, true, 4>), grid, dim3(BF_T), 0, s, d, nvec, ws, sync);   \
+            else LEDN_LAUNCH((bn_bwd_fused_kernel<ACT_, RES_, DRES_, false, 4>), grid, dim3(BF_T), 0, s, d, nvec, ws, sync);          \
+        }                                                                                                           \
+    } while (0)
+#define LEDN_BF_RES(ACT_)                                                                  \
+    do {                                                                                   \
+        if (d.res_mode == LEDN_RES_NONE) LEDN_BF(ACT_, LEDN_RES_NONE, false);              \
+        else if (has_dres) LEDN_BF(ACT_, LEDN_RES_ADD, true);                              \
+        else LEDN_BF(ACT_, LEDN_RES_ADD, false);                                           \
+    } while (0)
+    if (d.act == LEDN_ACT_NONE) LEDN_BF_RES(LEDN_ACT_NONE);
+    else if (d.act == LEDN_ACT_RELU) LEDN_BF_RES(LEDN_ACT_RELU);
+    else LEDN_BF_RES(LEDN_ACT_PRELU);
+#undef LEDN_BF_RES
+#undef LEDN_BF
+    return check_launch();
+}
+// the timeout word of the last fused launch on this stream's workspace (host-side check after a synchronisation):
+// nonzero = a barrier gave up; the fused form is then switched off for the rest of the process
+int bn_act_bwd_fused_check(int C, hipStream_t s) {
+    float* ws = ws_take(3L * C + 16);
+    if (!ws) return 0;
+    unsigned flag = 0;
+    if (hipMemcpyAsync(&flag, reinterpret_cast<unsigned*>(ws + 3 * C) + 1, sizeof(flag), hipMemcpyDeviceToHost, s) != hipSuccess) return 0;
+    if (hipStreamSynchronize(s) != hipSuccess) return 0;
+    if (flag) bf_state = -1;
+    return (int)flag;
+}
+#else
+int bn_act_bwd_fused(const ledn_bnbwd_desc&, hipStream_t) { return LEDN_ESKIP; }
+int bn_act_bwd_fused_check(int, hipStream_t) { return 0; }
+#endif
+
+// ===========================================================================
 // per-channel sum / sum of squares of x [+ xadd], bf16
 // ===========================================================================
 template <bool HAS_XADD, int UNR>

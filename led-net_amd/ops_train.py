@@ -12,7 +12,7 @@ from .ops import (ACT_NONE, RES_NONE, _DT, LednError, _check, _dt, _f32, _nb, _p
 
 class _BnBwd:
     """State of one BatchNorm(+activation, +residual) backward between its two kernels."""
-    __slots__ = ('lib', 'd', 'z', 'bn', 'Cc', 'P', 'local', 'sunk', 'dz', 'dres', 'dslope', 'slope_sunk', 'keep')
+    __slots__ = ('lib', 'd', 'z', 'bn', 'Cc', 'P', 'local', 'sunk', 'dz', 'dres', 'dslope', 'slope_sunk', 'keep', 'reduce_pending')
 
 
 from ._env import knob_int as _knob_int  # noqa: E402
@@ -21,7 +21,7 @@ BN_ROWS = _knob_int('LEDN_BN_ROWS', 0)   # measured r3k: 13.85 vs 13.85 ms -- th
 
 def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
                       res=None, res_mode=RES_NONE, count=None, want_dres=False, sinks=None, sync=False,
-                      dz_add=None, dres_add=None):
+                      dz_add=None, dres_add=None, launch=True):
     """First half of bn_act_bwd: the per-channel sums (sum g*xhat, sum g) of THIS rank's shard, reduced
     into the parameter-gradient sinks when given (they ARE d_gamma, d_beta of the local shard -- under
     SyncBN too: torch.nn.SyncBatchNorm keeps grad_weight / grad_bias local, DDP averages them later),
@@ -72,7 +72,9 @@ def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, 
         # summing launch between the two (ledn.h: ledn_bnbwd_desc.rows).  Not under SyncBN: the all-reduce needs totals.
         rows = _ops.zeros_f32((_lib.BNBWD_ROWS, 3, Cc), z.device)
         d.rows = _p(rows)
-    if bn or slope is not None:
+    st.reduce_pending = bool(bn or slope is not None)
+    if st.reduce_pending and launch:
+        st.reduce_pending = False
         _run(lib, 'ledn_bn_act_bwd_reduce', z, d, work=_ops._TIMING is not None and (f'bnbwd_reduce C{Cc} P{P}', _nb(z, dy, res), 6 * z.numel()))
     st.lib, st.d, st.z, st.bn, st.Cc, st.P, st.local, st.sunk = lib, d, z, bn, Cc, P, local, sunk
     st.dz, st.dres, st.dslope, st.slope_sunk = dz, dres, dslope, slope_sunk
@@ -88,6 +90,52 @@ def bn_act_bwd_sync(st, sync):
         sync.all_reduce(st.local, glob)
         st.d.sum_gx, st.d.sum_g = glob[0].data_ptr(), glob[1].data_ptr()
         st.keep += (glob,)
+
+
+BN_FUSED = _knob_int('LEDN_BN_FUSED', 0)      # the persistent one-pass BatchNorm backward (csrc/stream_fast.hip bn_bwd_fused_kernel)
+
+
+def set_bn_fused(flag):
+    """switch the one-pass BatchNorm backward on / off (library option + this module's dispatch)"""
+    global BN_FUSED
+    BN_FUSED = int(bool(flag))
+    _lib.get_lib().set_option(_lib.OPT_BN_FUSED, BN_FUSED)
+
+
+def _bn_bwd_fused(st):
+    """try ledn_bn_act_bwd_fused on the prepared descriptor: True = launched (both halves done), False = not applicable"""
+    lib, z = st.lib, st.z
+    if not lib.is_hip:
+        return False
+    if not getattr(lib, '_bn_fused_on', False):
+        lib.set_option(_lib.OPT_BN_FUSED, 1)
+        lib._bn_fused_on = True
+    stream = _ops._stream(lib, z)
+    lib.ensure_workspace(z.device, 0, stream=stream)
+    timing = _ops._TIMING is not None
+    if timing:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib.cdll.ledn_bn_act_bwd_fused(st.d, stream)
+    if rc == _lib.ESKIP:
+        return False
+    if rc != _lib.OK:
+        raise LednError(f'ledn_bn_act_bwd_fused failed: {rc}')
+    if timing:
+        e1.record()
+        _ops._TIMING.append(('ledn_bn_act_bwd_fused', (f'bnbwd_fused C{st.Cc} P{st.P}', _nb(z, st.keep[0], st.keep[1], st.dz, st.dres),
+                                                       14 * z.numel(), 'bn_bwd_fused_kernel'), e0, e1))
+    return True
+
+
+def _bn_bwd_result(st):
+    give = st.bn and not st.sunk
+    if give and st.keep[9] is not None and st.keep[10] is not None:
+        st.keep[9].add_(st.local[0])
+        st.keep[10].add_(st.local[1])
+        give = False
+    return (st.dz, st.dres, (st.local[0] if give else None), (st.local[1] if give else None),
+            None if st.slope_sunk else st.dslope)
 
 
 def bn_act_bwd_apply(st):
@@ -115,9 +163,19 @@ def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT
     dz_add / dres_add: partial gradients of z / res from another consumer of the same tensor, added in the apply pass.
     sinks: optional (dgamma, dbeta, dslope) ZEROED f32 [C] buffers (any may be None) the kernels
     reduce straight into (the trainer's gradient views); the matching return value is then None."""
+    fused = BN_FUSED and sync is None and z.is_cuda and z.dtype == torch.bfloat16 and _ops._slot(z) == 0
     st = bn_act_bwd_reduce(z, dy, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, slope=slope,
                            res=res, res_mode=res_mode, count=count, want_dres=want_dres, sinks=sinks,
-                           sync=sync is not None, dz_add=dz_add, dres_add=dres_add)
+                           sync=sync is not None, dz_add=dz_add, dres_add=dres_add, launch=not fused)
+    if fused:
+        # one persistent launch (reduce + grid barrier + apply; z held on chip): only from the step's MAIN stream -- its
+        # workgroups wait for each other, two such kernels on concurrent streams could starve each other of compute units
+        if _bn_bwd_fused(st):
+            return _bn_bwd_result(st)
+        if st.reduce_pending:
+            st.reduce_pending = False
+            _run(st.lib, 'ledn_bn_act_bwd_reduce', z, st.d, work=_ops._TIMING is not None and (
+                f'bnbwd_reduce C{st.Cc} P{st.P}', _nb(z, dy, res), 6 * z.numel()))
     bn_act_bwd_sync(st, sync)
     return bn_act_bwd_apply(st)
 

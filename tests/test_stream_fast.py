@@ -258,3 +258,84 @@ def test_dw8x8_lds_tile_weight_gradient(be, shape):
                            need_dx=False, dw_out=pre)
     want = w.grad[:, 0].permute(1, 2, 0) + 0.5
     torch.testing.assert_close(dw.cpu(), want, rtol=2e-2, atol=2e-2 * float(want.abs().max()))
+
+
+# --------------------------------------------------------------------------- #
+# one-pass BatchNorm backward (bn_bwd_fused_kernel: persistent workgroups, z held in LDS across a grid-wide barrier)
+# against the two-kernel form on the same tensors -- GPU only: the emulator runs workgroups one after another, so the
+# entry point reports LEDN_ESKIP there and ops_train falls back (asserted below).
+# --------------------------------------------------------------------------- #
+def _bn_bwd_case(dev, C, P, act, res_mode, want_dres, adds, seed):
+    from led_net_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(P, C, generator=g).bfloat16().to(dev).view(1, P, 1, C)
+    dy = torch.randn(P, C, generator=g).bfloat16().to(dev).view(1, P, 1, C)
+    res = torch.randn(P, C, generator=g).bfloat16().to(dev).view(1, P, 1, C) if res_mode != ops.RES_NONE else None
+    mean = z.float().mean((0, 1, 2))
+    var = z.float().var((0, 1, 2), unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    slope = (torch.rand(C, generator=g) * 0.3).to(dev) if act == ops.ACT_PRELU else None
+    dz_add = torch.randn(P, C, generator=g).bfloat16().to(dev).view(1, P, 1, C) if adds else None
+    dres_add = torch.randn(P, C, generator=g).bfloat16().to(dev).view(1, P, 1, C) if (adds and want_dres) else None
+    return dict(z=z, dy=dy, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, slope=slope, res=res,
+                res_mode=res_mode, count=P, want_dres=want_dres, dz_add=dz_add, dres_add=dres_add)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,P', [(64, 262144), (128, 65536), (16, 262144), (32, 100000), (64, 70001)])
+@pytest.mark.parametrize('variant', ['prelu', 'relu_res_dres', 'none_res_dres_adds', 'prelu_res', 'none'])
+def test_bn_bwd_fused_equals_two_kernels(C, P, variant):
+    from led_net_amd import ops, ops_train as T
+    dev = torch.device('cuda:0')
+    act = {'prelu': ops.ACT_PRELU, 'relu_res_dres': ops.ACT_RELU, 'none_res_dres_adds': ops.ACT_NONE,
+           'prelu_res': ops.ACT_PRELU, 'none': ops.ACT_NONE}[variant]
+    res_mode = ops.RES_ADD if 'res' in variant else ops.RES_NONE
+    kw = _bn_bwd_case(dev, C, P, act, res_mode, 'dres' in variant, 'adds' in variant, 7)
+    z, dy = kw.pop('z'), kw.pop('dy')
+    outs = []
+    for fused in (0, 1):
+        T.set_bn_fused(fused)
+        try:
+            sinks = (torch.zeros(C, device=dev), torch.zeros(C, device=dev),
+                     torch.zeros(C, device=dev) if act == ops.ACT_PRELU else None)
+            dz, dres, _, _, _ = T.bn_act_bwd(z, dy, sinks=sinks, **kw)
+            torch.cuda.synchronize()
+            if fused:
+                assert _lib_check(C) == 0, 'the fused launch gave up at its barrier'
+            outs.append((dz.float().cpu(), None if dres is None else dres.float().cpu(), [None if s is None else s.cpu() for s in sinks]))
+        finally:
+            T.set_bn_fused(0)
+    (dz0, dr0, s0), (dz1, dr1, s1) = outs
+    for a, b in zip(s0, s1):
+        if a is not None:
+            torch.testing.assert_close(b, a, rtol=2e-4, atol=2e-3 * max(1.0, a.abs().max().item()) * 1e-1)
+    # dz / dres: the same arithmetic on coefficients that differ by the summation order of the totals: bf16 outputs agree
+    # except for a rounding flip here and there
+    assert (dz1 - dz0).abs().max().item() <= 2e-2 * max(1.0, dz0.abs().max().item())
+    assert ((dz1 - dz0).abs() > 0).float().mean().item() < 0.02
+    if dr0 is not None:
+        assert torch.equal(dr0, dr1)
+
+
+def _lib_check(C):
+    from led_net_amd import _lib
+    lib = _lib.get_lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    return int(lib.cdll.ledn_bn_act_bwd_fused_check(C, stream))
+
+
+def test_bn_bwd_fused_is_skipped_on_the_emulator(emu):
+    """no grid barrier on the emulator: the entry reports LEDN_ESKIP and ops_train runs reduce + apply"""
+    from led_net_amd import _lib, ops, ops_train as T
+    lib = _lib.get_lib()
+    lib.set_option(_lib.OPT_BN_FUSED, 1)
+    try:
+        kw = _bn_bwd_case(torch.device('cpu'), 16, 4096, ops.ACT_NONE, ops.RES_NONE, False, False, 3)
+        st = T.bn_act_bwd_reduce(kw['z'], kw['dy'], scale=kw['scale'], shift=kw['shift'], mean=kw['mean'], invstd=kw['invstd'],
+                                 count=kw['count'], launch=False)
+        assert lib.cdll.ledn_bn_act_bwd_fused(st.d, None) == _lib.ESKIP
+    finally:
+        lib.set_option(_lib.OPT_BN_FUSED, 0)
