@@ -106,6 +106,8 @@ struct Ctx {
     Barrier* block_bar = nullptr;
     Barrier* wave_bar = nullptr;
     unsigned char* xchg = nullptr;  // this wave's exchange area: 64 lanes x 64 B
+    unsigned char* mx = nullptr;    // matrix-instruction operands: TWO such areas, used alternately (one barrier per MFMA)
+    int mphase = 0;
     void* sp = nullptr;             // saved stack pointer of this fiber
     bool done = false;
 };
@@ -158,7 +160,7 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem, F body) {
     constexpr size_t STACK = 96 * 1024;
     Barrier block_bar;
     std::vector<Barrier> wave_bars(nw);
-    std::vector<unsigned char> xchg((size_t)nw * 64 * 64);
+    std::vector<unsigned char> xchg((size_t)nw * 64 * 64 * 3);
     std::vector<unsigned char> smem(dyn_smem + 64);
     std::vector<unsigned char> stacks((size_t)nt * STACK + 64);
     std::vector<Ctx> fibers(nt);
@@ -179,7 +181,9 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem, F body) {
             c.wave = t / 64;
             c.block_bar = &block_bar;
             c.wave_bar = &wave_bars[c.wave];
-            c.xchg = xchg.data() + (size_t)c.wave * 64 * 64;
+            c.xchg = xchg.data() + (size_t)c.wave * 64 * 64 * 3;
+            c.mx = c.xchg + 64 * 64;
+            c.mphase = 0;
             c.done = false;
             // initial frame: 6 callee-saved slots + return address (16-B ABI alignment at entry)
             uintptr_t top = (uintptr_t)(stacks.data() + (size_t)(t + 1) * STACK);
@@ -323,8 +327,10 @@ inline float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsign
 // D: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5).
 inline emu_f32x16 mfma_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c) {
     Ctx& cx = *g_sched.cur;
-    std::memcpy(cx.xchg + cx.lane * 64, &a, 16);
-    std::memcpy(cx.xchg + cx.lane * 64 + 16, &b, 16);
+    unsigned char* const X = cx.mx + (size_t)cx.mphase * 64 * 64;     // alternate areas: a lane that runs ahead into the
+    cx.mphase ^= 1;                                                   // next MFMA writes the OTHER area (no trailing barrier)
+    std::memcpy(X + cx.lane * 64, &a, 16);
+    std::memcpy(X + cx.lane * 64 + 16, &b, 16);
     barrier_wait(cx.wave_bar);
     const int col = cx.lane & 31, hi = cx.lane >> 5;
     for (int reg = 0; reg < 16; ++reg) {
@@ -332,13 +338,12 @@ inline emu_f32x16 mfma_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c) {
         float acc = c[reg];
         for (int k = 0; k < 16; ++k) {
             unsigned short av, bv;
-            std::memcpy(&av, cx.xchg + (row + 32 * (k >> 3)) * 64 + 2 * (k & 7), 2);
-            std::memcpy(&bv, cx.xchg + (col + 32 * (k >> 3)) * 64 + 16 + 2 * (k & 7), 2);
+            std::memcpy(&av, X + (row + 32 * (k >> 3)) * 64 + 2 * (k & 7), 2);
+            std::memcpy(&bv, X + (col + 32 * (k >> 3)) * 64 + 16 + 2 * (k & 7), 2);
             acc = fmaf(bf16_bits_to_f32(av), bf16_bits_to_f32(bv), acc);
         }
         c[reg] = acc;
     }
-    barrier_wait(cx.wave_bar);
     return c;
 }
 
@@ -346,8 +351,10 @@ inline emu_f32x16 mfma_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c) {
 // D: col=l&15, row=(l>>4)*4+reg.
 inline emu_f32x4 mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
     Ctx& cx = *g_sched.cur;
-    std::memcpy(cx.xchg + cx.lane * 64, &a, 16);
-    std::memcpy(cx.xchg + cx.lane * 64 + 16, &b, 16);
+    unsigned char* const X = cx.mx + (size_t)cx.mphase * 64 * 64;     // alternate areas: a lane that runs ahead into the
+    cx.mphase ^= 1;                                                   // next MFMA writes the OTHER area (no trailing barrier)
+    std::memcpy(X + cx.lane * 64, &a, 16);
+    std::memcpy(X + cx.lane * 64 + 16, &b, 16);
     barrier_wait(cx.wave_bar);
     const int col = cx.lane & 15, q = cx.lane >> 4;
     for (int reg = 0; reg < 4; ++reg) {
@@ -355,21 +362,22 @@ inline emu_f32x4 mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
         float acc = c[reg];
         for (int k = 0; k < 32; ++k) {
             unsigned short av, bv;
-            std::memcpy(&av, cx.xchg + (row + 16 * (k >> 3)) * 64 + 2 * (k & 7), 2);
-            std::memcpy(&bv, cx.xchg + (col + 16 * (k >> 3)) * 64 + 16 + 2 * (k & 7), 2);
+            std::memcpy(&av, X + (row + 16 * (k >> 3)) * 64 + 2 * (k & 7), 2);
+            std::memcpy(&bv, X + (col + 16 * (k >> 3)) * 64 + 16 + 2 * (k & 7), 2);
             acc = fmaf(bf16_bits_to_f32(av), bf16_bits_to_f32(bv), acc);
         }
         c[reg] = acc;
     }
-    barrier_wait(cx.wave_bar);
     return c;
 }
 
 // v_mfma_f32_32x32x2_f32: lane l holds A[l&31][l>>5], B[l>>5][l&31]; D as 32x32 above.
 inline emu_f32x16 mfma_32x32x2_f32(float a, float b, emu_f32x16 c) {
     Ctx& cx = *g_sched.cur;
-    std::memcpy(cx.xchg + cx.lane * 64, &a, 4);
-    std::memcpy(cx.xchg + cx.lane * 64 + 4, &b, 4);
+    unsigned char* const X = cx.mx + (size_t)cx.mphase * 64 * 64;     // alternate areas: a lane that runs ahead into the
+    cx.mphase ^= 1;                                                   // next MFMA writes the OTHER area (no trailing barrier)
+    std::memcpy(X + cx.lane * 64, &a, 4);
+    std::memcpy(X + cx.lane * 64 + 4, &b, 4);
     barrier_wait(cx.wave_bar);
     const int col = cx.lane & 31, hi = cx.lane >> 5;
     for (int reg = 0; reg < 16; ++reg) {
@@ -377,13 +385,12 @@ inline emu_f32x16 mfma_32x32x2_f32(float a, float b, emu_f32x16 c) {
         float acc = c[reg];
         for (int k = 0; k < 2; ++k) {
             float av, bv;
-            std::memcpy(&av, cx.xchg + (row + 32 * k) * 64, 4);
-            std::memcpy(&bv, cx.xchg + (col + 32 * k) * 64 + 4, 4);
+            std::memcpy(&av, X + (row + 32 * k) * 64, 4);
+            std::memcpy(&bv, X + (col + 32 * k) * 64 + 4, 4);
             acc = fmaf(av, bv, acc);
         }
         c[reg] = acc;
     }
-    barrier_wait(cx.wave_bar);
     return c;
 }
 }  // namespace emu

@@ -149,6 +149,8 @@ def _product_grads_bf16(fanin_chain, monkeypatch, edge=None):
 def test_bf16_fanin_chains_match_plain_adds(be, monkeypatch):
     """bf16 whole step: gradients with the fan-in addend chains == gradients with plain elementwise gradient adds
     (identical forward, identical activation masks: what differs is only where the partial gradients are added)"""
+    from conftest import slow_on_emu
+    slow_on_emu(_DEV[0])          # (4.5 minutes on the emulator; since round 4 the GPU twin runs the same body in deterministic mode)
     import led_net_amd as L
     # two passes of the SAME bf16 step on the GPU differ by a median 25 % per parameter in the default mode (f32 atomics
     # order of the small-map statistics -> bf16 rounding -> activation masks: measured r3b), so round 3 could run this on

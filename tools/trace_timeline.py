@@ -32,7 +32,8 @@ rows.sort()
 # steps are delimited by the single sgd_step_kernel launch of each step
 ends = [i for i, r in enumerate(rows) if r[2] == 'sgd_kernel']
 if len(ends) < 4:      # inference: one planar im2col (or layout kernel) per step
-    first = 'im2col_stem_planar_kernel' if any(r[2] == 'im2col_stem_planar_kernel' for r in rows) else 'nchw_to_nhwc_kernel'
+    # (round 3 moved the inference stem onto stem_conv_reg_kernel: without it in this list the r03 inference timeline came out empty)
+    first = next((k for k in ('stem_conv_reg_kernel', 'im2col_stem_planar_kernel', 'nchw_to_nhwc_kernel') if any(r[2] == k for r in rows)), None)
     ends = [i - 1 for i, r in enumerate(rows) if r[2] == first]
 assert len(ends) >= 4, 'run bench.py --trace-only (steps are delimited by sgd_kernel / the first kernel of a pass)'
 lo, hi = ends[-4] + 1, ends[-1] + 1          # the last three steps (graph replays of the timed region)
