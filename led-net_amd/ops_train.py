@@ -180,6 +180,27 @@ def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT
     return bn_act_bwd_apply(st)
 
 
+# Depthwise / pyramid WEIGHT gradients of the main stream on an auxiliary stream (experimental knob, 0 = off): they have no
+# consumer inside the step (they reduce into the filter banks' gradient sinks, read by the flush at the end of the backward),
+# run at ~1-2 TB/s (latency-bound stencil reductions) and so fill the tails of the data-gradient -> BatchNorm-backward chain
+# without competing with it for HBM the way the convolution weight gradients did (LEDN_WGRAD_SLOT).
+DW_WGRAD_SLOT = _knob_int('LEDN_DW_WGRAD_SLOT', 0)
+
+
+def _on_side_stream(ref, sink, *keep):
+    """context manager: the auxiliary stream for a sink-bound weight gradient launched from the main stream, else a no-op"""
+    import contextlib
+    if not (DW_WGRAD_SLOT and _ops.MULTI_STREAM and ref.is_cuda and sink is not None and _ops._slot(ref) == 0):
+        return contextlib.nullcontext()
+    cur = torch.cuda.current_stream(ref.device)
+    side = _ops._aux_stream(ref.device, DW_WGRAD_SLOT)
+    side.wait_stream(cur)
+    for t in keep:
+        if isinstance(t, torch.Tensor):
+            t.record_stream(side)
+    return torch.cuda.stream(side)
+
+
 def _dw_desc(x_shape, dz, w_khwc, stride, pad, dil, group_size, ext1, dtype):
     N, H, W, Cc = x_shape
     KH, KW, _ = w_khwc.shape
@@ -214,7 +235,8 @@ def dwconv2d_bwd(x, dz, w_khwc, *, stride=1, pad=-1, dil=(1, 1, 1, 1), group_siz
             raise LednError('dwconv2d_bwd: dw_out shape/dtype mismatch')
         _check(lib, dw)
         d.dw = _p(dw)
-        _run(lib, 'ledn_dwconv2d_bwd_weight', x, d, work=_ops._TIMING is not None and (f'dwbwd_w{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(x, dz) , 2 * dz.numel() * KH * KW))
+        with _on_side_stream(x, dw_out, x, dz, dw):
+            _run(lib, 'ledn_dwconv2d_bwd_weight', x, d, work=_ops._TIMING is not None and (f'dwbwd_w{KH}x{KW} C{Cc} {tuple(x.shape)}', _nb(x, dz) , 2 * dz.numel() * KH * KW))
     return dx, dw
 
 
@@ -281,7 +303,8 @@ def sesp_pyramid_bwd(x, dy, w_b33n, dil, stride, dw_out=None):
         d.dil[i] = dil[i]
     d.dtype = _dt(x)
     _run(lib, 'ledn_sesp_pyramid_bwd_data', x, d, work=_ops._TIMING is not None and (f'pyrbwd_data n{n} {tuple(x.shape)}', _nb(dy, gsum, gsum, dx), 2 * dy.numel() * 9))
-    _run(lib, 'ledn_sesp_pyramid_bwd_weight', x, d, work=_ops._TIMING is not None and (f'pyrbwd_w n{n} {tuple(x.shape)}', _nb(x, gsum), 2 * dy.numel() * 9))
+    with _on_side_stream(x, dw_out, x, dy, gsum, dw):
+        _run(lib, 'ledn_sesp_pyramid_bwd_weight', x, d, work=_ops._TIMING is not None and (f'pyrbwd_w n{n} {tuple(x.shape)}', _nb(x, gsum), 2 * dy.numel() * 9))
     return dx, dw
 
 

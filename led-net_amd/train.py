@@ -315,6 +315,7 @@ class BNActFn(Function):
 
 
 WGRAD_DEFER = _knob_int('LEDN_WGRAD_DEFER', 1)   # one summing launch for all weight gradients of a step (ops.WgradDefer)
+WGRAD_SLOT_MAXPIX = _knob_int('LEDN_WGRAD_SLOT_MAXPIX', 0)   # with LEDN_WGRAD_SLOT: only layers of at most this many output pixels (the short, latency-bound 1/8-resolution ones)
 WGRAD_SLOT = _knob_int('LEDN_WGRAD_SLOT', 0)   # auxiliary stream of the weight gradients, 0 = launch stream (measured r02n: 782 img/s on its own stream vs 892 on the launch stream; round-3 kernels: 1098 vs 1225)
 
 
@@ -323,7 +324,9 @@ def _conv_wgrad(x, dz, w_shape, sw, sb, **kw):
     (it reduces into the flat gradient buffer, read by the exchange / SGD only): it runs on its own HIP
     stream, concurrently with the data-gradient -> BatchNorm-backward chain that IS the critical path."""
     if (WGRAD_SLOT and ops.MULTI_STREAM and dz.is_cuda and sw is not None
-            and (sb is not None or not kw.get('bias'))):
+            and (sb is not None or not kw.get('bias'))
+            and (not WGRAD_SLOT_MAXPIX or dz.shape[0] * dz.shape[1] * dz.shape[2] <= WGRAD_SLOT_MAXPIX)
+            and ops._slot(dz) == 0):
         cur = torch.cuda.current_stream(dz.device)
         side = ops._aux_stream(dz.device, WGRAD_SLOT)
         side.wait_stream(cur)
@@ -1571,10 +1574,11 @@ class Trainer:
         """the launch stream waits for the auxiliary streams that have no consumer inside the step
         (weight gradients)"""
         dev = self.flat_grad.device
-        if dev.type == 'cuda' and WGRAD_SLOT:
-            st = ops._AUX.get((dev, WGRAD_SLOT))
-            if st is not None:
-                torch.cuda.current_stream(dev).wait_stream(st)
+        if dev.type == 'cuda':
+            for slot in {WGRAD_SLOT, T.DW_WGRAD_SLOT} - {0}:
+                st = ops._AUX.get((dev, slot))
+                if st is not None:
+                    torch.cuda.current_stream(dev).wait_stream(st)
 
     def _exchange(self, lo, hi):
         """all-reduce flat_grad[lo:hi] in buckets on the gradient-exchange stream, after everything queued so
@@ -1603,8 +1607,8 @@ class Trainer:
         self._ready[tag] = self._ready.get(tag, 0) + 1
         if tag == 'post_stem' and self._ready[tag] == 3 and not self._early_done:
             self._early_done = True
+            self._join_side_streams()   # (LEDN_WGRAD_SLOT / LEDN_DW_WGRAD_SLOT: weight gradients written on auxiliary streams)
             _DwBanks.flush()            # (every depthwise filter lives outside the stem: their gradients are complete)
-            self._join_side_streams()   # (LEDN_WGRAD_SLOT: the partial tiles are written on the auxiliary stream)
             ops.WgradDefer.finish()     # (and the non-stem convolution weight gradients: summed into the buffer now)
             self._exchange(self.n_late, self.flat_grad.numel())
 
@@ -1627,8 +1631,8 @@ class Trainer:
             if 'loss' in k:
                 total = v if total is None else total + v
         total.backward()
+        self._join_side_streams()           # (the flush / summing launches read what auxiliary streams may have written)
         _DwBanks.flush()                    # all depthwise bank gradients -> the filters' gradient views, one launch
-        self._join_side_streams()           # (the summing launch reads partial tiles an auxiliary stream may have written)
         ops.WgradDefer.finish()             # all convolution weight gradients: partial tiles -> gradient views, one launch
         if first:
             # Parameters that never receive a gradient (SEAM conv_1: the binarised edge
