@@ -249,6 +249,8 @@ def main():
     ap.add_argument('--backbone', default='', help="reconstruction flags of LEDNet as key=value,... (e.g. cespb_depth=(2,3),context_tail='pappm'); default: the survey's contract")
     ap.add_argument('--deterministic', action='store_true',
                     help='run the whole bench in deterministic mode (LEDN_OPT_DETERMINISTIC: fixed-order reductions, no f32 atomics)')
+    ap.add_argument('--no-det-probe', action='store_true',
+                    help='skip the deterministic-mode cost measurement after the timed region (profiling runs: keeps its kernels out of the rocprofv3 statistics)')
     ap.add_argument('--trace-only', action='store_true',
                     help='stop after the timed region (for rocprofv3 timeline traces: no instrumented eager pass, no JSON)')
     args = ap.parse_args()
@@ -483,7 +485,7 @@ def main():
             'roofline': roof,
         }
         out['config']['deterministic'] = bool(L.is_deterministic())
-        if mode == 'train' and world == 1 and graphed and not L.is_deterministic():
+        if mode == 'train' and world == 1 and graphed and not L.is_deterministic() and not args.no_det_probe:
             # the price of deterministic mode on this box, measured after the timed region: the same step re-captured
             # with every reduction in a fixed order (partial rows + ordered summing launches instead of f32 atomics)
             try:

@@ -444,7 +444,7 @@ bool conv_wgrad_f32_mfma_supported(const ledn_wgrad_desc& d) {
     if (d.groups > 1 && d.KH != 1) return false;
     // (any input width: lanes beyond Cin load zeros -- the 3 -> 32 stem included: 3.2 -> 1.6 ms at 16 x 1024^2; the two-class
     //  heads' 32 -> 2 layers measured SLOWER here than on the VALU kernel, 4.4 vs 2.3 ms: 30 of 32 tile rows empty)
-    if (d.Cout < 16) return false;
+    if (d.Cout < 16 || d.Cin < 3) return false;      // (1 -> 64, SEAM: conv_wgrad_cin1's 20 us against 300 us here)
     if ((long)d.N * d.Ho * d.Wo < 2048) return false;
     if ((long)d.N * d.H * d.W * d.Cin >= (1L << 31) || (long)d.N * d.Ho * d.Wo * d.Cout >= (1L << 31)) return false;   // 32-bit offsets
     if (d.KH != d.KW) return false;

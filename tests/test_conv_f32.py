@@ -130,9 +130,9 @@ def test_f32_mfma_equals_the_direct_kernel_to_rounding(be):
     torch.testing.assert_close(got[..., :8].cpu(), ref.cpu(), rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize('cin,cout,stride,nhw', [(3, 32, 2, (2, 80, 84)), (1, 64, 1, (1, 48, 48)), (5, 16, 1, (1, 48, 48))])
+@pytest.mark.parametrize('cin,cout,stride,nhw', [(3, 32, 2, (2, 80, 84)), (5, 16, 1, (1, 48, 48))])
 def test_f32_mfma_wgrad_narrow_channels(be, cin, cout, stride, nhw):
-    """the 3 -> 32 stem and SEAM's 1 -> 64 layer: lanes beyond Cin carry zeros (Cout < 16 stays on the VALU kernel)"""
+    """the 3 -> 32 stem: lanes beyond Cin carry zeros (Cout < 16 and Cin < 3 stay on the VALU kernels)"""
     from led_net_amd import ops
     N, H, W = nhw
     x = torch.randn(N, cin, H, W)

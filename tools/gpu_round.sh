@@ -18,7 +18,7 @@ timeout -k 10 600 python bench.py --mode infer --batch 4 --height 1024 --width 2
 cat $OUT/bench_infer_bf16_configE.json
 timeout -k 10 600 python bench.py --collectives rccl --no-cpu-baseline > $OUT/bench_train_bf16_rccl_selftest.json 2> $OUT/bench_rccl.err || { echo "bench rccl failed"; tail -5 $OUT/bench_rccl.err; exit 1; }
 cat $OUT/bench_train_bf16_rccl_selftest.json
-(cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_train_bf16 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof_train.log 2>&1) || { echo "rocprof failed"; tail -5 $OUT/prof_train.log; exit 1; }
+(cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_train_bf16 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-det-probe > $GRAFT_REPO_ROOT/$OUT/prof_train.log 2>&1) || { echo "rocprof failed"; tail -5 $OUT/prof_train.log; exit 1; }
 f=$(find $OUT/prof_train_bf16 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/train_bf16_kernel_stats.csv && head -12 "$f" | cut -c1-160
 find $OUT/prof_train_bf16 -name "*kernel_trace.csv" -delete
 bash tools/gpu_trace.sh $TAG train > /dev/null 2>&1; head -3 $OUT/timeline_train.txt
