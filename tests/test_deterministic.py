@@ -172,3 +172,34 @@ def test_rccl_step_graph_replay_equals_eager_bit_exact(multi, forks, monkeypatch
     a = _run_steps(dev, torch.bfloat16, 3, True, graph=False, nb=4, collectives='rccl')
     b = _run_steps(dev, torch.bfloat16, 3, True, graph=True, nb=4, collectives='rccl')
     _assert_bit_equal(a, b, f'rccl step (LEDN_MULTI_COMM={multi}, CTX_FORKS={forks}): hipGraph replay vs eager')
+
+
+# --------------------------------------------------------------------------- #
+# the deterministic-mode kernels compute the SAME thing: the reference-generated block goldens (outputs, input gradients,
+# parameter gradients, running statistics) hold with the mode switched on -- emulator and MI355X.  Covers the kernels
+# that exist only in this mode: mfaf_dctx_det_kernel + mfaf_ctx_finish_kernel (Muti_AFF), window_attn_fold_kernel and the
+# fixed-point relative-position-bias adjoint (GETB on the odd 13 x 27 map), partial-row statistics of small grids.
+# --------------------------------------------------------------------------- #
+def _golden_cases():
+    import test_train as TT
+    cases = [('mfaf', n) for n in TT.train_names('g6_')] + [('getb', n) for n in TT.train_names('g5_')]
+    cases += [('sesp', TT.train_names('g2_')[0]), ('sesp', TT.train_names('g4')[0]), ('basic', TT.train_names('g11_')[-1]),
+              ('ppm', TT.train_names('g14_')[0]), ('head', 'g10')]
+    return cases
+
+
+@pytest.mark.parametrize('kind,name', _golden_cases())
+def test_block_goldens_hold_in_deterministic_mode(be, kind, name):
+    import led_net_amd as L
+    import test_train as TT
+    TT._DEV[0] = be.dev
+    L.set_deterministic(True)
+    try:
+        if kind == 'head':
+            TT.test_led_head_train_golden(be)
+        else:
+            {'mfaf': TT.test_mfaf_train_golden, 'getb': TT.test_getb_train_golden, 'sesp': TT.test_sesp_train_golden,
+             'basic': TT.test_basic_block_train_golden, 'ppm': TT.test_ppm_train_golden}[kind](be, name)
+    finally:
+        L.set_deterministic(False)
+        TT._DEV[0] = torch.device('cpu')
