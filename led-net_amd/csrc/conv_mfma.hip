@@ -1485,23 +1485,27 @@ static int conv_wgrad_mfma_x(const ledn_wgrad_desc& d, hipStream_t s, WgradDefer
     return d.stride == 1 ? launch_wgrad<1, 1>(a, s, df) : launch_wgrad<1, 2>(a, s, df);
 }
 
-// One launch for the deferred reductions of a whole backward pass.  Workgroup (1024 lanes) = 64 consecutive elements of
-// one (co, ci) tile pair of one table entry x 16 row groups, exactly as conv_wgrad_finish_kernel; the entry is found from
-// the chunk prefix (chunk0) of the table.
-__global__ void __launch_bounds__(1024) conv_wgrad_finish_multi_kernel(const ledn_wgrad_finish_entry* tab, int n) {
-    __shared__ float s_red[16][64];
+// One launch for the deferred reductions of a whole backward pass.  Workgroup (256 lanes) = ONE 32 x 32 tile (4 KB) of one
+// (co, ci) tile pair and tap of one table entry; a lane owns four consecutive elements and walks the partial rows with
+// eight 16-byte loads in flight, so every wave-load is 1 KB contiguous and a workgroup reads 4 KB per row.  (Round 3's
+// form -- 1024 lanes = 64 elements x 16 row groups -- read 256 B per row and workgroup, rows >= 36 KB apart: 429 MB in
+// 239 us = 1.8 TB/s, on the critical path between the backward and the optimizer.)  The entry is found from the chunk
+// prefix (chunk0, in 64-element chunks: 16 per tile) of the table.  Summation order: rows in order, 8 interleaved
+// partial sums -- fixed.
+__global__ void __launch_bounds__(256) conv_wgrad_finish_multi_kernel(const ledn_wgrad_finish_entry* tab, int n) {
     __shared__ int s_e;
+    const int chunk = (int)blockIdx.x * 16;
     if (threadIdx.x < 64) {
         int cnt = 0;
-        for (int i = threadIdx.x; i < n; i += 64) cnt += tab[i].chunk0 <= (int)blockIdx.x ? 1 : 0;
+        for (int i = threadIdx.x; i < n; i += 64) cnt += tab[i].chunk0 <= chunk ? 1 : 0;
         cnt = (int)wave_sum((float)cnt);
         if (threadIdx.x == 0) s_e = cnt - 1;
     }
     __syncthreads();
     const ledn_wgrad_finish_entry e = tab[s_e];
-    const int KK = e.KK, per_pair = KK * 16;                  // 64-element chunks per tile pair
-    const int local = (int)blockIdx.x - e.chunk0;
-    const int pair = local / per_pair, cx = local % per_pair;
+    const int KK = e.KK;
+    const int local = ((int)blockIdx.x * 16 - e.chunk0) / 16;          // tile index inside the entry: pair * KK + tap
+    const int pair = local / KK, tap = local % KK;
     const int ci_tile = pair % e.ci_tiles, co_tile = pair / e.ci_tiles;
     const int ci0 = ci_tile * 32, co0 = co_tile * 32;
     const int cig = e.Cin / e.groups, cog = e.Cout / e.groups;
@@ -1509,36 +1513,47 @@ __global__ void __launch_bounds__(1024) conv_wgrad_finish_multi_kernel(const led
         const int g_lo = co0 / cog, g_hi = min(co0 + 31, e.Cout - 1) / cog;
         if (ci0 + 31 < g_lo * cig || ci0 >= (g_hi + 1) * cig) return;
     }
-    const int el = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int el_idx = cx * 64 + el;
     const long stride = (long)e.pairs * (KK * 1024);
-    const float* src = e.part + (long)pair * (KK * 1024) + el_idx;
-    float acc = 0.f;
-    int b = rg;
-    for (; b + 112 < e.nbx; b += 128) {
-        float v[8];
+    const float4* src = reinterpret_cast<const float4*>(e.part + (long)pair * (KK * 1024) + (long)tap * 1024) + threadIdx.x;
+    const long s4 = stride / 4;
+    float4 acc[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(long)(b + 16 * u) * stride];
-        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    for (int u = 0; u < 8; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int b = 0;
+    for (; b + 8 <= e.nbx; b += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(long)(b + u) * s4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w;
+        }
     }
-    for (; b < e.nbx; b += 16) acc += src[(long)b * stride];
-    s_red[rg][el] = acc;
-    __syncthreads();
-    if (rg != 0) return;
-    float t = 0.f;
+    for (; b < e.nbx; ++b) {
+        const float4 v = src[(long)b * s4];
+        acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+    }
+    float t[4];
+    t[0] = ((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x)) + ((acc[4].x + acc[5].x) + (acc[6].x + acc[7].x));
+    t[1] = ((acc[0].y + acc[1].y) + (acc[2].y + acc[3].y)) + ((acc[4].y + acc[5].y) + (acc[6].y + acc[7].y));
+    t[2] = ((acc[0].z + acc[1].z) + (acc[2].z + acc[3].z)) + ((acc[4].z + acc[5].z) + (acc[6].z + acc[7].z));
+    t[3] = ((acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)) + ((acc[4].w + acc[5].w) + (acc[6].w + acc[7].w));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t += s_red[r][el];
-    const int tap = el_idx / 1024, co = co0 + (el_idx / 32) % 32, ci = ci0 + el_idx % 32;
-    if (co >= e.Cout || ci >= e.Cin) return;
-    const int g = co / cog;
-    if (ci / cig != g) return;
-    float* dst = e.dw + (long)co * e.ws_co + (long)(ci - g * cig) * e.ws_ci + (long)tap * e.ws_tap;
-    *dst += t;
+    for (int j = 0; j < 4; ++j) {
+        const int e1 = (int)threadIdx.x * 4 + j;
+        const int co = co0 + e1 / 32, ci = ci0 + e1 % 32;
+        if (co >= e.Cout || ci >= e.Cin) continue;
+        const int g = co / cog;
+        if (ci / cig != g) continue;
+        float* dst = e.dw + (long)co * e.ws_co + (long)(ci - g * cig) * e.ws_ci + (long)tap * e.ws_tap;
+        *dst += t[j];
+    }
 }
 
 int conv_wgrad_finish_multi_impl(const ledn_wgrad_finish_entry* table_dev, int n, int total_chunks, hipStream_t s) {
     LEDN_REQUIRE(table_dev && n > 0 && total_chunks > 0);
-    LEDN_LAUNCH(conv_wgrad_finish_multi_kernel, dim3((unsigned)total_chunks), dim3(1024), 0, s, table_dev, n);
+    LEDN_REQUIRE(total_chunks % 16 == 0);
+    LEDN_LAUNCH(conv_wgrad_finish_multi_kernel, dim3((unsigned)(total_chunks / 16)), dim3(256), 0, s, table_dev, n);
     return check_launch();
 }
 

@@ -362,7 +362,10 @@ __global__ void __launch_bounds__(256) bn_reduce_fast_kernel(ledn_bnbwd_desc d, 
 int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s) {
     if (d.dtype_z != LEDN_BF16 || d.dtype_y != LEDN_BF16 || !sf_channels_ok(d.C)) return -1;
     if (d.P * d.C / 8 < 4096) return -1;
-    constexpr int UNR = 4;
+#ifndef LEDN_BNR_UNR
+#define LEDN_BNR_UNR 4
+#endif
+    constexpr int UNR = LEDN_BNR_UNR;       // (A/B builds: -DLEDN_BNR_UNR=8 measured ... see EXPERIMENTS.md)
     const int rows = 256 / (d.C >> 3);
     // one trip per lane up to 1024 workgroups = ONE resident round (4 workgroups per CU by the 34 KB of LDS); whole step,
     // one box: cap 2048 13.13 ms, 1280 13.19, 1024 13.03 (three runs each), 768 13.05, 512 13.11  (LEDN_BNR_CAP: A/B knob).

@@ -329,3 +329,38 @@ def test_fused_stem_conv_equals_im2col_plus_gemm(be, shape, valid):
             xn[i, :, :, vw:] = 0.25
     ref = torch.nn.functional.conv2d(xn, w.cpu(), stride=2, padding=1).permute(0, 2, 3, 1)
     torch.testing.assert_close(zg.float().cpu(), ref, rtol=3e-2, atol=3e-2)
+
+
+def test_deferred_weight_gradients_one_summing_launch(be):
+    """ops.WgradDefer: several convolutions write their partial tiles, ONE ledn_conv2d_wgrad_finish_multi launch sums all of
+    them into their sinks (round 4: a workgroup per 32 x 32 tile, 16-byte row walks) == the immediate path, including a
+    grouped 1x1, a 1x1 on the wave-autonomous kernel and a sink that already holds a value (accumulation)."""
+    from led_net_amd import ops
+    shapes = [(32, 32, 3, 1, 1, (2, 24, 40)), (64, 64, 3, 1, 1, (2, 16, 33)), (64, 64, 1, 1, 4, (2, 32, 40)),
+              (128, 64, 3, 1, 1, (1, 12, 40)), (64, 128, 1, 1, 1, (2, 32, 40))]
+    items = []
+    for cin, cout, k, stride, groups, (N, H, W) in shapes:
+        x = r16(torch.randn(N, cin, H, W))
+        dz = r16(torch.randn(N, cout, H, W))
+        wshape = (cout, cin // groups, k, k)
+        base = torch.randn(wshape)
+        items.append((nhwc(x).bfloat16(), nhwc(dz).bfloat16(), wshape, dict(stride=stride, pad=k // 2, groups=groups), base))
+    want = []
+    for x, dz, wshape, kw, base in items:
+        sink = D(base.clone())
+        ops.conv2d_wgrad(x, dz, wshape, dw_out=sink, **kw)
+        want.append(sink.cpu())
+    ops.WgradDefer.reset()
+    ops.WgradDefer.active = True
+    try:
+        sinks = []
+        for x, dz, wshape, kw, base in items:
+            sink = D(base.clone())
+            sinks.append(sink)
+            ops.conv2d_wgrad(x, dz, wshape, dw_out=sink, **kw)
+        assert len(ops.WgradDefer.pending) >= 4, 'the MFMA weight gradients were not deferred'
+        ops.WgradDefer.finish()
+        for got, ref in zip(sinks, want):
+            torch.testing.assert_close(got.cpu(), ref, rtol=1e-4, atol=1e-3)
+    finally:
+        ops.WgradDefer.reset()
