@@ -8,19 +8,50 @@ namespace ledn {
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// v + the value of the lane `m` away in the coset pattern of an all-reduce (m a power of two): on the vector ALU where the
+// hardware has a lane-crossing form for it -- DPP row_ror inside a 16-lane row (m = 1, 2, 4, 8), v_permlane32_swap for the
+// two halves of the wave (m = 32) -- and through the LDS crossbar (ds_bpermute) only for m = 16.  The butterfly of
+// reduce_taps (72 accumulators x up to 6 levels per lane) was 360 ds_bpermute per lane for 16-channel maps: the epilogue
+// of the pyramid / depthwise weight-gradient kernels cost as much as their pixel loops.
+__device__ __forceinline__ float lane_step_sum(float v, int m) {
+#ifdef LEDN_CPU_EMU
+    return v + __shfl_xor(v, m);
+#else
+    if (m == 32) {
+        unsigned a = __float_as_uint(v), b = a;
+        permlane32_swap(a, b);                               // a = {low, low}, b = {high, high}
+        return __uint_as_float(a) + __uint_as_float(b);
+    }
+    if (m == 16) return v + __shfl_xor(v, 16);
+    const int iv = __float_as_int(v);
+    int r;
+    if (m == 8) r = __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xf, 0xf, false);        // row_ror:8
+    else if (m == 4) r = __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xf, 0xf, false);   // row_ror:4
+    else if (m == 2) r = __builtin_amdgcn_update_dpp(0, iv, 0x122, 0xf, 0xf, false);   // row_ror:2
+    else r = __builtin_amdgcn_update_dpp(0, iv, 0x121, 0xf, 0xf, false);               // row_ror:1
+    return v + __int_as_float(r);
+#endif
+}
+
 // sums `acc` (9 taps x 8 channels) over the pixel rows of one wave (lanes r*cvn + cv, cvn a power
 // of two), then over the 4 waves through LDS; thread e < nine*C then owns element e of [9][C]
 __device__ __forceinline__ void reduce_taps(f32x2_t (&acc)[9][4], int cvn, float* s_red /* [4][9*C] */, int C,
                                             int c) {
-    for (int m = 32; m >= cvn; m >>= 1) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[t][i].x += __shfl_xor(acc[t][i].x, m);
-                acc[t][i].y += __shfl_xor(acc[t][i].y, m);
-            }
+#define LEDN_RT_LEVEL(M)                                                        \
+    if (cvn <= (M)) {                                                           \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t)                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                     \
+                acc[t][i].x = lane_step_sum(acc[t][i].x, (M));                  \
+                acc[t][i].y = lane_step_sum(acc[t][i].y, (M));                  \
+            }                                                                   \
     }
+    LEDN_RT_LEVEL(32)
+    LEDN_RT_LEVEL(16)
+    LEDN_RT_LEVEL(8)
+    LEDN_RT_LEVEL(4)
+    LEDN_RT_LEVEL(2)
+    LEDN_RT_LEVEL(1)
+#undef LEDN_RT_LEVEL
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (lane < cvn) {   // cvn <= 64: the first cvn lanes of the wave hold its sums (cvn == 64: one row per wave)
 #pragma unroll
