@@ -185,10 +185,23 @@ __device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
     if (hi) a = recv;
     else b = recv;
 }
+// the same between neighbouring 16-lane rows (v_permlane16_swap_b32): a = {a.r0, b.r0, a.r2, b.r2}, b = {a.r1, b.r1, a.r3, b.r3}
+__device__ __forceinline__ void permlane16_swap(unsigned& a, unsigned& b) {
+    const bool odd = (lane_id() >> 4) & 1;
+    const unsigned recv = __shfl_xor(odd ? a : b, 16);
+    if (odd) a = recv;
+    else b = recv;
+}
 #else
 __device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     const u32x2_t r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r.x;
+    b = r.y;
+}
+__device__ __forceinline__ void permlane16_swap(unsigned& a, unsigned& b) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
     a = r.x;
     b = r.y;
 }

@@ -445,11 +445,159 @@ __global__ void __launch_bounds__(256) pyr_bwd_weight_bf16_kernel(ledn_pyrbwd_de
     }
 }
 
+// The same gradient when all four branches share one dilation (the spatial SESP blocks: eesp.py:40-62 with Spatial=True)
+// and the tiled data gradient left no suffix sums behind: ONE pass over the pixels for the four branches instead of one
+// workgroup column per branch -- the nine taps of x are the same for every branch, so a lane loads them once (and the four
+// dy vectors once) and feeds 4 x 9 accumulators per channel.  Lane = 4 channels of a pixel (8-byte loads; 144 f32
+// accumulators, two waves per SIMD), next pixel's 13 loads in flight under the 72 packed FMAs of this one.  The branch-per-
+// column kernel read x through the texture path 36 times and dy 10 times (386 MB for a 42 MB problem at n = 16) with
+// nothing in flight while it computed: 40 us at 16 x 128 x 128 x 16.
+// Epilogue: reduce-scatter over the two wave halves and the two rows of each half (v_permlane32_swap / v_permlane16_swap:
+// one swap + one add per register PAIR, 144 -> 36 registers), a butterfly inside the 16-lane row for the rest.
+__device__ __forceinline__ uint2 ld_tap8(const bf16_t* base, unsigned off, unsigned safe, bool valid) {
+    uint2 r = *reinterpret_cast<const uint2*>(base + (valid ? off : safe));
+    r.x = valid ? r.x : 0u;
+    r.y = valid ? r.y : 0u;
+    return r;
+}
+__device__ __forceinline__ void bf16x4_unpack(const uint2& r, f32x2_t* o) {
+    o[0] = f32x2_t{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
+    o[1] = f32x2_t{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void swap_add32(f32x2_t& a, f32x2_t& b) {
+    unsigned ax = __float_as_uint(a.x), bx = __float_as_uint(b.x), ay = __float_as_uint(a.y), by = __float_as_uint(b.y);
+    permlane32_swap(ax, bx);
+    permlane32_swap(ay, by);
+    a = f32x2_t{__uint_as_float(ax) + __uint_as_float(bx), __uint_as_float(ay) + __uint_as_float(by)};
+}
+__device__ __forceinline__ void swap_add16(f32x2_t& a, f32x2_t& b) {
+    unsigned ax = __float_as_uint(a.x), bx = __float_as_uint(b.x), ay = __float_as_uint(a.y), by = __float_as_uint(b.y);
+    permlane16_swap(ax, bx);
+    permlane16_swap(ay, by);
+    a = f32x2_t{__uint_as_float(ax) + __uint_as_float(bx), __uint_as_float(ay) + __uint_as_float(by)};
+}
+
+__global__ void __launch_bounds__(256, 2) pyr_bwd_weight_same_kernel(ledn_pyrbwd_desc d, float* part) {
+    constexpr int V = 4;
+    LEDN_DYN_SHARED(float, s_red);   // [4 waves][36][n]
+    const int dl = d.dil[0], n = d.n;
+    const int cvn = n / V;           // 4, 8 or 16 lanes per pixel
+    const int rows = 256 / cvn;
+    const int r = threadIdx.x / cvn, cv = threadIdx.x % cvn;
+    const int c = cv * V;
+    // acc[(b * 9 + t) * 2 + i]: branch b, tap t, channel pair i
+    f32x2_t acc[72];
+#pragma unroll
+    for (int j = 0; j < 72; ++j) acc[j] = f32x2_t{0.f, 0.f};
+    {
+        const bf16_t* x = reinterpret_cast<const bf16_t*>(d.x);
+        const bf16_t* g = reinterpret_cast<const bf16_t*>(d.dy);
+        int toff[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) toff[t] = ((t / 3 - 1) * dl * d.W + (t % 3 - 1) * dl) * n;
+        const long npix = (long)d.N * d.H * d.W;
+        const long ppb = cdiv(cdiv(npix, (long)gridDim.x), (long)rows) * rows;
+        const long p0 = (long)xcd_block(blockIdx.x, gridDim.x) * ppb, p1 = min(npix, p0 + ppb);
+        PixCursor cur;
+        cur.init(p0 + r, d.H, d.W);
+        uint2 xr[9], gr[4];
+        auto fetch = [&](long p, uint2 (&xo)[9], uint2 (&go)[4]) {
+            const bool in = p < p1;
+            const unsigned base = in ? (unsigned)(p * n + c) : (unsigned)c;
+            const unsigned mask = in ? tap_mask(cur.y, cur.x, dl, d.H, d.W) : 0u;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) xo[t] = ld_tap8(x, base + (unsigned)toff[t], base, (mask >> t) & 1u);
+            const unsigned gb = 4u * (base - (unsigned)c) + (unsigned)c;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) go[bb] = ld_tap8(g, gb + (unsigned)(bb * n), gb, in);
+            cur.advance(rows, d.H, d.W);
+        };
+        long p = p0 + r;
+        fetch(p, xr, gr);
+        for (; p < p1; p += rows) {
+            uint2 xn[9], gn[4];
+            fetch(p + rows, xn, gn);
+            f32x2_t gs[4][2];           // suffix sums g_b = sum_{b' >= b} dy_b' (the HFF adds of the forward, eesp.py:96-101)
+            bf16x4_unpack(gr[3], gs[3]);
+#pragma unroll
+            for (int bb = 2; bb >= 0; --bb) {
+                f32x2_t tv[2];
+                bf16x4_unpack(gr[bb], tv);
+                gs[bb][0] = gs[bb + 1][0] + tv[0];
+                gs[bb][1] = gs[bb + 1][1] + tv[1];
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                f32x2_t xv[2];
+                bf16x4_unpack(xr[t], xv);
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    acc[(bb * 9 + t) * 2] = pk_fma(xv[0], gs[bb][0], acc[(bb * 9 + t) * 2]);
+                    acc[(bb * 9 + t) * 2 + 1] = pk_fma(xv[1], gs[bb][1], acc[(bb * 9 + t) * 2 + 1]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) xr[t] = xn[t];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) gr[bb] = gn[bb];
+        }
+    }
+    // lanes r * cvn + cv, cvn <= 16: the two wave halves and the two rows of a half always hold different pixels
+#pragma unroll
+    for (int j = 0; j < 36; ++j) swap_add32(acc[j], acc[j + 36]);
+#pragma unroll
+    for (int j = 0; j < 18; ++j) swap_add16(acc[j], acc[j + 18]);
+    if (cvn <= 8) {
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            acc[j].x = lane_step_sum(acc[j].x, 8);
+            acc[j].y = lane_step_sum(acc[j].y, 8);
+        }
+    }
+    if (cvn <= 4) {
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            acc[j].x = lane_step_sum(acc[j].x, 4);
+            acc[j].y = lane_step_sum(acc[j].y, 4);
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if ((lane & 15) < cvn) {
+        // register j of this lane = float pair 2 j, 2 j + 1 of the 144 = [36 (branch, tap)][4 channels], offset by 36 floats
+        // in the odd rows and by 72 in the upper half of the wave
+        const int bt0 = 9 * ((lane >> 4) & 1) + 18 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            float* dst = s_red + (long)(wid * 36 + bt0 + j / 2) * n + c + 2 * (j % 2);
+            dst[0] = acc[j].x;
+            dst[1] = acc[j].y;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 36 * n; e += 256) {
+        const float sum = (s_red[e] + s_red[36 * n + e]) + (s_red[72 * n + e] + s_red[108 * n + e]);
+        if (part) part[(long)blockIdx.x * 36 * n + e] = sum;      // dw layout [4][3][3][n]
+        else atomicAdd(d.dw + e, sum);
+    }
+}
+
 int pyr_bwd_weight_bf16(const ledn_pyrbwd_desc& d, hipStream_t s) {
     const int cvn = d.n / 8;
     if (d.dtype != LEDN_BF16 || d.n % 8 || !pow2(cvn) || cvn > 64 || (long)d.N * d.H * d.W * d.n * 4 >= (1L << 31))
         return -1;
     const int rows = 256 / cvn;
+    static const bool same_on = exp_knob("LEDN_PYR_WGRAD_SAME", 1) != 0;     // (A/B knob)
+    if (same_on && pyr_tile_applies(d) && d.n <= 64 && d.dil[1] == d.dil[0] && d.dil[2] == d.dil[0] && d.dil[3] == d.dil[0]) {
+        const int rows4 = 256 / (d.n / 4);
+        long nb4 = cdiv((long)d.N * d.H * d.W, rows4 * 4);
+        if (nb4 > 512) nb4 = 512;            // one resident round: two workgroups per CU by the registers
+        float* part4 = (nb4 > 32 || det()) ? ws_take(nb4 * 36 * d.n) : nullptr;
+        if (!part4 && nb4 > 128) nb4 = 128;
+        LEDN_LAUNCH(pyr_bwd_weight_same_kernel, dim3((unsigned)nb4), dim3(256), (size_t)(144 * d.n) * sizeof(float), s, d,
+                    part4);
+        if (part4) return finish_partials(part4, (int)nb4, 36 * d.n, 1, d.dw, nullptr, nullptr, s);
+        return check_launch();
+    }
     long nb = cdiv((long)d.N * d.Ho * d.Wo, rows * 8);
     if (nb > 512) nb = 512;
     float* part = (nb > 32 || det()) ? ws_take(nb * 36 * d.n) : nullptr;
