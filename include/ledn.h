@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LEDN_ABI_VERSION 4
+#define LEDN_ABI_VERSION 5
 
 enum { LEDN_OK = 0, LEDN_EINVAL = 1, LEDN_ELAUNCH = 2, LEDN_ESKIP = 3 /* optional fast path not applicable: use the general entry */ };
 enum { LEDN_F32 = 0, LEDN_BF16 = 1, LEDN_U8 = 2 };
@@ -535,6 +535,35 @@ int ledn_bn_act_bwd_apply(const ledn_bnbwd_desc* d, void* stream);
  * (results of that launch are invalid); the fused form then stays off for the rest of the process. */
 int ledn_bn_act_bwd_fused(const ledn_bnbwd_desc* d, void* stream);
 int ledn_bn_act_bwd_fused_check(int C, void* stream);
+
+/* BatchNorm / activation backward of LEDHead's two-class heads -- norm -> act -> 3x3 conv 32 -> 2, stride 1, pad 1
+ * (mmseg/models/decode_heads/led_head.py:44-51, applied to the 1/2- and 1/4-resolution stem maps at :93-98) -- straight
+ * from the gradient of the head's LOGITS: the gradient of the activation dy = conv_transpose3x3(head_dz, w) is a function
+ * of the 3 x 3 x 2 patch of head_dz and is recomputed on the matrix cores inside both passes, never written (autograd of
+ * the reference materialises it: F.conv2d backward -> F.relu backward -> F.batch_norm backward).  Replaces, for these
+ * layers, ledn_conv2d(transposed) + ledn_bn_act_bwd_reduce + ledn_bn_act_bwd_apply; the head's weight / bias gradient is
+ * ledn_conv2d_wgrad as before.
+ *   bn: the descriptor of ledn_bn_act_bwd_reduce / _apply with z = the head's input x (bf16), dy = NULL, res_mode = none,
+ *       act in {none, ReLU, PReLU}; scale / shift / mean / invstd = the forward's batch-statistics affine; dz = the
+ *       gradient of x (apply pass, + dz_add when given); sum_g / sum_gx (/ dslope) accumulate d beta / d gamma (/ d slope)
+ *   reduce pass: sum_g, sum_gx, dslope exactly as ledn_bn_act_bwd_reduce (one partial row per workgroup in the bound
+ *       workspace + the summing launch: fixed order in deterministic mode)
+ *   apply pass: dz = scale * (g - sum_g / count - xhat * sum_gx / count) (+ dz_add), g = dy * act'.  Between the passes the
+ *       caller may all-reduce sum_g / sum_gx (SyncBN) exactly as with the layer-wise pair.
+ * w is rounded to bf16 for the matrix instruction (as in the MFMA data-gradient kernels it replaces); dy stays f32
+ * (the layer-wise form rounds it to bf16 once).
+ * Supported (ledn_head_bwd_supported != 0): Co = 2, C = 32, bf16 x and head_dz, >= 16384 pixels, a bound workspace;
+ * otherwise LEDN_EINVAL and the caller uses the layer-wise entries. */
+typedef struct {
+    ledn_bnbwd_desc bn;
+    const void* head_dz;    /* [N][H][W][Co] bf16 (dtype_dz): gradient of the head's logits */
+    const float* w;         /* [Co][C][3][3] f32 */
+    int N, H, W, Co;
+    int dtype_dz;
+} ledn_headbwd_desc;
+int ledn_head_bwd_supported(const ledn_headbwd_desc* d);
+int ledn_head_bwd_reduce(const ledn_headbwd_desc* d, void* stream);
+int ledn_head_bwd_apply(const ledn_headbwd_desc* d, void* stream);
 
 /* Depthwise convolution backward (geometry as ledn_dw_desc):
  *   data  : dx[N,H,W,C]  = sum_taps dz[...] * w   (+ `add` if given; ext1 folds the

@@ -125,6 +125,11 @@ class BnBwdDesc(C.Structure):
 BNBWD_ROWS = 32     # include/ledn.h LEDN_BNBWD_ROWS
 
 
+class HeadBwdDesc(C.Structure):
+    _fields_ = [('bn', BnBwdDesc), ('head_dz', vp), ('w', fp),
+                ('N', i32), ('H', i32), ('W', i32), ('Co', i32), ('dtype_dz', i32)]
+
+
 class DwBwdDesc(C.Structure):
     _fields_ = [('x', vp), ('dz', vp), ('w', fp), ('add', vp), ('dx', vp), ('dw', fp),
                 ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('Ho', i32), ('Wo', i32),
@@ -155,6 +160,9 @@ class SgdEntry(C.Structure):
 _PROTOS = {
     'ledn_bn_act_bwd_reduce': ([C.POINTER(BnBwdDesc), vp], i32),
     'ledn_bn_act_bwd_apply': ([C.POINTER(BnBwdDesc), vp], i32),
+    'ledn_head_bwd_supported': ([C.POINTER(HeadBwdDesc)], i32),
+    'ledn_head_bwd_reduce': ([C.POINTER(HeadBwdDesc), vp], i32),
+    'ledn_head_bwd_apply': ([C.POINTER(HeadBwdDesc), vp], i32),
     'ledn_bn_act_bwd_fused': ([C.POINTER(BnBwdDesc), vp], i32),
     'ledn_bn_act_bwd_fused_check': ([i32, vp], i32),
     'ledn_dwconv2d_bwd_data': ([C.POINTER(DwBwdDesc), vp], i32),
@@ -227,7 +235,7 @@ _PROTOS = {
 EXPORTS = tuple(_PROTOS)
 
 
-ABI_VERSION = 4      # include/ledn.h LEDN_ABI_VERSION: bumped with every struct / signature change
+ABI_VERSION = 5      # include/ledn.h LEDN_ABI_VERSION: bumped with every struct / signature change
 
 
 class LednError(RuntimeError):

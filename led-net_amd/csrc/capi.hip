@@ -438,6 +438,15 @@ int ledn_bn_act_bwd_fused(const ledn_bnbwd_desc* d, void* stream) {
     return bn_act_bwd_fused(*d, S(stream));
 }
 int ledn_bn_act_bwd_fused_check(int C, void* stream) { return bn_act_bwd_fused_check(C, S(stream)); }
+int ledn_head_bwd_supported(const ledn_headbwd_desc* d) { return d ? head_bwd_supported(*d) : 0; }
+int ledn_head_bwd_reduce(const ledn_headbwd_desc* d, void* stream) {
+    LEDN_REQUIRE(d);
+    return head_bwd_reduce(*d, S(stream));
+}
+int ledn_head_bwd_apply(const ledn_headbwd_desc* d, void* stream) {
+    LEDN_REQUIRE(d);
+    return head_bwd_apply(*d, S(stream));
+}
 int ledn_dwconv2d_bwd_data(const ledn_dwbwd_desc* d, void* stream) {
     return d ? dw_bwd_data_impl(*d, S(stream)) : LEDN_EINVAL;
 }

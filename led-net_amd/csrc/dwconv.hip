@@ -250,7 +250,8 @@ __global__ void __launch_bounds__(256) dw3x3_tile_kernel(ledn_dw_desc d, const b
     constexpr int TW = 32, PW = TW + 2 * HL, PH = TH + 2 * HL, CW = 32, PXB = CW * 2;
     constexpr int NL = (PH * PW * 4 + 255) / 256;
     __shared__ __attribute__((aligned(16))) unsigned char s_patch[PH * PW * PXB];
-    __shared__ float s_red[2][64 * CW];
+    static_assert(PH * PW * PXB >= 2 * 64 * CW * 4, "the statistics exchange reuses the patch");
+    float(*s_red)[64 * CW] = reinterpret_cast<float(*)[64 * CW]>(s_patch);     // the patch is dead by then (barrier first)
     const int tid = threadIdx.x;
     const int tx = (d.W + TW - 1) / TW, ty = (d.H + TH - 1) / TH, nch = d.C / CW;
     const unsigned bid = xcd_block(blockIdx.x, gridDim.x);
@@ -346,6 +347,7 @@ __global__ void __launch_bounds__(256) dw3x3_tile_kernel(ledn_dw_desc d, const b
     }
     if (FLIP || !part) return;
     // per-channel sums of the tile: [64 pixel lanes][32 channels] -> one partial row slice per workgroup
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         s_red[0][pl * CW + cg * 8 + 2 * i] = st1[i].x;
@@ -684,7 +686,8 @@ static int dw3x3_tile_launch(const ledn_dw_desc& d, bool flip, const bf16_t* add
     int hl = 0;
     for (int g = 0; g * d.group_size < d.C; ++g) hl = d.dil[g] > hl ? d.dil[g] : hl;
     if (hl > 5) return -1;
-    const int TH = hl <= 2 ? 16 : 8;
+    static const int th2 = (int)exp_knob("LEDN_DW_TH", 16);      // (A/B knob: 8 = more, shorter workgroups for dilation <= 2)
+    const int TH = (hl <= 2 && th2 != 8) ? 16 : 8;
     const long tiles = (long)d.N * cdiv(d.H, TH) * cdiv(d.W, 32);
     const long nb = tiles * (d.C / 32);
     if (nb > (1L << 30) || tiles > 16384) return -1;
@@ -693,9 +696,12 @@ static int dw3x3_tile_launch(const ledn_dw_desc& d, bool flip, const bf16_t* add
         part = ws_take(tiles * 2 * d.C);
         if (!part) return -1;
     }
-    if (hl <= 2) {
+    if (hl <= 2 && TH == 16) {
         if (flip) LEDN_LAUNCH((dw3x3_tile_kernel<1, 2, 16>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
         else LEDN_LAUNCH((dw3x3_tile_kernel<0, 2, 16>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
+    } else if (hl <= 2) {
+        if (flip) LEDN_LAUNCH((dw3x3_tile_kernel<1, 2, 8>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
+        else LEDN_LAUNCH((dw3x3_tile_kernel<0, 2, 8>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
     } else {
         if (flip) LEDN_LAUNCH((dw3x3_tile_kernel<1, 5, 8>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
         else LEDN_LAUNCH((dw3x3_tile_kernel<0, 5, 8>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);

@@ -1,0 +1,363 @@
+// head_bwd.hip -- BatchNorm / activation backward of LEDHead's two-class heads (led_head.py:44-51: norm -> act -> 3x3 conv
+// 32 -> num_classes on the 1/2- and 1/4-resolution stem maps) without ever writing the gradient of the activation:
+//
+//   forward   t = act(x * scale + shift)   (training-mode BatchNorm folded into scale / shift),   z = conv3x3(t, w) + b
+//   backward  dy[p][c] = sum_{k,o} dz[p - off(k)][o] * w[o][c][k]                 (transposed 3x3, pad 1; off(k) = (kh-1, kw-1))
+//             g = dy * act'(.),  sum_g, sum_g*xhat (, dslope)  ->  dx = scale * (g - mean_g - xhat * mean_gx) (+ addend)
+//
+// The layer-by-layer form writes dy (268 MB at 16 x 512 x 512 x 32 bf16) in a transposed-convolution launch and reads it
+// twice (BatchNorm-backward reduce and apply): 88 + 117 + 130 us.  dy is a function of 18 numbers per pixel (the 3 x 3 x 2
+// patch of dz), i.e. a [32 channels x 18] x [18 x pixels] product -- one and a bit v_mfma_f32_32x32x16_bf16 per 32 pixels:
+//   head_bwd_reduce_kernel: x + the dz patch -> per-workgroup rows [sum_g | sum_gx | dslope]       (285 MB instead of 821)
+//   head_bwd_apply_kernel:  x + the dz patch (+ fan-in addend) -> dx                               (no dy read)
+// A wave owns tiles of 32 consecutive pixels.  B operand = the patch: lane (pixel n, half h) loads the taps 4h .. 4h+3 of its
+// pixel as four dwords (bf16 pairs, both classes) + tap 8; A operand = the filter, [channel slot][tap, class], constant per
+// lane.  The channel slots are permuted so that the accumulator of lane (n, h) holds channels 16h .. 16h+15 of pixel n:
+// x, the addend and dx are then two 16-byte accesses per lane.  Next tile's loads are in flight under this tile's
+// arithmetic (7 vector operations per element; a first form on the vector ALU alone -- 18 FMAs per element for dy and 18
+// more for the head's weight gradient -- measured 375 us at 1/2 resolution against the 334 us of the layer-wise kernels).
+// The head's weight gradient stays with conv3x3_wgrad_narrow_kernel (conv3x3.hip).  C = 32, num_classes = 2, bf16 only.
+#include "stencil.h"
+
+namespace ledn {
+
+namespace {
+
+constexpr int HB_C = 32, HB_CO = 2;
+
+// channel of accumulator register `reg` in lane half h = 16 h + reg; MFMA row of that register = (reg & 3) + 8 (reg >> 2) + 4 h
+// -> row m carries channel 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3)
+__device__ __forceinline__ int hb_row_channel(int m) { return 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3); }
+
+// A fragments: lane (m = lane & 31, hk = lane >> 5) holds A[m][16 s + 8 hk + j] = w[o][channel(m)][k9], 2 k9 + o = 16 s + 8 hk + j
+__device__ __forceinline__ void hb_filter_frags(const float* w, bf16x8_t (&af)[2]) {
+    const int lane = threadIdx.x & 63, ch = hb_row_channel(lane & 31), hk = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = 16 * s + 8 * hk + j, k9 = kk >> 1, o = kk & 1;
+            af[s][j] = (short)(k9 < 9 ? f32_to_bf16(w[(o * HB_C + ch) * 9 + k9]) : (unsigned short)0);
+        }
+}
+
+struct HbTaps {
+    int dyo[5], dxo[5];     // position of the lane's taps relative to its pixel: taps 4h .. 4h+3, then tap 8
+    int lin[5];             // the same as a pixel offset
+};
+__device__ __forceinline__ void hb_taps(int h, int W, HbTaps& t) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int k9 = j < 4 ? 4 * h + j : 8;
+        t.dyo[j] = 1 - k9 / 3;
+        t.dxo[j] = 1 - k9 % 3;
+        t.lin[j] = t.dyo[j] * W + t.dxo[j];
+    }
+}
+
+struct HbRaw {
+    uint4 x0, x1;           // the lane's 16 channels of its pixel
+    unsigned dz[5];
+};
+
+__device__ __forceinline__ void hb_fetch(const bf16_t* x, const unsigned* dz, const HbTaps& tp, long p, long pend, int y, int xx,
+                                         int h, int H, int W, HbRaw& o) {
+    const bool in = p < pend;
+    const long q = in ? p : 0;
+    const uint4* xp = reinterpret_cast<const uint4*>(x + q * HB_C + 16 * h);
+    o.x0 = xp[0];
+    o.x1 = xp[1];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int ty = y + tp.dyo[j], tx = xx + tp.dxo[j];
+        const bool ok = in && ty >= 0 && ty < H && tx >= 0 && tx < W;
+        const unsigned v = dz[ok ? q + tp.lin[j] : q];
+        o.dz[j] = ok ? v : 0u;
+    }
+}
+
+// dy of the lane's pixel, channels 16 h .. 16 h + 15
+__device__ __forceinline__ f32x16_t hb_dy(const HbRaw& r, const bf16x8_t (&af)[2], int h) {
+    const uint4 b0 = make_uint4(r.dz[0], r.dz[1], r.dz[2], r.dz[3]);
+    const uint4 b1 = make_uint4(h == 0 ? r.dz[4] : 0u, 0u, 0u, 0u);
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    acc = mfma_32x32x16_bf16(af[0], __builtin_bit_cast(bf16x8_t, b0), acc);
+    acc = mfma_32x32x16_bf16(af[1], __builtin_bit_cast(bf16x8_t, b1), acc);
+    return acc;
+}
+
+__device__ __forceinline__ void hb_unpack16(const uint4& x0, const uint4& x1, float* v) {
+    const unsigned u[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[2 * i] = __uint_as_float(u[i] << 16);
+        v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+    }
+}
+
+// the wave's tile schedule: workgroup b owns tiles [t0, t1) of 32 pixels; wave w takes NT adjacent tiles per trip:
+// t0 + NT w .. + NT - 1, then 4 NT further on (two tiles' loads in flight per wave: at two waves per SIMD one tile's 84 bytes
+// per lane are ~11 MB on the whole chip, short of what 5 TB/s x the memory latency asks for)
+constexpr int HB_NT = 2;
+struct HbSched {
+    long tile, t1;
+    __device__ __forceinline__ void init(long ntiles) {
+        const long per = cdiv(cdiv(ntiles, (long)gridDim.x), (long)(4 * HB_NT)) * (4 * HB_NT);
+        const long t0 = (long)xcd_block(blockIdx.x, gridDim.x) * per;
+        t1 = min(ntiles, t0 + per);
+        tile = t0 + HB_NT * (threadIdx.x >> 6);
+    }
+};
+
+}  // namespace
+
+template <int ACT>
+__global__ void __launch_bounds__(256) head_bwd_reduce_kernel(ledn_headbwd_desc d, float* part) {
+    __shared__ float s_red[4][3][HB_C];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+    const int H = d.H, W = d.W;
+    bf16x8_t af[2];
+    hb_filter_frags(d.w, af);
+    HbTaps tp;
+    hb_taps(h, W, tp);
+    float sc[16], sh[16], mean[16], sl[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = 16 * h + i;
+        sc[i] = d.bn.scale ? d.bn.scale[c] : 1.f;
+        sh[i] = d.bn.shift ? d.bn.shift[c] : 0.f;
+        mean[i] = d.bn.bn_mode ? d.bn.mean[c] : 0.f;
+        sl[i] = ACT == LEDN_ACT_PRELU ? d.bn.slope[c] : 0.f;
+    }
+    float sg[16], sgx[16], sds[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sg[i] = sgx[i] = sds[i] = 0.f;
+    const bf16_t* x = reinterpret_cast<const bf16_t*>(d.bn.z);
+    const unsigned* dz = reinterpret_cast<const unsigned*>(d.head_dz);
+    const long npix = (long)d.N * H * W;
+    HbSched sch;
+    sch.init(cdiv(npix, 32L));
+    PixCursor cur[HB_NT];
+    HbRaw raw[HB_NT];
+#pragma unroll
+    for (int u = 0; u < HB_NT; ++u) {
+        cur[u].init(min((sch.tile + u) * 32 + n, npix - 1), H, W);
+        hb_fetch(x, dz, tp, sch.tile < sch.t1 ? (sch.tile + u) * 32 + n : npix, npix, cur[u].y, cur[u].x, h, H, W, raw[u]);
+    }
+    for (; sch.tile < sch.t1; sch.tile += 4 * HB_NT) {
+        HbRaw nxt[HB_NT];
+        const bool more = sch.tile + 4 * HB_NT < sch.t1;
+#pragma unroll
+        for (int u = 0; u < HB_NT; ++u) {
+            cur[u].advance(128 * HB_NT, H, W);
+            hb_fetch(x, dz, tp, more ? (sch.tile + 4 * HB_NT + u) * 32 + n : npix, npix, cur[u].y, cur[u].x, h, H, W, nxt[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < HB_NT; ++u) {
+            const long p = (sch.tile + u) * 32 + n;
+            const f32x16_t dy = hb_dy(raw[u], af, h);
+            if (p < npix) {
+                float xv[16];
+                hb_unpack16(raw[u].x0, raw[u].x1, xv);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = fmaf(xv[i], sc[i], sh[i]);
+                    float g = dy[i];
+                    if (ACT == LEDN_ACT_RELU) g = v > 0.f ? g : 0.f;
+                    else if (ACT == LEDN_ACT_PRELU) {
+                        sds[i] += v > 0.f ? 0.f : dy[i] * v;
+                        g = v > 0.f ? g : g * sl[i];
+                    }
+                    sg[i] += g;
+                    sgx[i] = fmaf(g, xv[i] - mean[i], sgx[i]);
+                }
+            }
+            raw[u] = nxt[u];
+        }
+    }
+    // the 32 pixel lanes of each half: the two rows of a half exchange (sum g | sum g x) by a reduce-scatter, then a butterfly
+    // inside the 16-lane row
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        unsigned a = __float_as_uint(sg[i]), b = __float_as_uint(sgx[i]);
+        permlane16_swap(a, b);                  // even rows: both rows' sg[i]; odd rows: both rows' sgx[i]
+        float v = __uint_as_float(a) + __uint_as_float(b);
+        v = lane_step_sum(v, 8);
+        v = lane_step_sum(v, 4);
+        v = lane_step_sum(v, 2);
+        v = lane_step_sum(v, 1);
+        sg[i] = v;
+        if (ACT == LEDN_ACT_PRELU) {
+            float t = sds[i];
+            t = lane_step_sum(t, 16);
+            t = lane_step_sum(t, 8);
+            t = lane_step_sum(t, 4);
+            t = lane_step_sum(t, 2);
+            t = lane_step_sum(t, 1);
+            sds[i] = t;
+        }
+    }
+    if ((lane & 15) == 0) {
+        const int row = lane >> 4;               // rows 0, 1: half 0 (sum g, sum g x); rows 2, 3: half 1
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_red[wid][row & 1][16 * (row >> 1) + i] = sg[i];
+        if (ACT == LEDN_ACT_PRELU && (row & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s_red[wid][2][16 * (row >> 1) + i] = sds[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * HB_C) {
+        const int kind = threadIdx.x / HB_C, c = threadIdx.x % HB_C;
+        float t = 0.f;
+        if (kind < 2 || ACT == LEDN_ACT_PRELU)
+            t = (s_red[0][kind][c] + s_red[1][kind][c]) + (s_red[2][kind][c] + s_red[3][kind][c]);
+        if (kind == 1) t *= d.bn.bn_mode ? d.bn.invstd[c] : 0.f;
+        part[(long)blockIdx.x * 3 * HB_C + threadIdx.x] = t;
+    }
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(256) head_bwd_apply_kernel(ledn_headbwd_desc d) {
+    const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    const int H = d.H, W = d.W;
+    bf16x8_t af[2];
+    hb_filter_frags(d.w, af);
+    HbTaps tp;
+    hb_taps(h, W, tp);
+    float sc[16], sh[16], ca[16], cb[16], sl[16];
+    const float inv_count = (float)(1.0 / d.bn.count);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = 16 * h + i;
+        const float s = d.bn.scale ? d.bn.scale[c] : 1.f;
+        float a = 0.f, b = 0.f;
+        if (d.bn.bn_mode) {           // dz = s * g + A * x + B,  A = -s * mean_gx * invstd,  B = -s * mean_g - A * mean
+            a = -s * (d.bn.sum_gx[c] * inv_count) * d.bn.invstd[c];
+            b = -s * (d.bn.sum_g[c] * inv_count) - a * d.bn.mean[c];
+        }
+        sc[i] = s;
+        sh[i] = d.bn.shift ? d.bn.shift[c] : 0.f;
+        sl[i] = ACT == LEDN_ACT_PRELU ? d.bn.slope[c] : 0.f;
+        ca[i] = a;
+        cb[i] = b;
+    }
+    const bf16_t* x = reinterpret_cast<const bf16_t*>(d.bn.z);
+    const bf16_t* add = reinterpret_cast<const bf16_t*>(d.bn.dz_add);
+    bf16_t* dx = reinterpret_cast<bf16_t*>(d.bn.dz);
+    const unsigned* dz = reinterpret_cast<const unsigned*>(d.head_dz);
+    const long npix = (long)d.N * H * W;
+    HbSched sch;
+    sch.init(cdiv(npix, 32L));
+    PixCursor cur[HB_NT];
+    HbRaw raw[HB_NT];
+    uint4 a0[HB_NT], a1[HB_NT];
+    auto fetch_add = [&](long p, uint4& o0, uint4& o1) {
+        o0 = o1 = make_uint4(0u, 0u, 0u, 0u);
+        if (!add) return;
+        const uint4* ap = reinterpret_cast<const uint4*>(add + (p < npix ? p : 0) * HB_C + 16 * h);
+        o0 = ap[0];
+        o1 = ap[1];
+    };
+#pragma unroll
+    for (int u = 0; u < HB_NT; ++u) {
+        cur[u].init(min((sch.tile + u) * 32 + n, npix - 1), H, W);
+        const long p = sch.tile < sch.t1 ? (sch.tile + u) * 32 + n : npix;
+        hb_fetch(x, dz, tp, p, npix, cur[u].y, cur[u].x, h, H, W, raw[u]);
+        fetch_add(p, a0[u], a1[u]);
+    }
+    for (; sch.tile < sch.t1; sch.tile += 4 * HB_NT) {
+        HbRaw nxt[HB_NT];
+        uint4 n0[HB_NT], n1[HB_NT];
+        const bool more = sch.tile + 4 * HB_NT < sch.t1;
+#pragma unroll
+        for (int u = 0; u < HB_NT; ++u) {
+            cur[u].advance(128 * HB_NT, H, W);
+            const long pn = more ? (sch.tile + 4 * HB_NT + u) * 32 + n : npix;
+            hb_fetch(x, dz, tp, pn, npix, cur[u].y, cur[u].x, h, H, W, nxt[u]);
+            fetch_add(pn, n0[u], n1[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < HB_NT; ++u) {
+            const long p = (sch.tile + u) * 32 + n;
+            const f32x16_t dy = hb_dy(raw[u], af, h);
+            if (p < npix) {
+                float xv[16], av[16], out[16];
+                hb_unpack16(raw[u].x0, raw[u].x1, xv);
+                hb_unpack16(a0[u], a1[u], av);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = fmaf(xv[i], sc[i], sh[i]);
+                    float g = dy[i];
+                    if (ACT == LEDN_ACT_RELU) g = v > 0.f ? g : 0.f;
+                    else if (ACT == LEDN_ACT_PRELU) g = v > 0.f ? g : g * sl[i];
+                    out[i] = fmaf(g, sc[i], fmaf(xv[i], ca[i], cb[i]));
+                    if (add) out[i] += av[i];
+                }
+                uint4 o0, o1;
+                o0.x = (unsigned)f32_to_bf16(out[0]) | ((unsigned)f32_to_bf16(out[1]) << 16);
+                o0.y = (unsigned)f32_to_bf16(out[2]) | ((unsigned)f32_to_bf16(out[3]) << 16);
+                o0.z = (unsigned)f32_to_bf16(out[4]) | ((unsigned)f32_to_bf16(out[5]) << 16);
+                o0.w = (unsigned)f32_to_bf16(out[6]) | ((unsigned)f32_to_bf16(out[7]) << 16);
+                o1.x = (unsigned)f32_to_bf16(out[8]) | ((unsigned)f32_to_bf16(out[9]) << 16);
+                o1.y = (unsigned)f32_to_bf16(out[10]) | ((unsigned)f32_to_bf16(out[11]) << 16);
+                o1.z = (unsigned)f32_to_bf16(out[12]) | ((unsigned)f32_to_bf16(out[13]) << 16);
+                o1.w = (unsigned)f32_to_bf16(out[14]) | ((unsigned)f32_to_bf16(out[15]) << 16);
+                uint4* op = reinterpret_cast<uint4*>(dx + p * HB_C + 16 * h);
+                op[0] = o0;
+                op[1] = o1;
+            }
+            raw[u] = nxt[u];
+            a0[u] = n0[u];
+            a1[u] = n1[u];
+        }
+    }
+}
+
+int head_bwd_supported(const ledn_headbwd_desc& d) {
+    if (!d.bn.z || !d.head_dz || !d.w || d.Co != HB_CO || d.bn.C != HB_C || d.dtype_dz != LEDN_BF16) return 0;
+    if (d.bn.dtype_z != LEDN_BF16 || d.bn.res || d.bn.res_mode != LEDN_RES_NONE || d.bn.dres || d.bn.rows) return 0;
+    if (d.bn.act != LEDN_ACT_NONE && d.bn.act != LEDN_ACT_RELU && d.bn.act != LEDN_ACT_PRELU) return 0;
+    if (d.bn.act == LEDN_ACT_PRELU && !d.bn.slope) return 0;
+    const long npix = (long)d.N * d.H * d.W;
+    if (d.N < 1 || d.H < 2 || d.W < 2 || npix != d.bn.P || npix < 16384 || npix * HB_C >= (1L << 31)) return 0;
+    if (d.bn.bn_mode && !(d.bn.mean && d.bn.invstd && d.bn.sum_g && d.bn.sum_gx)) return 0;
+    return 1;
+}
+
+int head_bwd_reduce(const ledn_headbwd_desc& d, hipStream_t s) {
+    LEDN_REQUIRE(head_bwd_supported(d));
+    const long ntiles = cdiv((long)d.N * d.H * d.W, 32L);
+    static const long cap = exp_knob("LEDN_HB_CAP", 512);
+    long nb = cdiv(ntiles, 32L);                 // >= 4 trips of two tiles per wave
+    if (nb > cap) nb = cap;
+    float* part = ws_take(nb * 3 * HB_C);
+    LEDN_REQUIRE(part);
+    switch (d.bn.act) {
+        case LEDN_ACT_NONE: LEDN_LAUNCH(head_bwd_reduce_kernel<LEDN_ACT_NONE>, dim3((unsigned)nb), dim3(256), 0, s, d, part); break;
+        case LEDN_ACT_RELU: LEDN_LAUNCH(head_bwd_reduce_kernel<LEDN_ACT_RELU>, dim3((unsigned)nb), dim3(256), 0, s, d, part); break;
+        default: LEDN_LAUNCH(head_bwd_reduce_kernel<LEDN_ACT_PRELU>, dim3((unsigned)nb), dim3(256), 0, s, d, part); break;
+    }
+    return finish_partials(part, (int)nb, HB_C, 3, d.bn.bn_mode ? d.bn.sum_g : nullptr, d.bn.bn_mode ? d.bn.sum_gx : nullptr,
+                           d.bn.act == LEDN_ACT_PRELU ? d.bn.dslope : nullptr, s);
+}
+
+int head_bwd_apply(const ledn_headbwd_desc& d, hipStream_t s) {
+    LEDN_REQUIRE(head_bwd_supported(d) && d.bn.dz);
+    const long ntiles = cdiv((long)d.N * d.H * d.W, 32L);
+    static const long cap = exp_knob("LEDN_HB_CAP_APPLY", 4096);
+    static const long tpw = exp_knob("LEDN_HB_TRIPS_APPLY", 16);      // trips of two tiles per wave: 1 238 us, 2 138, 8 125, 16 128, 32 116 (1/2 resolution; a
+                                                                      // workgroup starts with ~100 parameter loads per lane); step 12.46 / 12.43 / 12.41 / 12.44 ms
+    long nb = cdiv(ntiles, 8L * (tpw > 0 ? tpw : 2));
+    if (nb > cap) nb = cap;
+    switch (d.bn.act) {
+        case LEDN_ACT_NONE: LEDN_LAUNCH(head_bwd_apply_kernel<LEDN_ACT_NONE>, dim3((unsigned)nb), dim3(256), 0, s, d); break;
+        case LEDN_ACT_RELU: LEDN_LAUNCH(head_bwd_apply_kernel<LEDN_ACT_RELU>, dim3((unsigned)nb), dim3(256), 0, s, d); break;
+        default: LEDN_LAUNCH(head_bwd_apply_kernel<LEDN_ACT_PRELU>, dim3((unsigned)nb), dim3(256), 0, s, d); break;
+    }
+    return check_launch();
+}
+
+}  // namespace ledn

@@ -339,6 +339,10 @@ int bn_act_bwd_reduce_fast(const ledn_bnbwd_desc& d, hipStream_t s);
 int bn_act_bwd_apply_fast(const ledn_bnbwd_desc& d, hipStream_t s);
 int bn_act_bwd_fused(const ledn_bnbwd_desc& d, hipStream_t s);
 int bn_act_bwd_fused_check(int C, hipStream_t s);
+// head_bwd.hip
+int head_bwd_supported(const ledn_headbwd_desc& d);
+int head_bwd_reduce(const ledn_headbwd_desc& d, hipStream_t s);
+int head_bwd_apply(const ledn_headbwd_desc& d, hipStream_t s);
 int channel_stats_fast(const void* x, const void* xadd, long long P, int C, int dtype, float* sum, float* sqsum,
                        hipStream_t s);
 

@@ -8,31 +8,6 @@ namespace ledn {
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-// v + the value of the lane `m` away in the coset pattern of an all-reduce (m a power of two): on the vector ALU where the
-// hardware has a lane-crossing form for it -- DPP row_ror inside a 16-lane row (m = 1, 2, 4, 8), v_permlane32_swap for the
-// two halves of the wave (m = 32) -- and through the LDS crossbar (ds_bpermute) only for m = 16.  The butterfly of
-// reduce_taps (72 accumulators x up to 6 levels per lane) was 360 ds_bpermute per lane for 16-channel maps: the epilogue
-// of the pyramid / depthwise weight-gradient kernels cost as much as their pixel loops.
-__device__ __forceinline__ float lane_step_sum(float v, int m) {
-#ifdef LEDN_CPU_EMU
-    return v + __shfl_xor(v, m);
-#else
-    if (m == 32) {
-        unsigned a = __float_as_uint(v), b = a;
-        permlane32_swap(a, b);                               // a = {low, low}, b = {high, high}
-        return __uint_as_float(a) + __uint_as_float(b);
-    }
-    if (m == 16) return v + __shfl_xor(v, 16);
-    const int iv = __float_as_int(v);
-    int r;
-    if (m == 8) r = __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xf, 0xf, false);        // row_ror:8
-    else if (m == 4) r = __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xf, 0xf, false);   // row_ror:4
-    else if (m == 2) r = __builtin_amdgcn_update_dpp(0, iv, 0x122, 0xf, 0xf, false);   // row_ror:2
-    else r = __builtin_amdgcn_update_dpp(0, iv, 0x121, 0xf, 0xf, false);               // row_ror:1
-    return v + __int_as_float(r);
-#endif
-}
-
 // sums `acc` (9 taps x 8 channels) over the pixel rows of one wave (lanes r*cvn + cv, cvn a power
 // of two), then over the 4 waves through LDS; thread e < nine*C then owns element e of [9][C]
 __device__ __forceinline__ void reduce_taps(f32x2_t (&acc)[9][4], int cvn, float* s_red /* [4][9*C] */, int C,
@@ -454,29 +429,6 @@ __global__ void __launch_bounds__(256) pyr_bwd_weight_bf16_kernel(ledn_pyrbwd_de
 // nothing in flight while it computed: 40 us at 16 x 128 x 128 x 16.
 // Epilogue: reduce-scatter over the two wave halves and the two rows of each half (v_permlane32_swap / v_permlane16_swap:
 // one swap + one add per register PAIR, 144 -> 36 registers), a butterfly inside the 16-lane row for the rest.
-__device__ __forceinline__ uint2 ld_tap8(const bf16_t* base, unsigned off, unsigned safe, bool valid) {
-    uint2 r = *reinterpret_cast<const uint2*>(base + (valid ? off : safe));
-    r.x = valid ? r.x : 0u;
-    r.y = valid ? r.y : 0u;
-    return r;
-}
-__device__ __forceinline__ void bf16x4_unpack(const uint2& r, f32x2_t* o) {
-    o[0] = f32x2_t{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
-    o[1] = f32x2_t{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
-}
-__device__ __forceinline__ void swap_add32(f32x2_t& a, f32x2_t& b) {
-    unsigned ax = __float_as_uint(a.x), bx = __float_as_uint(b.x), ay = __float_as_uint(a.y), by = __float_as_uint(b.y);
-    permlane32_swap(ax, bx);
-    permlane32_swap(ay, by);
-    a = f32x2_t{__uint_as_float(ax) + __uint_as_float(bx), __uint_as_float(ay) + __uint_as_float(by)};
-}
-__device__ __forceinline__ void swap_add16(f32x2_t& a, f32x2_t& b) {
-    unsigned ax = __float_as_uint(a.x), bx = __float_as_uint(b.x), ay = __float_as_uint(a.y), by = __float_as_uint(b.y);
-    permlane16_swap(ax, bx);
-    permlane16_swap(ay, by);
-    a = f32x2_t{__uint_as_float(ax) + __uint_as_float(bx), __uint_as_float(ay) + __uint_as_float(by)};
-}
-
 __global__ void __launch_bounds__(256, 2) pyr_bwd_weight_same_kernel(ledn_pyrbwd_desc d, float* part) {
     constexpr int V = 4;
     LEDN_DYN_SHARED(float, s_red);   // [4 waves][36][n]

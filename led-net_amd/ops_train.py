@@ -12,7 +12,7 @@ from .ops import (ACT_NONE, RES_NONE, _DT, LednError, _check, _dt, _f32, _nb, _p
 
 class _BnBwd:
     """State of one BatchNorm(+activation, +residual) backward between its two kernels."""
-    __slots__ = ('lib', 'd', 'z', 'bn', 'Cc', 'P', 'local', 'sunk', 'dz', 'dres', 'dslope', 'slope_sunk', 'keep', 'reduce_pending')
+    __slots__ = ('lib', 'd', 'z', 'bn', 'Cc', 'P', 'local', 'sunk', 'dz', 'dres', 'dslope', 'slope_sunk', 'keep', 'reduce_pending', 'hd')
 
 
 from ._env import knob_int as _knob_int  # noqa: E402
@@ -21,7 +21,7 @@ BN_ROWS = _knob_int('LEDN_BN_ROWS', 0)   # measured r3k: 13.85 vs 13.85 ms -- th
 
 def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
                       res=None, res_mode=RES_NONE, count=None, want_dres=False, sinks=None, sync=False,
-                      dz_add=None, dres_add=None, launch=True):
+                      dz_add=None, dres_add=None, launch=True, head=None):
     """First half of bn_act_bwd: the per-channel sums (sum g*xhat, sum g) of THIS rank's shard, reduced
     into the parameter-gradient sinks when given (they ARE d_gamma, d_beta of the local shard -- under
     SyncBN too: torch.nn.SyncBatchNorm keeps grad_weight / grad_bias local, DDP averages them later),
@@ -51,6 +51,8 @@ def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, 
             dslope = _ops.zeros_f32(Cc, z.device)
     dz = torch.empty_like(z)
     dres = torch.empty_like(dy) if (want_dres and res_mode != RES_NONE) else None
+    if head is not None and (dy is not None or res is not None or want_dres):
+        raise LednError('bn_act_bwd: the two-class head form takes no dy / residual')
     if dz_add is not None and (dz_add.shape != z.shape or dz_add.dtype != z.dtype):
         raise LednError('bn_act_bwd: dz_add must match z')
     if dres_add is not None and (dres is None or dres_add.shape != dres.shape or dres_add.dtype != dres.dtype):
@@ -65,8 +67,28 @@ def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, 
     d.count = float(count if count is not None else P)
     d.P, d.C, d.act = P, Cc, act
     d.res_mode = res_mode if res is not None else RES_NONE
-    d.bn_mode, d.dtype_z, d.dtype_y = int(bn), _dt(z), _dt(dy)
+    d.bn_mode, d.dtype_z, d.dtype_y = int(bn), _dt(z), _dt(dy if dy is not None else z)
     rows = None
+    st.hd = None
+    if head is not None:
+        # LEDHead's two-class heads: dy = conv_transpose3x3(head_dz, w) is recomputed inside both passes
+        # (ledn_head_bwd_reduce / _apply)
+        hdz, hw = head
+        _check(lib, hdz, hw)
+        hd = st.hd = _lib.HeadBwdDesc()
+        hd.bn = d
+        hd.head_dz, hd.w = _p(hdz), _p(_f32(hw))
+        hd.N, hd.H, hd.W, hd.Co, hd.dtype_dz = z.shape[0], z.shape[1], z.shape[2], hw.shape[0], _dt(hdz)
+        if tuple(hdz.shape) != (z.shape[0], z.shape[1], z.shape[2], hw.shape[0]) or tuple(hw.shape) != (hw.shape[0], Cc, 3, 3) \
+                or not lib.cdll.ledn_head_bwd_supported(hd):
+            raise LednError('bn_act_bwd: shape outside the two-class head kernels (head_bwd_ok decides)')
+        st.reduce_pending = False
+        _run(lib, 'ledn_head_bwd_reduce', z, hd, work=_ops._TIMING is not None and (
+            f'headbwd_reduce C{Cc} P{P}', _nb(z, hdz), 10 * z.numel(), 'head_bwd_reduce_kernel'))
+        st.lib, st.d, st.z, st.bn, st.Cc, st.P, st.local, st.sunk = lib, d, z, bn, Cc, P, local, sunk
+        st.dz, st.dres, st.dslope, st.slope_sunk = dz, None, dslope, slope_sunk
+        st.keep = (hdz, None, scale, shift, slope, mean, invstd, sum_g, sum_gx, sk_g, sk_b, dz_add, None, None, hw)
+        return st
     if BN_ROWS and not sync and (bn or slope is not None) and z.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16:
         # the reduce pass leaves per-row sums (float atomics into 32 zeroed rows), the apply pass adds them up: no
         # summing launch between the two (ledn.h: ledn_bnbwd_desc.rows).  Not under SyncBN: the all-reduce needs totals.
@@ -141,8 +163,13 @@ def _bn_bwd_result(st):
 def bn_act_bwd_apply(st):
     """-> (dz, dres, dgamma, dbeta, dslope); a gradient that went into its sink is returned as None."""
     z, d = st.z, st.d
-    _run(st.lib, 'ledn_bn_act_bwd_apply', z, d, work=_ops._TIMING is not None and (
-        f'bnbwd_apply C{st.Cc} P{st.P}', _nb(z, st.keep[0], st.keep[1], st.dz, st.dres), 8 * z.numel()))
+    if getattr(st, 'hd', None) is not None:
+        st.hd.bn = d                       # (the SyncBN exchange re-pointed the sums)
+        _run(st.lib, 'ledn_head_bwd_apply', z, st.hd, work=_ops._TIMING is not None and (
+            f'headbwd_apply C{st.Cc} P{st.P}', _nb(z, st.keep[0], st.keep[11], st.dz), 8 * z.numel(), 'head_bwd_apply_kernel'))
+    else:
+        _run(st.lib, 'ledn_bn_act_bwd_apply', z, d, work=_ops._TIMING is not None and (
+            f'bnbwd_apply C{st.Cc} P{st.P}', _nb(z, st.keep[0], st.keep[1], st.dz, st.dres), 8 * z.numel()))
     give = st.bn and not st.sunk
     if give and st.keep[9] is not None and st.keep[10] is not None:
         st.keep[9].add_(st.local[0])       # sinks exist but were not adjacent (see reduce): add the local sums
@@ -154,8 +181,10 @@ def bn_act_bwd_apply(st):
 
 def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
                res=None, res_mode=RES_NONE, count=None, want_dres=False, sync=None, sinks=None, dz_add=None,
-               dres_add=None):
+               dres_add=None, head=None):
     """Backward of y = act(res_mode(z*scale+shift, res)).
+    head = (head_dz [N,H,W,2] bf16, w [2,32,3,3]): dy is NOT given but recomputed from the logits' gradient of a two-class
+    3x3 head on y (LEDHead's norm -> act -> conv; see head_bwd_ok).
     BN mode (mean/invstd given): returns (dz, dres, dgamma, dbeta, dslope).
     Plain mode: returns (dz, dres, None, None, dslope).
     sync: optional collective object (train._Collective) all-reducing the [2,C] (sum_gx, sum_g) sums (SyncBN);
@@ -163,10 +192,10 @@ def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT
     dz_add / dres_add: partial gradients of z / res from another consumer of the same tensor, added in the apply pass.
     sinks: optional (dgamma, dbeta, dslope) ZEROED f32 [C] buffers (any may be None) the kernels
     reduce straight into (the trainer's gradient views); the matching return value is then None."""
-    fused = BN_FUSED and sync is None and z.is_cuda and z.dtype == torch.bfloat16 and _ops._slot(z) == 0
+    fused = BN_FUSED and sync is None and z.is_cuda and z.dtype == torch.bfloat16 and _ops._slot(z) == 0 and head is None
     st = bn_act_bwd_reduce(z, dy, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, slope=slope,
                            res=res, res_mode=res_mode, count=count, want_dres=want_dres, sinks=sinks,
-                           sync=sync is not None, dz_add=dz_add, dres_add=dres_add, launch=not fused)
+                           sync=sync is not None, dz_add=dz_add, dres_add=dres_add, launch=not fused, head=head)
     if fused:
         # one persistent launch (reduce + grid barrier + apply; z held on chip): only from the step's MAIN stream -- its
         # workgroups wait for each other, two such kernels on concurrent streams could starve each other of compute units
@@ -178,6 +207,18 @@ def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT
                 f'bnbwd_reduce C{st.Cc} P{st.P}', _nb(z, dy, res), 6 * z.numel()))
     bn_act_bwd_sync(st, sync)
     return bn_act_bwd_apply(st)
+
+
+HEAD_BWD = _knob_int('LEDN_HEAD_BWD', 1)      # the two-pass backward of LEDHead's two-class heads (csrc/head_bwd.hip)
+
+
+def head_bwd_ok(x, dz, w, stride, pad, groups, act):
+    """the norm -> act -> 3x3 conv backward can take the two-pass form of csrc/head_bwd.hip (include/ledn.h
+    ledn_head_bwd_supported states the same gate)"""
+    return bool(HEAD_BWD and x.dtype == torch.bfloat16 and dz.dtype == torch.bfloat16 and tuple(w.shape[2:]) == (3, 3)
+                and w.shape[0] == 2 and w.shape[1] == 32 and x.shape[-1] == 32 and stride == 1 and pad == 1
+                and groups == 1 and act in (ACT_NONE, _ops.ACT_RELU, _ops.ACT_PRELU) and x.numel() // x.shape[-1] >= 16384
+                and x.numel() < (1 << 31) and dz.shape[1:3] == x.shape[1:3])
 
 
 # Depthwise / pyramid WEIGHT gradients of the main stream on an auxiliary stream (experimental knob, 0 = off): they have no

@@ -398,11 +398,13 @@ class BNActConvFn(Function):
         dz = _c(dz)
         dw, db = _conv_wgrad(x, dz, tuple(w.shape), sw, sbias, stride=stride, pad=pad, groups=groups, in_scale=scale,
                              in_shift=shift, in_act=act, in_slope=slope, bias=has_b)
-        dy = _conv_dgrad(dz, x, w, stride, pad, groups)
+        # LEDHead's two-class heads: no dy tensor -- the BatchNorm backward recomputes it from dz (ops_train.bn_act_bwd head=)
+        head = (dz, w) if T.head_bwd_ok(x, dz, w, stride, pad, groups, act) else None
+        dy = _conv_dgrad(dz, x, w, stride, pad, groups) if head is None else None
         prev = _take(ctx.acc, x)
         dx, _, dgamma, dbeta, dslope = T.bn_act_bwd(x, dy, scale=scale, shift=shift, mean=mean, invstd=invstd,
                                                      act=act, slope=slope, count=count, sync=_Env.sync_bn,
-                                                     sinks=(sg, sb_, ss), dz_add=prev)
+                                                     sinks=(sg, sb_, ss), dz_add=prev, head=head)
         if ctx.acc is not None:
             ctx.acc.put(dx, prev is not None)
         return (dx, dgamma, dbeta, dslope, None if sw is not None else dw, None if sbias is not None else db,

@@ -27,7 +27,7 @@ def test_hip_library_exports_every_symbol():
     lib = _lib.Library(_lib.HIP_LIB_PATH, is_hip=True)
     for name in declared_symbols():
         assert hasattr(lib.cdll, name), name
-    assert lib.cdll.ledn_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.cdll.ledn_abi_version() == _lib.ABI_VERSION == 5
     src = open(os.path.join(ROOT, 'include', 'ledn.h')).read()
     assert f'#define LEDN_ABI_VERSION {_lib.ABI_VERSION}' in src
 

@@ -1,0 +1,103 @@
+"""BatchNorm / activation backward of LEDHead's two-class heads (norm -> act -> 3x3 conv 32 -> 2, led_head.py:44-51) straight
+from the logits' gradient (csrc/head_bwd.hip: ledn_head_bwd_reduce / _apply, dy recomputed on the matrix cores): against
+torch autograd of F.batch_norm(training) -> act -> F.conv2d in f32 on the same bf16-rounded tensors, and against the
+layer-wise kernel sequence it replaces."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def _case(dev, N, H, W, act, addend, seed):
+    from led_net_amd import ops
+    C = 32
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=g).bfloat16().float()
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    w = (torch.randn(2, C, 3, 3, generator=g) * 0.1).bfloat16().float()     # (the kernels round the filter to bf16)
+    slope = torch.rand(C, generator=g) * 0.3 if act == ops.ACT_PRELU else None
+    dz = torch.randn(N, 2, H, W, generator=g).bfloat16().float()
+    add = torch.randn(N, C, H, W, generator=g).bfloat16().float() if addend else None
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    sr = slope.clone().requires_grad_(True) if slope is not None else None
+    y = F.batch_norm(xr, None, None, gr, br, training=True, eps=1e-5)
+    t = F.relu(y) if act == ops.ACT_RELU else (F.prelu(y, sr) if act == ops.ACT_PRELU else y)
+    z = F.conv2d(t, w, None, padding=1)
+    z.backward(dz)
+    want = dict(dx=xr.grad + (add if addend else 0), dgamma=gr.grad, dbeta=br.grad, dslope=sr.grad if sr is not None else None)
+    mean = x.mean((0, 2, 3))
+    var = x.var((0, 2, 3), unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    nhwc = lambda v: v.permute(0, 2, 3, 1).contiguous()      # noqa: E731
+    D = lambda v: None if v is None else v.to(dev)           # noqa: E731
+    args = dict(x=D(nhwc(x).bfloat16()), dz=D(nhwc(dz).bfloat16()), w=D(w), scale=D(scale), shift=D(shift), mean=D(mean),
+                invstd=D(invstd), slope=D(slope), add=D(nhwc(add).bfloat16()) if addend else None, count=N * H * W)
+    return args, want
+
+
+def _run_head(a, act, dev):
+    from led_net_amd import ops_train as T
+    sinks = (torch.zeros(32, device=dev), torch.zeros(32, device=dev), torch.zeros(32, device=dev) if a['slope'] is not None else None)
+    assert T.head_bwd_ok(a['x'], a['dz'], a['w'], 1, 1, 1, act)
+    dx, _, _, _, _ = T.bn_act_bwd(a['x'], None, scale=a['scale'], shift=a['shift'], mean=a['mean'], invstd=a['invstd'], act=act,
+                                   slope=a['slope'], count=a['count'], sinks=sinks, dz_add=a['add'], head=(a['dz'], a['w']))
+    return dx, sinks
+
+
+@pytest.mark.parametrize('nhw', [(1, 128, 130), (2, 97, 131), (1, 16, 1030)])
+@pytest.mark.parametrize('variant', ['relu_add', 'prelu', 'none', 'relu'])
+def test_head_bwd_against_autograd(be, nhw, variant):
+    from led_net_amd import ops
+    act = {'relu_add': ops.ACT_RELU, 'prelu': ops.ACT_PRELU, 'none': ops.ACT_NONE, 'relu': ops.ACT_RELU}[variant]
+    a, want = _case(be.dev, *nhw, act, 'add' in variant, nhw[1] + nhw[2])
+    dx, sinks = _run_head(a, act, be.dev)
+    got_dx = dx.float().cpu().permute(0, 3, 1, 2)
+    # dx is stored as bf16: half an ulp of the largest magnitude + the BatchNorm terms' cancellation
+    torch.testing.assert_close(got_dx, want['dx'], rtol=2e-2, atol=2e-2 * float(want['dx'].abs().max()))
+    torch.testing.assert_close(sinks[0].cpu(), want['dgamma'], rtol=2e-3, atol=2e-3 * float(want['dgamma'].abs().max()))
+    torch.testing.assert_close(sinks[1].cpu(), want['dbeta'], rtol=2e-3, atol=2e-3 * float(want['dbeta'].abs().max()))
+    if want['dslope'] is not None:
+        torch.testing.assert_close(sinks[2].cpu(), want['dslope'], rtol=2e-3, atol=2e-3 * float(want['dslope'].abs().max()))
+
+
+def test_head_bwd_accumulates_into_sinks(be):
+    """the BatchNorm sinks are accumulated into, not overwritten (they are the trainer's flat gradient buffer)"""
+    from led_net_amd import ops, ops_train as T
+    a, _ = _case(be.dev, 1, 128, 128, ops.ACT_RELU, True, 5)
+    _, s1 = _run_head(a, ops.ACT_RELU, be.dev)
+    sinks = (s1[0].clone(), s1[1].clone(), None)
+    T.bn_act_bwd(a['x'], None, scale=a['scale'], shift=a['shift'], mean=a['mean'], invstd=a['invstd'], act=ops.ACT_RELU,
+                 count=a['count'], sinks=sinks, dz_add=a['add'], head=(a['dz'], a['w']))
+    torch.testing.assert_close(sinks[0], 2 * s1[0], rtol=1e-3, atol=1e-3 * float(s1[0].abs().max()))
+    torch.testing.assert_close(sinks[1], 2 * s1[1], rtol=1e-3, atol=1e-3 * float(s1[1].abs().max()))
+
+
+def test_head_bwd_matches_layerwise_kernels(be):
+    """the head form vs the layer-wise sequence (transposed conv -> BatchNorm-backward reduce + apply): the same gradients
+    up to the bf16 rounding of dy the layer-wise form adds"""
+    from led_net_amd import ops, ops_train as T
+    a, _ = _case(be.dev, 1, 128, 136, ops.ACT_RELU, True, 11)
+    dx, sinks = _run_head(a, ops.ACT_RELU, be.dev)
+    x, dz, w = a['x'], a['dz'], a['w']
+    dy = ops.conv2d(dz, w, stride=1, pad=1, transposed=True, out_hw=(x.shape[1], x.shape[2]), out_dtype=x.dtype)
+    s2 = (torch.zeros(32, device=be.dev), torch.zeros(32, device=be.dev), None)
+    dx2, _, _, _, _ = T.bn_act_bwd(x, dy, scale=a['scale'], shift=a['shift'], mean=a['mean'], invstd=a['invstd'],
+                                    act=ops.ACT_RELU, count=a['count'], sinks=s2, dz_add=a['add'])
+    torch.testing.assert_close(sinks[0].cpu(), s2[0].cpu(), rtol=2e-2, atol=2e-2 * float(s2[0].abs().max()))
+    torch.testing.assert_close(sinks[1].cpu(), s2[1].cpu(), rtol=2e-2, atol=2e-2 * float(s2[1].abs().max()))
+    torch.testing.assert_close(dx.float().cpu(), dx2.float().cpu(), rtol=3e-2, atol=3e-2 * float(dx2.float().abs().max()))
+
+
+def test_head_bwd_gate():
+    """shapes outside the kernels' gate keep the layer-wise path (BNActConvFn.backward asks head_bwd_ok)"""
+    from led_net_amd import ops, ops_train as T
+    x = torch.zeros(1, 128, 128, 32, dtype=torch.bfloat16)
+    dz = torch.zeros(1, 128, 128, 2, dtype=torch.bfloat16)
+    w = torch.zeros(2, 32, 3, 3)
+    assert T.head_bwd_ok(x, dz, w, 1, 1, 1, ops.ACT_RELU)
+    assert not T.head_bwd_ok(x, dz.float(), w, 1, 1, 1, ops.ACT_RELU)                 # f32 logits
+    assert not T.head_bwd_ok(x, dz, w, 2, 1, 1, ops.ACT_RELU)                         # stride
+    assert not T.head_bwd_ok(x[:, :64], dz[:, :64], w, 1, 1, 1, ops.ACT_RELU)         # too few pixels
+    assert not T.head_bwd_ok(x, torch.zeros(1, 128, 128, 3, dtype=torch.bfloat16), torch.zeros(3, 32, 3, 3), 1, 1, 1, ops.ACT_RELU)
+    assert not T.head_bwd_ok(x, dz, w, 1, 1, 1, ops.ACT_RELU6)
