@@ -541,8 +541,9 @@ int ledn_bn_act_bwd_fused_check(int C, void* stream);
  * from the gradient of the head's LOGITS: the gradient of the activation dy = conv_transpose3x3(head_dz, w) is a function
  * of the 3 x 3 x 2 patch of head_dz and is recomputed on the matrix cores inside both passes, never written (autograd of
  * the reference materialises it: F.conv2d backward -> F.relu backward -> F.batch_norm backward).  Replaces, for these
- * layers, ledn_conv2d(transposed) + ledn_bn_act_bwd_reduce + ledn_bn_act_bwd_apply; the head's weight / bias gradient is
- * ledn_conv2d_wgrad as before.
+ * layers, ledn_conv2d(transposed) + ledn_bn_act_bwd_reduce + ledn_bn_act_bwd_apply -- and ledn_conv2d_wgrad when dw is
+ * given: the reduce pass then also accumulates the head's weight / bias gradient (input act(BatchNorm(x)) rounded to bf16
+ * as in ledn_conv2d_wgrad's prologue; one partial row per workgroup, added up in row order: bit-reproducible).
  *   bn: the descriptor of ledn_bn_act_bwd_reduce / _apply with z = the head's input x (bf16), dy = NULL, res_mode = none,
  *       act in {none, ReLU, PReLU}; scale / shift / mean / invstd = the forward's batch-statistics affine; dz = the
  *       gradient of x (apply pass, + dz_add when given); sum_g / sum_gx (/ dslope) accumulate d beta / d gamma (/ d slope)
@@ -558,6 +559,8 @@ typedef struct {
     ledn_bnbwd_desc bn;
     const void* head_dz;    /* [N][H][W][Co] bf16 (dtype_dz): gradient of the head's logits */
     const float* w;         /* [Co][C][3][3] f32 */
+    float* dw;              /* optional (reduce pass): [Co][C][3][3] f32, the head's weight gradient ADDED */
+    float* db;              /* optional, with dw: [Co] f32, the bias gradient ADDED */
     int N, H, W, Co;
     int dtype_dz;
 } ledn_headbwd_desc;

@@ -126,7 +126,7 @@ BNBWD_ROWS = 32     # include/ledn.h LEDN_BNBWD_ROWS
 
 
 class HeadBwdDesc(C.Structure):
-    _fields_ = [('bn', BnBwdDesc), ('head_dz', vp), ('w', fp),
+    _fields_ = [('bn', BnBwdDesc), ('head_dz', vp), ('w', fp), ('dw', fp), ('db', fp),
                 ('N', i32), ('H', i32), ('W', i32), ('Co', i32), ('dtype_dz', i32)]
 
 

@@ -16,7 +16,11 @@
 // x, the addend and dx are then two 16-byte accesses per lane.  Next tile's loads are in flight under this tile's
 // arithmetic (7 vector operations per element; a first form on the vector ALU alone -- 18 FMAs per element for dy and 18
 // more for the head's weight gradient -- measured 375 us at 1/2 resolution against the 334 us of the layer-wise kernels).
-// The head's weight gradient stays with conv3x3_wgrad_narrow_kernel (conv3x3.hip).  C = 32, num_classes = 2, bf16 only.
+// The head's weight gradient rides along in the reduce pass: dw[kidx][c] = sum_px P[px][kidx] * t[px][c], kidx = (tap, class)
+// -- the SAME patch values the dy product takes as its B operand, and t = act(BatchNorm(x)), both through a wave-private LDS
+// tile and the transposing read: two more matrix instructions and eight transposing reads per 32 pixels instead of
+// conv3x3_wgrad_narrow_kernel's 18 + 36 in a launch of its own that reads x once more (148 us at 1/2 resolution).
+// C = 32, num_classes = 2, bf16 only.
 #include "stencil.h"
 
 namespace ledn {
@@ -111,17 +115,42 @@ struct HbSched {
     }
 };
 
+
+// ---- weight gradient: dw[kidx][c] += P^T[kidx][px] t[px][c] per 32-pixel tile.  Both operands want 8 consecutive PIXELS per
+// lane while the wave holds them pixel-per-lane (P = the two B operands of the dy product, t = act(BatchNorm(x))): each goes
+// through a wave-private [32 px][32 columns] bf16 tile in LDS and comes back through the transposing read.
+// fragment M[px = 16 s + 8 hk + j][col = lane & 31], j < 8, of a [32 px][32 col] bf16 tile: per 16-lane group (columns
+// 16 (g & 1) ..), lane 4 q + p supplies the address of pixel row q, columns 4 p .. 4 p + 3
+__device__ __forceinline__ bf16x8_t hb_tr_frag(const unsigned char* tile, int s) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15, hk = lane >> 5;
+    const unsigned char* ap = tile + (16 * s + 8 * hk + (i >> 2)) * 64 + (16 * (g & 1) + 4 * (i & 3)) * 2;
+    const bf16x4_t lo = lds_read_tr16(ap), hi = lds_read_tr16(ap + 4 * 64);
+    bf16x8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// row of partial sums per workgroup: [sum_g | sum_gx | dslope (3 x 32) | dw 2 x 32 x 9 | db 2]
+constexpr int HB_ROW = 3 * HB_C, HB_ROW_W = 3 * HB_C + HB_CO * HB_C * 9 + HB_CO;
+
 }  // namespace
 
-template <int ACT>
+template <int ACT, bool WG>
 __global__ void __launch_bounds__(256) head_bwd_reduce_kernel(ledn_headbwd_desc d, float* part) {
     __shared__ float s_red[4][3][HB_C];
+    __shared__ __attribute__((aligned(16))) unsigned char s_t[WG ? 4 : 1][WG ? 2 * 32 * 64 : 16];   // per wave: t tile [32 px][32 ch], P tile [32 px][32 (tap, class)], bf16
+    __shared__ float s_w[WG ? 4 : 1][WG ? 18 * HB_C + 2 : 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
     const int H = d.H, W = d.W;
     bf16x8_t af[2];
     hb_filter_frags(d.w, af);
     HbTaps tp;
     hb_taps(h, W, tp);
+    f32x16_t dwacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dwacc[i] = 0.f;
+    float db0 = 0.f, db1 = 0.f;
     float sc[16], sh[16], mean[16], sl[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -158,6 +187,9 @@ __global__ void __launch_bounds__(256) head_bwd_reduce_kernel(ledn_headbwd_desc 
         for (int u = 0; u < HB_NT; ++u) {
             const long p = (sch.tile + u) * 32 + n;
             const f32x16_t dy = hb_dy(raw[u], af, h);
+            float tv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tv[i] = 0.f;
             if (p < npix) {
                 float xv[16];
                 hb_unpack16(raw[u].x0, raw[u].x1, xv);
@@ -165,14 +197,44 @@ __global__ void __launch_bounds__(256) head_bwd_reduce_kernel(ledn_headbwd_desc 
                 for (int i = 0; i < 16; ++i) {
                     const float v = fmaf(xv[i], sc[i], sh[i]);
                     float g = dy[i];
-                    if (ACT == LEDN_ACT_RELU) g = v > 0.f ? g : 0.f;
-                    else if (ACT == LEDN_ACT_PRELU) {
+                    tv[i] = v;
+                    if (ACT == LEDN_ACT_RELU) {
+                        g = v > 0.f ? g : 0.f;
+                        tv[i] = fmaxf(v, 0.f);
+                    } else if (ACT == LEDN_ACT_PRELU) {
                         sds[i] += v > 0.f ? 0.f : dy[i] * v;
                         g = v > 0.f ? g : g * sl[i];
+                        tv[i] = v > 0.f ? v : v * sl[i];
                     }
                     sg[i] += g;
                     sgx[i] = fmaf(g, xv[i] - mean[i], sgx[i]);
                 }
+                if (WG && h == 1) {              // tap 4 = the pixel itself: the bias gradient
+                    db0 += __uint_as_float(raw[u].dz[0] << 16);
+                    db1 += __uint_as_float(raw[u].dz[0] & 0xffff0000u);
+                }
+            }
+            if (WG) {
+                uint4 t0, t1;
+                t0.x = (unsigned)f32_to_bf16(tv[0]) | ((unsigned)f32_to_bf16(tv[1]) << 16);
+                t0.y = (unsigned)f32_to_bf16(tv[2]) | ((unsigned)f32_to_bf16(tv[3]) << 16);
+                t0.z = (unsigned)f32_to_bf16(tv[4]) | ((unsigned)f32_to_bf16(tv[5]) << 16);
+                t0.w = (unsigned)f32_to_bf16(tv[6]) | ((unsigned)f32_to_bf16(tv[7]) << 16);
+                t1.x = (unsigned)f32_to_bf16(tv[8]) | ((unsigned)f32_to_bf16(tv[9]) << 16);
+                t1.y = (unsigned)f32_to_bf16(tv[10]) | ((unsigned)f32_to_bf16(tv[11]) << 16);
+                t1.z = (unsigned)f32_to_bf16(tv[12]) | ((unsigned)f32_to_bf16(tv[13]) << 16);
+                t1.w = (unsigned)f32_to_bf16(tv[14]) | ((unsigned)f32_to_bf16(tv[15]) << 16);
+                wave_sync();                     // the previous tile's transposing reads are done
+                uint4* tw = reinterpret_cast<uint4*>(s_t[wid] + n * 64 + h * 32);
+                tw[0] = t0;
+                tw[1] = t1;
+                // P[px = n][kidx]: this lane's operands of the dy product ARE columns 8 h .. 8 h + 7 and 16 + 8 h .. of its pixel
+                unsigned char* pw = s_t[wid] + 32 * 64 + n * 64 + h * 16;
+                *reinterpret_cast<uint4*>(pw) = make_uint4(raw[u].dz[0], raw[u].dz[1], raw[u].dz[2], raw[u].dz[3]);
+                *reinterpret_cast<uint4*>(pw + 32) = make_uint4(h == 0 ? raw[u].dz[4] : 0u, 0u, 0u, 0u);
+                wave_sync();
+                dwacc = mfma_32x32x16_bf16(hb_tr_frag(s_t[wid] + 32 * 64, 0), hb_tr_frag(s_t[wid], 0), dwacc);
+                dwacc = mfma_32x32x16_bf16(hb_tr_frag(s_t[wid] + 32 * 64, 1), hb_tr_frag(s_t[wid], 1), dwacc);
             }
             raw[u] = nxt[u];
         }
@@ -215,8 +277,70 @@ __global__ void __launch_bounds__(256) head_bwd_reduce_kernel(ledn_headbwd_desc 
         if (kind < 2 || ACT == LEDN_ACT_PRELU)
             t = (s_red[0][kind][c] + s_red[1][kind][c]) + (s_red[2][kind][c] + s_red[3][kind][c]);
         if (kind == 1) t *= d.bn.bn_mode ? d.bn.invstd[c] : 0.f;
-        part[(long)blockIdx.x * 3 * HB_C + threadIdx.x] = t;
+        part[(long)blockIdx.x * (WG ? HB_ROW_W : HB_ROW) + threadIdx.x] = t;
     }
+    if (WG) {
+        // accumulator register reg of lane (c = n, h) = row kidx = (reg & 3) + 8 (reg >> 2) + 4 h of dw[kidx][c], kidx = 2 k9 + o
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int kidx = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (kidx < 18) s_w[wid][kidx * HB_C + n] = dwacc[reg];
+        }
+        float b0 = db0, b1 = db1;               // (lanes of half 1 hold the pixels' sums, half 0 zeros)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            b0 = lane_step_sum(b0, m);
+            b1 = lane_step_sum(b1, m);
+        }
+        if (lane == 0) {
+            s_w[wid][18 * HB_C] = b0;
+            s_w[wid][18 * HB_C + 1] = b1;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 18 * HB_C + 2; e += 256) {
+            const float t = (s_w[0][e] + s_w[1][e]) + (s_w[2][e] + s_w[3][e]);
+            int dst = HB_ROW + HB_CO * HB_C * 9 + (e - 18 * HB_C);          // db
+            if (e < 18 * HB_C) {
+                const int kidx = e / HB_C, c = e % HB_C;
+                dst = HB_ROW + ((kidx & 1) * HB_C + c) * 9 + (kidx >> 1);    // dw[o][c][k9]
+            }
+            part[(long)blockIdx.x * HB_ROW_W + dst] = t;
+        }
+    }
+}
+
+// adds the workgroups' rows up and ACCUMULATES into the sinks: workgroup = 16 outputs x 16 row slots (slot q sums rows q,
+// q + 16, ... with four loads in flight, the slots are then added in slot order: one fixed order in every mode).  (One lane
+// per output walking all 512 rows was a chain of 128 dependent L2 round trips: ~60 us.)
+__global__ void __launch_bounds__(256) head_bwd_finish_kernel(const float* part, int nrows, float* sum_g, float* sum_gx,
+                                                              float* dslope, float* dw, float* db) {
+    __shared__ float s_red[256];
+    const int j = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + j;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < HB_ROW_W) {
+        int b = slot;
+        for (; b + 48 < nrows; b += 64) {
+            a0 += part[(long)b * HB_ROW_W + e];
+            a1 += part[(long)(b + 16) * HB_ROW_W + e];
+            a2 += part[(long)(b + 32) * HB_ROW_W + e];
+            a3 += part[(long)(b + 48) * HB_ROW_W + e];
+        }
+        for (; b < nrows; b += 16) a0 += part[(long)b * HB_ROW_W + e];
+    }
+    s_red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (threadIdx.x >= 16 || e >= HB_ROW_W) return;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += s_red[q * 16 + threadIdx.x];
+    float* dst;
+    if (e < HB_C) dst = sum_g ? sum_g + e : nullptr;
+    else if (e < 2 * HB_C) dst = sum_gx ? sum_gx + (e - HB_C) : nullptr;
+    else if (e < 3 * HB_C) dst = dslope ? dslope + (e - 2 * HB_C) : nullptr;
+    else if (e < HB_ROW + HB_CO * HB_C * 9) dst = dw + (e - HB_ROW);
+    else dst = db ? db + (e - HB_ROW - HB_CO * HB_C * 9) : nullptr;
+    if (dst) *dst += t;
 }
 
 template <int ACT>
@@ -329,19 +453,32 @@ int head_bwd_supported(const ledn_headbwd_desc& d) {
 
 int head_bwd_reduce(const ledn_headbwd_desc& d, hipStream_t s) {
     LEDN_REQUIRE(head_bwd_supported(d));
+    const bool wg = d.dw != nullptr;              // the head's weight (and bias) gradient in the same pass
+    LEDN_REQUIRE(wg || !d.db);
     const long ntiles = cdiv((long)d.N * d.H * d.W, 32L);
     static const long cap = exp_knob("LEDN_HB_CAP", 512);
     long nb = cdiv(ntiles, 32L);                 // >= 4 trips of two tiles per wave
     if (nb > cap) nb = cap;
-    float* part = ws_take(nb * 3 * HB_C);
+    float* part = ws_take(nb * (wg ? HB_ROW_W : HB_ROW));
     LEDN_REQUIRE(part);
+#define LEDN_HB_GO(A_)                                                                                           \
+    do {                                                                                                         \
+        if (wg) LEDN_LAUNCH((head_bwd_reduce_kernel<A_, true>), dim3((unsigned)nb), dim3(256), 0, s, d, part);   \
+        else LEDN_LAUNCH((head_bwd_reduce_kernel<A_, false>), dim3((unsigned)nb), dim3(256), 0, s, d, part);     \
+    } while (0)
     switch (d.bn.act) {
-        case LEDN_ACT_NONE: LEDN_LAUNCH(head_bwd_reduce_kernel<LEDN_ACT_NONE>, dim3((unsigned)nb), dim3(256), 0, s, d, part); break;
-        case LEDN_ACT_RELU: LEDN_LAUNCH(head_bwd_reduce_kernel<LEDN_ACT_RELU>, dim3((unsigned)nb), dim3(256), 0, s, d, part); break;
-        default: LEDN_LAUNCH(head_bwd_reduce_kernel<LEDN_ACT_PRELU>, dim3((unsigned)nb), dim3(256), 0, s, d, part); break;
+        case LEDN_ACT_NONE: LEDN_HB_GO(LEDN_ACT_NONE); break;
+        case LEDN_ACT_RELU: LEDN_HB_GO(LEDN_ACT_RELU); break;
+        default: LEDN_HB_GO(LEDN_ACT_PRELU); break;
     }
-    return finish_partials(part, (int)nb, HB_C, 3, d.bn.bn_mode ? d.bn.sum_g : nullptr, d.bn.bn_mode ? d.bn.sum_gx : nullptr,
-                           d.bn.act == LEDN_ACT_PRELU ? d.bn.dslope : nullptr, s);
+#undef LEDN_HB_GO
+    float* sum_g = d.bn.bn_mode ? d.bn.sum_g : nullptr;
+    float* sum_gx = d.bn.bn_mode ? d.bn.sum_gx : nullptr;
+    float* dslope = d.bn.act == LEDN_ACT_PRELU ? d.bn.dslope : nullptr;
+    if (!wg) return finish_partials(part, (int)nb, HB_C, 3, sum_g, sum_gx, dslope, s);
+    LEDN_LAUNCH(head_bwd_finish_kernel, dim3((unsigned)cdiv(HB_ROW_W, 16)), dim3(256), 0, s, part, (int)nb, sum_g, sum_gx, dslope,
+                d.dw, d.db);
+    return check_launch();
 }
 
 int head_bwd_apply(const ledn_headbwd_desc& d, hipStream_t s) {

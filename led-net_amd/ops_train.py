@@ -73,12 +73,14 @@ def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, 
     if head is not None:
         # LEDHead's two-class heads: dy = conv_transpose3x3(head_dz, w) is recomputed inside both passes
         # (ledn_head_bwd_reduce / _apply)
-        hdz, hw = head
-        _check(lib, hdz, hw)
+        hdz, hw, hdw, hdb = (tuple(head) + (None, None))[:4]
+        _check(lib, hdz, hw, hdw, hdb)
         hd = st.hd = _lib.HeadBwdDesc()
         hd.bn = d
-        hd.head_dz, hd.w = _p(hdz), _p(_f32(hw))
+        hd.head_dz, hd.w, hd.dw, hd.db = _p(hdz), _p(_f32(hw)), _p(_f32(hdw)), _p(_f32(hdb))
         hd.N, hd.H, hd.W, hd.Co, hd.dtype_dz = z.shape[0], z.shape[1], z.shape[2], hw.shape[0], _dt(hdz)
+        if hdw is not None and (tuple(hdw.shape) != tuple(hw.shape) or (hdb is not None and hdb.numel() != hw.shape[0])):
+            raise LednError('bn_act_bwd: the head weight / bias gradient sinks do not match the filter')
         if tuple(hdz.shape) != (z.shape[0], z.shape[1], z.shape[2], hw.shape[0]) or tuple(hw.shape) != (hw.shape[0], Cc, 3, 3) \
                 or not lib.cdll.ledn_head_bwd_supported(hd):
             raise LednError('bn_act_bwd: shape outside the two-class head kernels (head_bwd_ok decides)')
@@ -87,7 +89,7 @@ def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, 
             f'headbwd_reduce C{Cc} P{P}', _nb(z, hdz), 10 * z.numel(), 'head_bwd_reduce_kernel'))
         st.lib, st.d, st.z, st.bn, st.Cc, st.P, st.local, st.sunk = lib, d, z, bn, Cc, P, local, sunk
         st.dz, st.dres, st.dslope, st.slope_sunk = dz, None, dslope, slope_sunk
-        st.keep = (hdz, None, scale, shift, slope, mean, invstd, sum_g, sum_gx, sk_g, sk_b, dz_add, None, None, hw)
+        st.keep = (hdz, None, scale, shift, slope, mean, invstd, sum_g, sum_gx, sk_g, sk_b, dz_add, None, None, hw, hdw, hdb)
         return st
     if BN_ROWS and not sync and (bn or slope is not None) and z.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16:
         # the reduce pass leaves per-row sums (float atomics into 32 zeroed rows), the apply pass adds them up: no
@@ -183,8 +185,8 @@ def bn_act_bwd(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT
                res=None, res_mode=RES_NONE, count=None, want_dres=False, sync=None, sinks=None, dz_add=None,
                dres_add=None, head=None):
     """Backward of y = act(res_mode(z*scale+shift, res)).
-    head = (head_dz [N,H,W,2] bf16, w [2,32,3,3]): dy is NOT given but recomputed from the logits' gradient of a two-class
-    3x3 head on y (LEDHead's norm -> act -> conv; see head_bwd_ok).
+    head = (head_dz [N,H,W,2] bf16, w [2,32,3,3][, dw sink, db sink or None]): dy is NOT given but recomputed from the logits'
+    gradient of a two-class 3x3 head on y (LEDHead's norm -> act -> conv; see head_bwd_ok); with a dw sink the reduce pass also ACCUMULATES the head's weight / bias gradient into the sinks.
     BN mode (mean/invstd given): returns (dz, dres, dgamma, dbeta, dslope).
     Plain mode: returns (dz, dres, None, None, dslope).
     sync: optional collective object (train._Collective) all-reducing the [2,C] (sum_gx, sum_g) sums (SyncBN);

@@ -358,6 +358,9 @@ def _conv_dgrad(dz, x, w, stride, pad, groups, acc=None):
     return dx
 
 
+HEAD_WGRAD = _knob_int('LEDN_HEAD_WGRAD', 1)     # the two-class heads' weight gradient inside their BatchNorm-backward reduce pass (csrc/head_bwd.hip)
+
+
 class BNActConvFn(Function):
     """z = conv2d(act(BN_train(x)), w) + b with the BatchNorm + activation (none / ReLU / PReLU) folded
     into the convolution's input staging: act(BN(x)) is never written (one write + one read of the
@@ -396,10 +399,16 @@ class BNActConvFn(Function):
         act, count, stride, pad, groups, has_b = ctx.cfg
         sg, sb_, ss, sw, sbias = ctx.sinks
         dz = _c(dz)
-        dw, db = _conv_wgrad(x, dz, tuple(w.shape), sw, sbias, stride=stride, pad=pad, groups=groups, in_scale=scale,
-                             in_shift=shift, in_act=act, in_slope=slope, bias=has_b)
-        # LEDHead's two-class heads: no dy tensor -- the BatchNorm backward recomputes it from dz (ops_train.bn_act_bwd head=)
+        # LEDHead's two-class heads: no dy tensor -- the BatchNorm backward recomputes it from dz, and its reduce pass also
+        # forms the head's weight gradient (ops_train.bn_act_bwd head=)
         head = (dz, w) if T.head_bwd_ok(x, dz, w, stride, pad, groups, act) else None
+        if head is not None and HEAD_WGRAD:
+            dw = sw if sw is not None else torch.zeros_like(w, dtype=torch.float32)
+            db = (sbias if sbias is not None else torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)) if has_b else None
+            head = (dz, w, dw, db)
+        else:
+            dw, db = _conv_wgrad(x, dz, tuple(w.shape), sw, sbias, stride=stride, pad=pad, groups=groups, in_scale=scale,
+                                 in_shift=shift, in_act=act, in_slope=slope, bias=has_b)
         dy = _conv_dgrad(dz, x, w, stride, pad, groups) if head is None else None
         prev = _take(ctx.acc, x)
         dx, _, dgamma, dbeta, dslope = T.bn_act_bwd(x, dy, scale=scale, shift=shift, mean=mean, invstd=invstd,

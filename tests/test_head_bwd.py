@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 
-def _case(dev, N, H, W, act, addend, seed):
+def _case(dev, N, H, W, act, addend, seed, bias=False):
     from led_net_amd import ops
     C = 32
     g = torch.Generator().manual_seed(seed)
@@ -22,9 +22,12 @@ def _case(dev, N, H, W, act, addend, seed):
     sr = slope.clone().requires_grad_(True) if slope is not None else None
     y = F.batch_norm(xr, None, None, gr, br, training=True, eps=1e-5)
     t = F.relu(y) if act == ops.ACT_RELU else (F.prelu(y, sr) if act == ops.ACT_PRELU else y)
-    z = F.conv2d(t, w, None, padding=1)
+    wr = w.clone().requires_grad_(True)
+    bb = torch.zeros(2, requires_grad=True) if bias else None
+    z = F.conv2d(t, wr, bb, padding=1)
     z.backward(dz)
-    want = dict(dx=xr.grad + (add if addend else 0), dgamma=gr.grad, dbeta=br.grad, dslope=sr.grad if sr is not None else None)
+    want = dict(dx=xr.grad + (add if addend else 0), dgamma=gr.grad, dbeta=br.grad, dslope=sr.grad if sr is not None else None,
+                dw=wr.grad, db=bb.grad if bias else None)
     mean = x.mean((0, 2, 3))
     var = x.var((0, 2, 3), unbiased=False)
     invstd = (var + 1e-5).rsqrt()
@@ -36,13 +39,42 @@ def _case(dev, N, H, W, act, addend, seed):
     return args, want
 
 
-def _run_head(a, act, dev):
+def _run_head(a, act, dev, wgrad=None):
     from led_net_amd import ops_train as T
     sinks = (torch.zeros(32, device=dev), torch.zeros(32, device=dev), torch.zeros(32, device=dev) if a['slope'] is not None else None)
     assert T.head_bwd_ok(a['x'], a['dz'], a['w'], 1, 1, 1, act)
+    head = (a['dz'], a['w']) + (tuple(wgrad) if wgrad is not None else ())
     dx, _, _, _, _ = T.bn_act_bwd(a['x'], None, scale=a['scale'], shift=a['shift'], mean=a['mean'], invstd=a['invstd'], act=act,
-                                   slope=a['slope'], count=a['count'], sinks=sinks, dz_add=a['add'], head=(a['dz'], a['w']))
+                                   slope=a['slope'], count=a['count'], sinks=sinks, dz_add=a['add'], head=head)
     return dx, sinks
+
+
+@pytest.mark.parametrize('nhw', [(1, 128, 128), (2, 33, 256), (1, 127, 131), (1, 16, 1030)])
+@pytest.mark.parametrize('variant', ['relu_bias', 'prelu', 'none_bias'])
+def test_head_bwd_weight_gradient(be, nhw, variant):
+    """the reduce pass with the head's weight / bias gradient riding along (ragged widths included): against autograd (the
+    activation enters the matrix instruction rounded to bf16, as in the layer-wise weight-gradient kernel), accumulating
+    into the sinks, two runs bit-identical"""
+    from led_net_amd import ops
+    act = {'relu_bias': ops.ACT_RELU, 'prelu': ops.ACT_PRELU, 'none_bias': ops.ACT_NONE}[variant]
+    a, want = _case(be.dev, *nhw, act, False, nhw[1] * 3 + nhw[2], bias='bias' in variant)
+    outs = []
+    for _ in range(2):
+        dw = torch.zeros(2, 32, 3, 3, device=be.dev)
+        db = torch.zeros(2, device=be.dev) if 'bias' in variant else None
+        dx, sinks = _run_head(a, act, be.dev, (dw, db))
+        outs.append((dx, sinks, dw, db))
+    (dx, sinks, dw, db), (dx2, _, dw2, db2) = outs
+    assert torch.equal(dw, dw2) and torch.equal(dx, dx2) and (db is None or torch.equal(db, db2))
+    torch.testing.assert_close(dw.cpu(), want['dw'], rtol=1e-2, atol=1e-2 * float(want['dw'].abs().max()))
+    if db is not None:
+        torch.testing.assert_close(db.cpu(), want['db'], rtol=1e-3, atol=1e-3 * float(want['db'].abs().max()))
+    torch.testing.assert_close(sinks[0].cpu(), want['dgamma'], rtol=2e-3, atol=2e-3 * float(want['dgamma'].abs().max()))
+    got_dx = dx.float().cpu().permute(0, 3, 1, 2)
+    torch.testing.assert_close(got_dx, want['dx'], rtol=2e-2, atol=2e-2 * float(want['dx'].abs().max()))
+    # accumulation into the sinks
+    _run_head(a, act, be.dev, (dw, db))
+    torch.testing.assert_close(dw, 2 * dw2, rtol=1e-6, atol=0)
 
 
 @pytest.mark.parametrize('nhw', [(1, 128, 130), (2, 97, 131), (1, 16, 1030)])
