@@ -186,6 +186,16 @@ int ledn_stem_conv(const void* x, int dtype_x, const void* wp, void* y, int N, i
 int ledn_stem_conv_wgrad(const void* x, int dtype_x, const void* dz, float* dw, int N, int H, int W, int C, int Ho, int Wo,
                          int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
                          float pad_val, void* stream);
+/* The same with dz formed INSIDE the kernel from the BatchNorm + activation behind the convolution (the stem's
+ * ConvModule, ddrnet.py:123-130 -> mmcv ConvModule conv -> norm -> act): bn describes that BatchNorm's backward exactly as
+ * for ledn_bn_act_bwd_apply (a later declaration: z = the convolution's output, dy = the gradient of act(BN(z)), sum_g /
+ * sum_gx = the totals of ledn_bn_act_bwd_reduce, SyncBN-reduced if applicable; act none / ReLU, no residual, no dz_add,
+ * bf16, C = 32) but bn->dz is NOT written: the stem's input needs no gradient, so this weight gradient is the only reader
+ * of dz, and the apply pass (two tensors read, one written) collapses into one more tensor read here. */
+struct ledn_bnbwd_desc_s;
+int ledn_stem_conv_wgrad_bn(const void* x, int dtype_x, const struct ledn_bnbwd_desc_s* bn, float* dw, int N, int H, int W, int C,
+                            int Ho, int Wo, int Cout, const float* in_scale, const float* in_shift, const int* map,
+                            const int* valid_hw, float pad_val, void* stream);
 
 /* Weight (and bias) gradient of the same convolution:
  *   dw(co,ci,tap) += sum_{n,ho,wo} pre(x)[n, ho*s-pad+kh*dil, .., ci] * dz[n,ho,wo,co]
@@ -489,7 +499,7 @@ int ledn_seam_edge(const float* seg, float* edge, float* scratch, int N, int h, 
  *               dslope[c] += sum dy*min(t,0)                      (PReLU)
  * apply pass  : bn_mode=1: dz = scale*(g_v - sum_g/count - x_hat*sum_gx/count)
  *               bn_mode=0: dz = g_v*scale (scale NULL = 1);  dres written if given. */
-typedef struct {
+typedef struct ledn_bnbwd_desc_s {
     const void* z;
     const void* res;
     const void* dy;

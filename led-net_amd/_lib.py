@@ -204,6 +204,7 @@ _PROTOS = {
     'ledn_im2col_stem_planar': ([vp, i32, vp, i32, i32, i32, i32, i32, i32, fp, fp, vp, vp, C.c_float, vp], i32),
     'ledn_stem_conv': ([vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, fp, fp, vp, vp, C.c_float, fp, fp, i32, fp, fp, vp], i32),
     'ledn_stem_conv_wgrad': ([vp, i32, vp, fp, i32, i32, i32, i32, i32, i32, i32, fp, fp, vp, vp, C.c_float, vp], i32),
+    'ledn_stem_conv_wgrad_bn': ([vp, i32, C.POINTER(BnBwdDesc), fp, i32, i32, i32, i32, i32, i32, i32, fp, fp, vp, vp, C.c_float, vp], i32),
     'ledn_pack_conv_weights': ([fp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ledn_conv2d_wgrad': ([C.POINTER(WgradDesc), vp], i32),
     'ledn_dwconv2d': ([C.POINTER(DwDesc), vp], i32),

@@ -45,7 +45,7 @@ int im2col_stem_planar_impl(const void* x, int dtype_x, void* p, int N, int H, i
                             hipStream_t s);
 int stem_conv_wgrad_impl(const void* x, int dtype_x, const void* dz, float* dw, int N, int H, int W, int C, int Ho, int Wo,
                          int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
-                         float pad_val, hipStream_t s);
+                         float pad_val, const ledn_bnbwd_desc* bn, hipStream_t s);
 int stem_conv_impl(const void* x, int dtype_x, const void* wp, void* y, int N, int H, int W, int C, int Ho, int Wo,
                    int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
                    float pad_val, const float* out_scale, const float* out_shift, int act_out, float* stat_sum,
@@ -385,7 +385,14 @@ int ledn_stem_conv_wgrad(const void* x, int dtype_x, const void* dz, float* dw, 
                          int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
                          float pad_val, void* stream) {
     return stem_conv_wgrad_impl(x, dtype_x, dz, dw, N, H, W, C, Ho, Wo, Cout, in_scale, in_shift, map, valid_hw, pad_val,
-                                S(stream));
+                                nullptr, S(stream));
+}
+int ledn_stem_conv_wgrad_bn(const void* x, int dtype_x, const ledn_bnbwd_desc* bn, float* dw, int N, int H, int W, int C, int Ho,
+                            int Wo, int Cout, const float* in_scale, const float* in_shift, const int* map,
+                            const int* valid_hw, float pad_val, void* stream) {
+    LEDN_REQUIRE(bn);
+    return stem_conv_wgrad_impl(x, dtype_x, nullptr, dw, N, H, W, C, Ho, Wo, Cout, in_scale, in_shift, map, valid_hw, pad_val,
+                                bn, S(stream));
 }
 int ledn_mfaf_ctx_fwd(const ledn_mfafctx_desc* d, int training, void* stream) {
     return d ? mfaf_ctx_fwd_impl(*d, training, S(stream)) : LEDN_EINVAL;

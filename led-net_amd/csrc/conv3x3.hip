@@ -1188,7 +1188,11 @@ int stem_conv_reg_impl(const void* x, int dtype_x, const void* wp, void* y, int 
 // ---------------------------------------------------------------------------
 struct StemWArgs {
     const void* x;
-    const bf16_t* dz;            // [N][Ho][Wo][32]
+    const bf16_t* dz;            // [N][Ho][Wo][32]  (BNP: the gradient of the BatchNorm + activation OUTPUT)
+    const bf16_t* bz;            // BNP: the convolution's output z, same shape
+    const float *b_scale, *b_shift, *b_mean, *b_invstd, *b_sum_g, *b_sum_gx;   // BNP: ledn_bnbwd_desc of the BatchNorm behind the conv
+    float b_inv_count;
+    int b_mode, b_act;
     float* part;                 // [gridDim.x][864]
     const float *in_scale, *in_shift;
     const int* map;
@@ -1201,7 +1205,11 @@ struct StemWArgs {
 #ifndef LEDN_SW_EXP
 #define LEDN_SW_EXP 0      // cost experiments (tools/gpu_exp_sw.sh; uint8 inputs only): 1 no matrix instructions, 2 no LDS tile, 3 no patch-row arithmetic
 #endif
-template <typename TX>
+// BNP: dz is not read but formed piece by piece from z and the gradient dy of y = act(BatchNorm(z)) -- the apply half of the
+// BatchNorm backward (dz = scale g + A z + B, g = dy act'(.): stream_fast.hip) as this kernel's operand prologue.  The
+// stem's input needs no gradient, so this weight gradient is the ONLY reader of dz: the apply pass (268 MB read twice, 268 MB
+// written, 130 us at 16 x 512 x 512 x 32) and this kernel's read of its output shrink to one more 268 MB read here.
+template <typename TX, bool BNP>
 __global__ void __launch_bounds__(256, 3) stem_wgrad_reg_kernel(StemWArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char s_z[4][32 * ST_PIXB];     // per wave: [pixel][32 channels] bf16
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1218,8 +1226,27 @@ __global__ void __launch_bounds__(256, 3) stem_wgrad_reg_kernel(StemWArgs a) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // BNP: coefficients of this lane's 8 channels 8 (lane & 3) .. (both pieces e = lane, lane + 64 share them)
+    float bsc[BNP ? 8 : 1], bsh[BNP ? 8 : 1], bca[BNP ? 8 : 1], bcb[BNP ? 8 : 1];
+    if constexpr (BNP) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = 8 * (lane & 3) + k;
+            const float sc = a.b_scale ? a.b_scale[c] : 1.f;
+            float ca = 0.f, cb = 0.f;
+            if (a.b_mode) {           // dz = sc g + A z + B,  A = -sc mean_gx invstd,  B = -sc mean_g - A mean
+                ca = -sc * (a.b_sum_gx[c] * a.b_inv_count) * a.b_invstd[c];
+                cb = -sc * (a.b_sum_g[c] * a.b_inv_count) - ca * a.b_mean[c];
+            }
+            bsc[k] = sc;
+            bsh[k] = a.b_shift ? a.b_shift[c] : 0.f;
+            bca[k] = ca;
+            bcb[k] = cb;
+        }
+    }
+    constexpr int NZ = BNP ? 4 : 2;
 
-    auto gather = [&](long it, StemRaw<TX> (&ra)[2], uint4 (&rz)[2]) {
+    auto gather = [&](long it, StemRaw<TX> (&ra)[2], uint4 (&rz)[NZ]) {
         const int row = (int)(it / a.strips), strip = (int)(it % a.strips);
         const int n = row / Ho, o = row - n * Ho;
         const bf16_t* zr = a.dz + (long)row * Wo * 32;
@@ -1232,12 +1259,36 @@ __global__ void __launch_bounds__(256, 3) stem_wgrad_reg_kernel(StemWArgs a) {
             uint4 v = *reinterpret_cast<const uint4*>(zr + (pok ? (long)px * 32 + 8 * (e & 3) : 0L));
             if (!pok) v = make_uint4(0u, 0u, 0u, 0u);
             rz[t] = v;
+            if constexpr (BNP) {
+                const bf16_t* zz = a.bz + (long)row * Wo * 32;
+                rz[2 + t] = *reinterpret_cast<const uint4*>(zz + (pok ? (long)px * 32 + 8 * (e & 3) : 0L));
+            }
         }
+    };
+    // BNP: the piece of dz from the piece of dy (zero beyond the row end: stays zero) and the piece of z
+    auto bn_piece = [&](const uint4& dyr, const uint4& zr) {
+        const unsigned dv[4] = {dyr.x, dyr.y, dyr.z, dyr.w}, zv[4] = {zr.x, zr.y, zr.z, zr.w};
+        unsigned o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r2[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int k = 2 * i + hh;
+                const float z = __uint_as_float(hh ? (zv[i] & 0xffff0000u) : (zv[i] << 16));
+                const float dy = __uint_as_float(hh ? (dv[i] & 0xffff0000u) : (dv[i] << 16));
+                const float v = fmaf(z, bsc[k], bsh[k]);
+                const float g = (a.b_act == LEDN_ACT_RELU && !(v > 0.f)) ? 0.f : dy;
+                r2[hh] = fmaf(g, bsc[k], fmaf(z, bca[k], bcb[k]));
+            }
+            o[i] = (unsigned)f32_to_bf16(r2[0]) | ((unsigned)f32_to_bf16(r2[1]) << 16);
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
     };
     const long nwaves = (long)gridDim.x * 4;
     long it = (long)blockIdx.x * 4 + wid;
     StemRaw<TX> acur[2], anext[2];
-    uint4 zcur[2], znext[2];
+    uint4 zcur[NZ], znext[NZ];
     if (it < a.iters) gather(it, acur, zcur);
     while (it < a.iters) {
         const long nit = it + nwaves;
@@ -1248,7 +1299,12 @@ __global__ void __launch_bounds__(256, 3) stem_wgrad_reg_kernel(StemWArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int e = lane + 64 * t;
-            *reinterpret_cast<uint4*>(sz + (e >> 2) * ST_PIXB + (e & 3) * 16) = zcur[t];
+            uint4 piece = zcur[t];
+            if constexpr (BNP) {
+                const int px = (int)(it % a.strips) * 32 + (e >> 2);
+                piece = px < Wo ? bn_piece(zcur[t], zcur[2 + t]) : make_uint4(0u, 0u, 0u, 0u);
+            }
+            *reinterpret_cast<uint4*>(sz + (e >> 2) * ST_PIXB + (e & 3) * 16) = piece;
         }
         wave_sync();
         }
@@ -1303,10 +1359,9 @@ __global__ void __launch_bounds__(256, 3) stem_wgrad_reg_kernel(StemWArgs a) {
         }
         if (exp_lds) wave_sync();                                // the tile is rewritten by the next iteration
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            zcur[t] = znext[t];
-            acur[t] = anext[t];
-        }
+        for (int t = 0; t < 2; ++t) acur[t] = anext[t];
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) zcur[t] = znext[t];
         it = nit;
     }
     // acc[mt][nt][i] = dW^T[k = 16 mt + 4 q + i][co = 16 nt + m16]: the four waves meet in LDS, one OIHW row per workgroup
@@ -1328,7 +1383,14 @@ __global__ void __launch_bounds__(256, 3) stem_wgrad_reg_kernel(StemWArgs a) {
 
 int stem_conv_wgrad_impl(const void* x, int dtype_x, const void* dz, float* dw, int N, int H, int W, int C, int Ho, int Wo,
                          int Cout, const float* in_scale, const float* in_shift, const int* map, const int* valid_hw,
-                         float pad_val, hipStream_t s) {
+                         float pad_val, const ledn_bnbwd_desc* bn, hipStream_t s) {
+    if (bn) {       // dz = the apply half of this BatchNorm backward, formed inside the kernel (ledn_stem_conv_wgrad_bn)
+        LEDN_REQUIRE(!dz && bn->z && bn->dy && bn->C == 32 && bn->P == (long long)N * Ho * Wo && bn->count > 0);
+        LEDN_REQUIRE(bn->dtype_z == LEDN_BF16 && bn->dtype_y == LEDN_BF16 && !bn->res && bn->res_mode == LEDN_RES_NONE);
+        LEDN_REQUIRE((bn->act == LEDN_ACT_NONE || bn->act == LEDN_ACT_RELU) && !bn->dz_add && !bn->dres && !bn->rows);
+        LEDN_REQUIRE(!bn->bn_mode || (bn->mean && bn->invstd && bn->sum_g && bn->sum_gx));
+        dz = bn->dy;
+    }
     LEDN_REQUIRE(x && dz && dw && N > 0 && H > 0 && W > 0 && C == 3 && Cout == 32);
     LEDN_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1);
     LEDN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
@@ -1344,9 +1406,25 @@ int stem_conv_wgrad_impl(const void* x, int dtype_x, const void* dz, float* dw, 
     if (nb > cap) nb = cap;
     a.part = ws_take(nb * 864);
     if (!a.part) return LEDN_EINVAL;        // the kernel writes its partial tiles unconditionally: no workspace, no launch
-    if (dtype_x == LEDN_U8) LEDN_LAUNCH((stem_wgrad_reg_kernel<unsigned char>), dim3((unsigned)nb), dim3(256), 0, s, a);
-    else if (dtype_x == LEDN_F32) LEDN_LAUNCH((stem_wgrad_reg_kernel<float>), dim3((unsigned)nb), dim3(256), 0, s, a);
-    else if (dtype_x == LEDN_BF16) LEDN_LAUNCH((stem_wgrad_reg_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    a.bz = nullptr;
+    a.b_scale = a.b_shift = a.b_mean = a.b_invstd = a.b_sum_g = a.b_sum_gx = nullptr;
+    a.b_inv_count = 0.f;
+    a.b_mode = a.b_act = 0;
+    if (bn) {
+        a.bz = (const bf16_t*)bn->z;
+        a.b_scale = bn->scale; a.b_shift = bn->shift; a.b_mean = bn->mean; a.b_invstd = bn->invstd;
+        a.b_sum_g = bn->sum_g; a.b_sum_gx = bn->sum_gx;
+        a.b_inv_count = (float)(1.0 / bn->count);
+        a.b_mode = bn->bn_mode; a.b_act = bn->act;
+        if (dtype_x == LEDN_U8) LEDN_LAUNCH((stem_wgrad_reg_kernel<unsigned char, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+        else if (dtype_x == LEDN_F32) LEDN_LAUNCH((stem_wgrad_reg_kernel<float, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+        else if (dtype_x == LEDN_BF16) LEDN_LAUNCH((stem_wgrad_reg_kernel<bf16_t, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+        else return LEDN_EINVAL;
+        return finish_partials(a.part, (int)nb, 864, 1, dw, nullptr, nullptr, s);
+    }
+    if (dtype_x == LEDN_U8) LEDN_LAUNCH((stem_wgrad_reg_kernel<unsigned char, false>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else if (dtype_x == LEDN_F32) LEDN_LAUNCH((stem_wgrad_reg_kernel<float, false>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else if (dtype_x == LEDN_BF16) LEDN_LAUNCH((stem_wgrad_reg_kernel<bf16_t, false>), dim3((unsigned)nb), dim3(256), 0, s, a);
     else return LEDN_EINVAL;
     return finish_partials(a.part, (int)nb, 864, 1, dw, nullptr, nullptr, s);
 }

@@ -353,9 +353,11 @@ def stem_conv(x, w_pack, scale=None, shift=None, chan_map=None, valid=None, pad_
     return y
 
 
-def stem_conv_wgrad(x, dz, dw, scale=None, shift=None, chan_map=None, valid=None, pad_val=0.0):
+def stem_conv_wgrad(x, dz, dw, scale=None, shift=None, chan_map=None, valid=None, pad_val=0.0, bn_desc=None):
     """dw [32,3,3,3] f32 += weight gradient of stem_conv from the planar batch x [N,3,H,W] and dz [N,Ho,Wo,32] bf16
-    (ledn_stem_conv_wgrad: no patch matrix).  -> dw"""
+    (ledn_stem_conv_wgrad: no patch matrix).  -> dw
+    bn_desc: a prepared _lib.BnBwdDesc whose reduce half has run -- dz is then the gradient of act(BN(z)) and the apply half
+    happens inside the kernel (ledn_stem_conv_wgrad_bn)."""
     lib = _lib.get_lib()
     N, Cc, H, W = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -370,6 +372,11 @@ def stem_conv_wgrad(x, dz, dw, scale=None, shift=None, chan_map=None, valid=None
     _check(lib, x, dz, dw, scale, shift, chan_map, valid)
     dtx = {torch.uint8: _lib.U8, torch.float32: F32, torch.bfloat16: BF16}[x.dtype]
     valid = _valid_hw(valid, N, x)
+    if bn_desc is not None:
+        _run(lib, 'ledn_stem_conv_wgrad_bn', x, _p(x), dtx, bn_desc, _p(dw), N, H, W, Cc, Ho, Wo, 32,
+             _p(_f32(scale, Cc)), _p(_f32(shift, Cc)), _p(chan_map), _p(valid), float(pad_val),
+             work=_TIMING is not None and (f'stem_conv_wgrad_bn {N}x{H}x{W}', _nb(x, dz, dz), 2 * dz.numel() * 27, 'stem_wgrad_reg_kernel'))
+        return dw
     _run(lib, 'ledn_stem_conv_wgrad', x, _p(x), dtx, _p(dz), _p(dw), N, H, W, Cc, Ho, Wo, 32,
          _p(_f32(scale, Cc)), _p(_f32(shift, Cc)), _p(chan_map), _p(valid), float(pad_val),
          work=_TIMING is not None and (f'stem_conv_wgrad {N}x{H}x{W}', _nb(x, dz), 2 * dz.numel() * 27, 'stem_wgrad_reg_kernel'))

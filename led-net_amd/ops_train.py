@@ -21,7 +21,7 @@ BN_ROWS = _knob_int('LEDN_BN_ROWS', 0)   # measured r3k: 13.85 vs 13.85 ms -- th
 
 def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, act=ACT_NONE, slope=None,
                       res=None, res_mode=RES_NONE, count=None, want_dres=False, sinks=None, sync=False,
-                      dz_add=None, dres_add=None, launch=True, head=None):
+                      dz_add=None, dres_add=None, launch=True, head=None, no_dz=False):
     """First half of bn_act_bwd: the per-channel sums (sum g*xhat, sum g) of THIS rank's shard, reduced
     into the parameter-gradient sinks when given (they ARE d_gamma, d_beta of the local shard -- under
     SyncBN too: torch.nn.SyncBatchNorm keeps grad_weight / grad_bias local, DDP averages them later),
@@ -49,7 +49,7 @@ def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, 
             dslope, slope_sunk = _f32(sk_s, Cc), True
         else:
             dslope = _ops.zeros_f32(Cc, z.device)
-    dz = torch.empty_like(z)
+    dz = torch.empty_like(z) if not no_dz else None      # (no_dz: the apply half belongs to the consumer -- ledn_stem_conv_wgrad_bn)
     dres = torch.empty_like(dy) if (want_dres and res_mode != RES_NONE) else None
     if head is not None and (dy is not None or res is not None or want_dres):
         raise LednError('bn_act_bwd: the two-class head form takes no dy / residual')

@@ -29,6 +29,7 @@ class _Env:
     world = 1
     head_acc = {}       # gradient fan-in accumulators (_Acc) of the stem tensors LEDHead reads: {'x1': .., 'x2': ..}
     grad_ready = None   # callable(tag) fired from the backward by GradReadyFn, or None
+    lazy_bn = {}        # dy.data_ptr() -> ops_train._BnBwd whose apply half the consumer of dz performs itself (BNActFn lazy_dz -> StemConvFn)
     ctx_fin = {}        # z2.data_ptr() -> (scale, shift, mean, invstd) of its trailing BatchNorm (MfafCtxFn -> MfafTailFn)
 
 
@@ -275,9 +276,13 @@ class BNActFn(Function):
     the producing kernel) or are reduced here; running stats updated in place."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, slope, res, stats, bn, act, res_mode, out_dtype, acc_res=None, acc_z=None):
+    def forward(ctx, z, gamma, beta, slope, res, stats, bn, act, res_mode, out_dtype, acc_res=None, acc_z=None, lazy_dz=False):
+        """lazy_dz: z's producer is StemConvFn, the only reader of dz -- the backward then runs the reduce half only and hands
+        dy + the prepared descriptor on (_Env.lazy_bn); the stem's weight-gradient kernel forms dz itself"""
         Cc = z.shape[-1]
         count = z.numel() // Cc
+        ctx.lazy = bool(lazy_dz and STEM_LAZY_BN and res is None and act in (ACT_NONE, ACT_RELU) and z.dtype == torch.bfloat16
+                        and Cc == 32 and acc_z is None)
         if stats is None:
             stats = ops.zeros_f32((2, Cc), z.device)
             ops.channel_stats(z, stats=(stats[0], stats[1]), defer_stats=_Env.sync_bn is None)
@@ -300,6 +305,14 @@ class BNActFn(Function):
         z, res, scale, shift, mean, invstd, slope = ctx.saved_tensors
         act, res_mode, count = ctx.cfg
         dy = _c(dy)
+        if ctx.lazy and dy.dtype == torch.bfloat16:
+            st = T.bn_act_bwd_reduce(z, dy, scale=scale, shift=shift, mean=mean, invstd=invstd, act=act, count=count,
+                                     sinks=ctx.sinks, sync=_Env.sync_bn is not None, no_dz=True)
+            T.bn_act_bwd_sync(st, _Env.sync_bn)
+            _Env.lazy_bn.clear()                    # (one stem per model; an entry nobody collected -- frozen stem -- must not linger)
+            _Env.lazy_bn[dy.data_ptr()] = st
+            _, _, dgamma, dbeta, _ = T._bn_bwd_result(st)
+            return dy, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
         want_dres = res is not None and ctx.needs_input_grad[4]
         prev = _take(ctx.acc_res, dy) if want_dres else None
         prev_z = _take(ctx.acc_z, z)
@@ -311,9 +324,10 @@ class BNActFn(Function):
             ctx.acc_res.put(dres, prev is not None)
         if ctx.acc_z is not None:
             ctx.acc_z.put(dz, prev_z is not None)
-        return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None, None, None
+        return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None, None, None, None
 
 
+STEM_LAZY_BN = _knob_int('LEDN_STEM_LAZY_BN', 1)   # the stem BatchNorm's apply half inside the stem weight-gradient kernel (ledn_stem_conv_wgrad_bn)
 WGRAD_DEFER = _knob_int('LEDN_WGRAD_DEFER', 1)   # one summing launch for all weight gradients of a step (ops.WgradDefer)
 WGRAD_SLOT_MAXPIX = _knob_int('LEDN_WGRAD_SLOT_MAXPIX', 0)   # with LEDN_WGRAD_SLOT: only layers of at most this many output pixels (the short, latency-bound 1/8-resolution ones)
 WGRAD_SLOT = _knob_int('LEDN_WGRAD_SLOT', 0)   # auxiliary stream of the weight gradients, 0 = launch stream (measured r02n: 782 img/s on its own stream vs 892 on the launch stream; round-3 kernels: 1098 vs 1225)
@@ -816,7 +830,9 @@ class StemConvFn(Function):
     def backward(ctx, dz):
         x, s, b, mp, valid = ctx.saved_tensors
         dw = ctx.sink if ctx.sink is not None else ops.zeros_f32(ctx.wshape, dz.device)
-        ops.stem_conv_wgrad(x, _c(dz), dw, s, b, mp, valid, ctx.pad_val)
+        dz = _c(dz)
+        st = _Env.lazy_bn.pop(dz.data_ptr(), None)       # BNActFn(lazy_dz): dz is still the gradient of act(BN(z))
+        ops.stem_conv_wgrad(x, dz, dw, s, b, mp, valid, ctx.pad_val, bn_desc=st.d if st is not None else None)
         return None, (None if ctx.sink is not None else dw), None, None
 
 
@@ -1180,7 +1196,7 @@ def lednet_forward_train(m, x, pre=None):
         # read twice per step) is never materialised
         st = _stats(m.channels, x)
         z = StemConvFn.apply(x.contiguous(), s0.conv.weight, (s, b, mp, valid, pad_val), st)
-        x1 = BNActFn.apply(z, s0.bn.weight, s0.bn.bias, None, None, st, s0.bn, ACT_RELU, RES_NONE, None)
+        x1 = BNActFn.apply(z, s0.bn.weight, s0.bn.bias, None, None, st, s0.bn, ACT_RELU, RES_NONE, None, None, None, True)
     elif m.act_dtype == torch.bfloat16 and 9 * m.in_channels <= 32 and m.channels % 32 == 0:
         # stem as a K=32 GEMM on the MFMA path: im2col patches straight from the planar batch
         # (normalisation folded in; the input needs no gradient) x reshaped weight

@@ -209,6 +209,37 @@ def test_stem_conv_wgrad_from_planar_batch(be, shape, valid):
     torch.testing.assert_close(dw.cpu() - 0.5, ref.cpu(), rtol=1e-3, atol=1e-3 * scale)
 
 
+@pytest.mark.parametrize('shape,act', [((2, 3, 64, 128), 'relu'), ((1, 3, 70, 150), 'relu'), ((2, 3, 66, 92), 'none')])
+def test_stem_conv_wgrad_with_batchnorm_apply_prologue(be, shape, act):
+    """ledn_stem_conv_wgrad_bn: the stem weight gradient with dz formed inside the kernel from z, the gradient dy of
+    act(BatchNorm(z)) and the BatchNorm-backward sums (the apply half of ledn_bn_act_bwd as an operand prologue) -- against
+    the two-launch form (ledn_bn_act_bwd_apply writes dz, ledn_stem_conv_wgrad reads it) on the same tensors."""
+    from led_net_amd import ops, ops_train as T
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = D(torch.randint(0, 256, shape, dtype=torch.uint8, generator=g))
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    z = D(torch.randn(N, Ho, Wo, 32, generator=g).bfloat16())
+    dy = D(torch.randn(N, Ho, Wo, 32, generator=g).bfloat16())
+    gamma, beta = D(torch.rand(32, generator=g) + 0.5), D(torch.randn(32, generator=g) * 0.1)
+    mean = z.float().mean((0, 1, 2))
+    invstd = (z.float().var((0, 1, 2), unbiased=False) + 1e-5).rsqrt()
+    kw = dict(scale=gamma * invstd, shift=beta - mean * gamma * invstd, mean=mean, invstd=invstd,
+              act=ops.ACT_RELU if act == 'relu' else ops.ACT_NONE, count=N * Ho * Wo)
+    sc, sh = D(torch.tensor([0.017, 0.0175, 0.0174])), D(torch.tensor([-2.1, -2.0, -1.8]))
+    # two launches
+    dz, _, dgamma, dbeta, _ = T.bn_act_bwd(z, dy, **kw)
+    want = ops.stem_conv_wgrad(x, dz, torch.zeros(32, 3, 3, 3, device=_DEV[0]), sc, sh)
+    # reduce half, then the weight gradient with the apply half as its prologue
+    st = T.bn_act_bwd_reduce(z, dy, no_dz=True, **kw)
+    got = ops.stem_conv_wgrad(x, dy, torch.zeros(32, 3, 3, 3, device=_DEV[0]), sc, sh, bn_desc=st.d)
+    _, _, dgamma2, dbeta2, _ = T._bn_bwd_result(st)
+    torch.testing.assert_close(dgamma2.cpu(), dgamma.cpu(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dbeta2.cpu(), dbeta.cpu(), rtol=1e-5, atol=1e-5)
+    # (the two-launch form rounds dz to bf16 in memory, the prologue rounds the same f32 value: identical operands)
+    torch.testing.assert_close(got.cpu(), want.cpu(), rtol=1e-4, atol=1e-4 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize('cout,pro,nhw', [(2, True, (3, 21, 44)), (2, False, (1, 35, 64)), (1, True, (2, 9, 70)), (4, True, (1, 17, 33)),
                                           (2, True, (2, 40, 100))])
 def test_narrow_output_wgrad_lds_ring(be, cout, pro, nhw):
