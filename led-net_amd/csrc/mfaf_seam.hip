@@ -44,10 +44,98 @@ __global__ void __launch_bounds__(256) mfaf_gate_kernel(ledn_mfaf_desc d) {
     stv<V>(reinterpret_cast<T*>(d.out) + pix * d.C + c, o);
 }
 
+// The same for bf16 maps with C a power of two in 8 .. 256, at the streaming rate: lane = 8 channels (16-byte accesses) of UNR
+// pixels 256 / (C / 8) apart, all their loads issued before the first use; the five per-channel scales and the sum of the
+// five shifts sit in registers (the form above issues ~40 parameter loads per lane for its three 8-byte tensor loads:
+// 50 us for 134 MB at 16 x 128 x 128 x 64).
+template <int UNR>
+__global__ void __launch_bounds__(256) mfaf_gate_fast_kernel(ledn_mfaf_desc d) {
+    const int cvn = d.C >> 3, rows = 256 / cvn;
+    const int cv = (int)(threadIdx.x % (unsigned)cvn), r = (int)(threadIdx.x / (unsigned)cvn), c = cv * 8;
+    float sc[5][8], shs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            sc[k][i] = d.scale[k][c + i];
+            t += d.shift[k][c + i];
+        }
+        shs[i] = t;
+    }
+    const long npix = (long)d.N * d.H * d.W;
+    const long p0 = (long)blockIdx.x * (rows * UNR) + r;
+    const bf16_t* x = reinterpret_cast<const bf16_t*>(d.x);
+    const bf16_t* rr = reinterpret_cast<const bf16_t*>(d.r);
+    const bf16_t* xl = reinterpret_cast<const bf16_t*>(d.xl);
+    uint4 xv[UNR], rv[UNR], lv[UNR];
+    float4 cx[UNR][4][2];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const long p = p0 + (long)u * rows, q = p < npix ? p : 0;
+        xv[u] = *reinterpret_cast<const uint4*>(x + q * d.C + c);
+        rv[u] = *reinterpret_cast<const uint4*>(rr + q * d.C + c);
+        lv[u] = *reinterpret_cast<const uint4*>(xl + q * d.C + c);
+        const int px = (int)(q % d.W), py = (int)((q / d.W) % d.H), n = (int)(q / ((long)d.W * d.H));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int S = d.ctx_size[k];
+            // F.interpolate(mode='nearest'): src = floor(dst * in / out)
+            int sy = (int)((float)py * ((float)S / (float)d.H));
+            int sx = (int)((float)px * ((float)S / (float)d.W));
+            if (sy > S - 1) sy = S - 1;
+            if (sx > S - 1) sx = S - 1;
+            const float4* cp = reinterpret_cast<const float4*>(d.ctx[k] + (((long)n * S + sy) * S + sx) * d.C + c);
+            cx[u][k][0] = cp[0];
+            cx[u][k][1] = cp[1];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const long p = p0 + (long)u * rows;
+        if (p >= npix) break;
+        const unsigned xw[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, rw[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+        const unsigned lw[4] = {lv[u].x, lv[u].y, lv[u].z, lv[u].w};
+        unsigned ow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float o2[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int i = 2 * j + hh;
+                const float xf = __uint_as_float(hh ? (xw[j] & 0xffff0000u) : (xw[j] << 16));
+                const float rf = __uint_as_float(hh ? (rw[j] & 0xffff0000u) : (rw[j] << 16));
+                const float lf = __uint_as_float(hh ? (lw[j] & 0xffff0000u) : (lw[j] << 16));
+                float s = lf * sc[0][i] + shs[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 a = cx[u][k][i >> 2];
+                    const float cvv = (i & 3) == 0 ? a.x : ((i & 3) == 1 ? a.y : ((i & 3) == 2 ? a.z : a.w));
+                    s = fmaf(cvv, sc[k + 1][i], s);
+                }
+                const float w = 1.f / (1.f + __expf(-s));
+                float o = 2.f * xf * w + 2.f * rf * (1.f - w);
+                if (d.act == LEDN_ACT_RELU) o = fmaxf(o, 0.f);
+                o2[hh] = o;
+            }
+            ow[j] = (unsigned)f32_to_bf16(o2[0]) | ((unsigned)f32_to_bf16(o2[1]) << 16);
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(d.out) + p * d.C + c) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+}
+
 int mfaf_gate_impl(const ledn_mfaf_desc& d, hipStream_t s) {
     LEDN_REQUIRE(d.x && d.r && d.xl && d.out && d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.C % 4 == 0);
     for (int k = 0; k < 4; ++k) LEDN_REQUIRE(d.ctx[k] && d.ctx_size[k] > 0);
     for (int k = 0; k < 5; ++k) LEDN_REQUIRE(d.scale[k] && d.shift[k]);
+    static const bool fast_on = exp_knob("LEDN_MFAF_FAST", 1) != 0;     // (A/B knob)
+    if (fast_on && (options().stream_fast & 1) && d.dtype == LEDN_BF16 && d.C >= 8 && d.C <= 256 && (d.C & (d.C - 1)) == 0 &&
+        (long)d.N * d.H * d.W >= 4096) {
+        constexpr int UNR = 2;
+        const int rows = 256 / (d.C >> 3);
+        LEDN_LAUNCH(mfaf_gate_fast_kernel<UNR>, dim3((unsigned)cdiv((long)d.N * d.H * d.W, (long)rows * UNR)), dim3(256), 0, s, d);
+        return check_launch();
+    }
     const long total = (long)d.N * d.H * d.W * (d.C / 4);
     const dim3 grid((unsigned)cdiv(total, 256));
     if (d.dtype == LEDN_F32) LEDN_LAUNCH((mfaf_gate_kernel<float, 4>), grid, dim3(256), 0, s, d);

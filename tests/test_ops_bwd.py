@@ -245,6 +245,49 @@ def test_mfaf_gate_bwd_and_combine(be, H, W):
     close(nchw(drc), r.grad + xa.grad, 1e-3, 1e-5)
 
 
+@pytest.mark.parametrize('N,H,W,Cc', [(1, 64, 72, 64), (2, 40, 56, 16), (1, 33, 130, 128)])
+def test_mfaf_gate_bf16_streaming_kernel(be, N, H, W, Cc):
+    """mfaf_gate_fast_kernel (bf16, C a power of two, >= 4096 pixels: 16-byte lanes, parameters in registers) against the
+    gate formula in f32 on the same bf16-rounded maps (classification/model_utils.py:377-400), ragged sizes"""
+    from led_net_amd import ops
+    g = torch.Generator().manual_seed(H * W + Cc)
+    x, r, xl = (torch.randn(N, Cc, H, W, generator=g).bfloat16().float() for _ in range(3))
+    sizes = [4, 8, 16, 1]
+    ctx = [torch.randn(N, Cc, s, s, generator=g) for s in sizes]
+    aff = [(torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1) for _ in range(5)]
+
+    def a(t, k):
+        return t * aff[k][0].view(1, -1, 1, 1) + aff[k][1].view(1, -1, 1, 1)
+    s = a(xl, 0)
+    for k in range(4):
+        s = s + F.interpolate(a(ctx[k], k + 1), size=[H, W], mode='nearest')
+    w = torch.sigmoid(s)
+    for act, ref in ((ops.ACT_RELU, F.relu(2 * x * w + 2 * r * (1 - w))), (ops.ACT_NONE, 2 * x * w + 2 * r * (1 - w))):
+        got = ops.mfaf_gate(nhwc(x).bfloat16(), nhwc(r).bfloat16(), nhwc(xl).bfloat16(), [nhwc(c) for c in ctx],
+                            [(D(p), D(q)) for p, q in aff], act=act)
+        assert got.dtype == torch.bfloat16
+        torch.testing.assert_close(nchw(got.float()), ref, rtol=1e-2, atol=1e-2 * float(ref.abs().max()))
+    # backward (mfaf_gate_bwd_fast_kernel): against autograd of the same expression
+    from led_net_amd import ops_train as T
+    xg, rg, lg = (t.clone().requires_grad_(True) for t in (x, r, xl))
+    cg = [c.clone().requires_grad_(True) for c in ctx]
+    s2 = a(lg, 0)
+    for k in range(4):
+        s2 = s2 + F.interpolate(a(cg[k], k + 1), size=[H, W], mode='nearest')
+    w2 = torch.sigmoid(s2)
+    out = F.relu(2 * xg * w2 + 2 * rg * (1 - w2))
+    dout = torch.randn(out.shape, generator=g).bfloat16().float()
+    out.backward(dout)
+    dx, dr, ds, dctx = T.mfaf_gate_bwd(nhwc(x).bfloat16(), nhwc(r).bfloat16(), nhwc(xl).bfloat16(), [nhwc(c) for c in ctx],
+                                       [(D(p), D(q)) for p, q in aff], nhwc(dout).bfloat16(), act=ops.ACT_RELU)
+    tol = lambda t: dict(rtol=2e-2, atol=2e-2 * float(t.abs().max()))     # noqa: E731
+    torch.testing.assert_close(nchw(dx.float()), xg.grad, **tol(xg.grad))
+    torch.testing.assert_close(nchw(dr.float()), rg.grad, **tol(rg.grad))
+    torch.testing.assert_close(nchw(ds.float()) * aff[0][0].view(1, -1, 1, 1), lg.grad, **tol(lg.grad))
+    for k in range(4):
+        torch.testing.assert_close(nchw(dctx[k]) * aff[k + 1][0].view(1, -1, 1, 1), cg[k].grad, **tol(cg[k].grad))
+
+
 @pytest.mark.parametrize('name', ['g7_ohem_k1000', 'g7_ohem_k131072', 'g7_ohem_k100_confident', 'g7_ohem_c5',
                                   'g7_ohem_all_ignored'])
 def test_ohem_golden(be, name):
