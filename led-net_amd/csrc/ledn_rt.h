@@ -149,11 +149,7 @@ __device__ __forceinline__ float act_grad(int act, float v, float slope) {
 }
 
 // ---- wave reductions (64 lanes; every lane of the wave must call) --------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v);      // (defined below, after the lane-crossing helpers)
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
@@ -206,6 +202,42 @@ __device__ __forceinline__ void permlane16_swap(unsigned& a, unsigned& b) {
     b = r.y;
 }
 #endif
+
+// v + the value of the lane `m` away in the coset pattern of an all-reduce (m a power of two): on the vector ALU where the
+// hardware has a lane-crossing form for it -- DPP row_ror inside a 16-lane row (m = 1, 2, 4, 8), v_permlane32_swap for the
+// two halves of the wave (m = 32) -- and through the LDS crossbar (ds_bpermute) only for m = 16.  The butterfly of
+// reduce_taps (72 accumulators x up to 6 levels per lane) was 360 ds_bpermute per lane for 16-channel maps: the epilogue
+// of the pyramid / depthwise weight-gradient kernels cost as much as their pixel loops.
+__device__ __forceinline__ float lane_step_sum(float v, int m) {
+#ifdef LEDN_CPU_EMU
+    return v + __shfl_xor(v, m);
+#else
+    if (m == 32) {
+        unsigned a = __float_as_uint(v), b = a;
+        permlane32_swap(a, b);                               // a = {low, low}, b = {high, high}
+        return __uint_as_float(a) + __uint_as_float(b);
+    }
+    if (m == 16) return v + __shfl_xor(v, 16);
+    const int iv = __float_as_int(v);
+    int r;
+    if (m == 8) r = __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xf, 0xf, false);        // row_ror:8
+    else if (m == 4) r = __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xf, 0xf, false);   // row_ror:4
+    else if (m == 2) r = __builtin_amdgcn_update_dpp(0, iv, 0x122, 0xf, 0xf, false);   // row_ror:2
+    else r = __builtin_amdgcn_update_dpp(0, iv, 0x121, 0xf, 0xf, false);               // row_ror:1
+    return v + __int_as_float(r);
+#endif
+}
+
+// sum over the 64 lanes of the wave, returned in every lane (the xor butterfly 32, 16, .. 1: bit-identical to six __shfl_xor
+// steps, one ds_bpermute instead of six)
+__device__ __forceinline__ float wave_sum(float v) {
+    v = lane_step_sum(v, 32);
+    v = lane_step_sum(v, 16);
+    v = lane_step_sum(v, 8);
+    v = lane_step_sum(v, 4);
+    v = lane_step_sum(v, 2);
+    return lane_step_sum(v, 1);
+}
 
 // F.interpolate(mode='bilinear', align_corners=False) source coordinates
 // (ATen area_pixel_compute_source_index: scale*(dst+0.5)-0.5 clamped at 0).

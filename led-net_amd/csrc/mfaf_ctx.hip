@@ -43,11 +43,7 @@ static int mc_blocks(const int* P) {
 }
 
 // sum over the 64 lanes of a wave, then over the workgroup's waves through LDS; lane 0 of wave 0 returns the total
-__device__ __forceinline__ float mc_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float mc_wave_sum(float v) { return wave_sum(v); }
 
 // Deterministic mode (LEDN_OPT_DETERMINISTIC): the workgroups of a launch write their partial sums as rows
 // part[blockIdx.x][K] instead of adding them atomically, and this kernel adds every scale's rows up in block order.

@@ -66,31 +66,6 @@ __device__ __forceinline__ unsigned tap_mask(int y, int x, int dl, int H, int W)
     return (r0 ? cols : 0u) | (cols << 3) | (r2 ? cols << 6 : 0u);
 }
 
-// v + the value of the lane `m` away in the coset pattern of an all-reduce (m a power of two): on the vector ALU where the
-// hardware has a lane-crossing form for it -- DPP row_ror inside a 16-lane row (m = 1, 2, 4, 8), v_permlane32_swap for the
-// two halves of the wave (m = 32) -- and through the LDS crossbar (ds_bpermute) only for m = 16.  The butterfly of
-// reduce_taps (72 accumulators x up to 6 levels per lane) was 360 ds_bpermute per lane for 16-channel maps: the epilogue
-// of the pyramid / depthwise weight-gradient kernels cost as much as their pixel loops.
-__device__ __forceinline__ float lane_step_sum(float v, int m) {
-#ifdef LEDN_CPU_EMU
-    return v + __shfl_xor(v, m);
-#else
-    if (m == 32) {
-        unsigned a = __float_as_uint(v), b = a;
-        permlane32_swap(a, b);                               // a = {low, low}, b = {high, high}
-        return __uint_as_float(a) + __uint_as_float(b);
-    }
-    if (m == 16) return v + __shfl_xor(v, 16);
-    const int iv = __float_as_int(v);
-    int r;
-    if (m == 8) r = __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xf, 0xf, false);        // row_ror:8
-    else if (m == 4) r = __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xf, 0xf, false);   // row_ror:4
-    else if (m == 2) r = __builtin_amdgcn_update_dpp(0, iv, 0x122, 0xf, 0xf, false);   // row_ror:2
-    else r = __builtin_amdgcn_update_dpp(0, iv, 0x121, 0xf, 0xf, false);               // row_ror:1
-    return v + __int_as_float(r);
-#endif
-}
-
 // ---- 8-byte (4-channel) forms and the reduce-scatter steps between wave halves / neighbouring rows
 __device__ __forceinline__ uint2 ld_tap8(const bf16_t* base, unsigned off, unsigned safe, bool valid) {
     uint2 r = *reinterpret_cast<const uint2*>(base + (valid ? off : safe));
