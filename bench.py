@@ -518,7 +518,7 @@ def main():
             n_sig = int(verbose) if verbose.isdigit() and int(verbose) > 1 else 25     # signatures listed
             for (e, sg), v in top[:n_sig]:
                 print(f'{v["ms"] / k_steps:9.3f} ms/step  x{v["n"] // k_steps:3d}  {v["bytes"] * v["n"] / max(1e-9, v["ms"]) / 1e6:8.1f} GB/s '
-                      f'{v["flops"] * v["n"] / max(1e-9, v["ms"]) / 1e9:8.2f} TF/s  {e} [{sg}]', file=sys.stderr)
+                      f'{v["flops"] * v["n"] / max(1e-9, v["ms"]) / 1e9:8.2f} TF/s  {e} [{sg}] <{v["kernel"]}>', file=sys.stderr)
         print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.destroy_process_group()

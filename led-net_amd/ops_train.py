@@ -91,7 +91,7 @@ def bn_act_bwd_reduce(z, dy, *, scale=None, shift=None, mean=None, invstd=None, 
         st.dz, st.dres, st.dslope, st.slope_sunk = dz, None, dslope, slope_sunk
         st.keep = (hdz, None, scale, shift, slope, mean, invstd, sum_g, sum_gx, sk_g, sk_b, dz_add, None, None, hw, hdw, hdb)
         return st
-    if BN_ROWS and not sync and (bn or slope is not None) and z.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16:
+    if BN_ROWS and not sync and not no_dz and (bn or slope is not None) and z.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16:
         # the reduce pass leaves per-row sums (float atomics into 32 zeroed rows), the apply pass adds them up: no
         # summing launch between the two (ledn.h: ledn_bnbwd_desc.rows).  Not under SyncBN: the all-reduce needs totals.
         rows = _ops.zeros_f32((_lib.BNBWD_ROWS, 3, Cc), z.device)

@@ -245,6 +245,21 @@ def test_mfaf_gate_bwd_and_combine(be, H, W):
     close(nchw(drc), r.grad + xa.grad, 1e-3, 1e-5)
 
 
+@pytest.mark.parametrize('shape', [(2, 32, 48, 16), (1, 64, 64, 64), (1, 40, 56, 8)])
+def test_mfaf_context_pools_from_the_finest_pool(be, shape):
+    """train.multi_pool: Muti_AFF's 4x4 / 8x8 / 1x1 context pools as averages of the 16x16 pool's cells (map sides multiples
+    of 16) against F.adaptive_avg_pool2d of the map itself (classification/model_utils.py:402-423); the last shape is not
+    divisible and takes the four direct pools"""
+    from led_net_amd import train as TR
+    N, H, W, Cc = shape
+    g = torch.Generator().manual_seed(H + W + Cc)
+    x = torch.randn(N, Cc, H, W, generator=g).bfloat16().float()
+    got = TR.multi_pool(nhwc(x).bfloat16(), TR.MultiPoolFn.SIZES)
+    for S, p in zip(TR.MultiPoolFn.SIZES, got):
+        assert p.dtype == torch.float32 and tuple(p.shape) == (N, S, S, Cc)
+        torch.testing.assert_close(nchw(p), F.adaptive_avg_pool2d(x, S), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('N,H,W,Cc', [(1, 64, 72, 64), (2, 40, 56, 16), (1, 33, 130, 128)])
 def test_mfaf_gate_bf16_streaming_kernel(be, N, H, W, Cc):
     """mfaf_gate_fast_kernel (bf16, C a power of two, >= 4096 pixels: 16-byte lanes, parameters in registers) against the
@@ -489,7 +504,9 @@ def test_mfaf_context_mlps_fused(be, training):
         close(nchw(dps[k]), ins[k].grad, 2e-4, 2e-5)
         want = [c1.weight.grad, c1.bias.grad, bn.weight.grad, bn.bias.grad, c2.weight.grad, c2.bias.grad]
         assert grads[k][0] is None                          # taken by the sink (pre-filled with 0.25)
-        close(sinks[k][0], want[0] + 0.25, 2e-4, 2e-4)
+        # (absolute tolerance relative to the gradient's scale, as for the others: the sums end in float atomics whose
+        #  arrival order varies from run to run -- 2.2e-4 on a value of 13 was seen once in ~10 emulator runs)
+        close(sinks[k][0], want[0] + 0.25, 2e-4, 2e-4 * max(1.0, float(want[0].abs().max())))
         for j in range(1, 6):
             close(grads[k][j], want[j], 2e-4, 2e-4 * max(1.0, float(want[j].abs().max())))
 
