@@ -380,7 +380,8 @@ __global__ void __launch_bounds__(256) window_attn_fold_kernel(const float* pad,
     if (idx >= total) return;
     const int c = (int)(idx % C3);
     const long pix = idx / C3;
-    const int xs = (int)(pix % W), ys = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    const NhwcIdx ix_ = pix_split(pix, W, H);
+    const int xs = ix_.x, ys = ix_.y, n = ix_.n;
     const int ym = 2 * H - 2 - ys, xm = 2 * W - 2 - xs;
     const bool my = ym >= H && ym < Hp, mx = xm >= W && xm < Wp;
     const float* base = pad + (long)n * Hp * Wp * C3 + c;

@@ -272,11 +272,10 @@ __global__ void __launch_bounds__(256) dw_bwd_data_kernel(ledn_dwbwd_desc d) {
     const long total = (long)d.N * d.H * d.W * cv;
     const long idx = (long)xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int x = (int)(pix % d.W);
-    const int y = (int)((pix / d.W) % d.H);
-    const int n = (int)(pix / ((long)d.W * d.H));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, d.W, d.H);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int x = ix_.x, y = ix_.y, n = ix_.n;
     const int dl = d.dil[c / d.group_size];
     const int padh = d.pad >= 0 ? d.pad : dl * (d.KH - 1) / 2;
     const int padw = d.pad >= 0 ? d.pad : dl * (d.KW - 1) / 2;
@@ -680,11 +679,10 @@ __global__ void __launch_bounds__(256) pyr_bwd_data_kernel(ledn_pyrbwd_desc d) {
     const long total = (long)d.N * d.H * d.W * cv;
     const long idx = (long)xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int x = (int)(pix % d.W);
-    const int y = (int)((pix / d.W) % d.H);
-    const int n = (int)(pix / ((long)d.W * d.H));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, d.W, d.H);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int x = ix_.x, y = ix_.y, n = ix_.n;
     const T* g = reinterpret_cast<const T*>(d.gsum);
     float acc[V];
 #pragma unroll
@@ -866,11 +864,10 @@ __global__ void __launch_bounds__(256) bilinear_bwd_kernel(const TY* dy, TX* dx,
     const long total = (long)N * H * W * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long)W * H));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, W, H);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int x = ix_.x, y = ix_.y, n = ix_.n;
     int ylo, yhi, xlo, xhi;
     dst_range(y, H, Ho, ylo, yhi);
     dst_range(x, W, Wo, xlo, xhi);
@@ -906,11 +903,10 @@ __global__ void __launch_bounds__(256) bilinear_bwd2x_kernel(const TY* dy, TX* d
     const long total = (long)N * H * W * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long)W * H));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, W, H);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int x = ix_.x, y = ix_.y, n = ix_.n;
     float wy[4], wx[4];
     int yy[4], xx[4];
 #pragma unroll
@@ -956,7 +952,8 @@ __global__ void __launch_bounds__(256) bilinear_bwd_wide_kernel(const TY* dy, TX
     const int cv = C / V, slots = 256 / cv;
     const int cg = threadIdx.x % cv, slot = threadIdx.x / cv, c = cg * V;
     const long pix = blockIdx.x;
-    const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    const NhwcIdx ix_ = pix_split(pix, W, H);
+    const int x = ix_.x, y = ix_.y, n = ix_.n;
     int ylo, yhi, xlo, xhi;
     dst_range(y, H, Ho, ylo, yhi);
     dst_range(x, W, Wo, xlo, xhi);
@@ -1033,11 +1030,10 @@ __global__ void __launch_bounds__(256) avgpool3x3s2_bwd_kernel(const T* dy, cons
     const long total = (long)N * H * W * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long)W * H));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, W, H);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int x = ix_.x, y = ix_.y, n = ix_.n;
     float acc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v] = 0.f;
@@ -1100,11 +1096,10 @@ __global__ void __launch_bounds__(256) getb_pool_bwd_kernel(const T* dout, T* da
     const long total = (long)N * H * W * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long)W * H));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, W, H);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int x = ix_.x, y = ix_.y, n = ix_.n;
     const T* base = dout + (long)n * H * W * C + c;
     const int p = ws / 2 - 1;
     float acc[V];
@@ -1389,11 +1384,10 @@ __global__ void __launch_bounds__(256) mfaf_combine_kernel(T* dx, T* dr, const T
     const long total = (long)N * H * W * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long)W * H));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, W, H);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int x = ix_.x, y = ix_.y, n = ix_.n;
     float a[V];
     if (dxl) ldv<V>(dxl + pix * C + c, a);
     else {

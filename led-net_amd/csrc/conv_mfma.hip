@@ -816,9 +816,8 @@ __global__ void __launch_bounds__(256) im2col_stem_kernel(const bf16_t* x, bf16_
     const long total = (long)N * Ho * Wo;
     const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= total) return;
-    const int wo = (int)(pix % Wo);
-    const int ho = (int)((pix / Wo) % Ho);
-    const int n = (int)(pix / ((long)Wo * Ho));
+    const NhwcIdx ix_ = pix_split(pix, Wo, Ho);
+    const int wo = ix_.x, ho = ix_.y, n = ix_.n;
     unsigned short e[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) e[i] = 0;

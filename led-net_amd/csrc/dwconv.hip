@@ -46,9 +46,8 @@ __global__ void __launch_bounds__(256) dwconv_kernel(ledn_dw_desc d, float* part
         const long ppb = cdiv(cdiv(npix, (long)gridDim.x), (long)rows) * rows;
         const long p0 = (long)xcd_block(blockIdx.x, gridDim.x) * ppb, p1 = min(npix, p0 + ppb);
         for (long pix = p0 + r; pix < p1; pix += rows) {
-            const int wo = (int)(pix % d.Wo);
-            const int ho = (int)((pix / d.Wo) % d.Ho);
-            const int n = (int)(pix / ((long)d.Wo * d.Ho));
+            const NhwcIdx ix_ = pix_split(pix, d.Wo, d.Ho);
+            const int wo = ix_.x, ho = ix_.y, n = ix_.n;
             float acc[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) acc[v] = 0.f;
@@ -518,9 +517,10 @@ __global__ void __launch_bounds__(256) dw8x8_fold_kernel(const bf16_t* t, const 
     const long total = (long)N * H * W * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * 8;
-    const long pix = idx / cv;
-    const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, W, H);
+    const int c = ix_.cv * 8;
+    const long pix = ix_.pix;
+    const int x = ix_.x, y = ix_.y, n = ix_.n;
     const int We = W + 1;
     const bf16_t* tn = t + (long)n * (H + 1) * We * C + c;
     float acc[8], v[8];
@@ -831,11 +831,10 @@ __global__ void __launch_bounds__(256) sesp_pyramid_kernel(ledn_pyr_desc d) {
     const long total = (long)d.N * d.Ho * d.Wo * cv;
     const long idx = (long)xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int wo = (int)(pix % d.Wo);
-    const int ho = (int)((pix / d.Wo) % d.Ho);
-    const int n = (int)(pix / ((long)d.Wo * d.Ho));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, d.Wo, d.Ho);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int wo = ix_.x, ho = ix_.y, n = ix_.n;
     const TX* x = reinterpret_cast<const TX*>(d.x);
     TY* y = reinterpret_cast<TY*>(d.y) + pix * (4L * d.n) + c;
     float run[V];

@@ -232,11 +232,10 @@ __global__ void __launch_bounds__(256) getb_pool_kernel(const T* a, const T* loc
     const long total = (long)N * H * W * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long)W * H));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, W, H);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int x = ix_.x, y = ix_.y, n = ix_.n;
     const T* base = a + (long)n * H * W * C + c;
     float acc[V];
 #pragma unroll

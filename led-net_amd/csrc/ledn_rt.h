@@ -258,6 +258,42 @@ __device__ __forceinline__ Lerp lerp_coord(int dst, int in, int out) {
     return l;
 }
 
+// ---- flat index -> (channel vector, x, y, image) --------------------------------------------------------
+// 32-bit divisions whenever the index fits (every tensor of this network: < 2^31 vectors); a 64-bit integer division is
+// ~100 vector instructions on this ISA, and the five of them a lane spent on `idx % cv, idx / cv, pix % W, (pix / W) % H,
+// pix / (W H)` made the gather kernels (bilinear and its adjoints, the pool adjoints, the MFAF combine) VALU-bound.
+struct NhwcIdx {
+    long pix;
+    int cv, x, y, n;
+};
+__device__ __forceinline__ NhwcIdx pix_split(long pix, int W, int H) {
+    NhwcIdx r;
+    r.pix = pix;
+    r.cv = 0;
+    if (pix < 0x7fffffffL) {
+        const unsigned p = (unsigned)pix, row = p / (unsigned)W, n = row / (unsigned)H;
+        r.x = (int)(p - row * (unsigned)W);
+        r.y = (int)(row - n * (unsigned)H);
+        r.n = (int)n;
+    } else {
+        r.x = (int)(pix % W);
+        r.y = (int)((pix / W) % H);
+        r.n = (int)(pix / ((long)W * H));
+    }
+    return r;
+}
+__device__ __forceinline__ NhwcIdx nhwc_split(long idx, int cvn, int W, int H) {
+    if (idx < 0x7fffffffL) {
+        const unsigned i = (unsigned)idx, pix = i / (unsigned)cvn;
+        NhwcIdx r = pix_split((long)pix, W, H);
+        r.cv = (int)(i - pix * (unsigned)cvn);
+        return r;
+    }
+    NhwcIdx r = pix_split(idx / cvn, W, H);
+    r.cv = (int)(idx % cvn);
+    return r;
+}
+
 // ---- XCD-aware block numbering ----------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  xcd_block() renumbers
 // them so that the workgroups resident on one XCD own ONE contiguous eighth of the logical block

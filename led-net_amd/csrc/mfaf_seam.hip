@@ -11,11 +11,10 @@ __global__ void __launch_bounds__(256) mfaf_gate_kernel(ledn_mfaf_desc d) {
     const long total = (long)d.N * d.H * d.W * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int x = (int)(pix % d.W);
-    const int y = (int)((pix / d.W) % d.H);
-    const int n = (int)(pix / ((long)d.W * d.H));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, d.W, d.H);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int x = ix_.x, y = ix_.y, n = ix_.n;
     float s[V], t[V];
     ldv<V>(reinterpret_cast<const T*>(d.xl) + pix * d.C + c, t);
 #pragma unroll

@@ -11,11 +11,10 @@ __global__ void __launch_bounds__(256) bilinear_nhwc_kernel(ledn_resize_desc d) 
     const long total = (long)d.N * d.Ho * d.Wo * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int wo = (int)(pix % d.Wo);
-    const int ho = (int)((pix / d.Wo) % d.Ho);
-    const int n = (int)(pix / ((long)d.Wo * d.Ho));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, d.Wo, d.Ho);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int wo = ix_.x, ho = ix_.y, n = ix_.n;
     const Lerp ly = lerp_coord(ho, d.H, d.Ho), lx = lerp_coord(wo, d.W, d.Wo);
     const TX* x = reinterpret_cast<const TX*>(d.x) + (long)n * d.H * d.W * d.C + c;
     float v00[V], v01[V], v10[V], v11[V], o[V];
@@ -42,9 +41,8 @@ __global__ void __launch_bounds__(256) bilinear_nchw_kernel(ledn_resize_desc d) 
     const long total = (long)d.N * d.Ho * d.Wo;
     const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= total) return;
-    const int wo = (int)(pix % d.Wo);
-    const int ho = (int)((pix / d.Wo) % d.Ho);
-    const int n = (int)(pix / ((long)d.Wo * d.Ho));
+    const NhwcIdx ix_ = pix_split(pix, d.Wo, d.Ho);
+    const int wo = ix_.x, ho = ix_.y, n = ix_.n;
     const Lerp ly = lerp_coord(ho, d.H, d.Ho), lx = lerp_coord(wo, d.W, d.Wo);
     const TX* x = reinterpret_cast<const TX*>(d.x) + (long)n * d.H * d.W * C;
     float v00[C], v01[C], v10[C], v11[C], o[C];
@@ -208,11 +206,10 @@ __global__ void __launch_bounds__(256) avgpool3x3s2_kernel(const T* x, T* y, int
     const long total = (long)N * Ho * Wo * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int wo = (int)(pix % Wo);
-    const int ho = (int)((pix / Wo) % Ho);
-    const int n = (int)(pix / ((long)Wo * Ho));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, Wo, Ho);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int wo = ix_.x, ho = ix_.y, n = ix_.n;
     float acc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v] = 0.f;
@@ -261,11 +258,10 @@ __global__ void __launch_bounds__(256) avgpool2d_kernel(const T* x, T* y, int N,
     const long total = (long)N * Ho * Wo * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int wo = (int)(pix % Wo);
-    const int ho = (int)((pix / Wo) % Ho);
-    const int n = (int)(pix / ((long)Wo * Ho));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, Wo, Ho);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int wo = ix_.x, ho = ix_.y, n = ix_.n;
     float acc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v] = 0.f;
@@ -311,11 +307,10 @@ __global__ void __launch_bounds__(256) avgpool2d_bwd_kernel(const T* dy, T* dx, 
     const long total = (long)N * H * W * cv;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int c = (int)(idx % cv) * V;
-    const long pix = idx / cv;
-    const int xx = (int)(pix % W);
-    const int yy = (int)((pix / W) % H);
-    const int n = (int)(pix / ((long)W * H));
+    const NhwcIdx ix_ = nhwc_split(idx, cv, W, H);
+    const int c = ix_.cv * V;
+    const long pix = ix_.pix;
+    const int xx = ix_.x, yy = ix_.y, n = ix_.n;
     // windows ho with ho*st - pad <= yy < ho*st - pad + k
     const int ho1 = min((yy + pad) / st, Ho - 1), wo1 = min((xx + pad) / st, Wo - 1);
     const int ho0 = max((yy + pad - k + st) / st, 0), wo0 = max((xx + pad - k + st) / st, 0);
