@@ -77,7 +77,7 @@ for s, e, k, _g in seg:
     tot[k] += e - s
     cnt[k] += 1
 print('--- exclusive time (ms/step), total duration, launches/step')
-for k, v in sorted(excl.items(), key=lambda kv: -kv[1])[:28]:
+for k, v in sorted(excl.items(), key=lambda kv: -kv[1])[:60]:
     print(f'{v / nsteps / 1e6:8.3f}  {tot[k] / nsteps / 1e6:8.3f}  x{cnt[k] / nsteps:6.1f}  {k}')
 print('--- idle gaps following a kernel (ms/step)')
 for k, v in sorted(gap_after.items(), key=lambda kv: -kv[1])[:10]:
