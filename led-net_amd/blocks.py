@@ -443,7 +443,7 @@ class MFAF(Block):
             from . import ops_train as T
             f = ops.Fork(x, 3, r)
             with f:
-                pooled = [ops.adaptive_avgpool(x, S, xadd=r) for _, S in self.POOLS]
+                pooled = list(ops.multi_pool(x, [S for _, S in self.POOLS], xadd=r))
                 ctx, _ = T.mfaf_ctx_fwd(pooled, [(sq[1], sq[2], sq[4]) for sq in seqs], False)
             affs_ctx = [self.cached(f'{id(sq)}b', lambda sq=sq: fold_bn(sq[5])) for sq in seqs]
             forks = [(f, tuple(ctx))]

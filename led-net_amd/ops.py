@@ -688,6 +688,22 @@ def adaptive_avgpool(x, S, xadd=None):
     return y
 
 
+POOL_PYRAMID = _knob_int('LEDN_POOL_PYRAMID', 1)    # the coarse context pools from the finest one (one pass over the map instead of four)
+
+
+def multi_pool(x, sizes, xadd=None):
+    """adaptive average pools of x (+ xadd) [N,H,W,C] to S x S for S in sizes (f32).  When every window grid is a
+    refinement of the finest one (H, W multiples of the largest S, which the others divide) the coarser pools are averages of
+    equal numbers of the finest pool's cells: the map is read ONCE (the 16x16 pool) and the others come from that small map
+    -- Muti_AFF's four pools (classification/model_utils.py:402-423) cost four passes over the map otherwise."""
+    big = max(sizes)
+    H, W = x.shape[1], x.shape[2]
+    if not (POOL_PYRAMID and H % big == 0 and W % big == 0 and all(big % S == 0 for S in sizes)):
+        return tuple(adaptive_avgpool(x, S, xadd=xadd) for S in sizes)
+    fine = adaptive_avgpool(x, big, xadd=xadd)
+    return tuple(fine if S == big else adaptive_avgpool(fine, S) for S in sizes)
+
+
 def avgpool2d(x, k, stride, pad):
     """nn.AvgPool2d(k, stride, pad) (zero padding counted in the divisor) on NHWC x."""
     lib = _lib.get_lib()

@@ -577,20 +577,7 @@ class AvgPoolFn(Function):
         return dx, None
 
 
-POOL_PYRAMID = _knob_int('LEDN_POOL_PYRAMID', 1)    # the 4x4 / 8x8 / 1x1 context pools from the 16x16 one (one pass over xa instead of four)
-
-
-def multi_pool(xa, sizes):
-    """adaptive average pools of xa [N,H,W,C] to S x S for S in sizes (f32).  When every window grid is a refinement of the
-    finest one (H, W multiples of the largest S, which the others divide) the coarser pools are averages of equal
-    numbers of the finest pool's cells: xa is read ONCE (the 16x16 pool) and the others come from that 1 MB map --
-    Muti_AFF's four pools (classification/model_utils.py:402-423) cost four passes over a 33.5 MB map otherwise."""
-    big = max(sizes)
-    H, W = xa.shape[1], xa.shape[2]
-    if not (POOL_PYRAMID and H % big == 0 and W % big == 0 and all(big % S == 0 for S in sizes)):
-        return tuple(ops.adaptive_avgpool(xa, S) for S in sizes)
-    fine = ops.adaptive_avgpool(xa, big)
-    return tuple(fine if S == big else ops.adaptive_avgpool(fine, S) for S in sizes)
+multi_pool = ops.multi_pool      # (the pool pyramid lives with the other tensor-level wrappers: the eval path uses it too)
 
 
 class MultiPoolFn(Function):
