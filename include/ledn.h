@@ -366,6 +366,13 @@ typedef struct {
     long long P;
     int C, act, res_mode;
     int dtype_x, dtype_y;
+    /* optional: per-channel sums of the OUTPUT y (as stored: rounded to dtype_y), ACCUMULATED: stat_sum[c] += sum_p y[p,c],
+     * stat_sqsum[c] += sum_p y[p,c]^2 -- the batch statistics a BatchNorm on y needs (LEDHead's norm -> act -> conv heads
+     * on the stem maps, led_head.py:44-51), from the pass that writes y instead of a pass of their own.  Only with bf16
+     * x / y, no xadd / residual, C a power of two in 8 .. 512 and >= 4096 vectors (else LEDN_EINVAL: call
+     * ledn_channel_stats).  Partial rows in the bound workspace, added up in row order. */
+    float* stat_sum;
+    float* stat_sqsum;
 } ledn_affine_desc;
 /* ledn_bn_finalize from statistic rows part[rows][2][C] (see ledn_conv2d_deferred_stats): sums the rows and
  * finalizes in one launch; sum / sqsum (optional) receive the totals. */

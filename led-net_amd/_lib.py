@@ -99,7 +99,8 @@ class PyrDesc(C.Structure):
 
 class AffineDesc(C.Structure):
     _fields_ = [('x', vp), ('xadd', vp), ('y', vp), ('res', vp), ('scale', fp), ('shift', fp), ('slope', fp),
-                ('P', i64), ('C', i32), ('act', i32), ('res_mode', i32), ('dtype_x', i32), ('dtype_y', i32)]
+                ('P', i64), ('C', i32), ('act', i32), ('res_mode', i32), ('dtype_x', i32), ('dtype_y', i32),
+                ('stat_sum', fp), ('stat_sqsum', fp)]
 
 
 class ResizeDesc(C.Structure):

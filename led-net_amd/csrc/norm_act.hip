@@ -224,10 +224,12 @@ int affine_act_impl(const ledn_affine_desc& d, hipStream_t s) {
     LEDN_REQUIRE((d.scale == nullptr) == (d.shift == nullptr));
     LEDN_REQUIRE(d.res_mode == LEDN_RES_NONE || d.res != nullptr);
     LEDN_REQUIRE(d.act != LEDN_ACT_PRELU || d.slope != nullptr);
+    LEDN_REQUIRE((d.stat_sum == nullptr) == (d.stat_sqsum == nullptr));
     if ((options().stream_fast & 1) && d.act != LEDN_ACT_SIGMOID) {
         const int rc = affine_act_fast(d, s);
         if (rc >= 0) return rc;
     }
+    LEDN_REQUIRE(!d.stat_sum);      // output statistics: the streaming kernel only (include/ledn.h)
     const bool v4 = d.C % 4 == 0;
     const bool v8 = false;   // 16 B per lane measured slower than 8 B per lane (see channel_stats_impl)
     const int cvn = v8 ? d.C / 8 : (v4 ? d.C / 4 : d.C);

@@ -106,11 +106,109 @@ __global__ void __launch_bounds__(256) affine_fast_kernel(ledn_affine_desc d, lo
         default: return -1;                                                       \
     }
 
+// y = act(x * scale + shift) AND the per-channel sums of y, y^2 (of the stored, bf16-rounded values): the batch statistics
+// of a BatchNorm that follows (LEDHead's norm -> act -> conv on the stem maps) without a pass of their own over y -- 69 us
+// for the 268 MB map at 1/2 resolution.  Shape of bn_reduce_fast_kernel: a capped grid, lane (row, channel group) owns UNR
+// pixels per trip, workgroup totals -> part[block][2][C].
+template <int ACT, int UNR>
+__global__ void __launch_bounds__(256) affine_stats_fast_kernel(ledn_affine_desc d, float* part) {
+    __shared__ float s_par[3][SF_MAXC];
+    __shared__ float s_red[2][256 * 8];
+    for (int c = threadIdx.x; c < d.C; c += 256) {
+        s_par[0][c] = d.scale ? d.scale[c] : 1.f;
+        s_par[1][c] = d.shift ? d.shift[c] : 0.f;
+        s_par[2][c] = d.slope ? d.slope[c] : 0.f;
+    }
+    __syncthreads();
+    const int cvn = d.C >> 3, rows = 256 / cvn;
+    const int cg = (int)(threadIdx.x % (unsigned)cvn), r = (int)(threadIdx.x / (unsigned)cvn);
+    const int c0 = cg * 8;
+    float sc[8], sh[8], sl[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = s_par[0][c0 + k];
+        sh[k] = s_par[1][c0 + k];
+        sl[k] = ACT == LEDN_ACT_PRELU ? s_par[2][c0 + k] : 0.f;
+    }
+    float a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = b[k] = 0.f;
+    const long stride = (long)gridDim.x * rows;
+    for (long p0 = (long)blockIdx.x * rows + r; p0 < d.P; p0 += UNR * stride) {
+        uint4 xr[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long p = p0 + u * stride;
+            xr[u] = ldraw(d.x, (p < d.P ? p : p0) * cvn + cg);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long p = p0 + u * stride;
+            if (p >= d.P) break;
+            float v[8];
+            unpack8(xr[u], v);
+            unsigned o[4];
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                float y0 = v[k] * sc[k] + sh[k], y1 = v[k + 1] * sc[k + 1] + sh[k + 1];
+                if (ACT != LEDN_ACT_NONE) {
+                    y0 = act_apply(ACT, y0, sl[k]);
+                    y1 = act_apply(ACT, y1, sl[k + 1]);
+                }
+                const unsigned w = (unsigned)f32_to_bf16(y0) | ((unsigned)f32_to_bf16(y1) << 16);
+                o[k >> 1] = w;
+                const float r0 = __uint_as_float(w << 16), r1 = __uint_as_float(w & 0xffff0000u);    // as stored
+                a[k] += r0;
+                a[k + 1] += r1;
+                b[k] = fmaf(r0, r0, b[k]);
+                b[k + 1] = fmaf(r1, r1, b[k + 1]);
+            }
+            reinterpret_cast<uint4*>(d.y)[p * cvn + cg] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s_red[0][threadIdx.x * 8 + k] = a[k];
+        s_red[1][threadIdx.x * 8 + k] = b[k];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * d.C; o += 256) {
+        const int j = o / d.C, c = o % d.C;
+        const float* src = s_red[j] + (c >> 3) * 8 + (c & 7);
+        float t0 = 0.f, t1 = 0.f;
+        int rr2 = 0;
+        for (; rr2 + 1 < rows; rr2 += 2) {
+            t0 += src[rr2 * cvn * 8];
+            t1 += src[(rr2 + 1) * cvn * 8];
+        }
+        if (rr2 < rows) t0 += src[rr2 * cvn * 8];
+        part[(long)blockIdx.x * 2 * d.C + o] = t0 + t1;
+    }
+}
+
 // -> LEDN_OK when handled, -1 when the generic kernel must take the call
 int affine_act_fast(const ledn_affine_desc& d, hipStream_t s) {
     if (d.dtype_x != LEDN_BF16 || d.dtype_y != LEDN_BF16 || !sf_channels_ok(d.C)) return -1;
     const long nvec = d.P * d.C / 8;
     if (nvec < 4096) return -1;
+    if (d.stat_sum) {
+        if (d.xadd || d.res_mode != LEDN_RES_NONE || d.act == LEDN_ACT_RELU6) return -1;
+        constexpr int UNR = 4;
+        const int rows = 256 / (d.C >> 3);
+        long nb = cdiv(d.P, (long)rows * UNR);
+        static const long cap = exp_knob("LEDN_AFS_CAP", 2048);
+        if (nb > cap) nb = cap;
+        float* part = ws_take(nb * 2 * d.C);
+        if (!part) return -1;
+        const dim3 grid((unsigned)nb);
+        switch (d.act) {
+            case LEDN_ACT_NONE: LEDN_LAUNCH((affine_stats_fast_kernel<LEDN_ACT_NONE, UNR>), grid, dim3(256), 0, s, d, part); break;
+            case LEDN_ACT_RELU: LEDN_LAUNCH((affine_stats_fast_kernel<LEDN_ACT_RELU, UNR>), grid, dim3(256), 0, s, d, part); break;
+            case LEDN_ACT_PRELU: LEDN_LAUNCH((affine_stats_fast_kernel<LEDN_ACT_PRELU, UNR>), grid, dim3(256), 0, s, d, part); break;
+            default: return -1;
+        }
+        return finish_partials(part, (int)nb, d.C, 2, d.stat_sum, d.stat_sqsum, nullptr, s);
+    }
     constexpr int UNR = 4;
     const dim3 grid((unsigned)cdiv(nvec, 256 * UNR));
     if (d.xadd) {

@@ -624,8 +624,16 @@ def bn_finalize(stats, count, gamma, beta, running_mean=None, running_var=None, 
     return scale, shift, mean, invstd
 
 
+def affine_stats_ok(x, act, out_dtype=None):
+    """ledn_affine_act can also deliver the per-channel sums of its output (the statistics of a BatchNorm that follows)"""
+    Cc = x.shape[-1]
+    return (x.dtype == torch.bfloat16 and out_dtype in (None, torch.bfloat16) and 8 <= Cc <= 512 and Cc & (Cc - 1) == 0
+            and x.numel() // 8 >= 4096 and act in (ACT_NONE, ACT_RELU, ACT_PRELU))
+
+
 def affine_act(x, scale=None, shift=None, *, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE,
-               xadd=None, out_dtype=None):
+               xadd=None, out_dtype=None, stats=None):
+    """stats = (sum, sqsum) f32 [C]: ACCUMULATE the per-channel sums of the output into them (affine_stats_ok decides)"""
     lib = _lib.get_lib()
     Cc = x.shape[-1]
     y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
@@ -638,7 +646,17 @@ def affine_act(x, scale=None, shift=None, *, act=ACT_NONE, slope=None, res=None,
     d.P, d.C, d.act = x.numel() // Cc, Cc, act
     d.res_mode = res_mode if res is not None else RES_NONE
     d.dtype_x, d.dtype_y = _dt(x), _dt(y)
+    if stats is not None:
+        _check(lib, stats[0], stats[1])
+        d.stat_sum, d.stat_sqsum = _p(_f32(stats[0], Cc)), _p(_f32(stats[1], Cc))
+        try:
+            _run(lib, 'ledn_affine_act', x, d, work=_TIMING is not None and (f'affine+stats C{Cc} P{x.numel() // Cc}', _nb(x, y), 4 * x.numel(), 'affine_stats_fast_kernel'))
+            return y
+        except LednError:       # outside the streaming kernel's gate (include/ledn.h): the two-launch form
+            d.stat_sum = d.stat_sqsum = None
     _run(lib, 'ledn_affine_act', x, d, work=_TIMING is not None and (f'affine C{Cc} P{x.numel() // Cc}', _nb(x, xadd, y, res), 2 * x.numel()))
+    if stats is not None:
+        channel_stats(y, stats=stats)
     return y
 
 

@@ -29,6 +29,7 @@ class _Env:
     world = 1
     head_acc = {}       # gradient fan-in accumulators (_Acc) of the stem tensors LEDHead reads: {'x1': .., 'x2': ..}
     grad_ready = None   # callable(tag) fired from the backward by GradReadyFn, or None
+    out_stats = {}      # y.data_ptr() -> [2, C] per-channel sums of y left by the pass that wrote it (BNActFn out_stats -> conv_module norm_first)
     lazy_bn = {}        # dy.data_ptr() -> ops_train._BnBwd whose apply half the consumer of dz performs itself (BNActFn lazy_dz -> StemConvFn)
     ctx_fin = {}        # z2.data_ptr() -> (scale, shift, mean, invstd) of its trailing BatchNorm (MfafCtxFn -> MfafTailFn)
 
@@ -276,7 +277,7 @@ class BNActFn(Function):
     the producing kernel) or are reduced here; running stats updated in place."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, slope, res, stats, bn, act, res_mode, out_dtype, acc_res=None, acc_z=None, lazy_dz=False):
+    def forward(ctx, z, gamma, beta, slope, res, stats, bn, act, res_mode, out_dtype, acc_res=None, acc_z=None, lazy_dz=False, out_stats=False):
         """lazy_dz: z's producer is StemConvFn, the only reader of dz -- the backward then runs the reduce half only and hands
         dy + the prepared descriptor on (_Env.lazy_bn); the stem's weight-gradient kernel forms dz itself"""
         Cc = z.shape[-1]
@@ -291,8 +292,15 @@ class BNActFn(Function):
             count *= _Env.world
         scale, shift, mean, invstd = ops.bn_finalize((stats[0], stats[1]), count, gamma, beta,
                                                      bn.running_mean, bn.running_var, BN_MOMENTUM, bn.eps)
+        # out_stats: a BatchNorm reads y next (LEDHead's norm -> act -> conv on the stem maps): its batch statistics come out
+        # of this pass (conv_module picks them up from _Env.out_stats by the tensor's address)
+        st_y = None
+        if out_stats and OUT_STATS and res is None and ops.affine_stats_ok(z, act, out_dtype):
+            st_y = ops.zeros_f32((2, Cc), z.device)
         y = ops.affine_act(z, scale, shift, act=act, slope=slope, res=res, res_mode=res_mode,
-                           out_dtype=out_dtype)
+                           out_dtype=out_dtype, stats=(st_y[0], st_y[1]) if st_y is not None else None)
+        if st_y is not None:
+            _Env.out_stats[y.data_ptr()] = st_y
         ctx.save_for_backward(z, res, scale, shift, mean, invstd, slope)
         ctx.cfg = (act, res_mode, count)
         ctx.sinks = (_Sinks.get(gamma), _Sinks.get(beta), _Sinks.get(slope))
@@ -312,7 +320,7 @@ class BNActFn(Function):
             _Env.lazy_bn.clear()                    # (one stem per model; an entry nobody collected -- frozen stem -- must not linger)
             _Env.lazy_bn[dy.data_ptr()] = st
             _, _, dgamma, dbeta, _ = T._bn_bwd_result(st)
-            return dy, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+            return dy, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
         want_dres = res is not None and ctx.needs_input_grad[4]
         prev = _take(ctx.acc_res, dy) if want_dres else None
         prev_z = _take(ctx.acc_z, z)
@@ -324,9 +332,10 @@ class BNActFn(Function):
             ctx.acc_res.put(dres, prev is not None)
         if ctx.acc_z is not None:
             ctx.acc_z.put(dz, prev_z is not None)
-        return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None, None, None, None
+        return dz, dgamma, dbeta, dslope, dres, None, None, None, None, None, None, None, None, None
 
 
+OUT_STATS = _knob_int('LEDN_OUT_STATS', 1)      # statistics of a BatchNorm's input from the affine pass that writes it (ledn_affine_desc.stat_sum)
 STEM_LAZY_BN = _knob_int('LEDN_STEM_LAZY_BN', 1)   # the stem BatchNorm's apply half inside the stem weight-gradient kernel (ledn_stem_conv_wgrad_bn)
 WGRAD_DEFER = _knob_int('LEDN_WGRAD_DEFER', 1)   # one summing launch for all weight gradients of a step (ops.WgradDefer)
 WGRAD_SLOT_MAXPIX = _knob_int('LEDN_WGRAD_SLOT_MAXPIX', 0)   # with LEDN_WGRAD_SLOT: only layers of at most this many output pixels (the short, latency-bound 1/8-resolution ones)
@@ -890,15 +899,16 @@ def relu(x, acc=None):
 
 
 def conv_bn_act(x, conv, bn, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE, xadd=None, out_dtype=None,
-                acc=None, acc_res=None):
-    """acc / acc_res: gradient fan-in (_Acc) of x / res when they are aliases handed out by fanout()"""
+                acc=None, acc_res=None, out_stats=False):
+    """acc / acc_res: gradient fan-in (_Acc) of x / res when they are aliases handed out by fanout(); out_stats: a BatchNorm
+    reads the output next (see BNActFn)"""
     st = _stats(conv.out_channels, x) if bn is not None else None
     z = ConvFn.apply(x, conv.weight, conv.bias, xadd, conv.stride[0], conv.padding[0], conv.groups, st,
                      out_dtype if bn is None else None, bn is not None, acc)
     if bn is None:
         assert act == ACT_NONE and res is None
         return z
-    return BNActFn.apply(z, bn.weight, bn.bias, slope, res, st, bn, act, res_mode, out_dtype, acc_res)
+    return BNActFn.apply(z, bn.weight, bn.bias, slope, res, st, bn, act, res_mode, out_dtype, acc_res, None, False, out_stats)
 
 
 def bn_act(x, bn, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE, stats=None, out_dtype=None, acc_z=None):
@@ -908,19 +918,20 @@ def bn_act(x, bn, act=ACT_NONE, slope=None, res=None, res_mode=RES_NONE, stats=N
 _ACT = {None: ACT_NONE, 'relu': ACT_RELU, 'relu6': ACT_RELU6}
 
 
-def conv_module(m, x, act_override=None, res=None, res_mode=RES_NONE, out_dtype=None, acc=None, acc_res=None):
-    """blocks.ConvModule in training mode (acc / acc_res: see conv_bn_act)."""
+def conv_module(m, x, act_override=None, res=None, res_mode=RES_NONE, out_dtype=None, acc=None, acc_res=None, out_stats=False):
+    """blocks.ConvModule in training mode (acc / acc_res, out_stats: see conv_bn_act)."""
     act = _ACT[m.act] if act_override is None else act_override
     if m.norm_first:
         if FUSE_BN_INTO_CONV and act in BNActConvFn.ACTS:
-            z = BNActConvFn.apply(x, m.bn.weight, m.bn.bias, None, m.conv.weight, m.conv.bias, None, m.bn, act,
+            st_in = _Env.out_stats.pop(x.data_ptr(), None)     # left by the pass that wrote x (BNActFn out_stats), else None
+            z = BNActConvFn.apply(x, m.bn.weight, m.bn.bias, None, m.conv.weight, m.conv.bias, st_in, m.bn, act,
                                   m.stride, m.padding, m.conv.groups, None, out_dtype, acc)
         else:
             z = ConvFn.apply(bn_act(x, m.bn, act), m.conv.weight, m.conv.bias, None, m.stride, m.padding,
                              m.conv.groups, None, out_dtype)
         return z if res is None else ActFn.apply(z, res, ACT_NONE)      # (res_mode ADD: the PPM shortcut)
     return conv_bn_act(x, m.conv, m.bn if m.with_norm else None, act, res=res, res_mode=res_mode,
-                       out_dtype=out_dtype, acc=acc, acc_res=acc_res)
+                       out_dtype=out_dtype, acc=acc, acc_res=acc_res, out_stats=out_stats and m.with_norm)
 
 
 def basic_block(m, x, final_relu=False, pre=None):
@@ -1192,6 +1203,7 @@ def lednet_forward_train(m, x, pre=None):
     out_size = (math.ceil(H / 8), math.ceil(W / 8))
     s, b, mp, valid, pad_val = (tuple(pre) + (None, 0.0))[:5] if pre is not None else (None, None, None, None, 0.0)
     s0 = m.stem['0']
+    _Env.out_stats = {}         # (per forward: an entry nobody collected must not meet another tensor at the same address)
     if (STEM_DIRECT and m.act_dtype == torch.bfloat16 and m.in_channels == 3 and m.channels == 32
             and x.dtype in (torch.uint8, torch.float32, torch.bfloat16) and s0.conv.bias is None):
         # the first stem convolution and its weight gradient straight from the planar batch (ledn_stem_conv /
@@ -1199,7 +1211,7 @@ def lednet_forward_train(m, x, pre=None):
         # read twice per step) is never materialised
         st = _stats(m.channels, x)
         z = StemConvFn.apply(x.contiguous(), s0.conv.weight, (s, b, mp, valid, pad_val), st)
-        x1 = BNActFn.apply(z, s0.bn.weight, s0.bn.bias, None, None, st, s0.bn, ACT_RELU, RES_NONE, None, None, None, True)
+        x1 = BNActFn.apply(z, s0.bn.weight, s0.bn.bias, None, None, st, s0.bn, ACT_RELU, RES_NONE, None, None, None, True, True)
     elif m.act_dtype == torch.bfloat16 and 9 * m.in_channels <= 32 and m.channels % 32 == 0:
         # stem as a K=32 GEMM on the MFMA path: im2col patches straight from the planar batch
         # (normalisation folded in; the input needs no gradient) x reshaped weight
@@ -1212,7 +1224,7 @@ def lednet_forward_train(m, x, pre=None):
     # x1 and x2 also feed LEDHead's head_x1 / head_x2: fan them out here, the head picks its accumulators up
     # from _Env.head_acc (its consumer is a BNActConvFn whose BatchNorm-backward takes the addend)
     (x1, x1_head), acc1 = fanout(x1, 2)
-    x2 = conv_module(m.stem['1'], x1, acc=acc1)
+    x2 = conv_module(m.stem['1'], x1, acc=acc1, out_stats=True)      # (head_x2's BatchNorm reads x2)
     (x2a, x2b, x2_head), acc2 = fanout(x2, 3)
     _Env.head_acc = {'x1': (acc1, x1_head.data_ptr()), 'x2': (acc2, x2_head.data_ptr())}
     x1, x2 = x1_head, x2_head

@@ -339,3 +339,24 @@ def test_bn_bwd_fused_is_skipped_on_the_emulator(emu):
         assert lib.cdll.ledn_bn_act_bwd_fused(st.d, None) == _lib.ESKIP
     finally:
         lib.set_option(_lib.OPT_BN_FUSED, 0)
+
+
+@pytest.mark.parametrize('C,P,act', [(32, 70001, 'relu'), (64, 40000, 'prelu'), (16, 33000, 'none'), (128, 4099, 'relu')])
+def test_affine_with_output_statistics(be, C, P, act):
+    """ledn_affine_act with stat_sum / stat_sqsum: the output of the plain pass and the per-channel sums ledn_channel_stats
+    finds on it (the statistics are those of the STORED bf16 values), accumulated into the sinks; ragged vector counts"""
+    from led_net_amd import ops
+    g = torch.Generator().manual_seed(C + P)
+    x = torch.randn(1, P, 1, C, generator=g).bfloat16().to(be.dev)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(be.dev), (torch.randn(C, generator=g) * 0.3).to(be.dev)
+    a = {'relu': ops.ACT_RELU, 'prelu': ops.ACT_PRELU, 'none': ops.ACT_NONE}[act]
+    sl = (torch.rand(C, generator=g) * 0.3).to(be.dev) if act == 'prelu' else None
+    assert ops.affine_stats_ok(x, a)
+    want = ops.affine_act(x, sc, sh, act=a, slope=sl)
+    ws = (torch.zeros(C, device=be.dev), torch.zeros(C, device=be.dev))
+    ops.channel_stats(want, stats=ws)
+    st = (torch.full((C,), 0.5, device=be.dev), torch.full((C,), 0.25, device=be.dev))
+    got = ops.affine_act(x, sc, sh, act=a, slope=sl, stats=st)
+    assert torch.equal(got, want)
+    torch.testing.assert_close(st[0] - 0.5, ws[0], rtol=1e-4, atol=1e-3 * float(ws[0].abs().max()) + 1e-3)
+    torch.testing.assert_close(st[1] - 0.25, ws[1], rtol=1e-4, atol=1e-4 * float(ws[1].abs().max()) + 1e-3)
