@@ -196,6 +196,7 @@ int ledn_conv2d(const ledn_conv_desc* d, void* stream) {
     if (!d) return LEDN_EINVAL;
     const int rc = conv_validate(*d);
     if (rc != LEDN_OK) return rc;
+    if (head_fwd_supported(*d)) return head_fwd(*d, S(stream));      // the two-class heads (head_bwd.hip)
     if (conv_mfma_supported(*d)) {
         if (conv1x1_reg_supported(*d)) return conv1x1_reg(*d, S(stream));
         if (conv3x3_reg_supported(*d)) return conv3x3_reg(*d, S(stream));
@@ -250,6 +251,7 @@ int ledn_bn_finalize_rows(const float* part, int rows, double count, const float
 }
 
 int ledn_conv2d_uses_mfma(const ledn_conv_desc* d) {
+    if (d && conv_validate(*d) == LEDN_OK && head_fwd_supported(*d)) return 6;
     if (d && !conv_mfma_supported(*d) && conv3x3_narrowin_mfma_supported(*d)) return 4;
     if (d && !conv_mfma_supported(*d) && conv_validate(*d) == LEDN_OK && conv_f32_mfma_supported(*d)) return 5;
     if (!d || !conv_mfma_supported(*d)) return 0;

@@ -440,6 +440,172 @@ __global__ void __launch_bounds__(256) head_bwd_apply_kernel(ledn_headbwd_desc d
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward of the same heads: z[p][o] = b[o] + sum_{tap, c} t[p + off(tap)][c] w[o][c][tap], t = act(x * scale + shift).
+// Instead of 9 taps x 2 K-steps of matrix instructions whose N dimension holds 2 useful columns of 32 (conv_mfma_kernel's
+// narrow epilogue: 118 us at 16 x 512 x 512), the channel contraction runs ONCE per pixel for all 18 (tap, class)
+// combinations -- Y[(tap, class)][px] = Wm[18 x 32] t[32 x px], two v_mfma_f32_32x32x16_bf16 per 32 pixels with t as the B
+// operand in its natural layout (lane = pixel, 8 consecutive channels: the two 16-byte loads of the lane) -- and the nine
+// taps become a shifted sum of 9 of those partial products per output: through a wave-private LDS row [18][34] for the
+// column shifts, through a three-row register ring for the row shifts.  A wave owns a strip of 32 pixel columns (30 valid
+// outputs: columns 30 j - 1 .. 30 j + 30) and walks down a chunk of rows; lane (n, h) emits class h of column n.
+template <int ACT, bool OUT16>
+__global__ void __launch_bounds__(256) head_fwd_kernel(ledn_conv_desc d, int strips, int chunks, int rows_per_chunk) {
+    __shared__ float s_y[4][18 * 34];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+    const int H = d.H, W = d.W;
+    bf16x8_t af[2];                                            // A[m = 2 tap + class][c = 16 s + 8 hk + j]
+    {
+        const int m = lane & 31, hk = lane >> 5, k9 = m >> 1, o = m & 1;
+        const float* w = reinterpret_cast<const float*>(d.w);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * s + 8 * hk + j;
+                af[s][j] = (short)(m < 18 ? f32_to_bf16(w[(o * HB_C + c) * 9 + k9]) : (unsigned short)0);
+            }
+    }
+    float sc[16], sh[16], sl[16];                              // channels 8 h + j (j < 8) and 16 + 8 h + j
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = (i < 8 ? 0 : 16) + 8 * h + (i & 7);
+        sc[i] = d.in_scale ? d.in_scale[c] : 1.f;
+        sh[i] = d.in_shift ? d.in_shift[c] : 0.f;
+        sl[i] = ACT == LEDN_ACT_PRELU ? d.in_slope[c] : 0.f;
+    }
+    const float bias = d.out_shift ? d.out_shift[h] : 0.f;
+    float* ys = s_y[wid];
+    const bf16_t* x = reinterpret_cast<const bf16_t*>(d.x);
+    const long ntask = (long)d.N * strips * chunks;
+    for (long task = (long)blockIdx.x * 4 + wid; task < ntask; task += (long)gridDim.x * 4) {
+        const int ck = (int)(task % chunks), j = (int)((task / chunks) % strips), img = (int)(task / ((long)chunks * strips));
+        const int r0 = ck * rows_per_chunk, r1 = min(H, r0 + rows_per_chunk);
+        const int px = 30 * j - 1 + n;
+        const bool col_ok = px >= 0 && px < W;
+        const bf16_t* xi = x + (long)img * H * W * HB_C;
+        auto fetch = [&](int r, uint4& v0, uint4& v1) {
+            const bool ok = col_ok && r >= 0 && r < H;
+            const uint4* p = reinterpret_cast<const uint4*>(xi + ((long)(ok ? r : 0) * W + (ok ? px : 0)) * HB_C + 8 * h);
+            v0 = p[0];
+            v1 = p[2];                                         // channels 16 + 8 h ..
+            if (!ok) v0 = v1 = make_uint4(0u, 0u, 0u, 0u);
+        };
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;                    // partial outputs of rows r - 1, r, r + 1
+        auto process = [&](int r, const uint4& c0, const uint4& c1) {
+            const bool row_ok = col_ok && r >= 0 && r < H;
+            float xv[16];
+            hb_unpack16(c0, c1, xv);
+            unsigned tw[8];
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                float a = fmaf(xv[i], sc[i], sh[i]), b = fmaf(xv[i + 1], sc[i + 1], sh[i + 1]);
+                if (ACT == LEDN_ACT_RELU) {
+                    a = fmaxf(a, 0.f);
+                    b = fmaxf(b, 0.f);
+                } else if (ACT == LEDN_ACT_PRELU) {
+                    a = a > 0.f ? a : a * sl[i];
+                    b = b > 0.f ? b : b * sl[i + 1];
+                }
+                tw[i >> 1] = row_ok ? ((unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16)) : 0u;   // zero padding of t
+            }
+            f32x16_t acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            acc = mfma_32x32x16_bf16(af[0], __builtin_bit_cast(bf16x8_t, make_uint4(tw[0], tw[1], tw[2], tw[3])), acc);
+            acc = mfma_32x32x16_bf16(af[1], __builtin_bit_cast(bf16x8_t, make_uint4(tw[4], tw[5], tw[6], tw[7])), acc);
+            wave_sync();                                       // the previous row's reads of the LDS row are done
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int kidx = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (kidx < 18) ys[kidx * 34 + n + 1] = acc[reg];
+            }
+            wave_sync();
+            // class h of column n: P[kh] = sum_kw Y[(3 kh + kw, h)][n + kw - 1]
+            float P[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float* row = ys + ((3 * kh) * 2 + h) * 34 + n;
+                P[kh] = (row[0] + row[2 * 34 + 1]) + row[4 * 34 + 2];
+            }
+            // input row r feeds output rows r + 1 (kh = 0), r (kh = 1), r - 1 (kh = 2)
+            const float done = t0 + P[2];
+            t0 = t1 + P[1];
+            t1 = t2 + P[0];
+            t2 = 0.f;
+            const int ro = r - 1;
+            if (ro >= r0 && ro < r1 && n >= 1 && n <= 30 && px < W) {
+                const long o = (((long)img * H + ro) * W + px) * HB_CO + h;
+                if (OUT16) reinterpret_cast<bf16_t*>(d.y)[o].v = f32_to_bf16(done + bias);
+                else reinterpret_cast<float*>(d.y)[o] = done + bias;
+            }
+        };
+        // rows r0 - 1 .. r1 in groups of HF_D, the next group's loads in flight under this group's arithmetic (one row ahead
+        // left every row waiting for its own load: 129 us at 16 x 512 x 512)
+        constexpr int HF_D = 4;
+        uint4 c0[HF_D], c1[HF_D];
+#pragma unroll
+        for (int u = 0; u < HF_D; ++u) fetch(min(r0 - 1 + u, r1), c0[u], c1[u]);
+        for (int r = r0 - 1; r <= r1; r += HF_D) {
+            uint4 n0[HF_D], n1[HF_D];
+#pragma unroll
+            for (int u = 0; u < HF_D; ++u) fetch(min(r + HF_D + u, r1), n0[u], n1[u]);
+#pragma unroll
+            for (int u = 0; u < HF_D; ++u) {
+                if (r + u <= r1) process(r + u, c0[u], c1[u]);
+                c0[u] = n0[u];
+                c1[u] = n1[u];
+            }
+        }
+    }
+}
+
+bool head_fwd_supported(const ledn_conv_desc& d) {
+    static const bool on = exp_knob("LEDN_HEAD_FWD", 1) != 0;     // (A/B knob)
+    if (!on || !(options().stream_fast & 1)) return false;
+    if (d.dtype_x != LEDN_BF16 || (d.dtype_y != LEDN_BF16 && d.dtype_y != LEDN_F32) || !d.w) return false;
+    if (d.Cin != HB_C || d.Cout != HB_CO || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.dil != 1 || d.groups != 1)
+        return false;
+    if (d.transposed || d.xadd || d.res || d.res_mode != LEDN_RES_NONE || d.out_scale || d.stat_sum || d.act_out != LEDN_ACT_NONE)
+        return false;
+    if (d.Ho != d.H || d.Wo != d.W || d.W < 32 || (long)d.N * d.H * d.W < 16384 || (long)d.N * d.H * d.W * HB_C >= (1L << 31))
+        return false;
+    if ((d.in_scale == nullptr) != (d.in_shift == nullptr)) return false;
+    if (d.in_act != LEDN_ACT_NONE && d.in_act != LEDN_ACT_RELU && !(d.in_act == LEDN_ACT_PRELU && d.in_slope)) return false;
+    // the filter in its natural OIHW strides (ledn_conv_desc.ws_*)
+    return d.ws_co == (long long)HB_C * 9 && d.ws_ci == 9 && d.ws_tap == 1;
+}
+
+int head_fwd(const ledn_conv_desc& d, hipStream_t s) {
+    const int strips = (int)cdiv(d.W, 30);
+    // rows per wave task: enough tasks to fill the chip twice over (a task is one serial chain of rows; 2 halo rows per chunk):
+    // 16 x 512 x 512 -> 16 rows (101 us; 32 rows 110, 64 rows 126), 16 x 256 x 256 -> 8
+    static const int rpc = (int)exp_knob("LEDN_HEAD_FWD_ROWS", 0);
+    int rows_per_chunk = rpc;
+    if (rows_per_chunk <= 0) {
+        const long want = ((long)d.N * strips * d.H) / 8192;
+        rows_per_chunk = want >= 32 ? 32 : (want >= 16 ? 16 : 8);
+    }
+    const int chunks = (int)cdiv(d.H, rows_per_chunk);
+    const long ntask = (long)d.N * strips * chunks;
+    long nb = cdiv(ntask, 4L);
+    if (nb > 2048) nb = 2048;
+#define LEDN_HF_GO(A_)                                                                                                       \
+    do {                                                                                                                     \
+        if (d.dtype_y == LEDN_BF16)                                                                                          \
+            LEDN_LAUNCH((head_fwd_kernel<A_, true>), dim3((unsigned)nb), dim3(256), 0, s, d, strips, chunks, rows_per_chunk);  \
+        else                                                                                                                 \
+            LEDN_LAUNCH((head_fwd_kernel<A_, false>), dim3((unsigned)nb), dim3(256), 0, s, d, strips, chunks, rows_per_chunk); \
+    } while (0)
+    switch (d.in_act) {
+        case LEDN_ACT_NONE: LEDN_HF_GO(LEDN_ACT_NONE); break;
+        case LEDN_ACT_RELU: LEDN_HF_GO(LEDN_ACT_RELU); break;
+        default: LEDN_HF_GO(LEDN_ACT_PRELU); break;
+    }
+#undef LEDN_HF_GO
+    return check_launch();
+}
+
 int head_bwd_supported(const ledn_headbwd_desc& d) {
     if (!d.bn.z || !d.head_dz || !d.w || d.Co != HB_CO || d.bn.C != HB_C || d.dtype_dz != LEDN_BF16) return 0;
     if (d.bn.dtype_z != LEDN_BF16 || d.bn.res || d.bn.res_mode != LEDN_RES_NONE || d.bn.dres || d.bn.rows) return 0;

@@ -411,6 +411,8 @@ int bn_act_bwd_fused_check(int C, hipStream_t s);
 int head_bwd_supported(const ledn_headbwd_desc& d);
 int head_bwd_reduce(const ledn_headbwd_desc& d, hipStream_t s);
 int head_bwd_apply(const ledn_headbwd_desc& d, hipStream_t s);
+bool head_fwd_supported(const ledn_conv_desc& d);
+int head_fwd(const ledn_conv_desc& d, hipStream_t s);
 int channel_stats_fast(const void* x, const void* xadd, long long P, int C, int dtype, float* sum, float* sqsum,
                        hipStream_t s);
 

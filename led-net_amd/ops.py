@@ -272,13 +272,13 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, groups=1, xadd=None, in_scale=None, 
     _run_stats(lib, 'ledn_conv2d', x, stats, defer_stats, d, work=_TIMING is not None and (
         f'conv{KH}x{KW}{"T" if transposed else ""} {Cin}->{Cout} g{groups} s{stride} {N}x{H}x{W} {str(x.dtype)[6:]}',
         _nb(x, xadd, y, res, w), 2 * N * Ho * Wo * Cout * (Cin // groups) * KH * KW,
-        ('conv_direct_kernel', 'conv_mfma_kernel', 'conv1x1_mfma_kernel', 'conv3x3_reg_kernel', 'conv3x3_narrowin_mfma_kernel', 'conv_f32_mfma_kernel')[lib.cdll.ledn_conv2d_uses_mfma(d)]))
+        ('conv_direct_kernel', 'conv_mfma_kernel', 'conv1x1_mfma_kernel', 'conv3x3_reg_kernel', 'conv3x3_narrowin_mfma_kernel', 'conv_f32_mfma_kernel', 'head_fwd_kernel')[lib.cdll.ledn_conv2d_uses_mfma(d)]))
     return y
 
 
 def conv2d_kernel_id(x, w, **kw):
     """which kernel ledn_conv2d runs these arguments on (no launch): 0 conv_direct_kernel (VALU), 1 conv_mfma_kernel,
-    2 conv1x1_mfma_kernel, 3 conv3x3_reg_kernel"""
+    2 conv1x1_mfma_kernel, 3 conv3x3_reg_kernel, 4 conv3x3_narrowin_mfma_kernel, 5 conv_f32_mfma_kernel, 6 head_fwd_kernel"""
     return conv2d(x, w, _query=True, **kw)
 
 

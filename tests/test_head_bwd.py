@@ -133,3 +133,37 @@ def test_head_bwd_gate():
     assert not T.head_bwd_ok(x[:, :64], dz[:, :64], w, 1, 1, 1, ops.ACT_RELU)         # too few pixels
     assert not T.head_bwd_ok(x, torch.zeros(1, 128, 128, 3, dtype=torch.bfloat16), torch.zeros(3, 32, 3, 3), 1, 1, 1, ops.ACT_RELU)
     assert not T.head_bwd_ok(x, dz, w, 1, 1, 1, ops.ACT_RELU6)
+
+
+@pytest.mark.parametrize('nhw', [(1, 128, 130), (2, 97, 131), (1, 16, 1030), (1, 520, 32)])
+@pytest.mark.parametrize('variant', ['relu_bias_f32', 'prelu_bf16', 'plain_bf16', 'relu_bf16'])
+def test_head_forward_kernel(be, nhw, variant):
+    """head_fwd_kernel (the two-class heads' forward: one channel contraction per pixel for all 18 (tap, class) pairs, the
+    taps as a shifted sum) against F.conv2d on the bf16-rounded activation; ragged widths / heights, both output types"""
+    from led_net_amd import ops
+    N, H, W = nhw
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(N, 32, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(2, 32, 3, 3, generator=g) * 0.1).bfloat16().float()
+    bias = torch.randn(2, generator=g) * 0.1 if 'bias' in variant else None
+    sc, sh = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.3
+    act = ops.ACT_RELU if 'relu' in variant else (ops.ACT_PRELU if 'prelu' in variant else ops.ACT_NONE)
+    sl = torch.rand(32, generator=g) * 0.3 if act == ops.ACT_PRELU else None
+    plain = 'plain' in variant
+    t = x if plain else x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if act == ops.ACT_RELU:
+        t = F.relu(t)
+    elif act == ops.ACT_PRELU:
+        t = F.prelu(t, sl)
+    want = F.conv2d(t.bfloat16().float(), w, bias, padding=1)
+    od = torch.float32 if 'f32' in variant else torch.bfloat16
+    D = lambda v: None if v is None else v.to(be.dev)     # noqa: E731
+    kw = dict(stride=1, pad=1, out_dtype=od, out_shift=D(bias))
+    if not plain:
+        kw.update(in_scale=D(sc), in_shift=D(sh), in_act=act, in_slope=D(sl))
+    xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(be.dev)
+    assert ops.conv2d_kernel_id(xd, D(w), **kw) == 6
+    got = ops.conv2d(xd, D(w), **kw)
+    assert got.dtype == od
+    tol = 2e-2 if od == torch.bfloat16 else 2e-3
+    torch.testing.assert_close(got.float().cpu().permute(0, 3, 1, 2), want, rtol=tol, atol=tol * float(want.abs().max()))
