@@ -303,7 +303,86 @@ static int launch_narrowin(const ledn_conv_desc& d, hipStream_t s) {
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------
+// 1x1 convolution with Cout <= 2 on bf16 maps (the classifiers cls_seg / aux_cls_seg 64 -> 2, led_head.py:87-98) at the
+// streaming shape: lane = 8 input channels of a pixel (one 16-byte load), the 2 x 8 filter values in registers, the pixel's
+// C / 8 lanes add their partial dot products with DPP steps inside the group; the group's first lane stores.  (The
+// generic output-tiled kernel: 27 us for the 33.5 MB map at 16 x 128 x 128 x 64 = 1.3 TB/s.)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float c11n_group_sum(float v, int cgn) {      // sum over the cgn (power of two <= 16) lanes of a pixel
+#ifdef LEDN_CPU_EMU
+    for (int m = 1; m < cgn; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+#else
+    const int iv0 = __float_as_int(v);
+    if (cgn >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, iv0, 0xB1, 0xf, 0xf, false));                       // quad_perm [1,0,3,2]
+    if (cgn >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));         // quad_perm [2,3,0,1]
+    if (cgn >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));        // row_half_mirror
+    if (cgn >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));       // row_mirror
+    return v;
+#endif
+}
+template <typename TY, int UNR>
+__global__ void __launch_bounds__(256) conv1x1_narrow_kernel(ledn_conv_desc d) {
+    const int cgn = d.Cin >> 3, rows = 256 / cgn;
+    const int cg = (int)(threadIdx.x % (unsigned)cgn), r = (int)(threadIdx.x / (unsigned)cgn), c = cg * 8;
+    const float* w = reinterpret_cast<const float*>(d.w);
+    float w0[8], w1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        w0[i] = w[(long)(c + i) * d.ws_ci];
+        w1[i] = d.Cout > 1 ? w[d.ws_co + (long)(c + i) * d.ws_ci] : 0.f;
+    }
+    const float b0 = d.out_shift ? d.out_shift[0] : 0.f, b1 = (d.out_shift && d.Cout > 1) ? d.out_shift[1] : 0.f;
+    const bf16_t* x = reinterpret_cast<const bf16_t*>(d.x);
+    TY* y = reinterpret_cast<TY*>(d.y);
+    const long npix = (long)d.N * d.H * d.W;
+    const long p0 = (long)blockIdx.x * (rows * UNR) + r;
+    uint4 xr[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const long p = p0 + (long)u * rows;
+        xr[u] = *reinterpret_cast<const uint4*>(x + (p < npix ? p : 0) * d.Cin + c);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const long p = p0 + (long)u * rows;
+        float xv[8];
+        ld8(reinterpret_cast<const bf16_t*>(&xr[u]), xv);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a0 = fmaf(xv[i], w0[i], a0);
+            a1 = fmaf(xv[i], w1[i], a1);
+        }
+        a0 = c11n_group_sum(a0, cgn);           // (every lane of the wave takes part: no early exit above)
+        a1 = c11n_group_sum(a1, cgn);
+        if (cg == 0 && p < npix) {
+            st(y + p * d.Cout, a0 + b0);
+            if (d.Cout > 1) st(y + p * d.Cout + 1, a1 + b1);
+        }
+    }
+}
+
+static bool conv1x1_narrow_ok(const ledn_conv_desc& d) {
+    if (!(options().stream_fast & 1) || d.dtype_x != LEDN_BF16 || (d.dtype_y != LEDN_BF16 && d.dtype_y != LEDN_F32)) return false;
+    if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.pad != 0 || d.groups != 1 || d.transposed || d.Cout > 2) return false;
+    if (d.Cin < 8 || d.Cin > 128 || (d.Cin & (d.Cin - 1))) return false;
+    if (d.xadd || d.in_scale || d.in_act != LEDN_ACT_NONE || d.out_scale || d.stat_sum || d.res || d.res_mode != LEDN_RES_NONE ||
+        d.act_out != LEDN_ACT_NONE)
+        return false;
+    return d.ws_tap == 1 && (long)d.N * d.H * d.W >= 4096 && (long)d.N * d.H * d.W * d.Cin < (1L << 31);
+}
+
 int conv_direct(const ledn_conv_desc& d, hipStream_t s) {
+    if (conv1x1_narrow_ok(d)) {
+        constexpr int UNR = 4;
+        const int rows = 256 / (d.Cin >> 3);
+        const dim3 grid((unsigned)cdiv((long)d.N * d.H * d.W, (long)rows * UNR));
+        if (d.dtype_y == LEDN_F32) LEDN_LAUNCH((conv1x1_narrow_kernel<float, UNR>), grid, dim3(256), 0, s, d);
+        else LEDN_LAUNCH((conv1x1_narrow_kernel<bf16_t, UNR>), grid, dim3(256), 0, s, d);
+        return check_launch();
+    }
     if (narrowin_ok(d)) {
         if (d.dtype_x == LEDN_F32 && d.dtype_y == LEDN_F32) return launch_narrowin<float, float>(d, s);
         if (d.dtype_x == LEDN_BF16 && d.dtype_y == LEDN_BF16) return launch_narrowin<bf16_t, bf16_t>(d, s);
@@ -609,7 +688,36 @@ __global__ void __launch_bounds__(256) conv_wgrad_cout2_kernel(ledn_wgrad_desc d
     const TZ* dz = reinterpret_cast<const TZ*>(d.dz);
     const long npix = (long)d.N * d.H * d.W;
     const long stride = (long)gridDim.x * slots;
-    if (slot < slots) {
+    if (K == 1 && slot < slots) {
+        // 1x1: dz[q] multiplies x[q] -- no coordinates; four pixels per trip, all eight loads issued before the first use
+        // (the loop below walked its pixels one dependent round trip at a time, with three 64-bit divisions each)
+        for (long q = (long)blockIdx.x * slots + slot; q < npix; q += 4 * stride) {
+            uint4 xr[4];
+            float g0[4], g1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long qq = q + u * stride;
+                const bool ok = qq < npix;
+                const long qs = ok ? qq : q;
+                xr[u] = *reinterpret_cast<const uint4*>(x + qs * d.Cin + c);
+                const float a = ld(dz + qs * d.Cout), b = d.Cout > 1 ? ld(dz + qs * d.Cout + 1) : 0.f;
+                g0[u] = ok ? a : 0.f;
+                g1[u] = ok ? b : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float xv[8];
+                ld8(reinterpret_cast<const bf16_t*>(&xr[u]), xv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    xv[i] = xv[i] * sc[i] + sh[i];
+                    if (d.in_act == LEDN_ACT_RELU) xv[i] = fmaxf(xv[i], 0.f);
+                    acc[0][0][i] = fmaf(xv[i], g0[u], acc[0][0][i]);
+                    acc[0][1][i] = fmaf(xv[i], g1[u], acc[0][1][i]);
+                }
+            }
+        }
+    } else if (slot < slots) {
         for (long q = (long)blockIdx.x * slots + slot; q < npix; q += stride) {
             const int wi = (int)(q % d.W);
             const int hi = (int)((q / d.W) % d.H);

@@ -167,3 +167,30 @@ def test_head_forward_kernel(be, nhw, variant):
     assert got.dtype == od
     tol = 2e-2 if od == torch.bfloat16 else 2e-3
     torch.testing.assert_close(got.float().cpu().permute(0, 3, 1, 2), want, rtol=tol, atol=tol * float(want.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(1, 64, 70, 64), (2, 33, 64, 32), (1, 40, 103, 128)])
+@pytest.mark.parametrize('cout,od', [(2, 'f32'), (1, 'bf16'), (2, 'bf16')])
+def test_classifier_1x1_narrow_forward_and_weight_gradient(be, shape, cout, od):
+    """the 1x1 classifiers (cls_seg / aux_cls_seg, led_head.py:87-98: C -> num_classes <= 2) on the streaming kernels:
+    conv1x1_narrow_kernel (forward) and the unrolled 1x1 path of conv_wgrad_cout2_kernel, against torch"""
+    from led_net_amd import ops
+    N, H, W, Cc = shape
+    g = torch.Generator().manual_seed(H + W + Cc + cout)
+    x = torch.randn(N, Cc, H, W, generator=g).bfloat16().float().requires_grad_(True)
+    w = (torch.randn(cout, Cc, 1, 1, generator=g) * 0.2).requires_grad_(True)
+    b = (torch.randn(cout, generator=g) * 0.1).requires_grad_(True)
+    z = F.conv2d(x, w, b)
+    dz = torch.randn(z.shape, generator=g)
+    if od == 'bf16':
+        dz = dz.bfloat16().float()
+    z.backward(dz)
+    dt = torch.float32 if od == 'f32' else torch.bfloat16
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().bfloat16().to(be.dev)
+    got = ops.conv2d(xd, w.detach().to(be.dev), out_shift=b.detach().to(be.dev), out_dtype=dt)
+    tol = 2e-3 if od == 'f32' else 1.5e-2
+    torch.testing.assert_close(got.float().cpu().permute(0, 3, 1, 2), z.detach(), rtol=tol, atol=tol * float(z.abs().max()))
+    dzd = dz.permute(0, 2, 3, 1).contiguous().to(dt).to(be.dev)
+    dw, db = ops.conv2d_wgrad(xd, dzd, (cout, Cc, 1, 1), bias=True)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=2e-3, atol=2e-3 * float(w.grad.abs().max()))
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=2e-3, atol=2e-3 * float(b.grad.abs().max()))
