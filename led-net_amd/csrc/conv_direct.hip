@@ -232,12 +232,8 @@ __global__ void __launch_bounds__(256, 2) conv_narrowin_kernel(ledn_conv_desc d)
     const TX* x = reinterpret_cast<const TX*>(d.x);
     TY* y = reinterpret_cast<TY*>(d.y);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(idx % cgn);
-        long q = idx / cgn;
-        const int wo0 = (int)(q % wq) * PX;
-        q /= wq;
-        const int ho = (int)(q % d.Ho);
-        const int n = (int)(q / d.Ho);
+        const NhwcIdx ix_ = nhwc_split(idx, cgn, wq, d.Ho);      // (32-bit divisions: ledn_rt.h)
+        const int cg = ix_.cv, wo0 = ix_.x * PX, ho = ix_.y, n = ix_.n;
         float xv[K][K + PX - 1][CIN];
 #pragma unroll
         for (int r = 0; r < K; ++r)
@@ -297,7 +293,8 @@ static int launch_narrowin(const ledn_conv_desc& d, hipStream_t s) {
         if (d.transposed) LEDN_LAUNCH((conv_narrowin_kernel<TX, TY, CI, KK, true>), grid, dim3(256), 0, s, d); \
         else LEDN_LAUNCH((conv_narrowin_kernel<TX, TY, CI, KK, false>), grid, dim3(256), 0, s, d);        \
     } while (0)
-    if (d.KH == 3) LEDN_NI(2, 3);
+    if (d.Cin == 1 && d.KH == 3) LEDN_NI(1, 3);          // SEAM's conv_2 (1 -> 64): half the loads and FMAs of the 2-channel instance
+    else if (d.KH == 3) LEDN_NI(2, 3);
     else LEDN_NI(2, 1);
 #undef LEDN_NI
     return check_launch();
