@@ -244,7 +244,9 @@ __global__ void __launch_bounds__(256) dw3x3_bf16_kernel(ledn_dw_desc d, const b
 // conflict-free), the output is written as 64-byte pixel halves.  Halo re-reads 1.41x (HL = 2, TH = 16).
 // HL = the largest dilation among the workgroup's channel groups (SESP's second stage uses dil + 1: 2 on the
 // spatial branch, 2..5 on the context branch).  Statistics: one partial row per tile.
-template <int FLIP, int HL, int TH>
+// EPI: an output epilogue (folded BatchNorm / activation: the inference form) exists; the training forward writes the raw
+// convolution + statistics and does without the 24 coefficient registers (186 -> 162: three workgroups per CU instead of two)
+template <int FLIP, int HL, int TH, bool EPI = true>
 __global__ void __launch_bounds__(256) dw3x3_tile_kernel(ledn_dw_desc d, const bf16_t* add, float* part) {
     constexpr int TW = 32, PW = TW + 2 * HL, PH = TH + 2 * HL, CW = 32, PXB = CW * 2;
     constexpr int NL = (PH * PW * 4 + 255) / 256;
@@ -286,20 +288,21 @@ __global__ void __launch_bounds__(256) dw3x3_tile_kernel(ledn_dw_desc d, const b
         f32x8_load(d.w + (long)(FLIP ? 8 - t : t) * d.C + c, w[t]);
         toff[t] = (((t / 3 - 1) * dl) * PW + (t % 3 - 1) * dl) * PXB;
     }
-    f32x2_t sc[4], sh[4], ng[4];
+    constexpr bool EP = EPI && !FLIP;
+    f32x2_t sc[EP ? 4 : 1], sh[EP ? 4 : 1], ng[EP ? 4 : 1];
+    if constexpr (EP) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        sc[i] = f32x2_t{1.f, 1.f};
-        sh[i] = f32x2_t{0.f, 0.f};
-        ng[i] = d.act_out == LEDN_ACT_NONE ? f32x2_t{1.f, 1.f} : f32x2_t{0.f, 0.f};
-    }
-    if (!FLIP) {
+        for (int i = 0; i < 4; ++i) {
+            sc[i] = f32x2_t{1.f, 1.f};
+            sh[i] = f32x2_t{0.f, 0.f};
+            ng[i] = d.act_out == LEDN_ACT_NONE ? f32x2_t{1.f, 1.f} : f32x2_t{0.f, 0.f};
+        }
         if (d.out_scale) f32x8_load(d.out_scale + c, sc);
         if (d.out_shift) f32x8_load(d.out_shift + c, sh);
         if (d.act_out == LEDN_ACT_PRELU) f32x8_load(d.slope + c, ng);
     }
-    const float hi = (!FLIP && d.act_out == LEDN_ACT_RELU6) ? 6.f : 3.0e38f;
-    const bool has_act = !FLIP && d.act_out != LEDN_ACT_NONE;
+    const float hi = (EP && d.act_out == LEDN_ACT_RELU6) ? 6.f : 3.0e38f;
+    const bool has_act = EP && d.act_out != LEDN_ACT_NONE;
     f32x2_t st1[4], st2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) st1[i] = st2[i] = f32x2_t{0.f, 0.f};
@@ -330,11 +333,11 @@ __global__ void __launch_bounds__(256) dw3x3_tile_kernel(ledn_dw_desc d, const b
         if (!FLIP) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                acc[i] = pk_fma(acc[i], sc[i], sh[i]);
+                if constexpr (EP) acc[i] = pk_fma(acc[i], sc[i], sh[i]);
                 st1[i] += acc[i];
                 st2[i] = pk_fma(acc[i], acc[i], st2[i]);
             }
-            if (has_act) {
+            if constexpr (EP) if (has_act) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     acc[i].x = fminf(fmaxf(acc[i].x, 0.f) + ng[i].x * fminf(acc[i].x, 0.f), hi);
@@ -696,14 +699,17 @@ static int dw3x3_tile_launch(const ledn_dw_desc& d, bool flip, const bf16_t* add
         part = ws_take(tiles * 2 * d.C);
         if (!part) return -1;
     }
+    const bool plain = !flip && !d.out_scale && !d.out_shift && d.act_out == LEDN_ACT_NONE;     // the training forward
     if (hl <= 2 && TH == 16) {
         if (flip) LEDN_LAUNCH((dw3x3_tile_kernel<1, 2, 16>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
+        else if (plain) LEDN_LAUNCH((dw3x3_tile_kernel<0, 2, 16, false>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
         else LEDN_LAUNCH((dw3x3_tile_kernel<0, 2, 16>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
     } else if (hl <= 2) {
         if (flip) LEDN_LAUNCH((dw3x3_tile_kernel<1, 2, 8>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
         else LEDN_LAUNCH((dw3x3_tile_kernel<0, 2, 8>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
     } else {
         if (flip) LEDN_LAUNCH((dw3x3_tile_kernel<1, 5, 8>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
+        else if (plain) LEDN_LAUNCH((dw3x3_tile_kernel<0, 5, 8, false>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
         else LEDN_LAUNCH((dw3x3_tile_kernel<0, 5, 8>), dim3((unsigned)nb), dim3(256), 0, s, d, add, part);
     }
     *part_out = part;
